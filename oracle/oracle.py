@@ -1,0 +1,222 @@
+"""ctypes bindings for the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Two libraries live here:
+
+* ``libmgm_oracle.so``  -- the plain-C restatement (oracle/mgm_oracle.c),
+  class :class:`Oracle`.
+* ``_ref/libmgm_ref.so`` -- the real reference (gfacciol/mgm) compiled from
+  ``/root/reference`` behind oracle/ref_harness.cc, class :class:`Reference`.
+  It exists only if it was built in the container that has the reference.
+
+Nothing in the product (mgm_amd/, include/, src/) may import this module; only
+tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg do.
+
+Array conventions: images are numpy float32 ``(nch, ny, nx)`` (planar, the
+reference's ``Img`` layout, img.h:35-51); volumes are ``(ny, nx, L)``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libmgm_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libmgm_ref.so")
+REF_MGM = os.path.join(HERE, "_ref", "mgm")
+REF_MGM_O = os.path.join(HERE, "_ref", "mgm_o")
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile the oracle (and, when /root/reference exists, oracle/_ref)."""
+    if force or not os.path.exists(ORACLE_SO) or (
+        os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "mgm_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", HERE, "libmgm_oracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(REF_SO)):
+        subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def _img(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim == 2:
+        a = a[None]
+    assert a.ndim == 3
+    return a
+
+
+def _optp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """The C restatement.  One instance per process is enough (stateless)."""
+
+    def __init__(self):
+        build()
+        L = self.lib = C.CDLL(ORACLE_SO)
+        L.orc_census_nwords.argtypes = [C.c_int, C.c_int]
+        L.orc_census.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _u32p]
+        L.orc_distance_index.argtypes = [C.c_char_p]
+        L.orc_prefilter_index.argtypes = [C.c_char_p]
+        L.orc_refinement_index.argtypes = [C.c_char_p]
+        L.orc_costvolume.argtypes = [_f32p, _f32p] + [C.c_int] * 7 + [C.c_int, C.c_int, C.c_float, C.c_int, _f32p]
+        L.orc_weights.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _f32p]
+        L.orc_mgm.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float,
+                              C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_void_p]
+        L.orc_refine.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p]
+
+    def census(self, u, winradius):
+        u = _img(u)
+        nch, ny, nx = u.shape
+        nw = self.lib.orc_census_nwords(nch, winradius)
+        out = np.zeros((nw, ny, nx), np.uint32)
+        r = self.lib.orc_census(u, nx, ny, nch, winradius, out)
+        if r < 0:
+            raise ValueError("census window/channels not byte aligned (%d)" % r)
+        return out
+
+    def costvolume(self, u, v, dmin, dmax, prefilter="none", distance="ad", truncDist=np.inf, census_win=3):
+        u, v = _img(u), _img(v)
+        nch, ny, nx = u.shape
+        _, vny, vnx = v.shape
+        Cv = np.empty((ny, nx, dmax - dmin + 1), np.float32)
+        r = self.lib.orc_costvolume(u, v, nx, ny, nch, vnx, vny, dmin, dmax,
+                                    self.lib.orc_prefilter_index(prefilter.encode()),
+                                    self.lib.orc_distance_index(distance.encode()),
+                                    truncDist, census_win, Cv)
+        if r:
+            raise NotImplementedError("oracle: cost mode not restated (%d)" % r)
+        return Cv
+
+    def weights(self, u, aP, aThresh):
+        u = _img(u)
+        nch, ny, nx = u.shape
+        w = np.empty((8, ny, nx), np.float32)
+        self.lib.orc_weights(u, nx, ny, nch, aP, aThresh, w)
+        return w
+
+    def mgm(self, Cv, dmin, P1, P2, NDIR, MGM, FH=0, FIX=1, w8=None, dump_lr=False):
+        Cv = np.ascontiguousarray(Cv, np.float32)
+        ny, nx, L = Cv.shape
+        S = np.empty_like(Cv)
+        out = np.empty((ny, nx), np.float32)
+        outc = np.empty((ny, nx), np.float32)
+        if w8 is not None:
+            w8 = np.ascontiguousarray(w8, np.float32)
+            assert w8.shape == (8, ny, nx)
+        lr = np.empty((NDIR, ny, nx, L), np.float32) if dump_lr else None
+        r = self.lib.orc_mgm(Cv, nx, ny, L, dmin, _optp(w8), P1, P2, NDIR, MGM, FH, FIX, S, out, outc, _optp(lr))
+        if r:
+            raise ValueError("orc_mgm failed (%d)" % r)
+        return (S, out, outc, lr) if dump_lr else (S, out, outc)
+
+    def refine(self, S, dmin, method, out, outcost):
+        S = np.ascontiguousarray(S, np.float32)
+        ny, nx, L = S.shape
+        out = np.array(out, np.float32, copy=True)
+        outcost = np.array(outcost, np.float32, copy=True)
+        r = self.lib.orc_refine(S, nx, ny, L, dmin, self.lib.orc_refinement_index(method.encode()), out, outcost)
+        if r < 0:
+            raise ValueError("orc_refine failed (%d)" % r)
+        return out, outcost
+
+
+class Reference:
+    """The compiled reference itself (only where oracle/_ref was built)."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SO)
+
+    def __init__(self):
+        if not os.path.exists(REF_SO):
+            build()
+        L = self.lib = C.CDLL(REF_SO)
+        L.ref_census_win.restype = C.c_int
+        L.ref_costvolume.argtypes = [_f32p, _f32p] + [C.c_int] * 7 + [C.c_char_p, C.c_char_p, C.c_float, _f32p]
+        L.ref_census.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]
+        L.ref_weights.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _f32p]
+        L.ref_mgm.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, _f32p, _f32p]
+        L.ref_refine.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _f32p, _f32p]
+
+    def census_win(self):
+        """CENSUS_NCC_WIN as cached by the reference (one value per process)."""
+        return self.lib.ref_census_win()
+
+    def census(self, u, winradius):
+        u = _img(u)
+        nch, ny, nx = u.shape
+        out = np.zeros((16, ny, nx), np.float32)
+        nw = self.lib.ref_census(u, nx, ny, nch, winradius, out, 16)
+        return out[:nw].view(np.uint32).copy()
+
+    def costvolume(self, u, v, dmin, dmax, prefilter="none", distance="ad", truncDist=np.inf):
+        u, v = _img(u), _img(v)
+        nch, ny, nx = u.shape
+        _, vny, vnx = v.shape
+        Cv = np.empty((ny, nx, dmax - dmin + 1), np.float32)
+        self.lib.ref_costvolume(u, v, nx, ny, nch, vnx, vny, dmin, dmax, prefilter.encode(), distance.encode(),
+                                truncDist, Cv)
+        return Cv
+
+    def weights(self, u, aP, aThresh):
+        u = _img(u)
+        nch, ny, nx = u.shape
+        w = np.empty((8, ny, nx), np.float32)
+        self.lib.ref_weights(u, nx, ny, nch, aP, aThresh, w)
+        return w
+
+    def mgm(self, Cv, dmin, P1, P2, NDIR, MGM, FH=0, FIX=1, w8=None):
+        Cv = np.ascontiguousarray(Cv, np.float32)
+        ny, nx, L = Cv.shape
+        S = np.empty_like(Cv)
+        out = np.empty((ny, nx), np.float32)
+        outc = np.empty((ny, nx), np.float32)
+        if w8 is not None:
+            w8 = np.ascontiguousarray(w8, np.float32)
+        with _quiet_stdout():
+            self.lib.ref_mgm(Cv, nx, ny, dmin, dmin + L - 1, _optp(w8), P1, P2, NDIR, MGM, FH, FIX,
+                             S.ctypes.data_as(C.c_void_p), out, outc)
+        return S, out, outc
+
+    def refine(self, S, dmin, method, out, outcost):
+        S = np.ascontiguousarray(S, np.float32)
+        ny, nx, L = S.shape
+        out = np.array(out, np.float32, copy=True)
+        outcost = np.array(outcost, np.float32, copy=True)
+        self.lib.ref_refine(S, nx, ny, dmin, dmin + L - 1, method.encode(), out, outcost)
+        return out, outcost
+
+
+class _quiet_stdout:
+    """The reference prints pass digits with printf (mgm_core.cc:491)."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        self.null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self.null, 1)
+
+    def __exit__(self, *a):
+        C.CDLL(None).fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        os.close(self.null)
+
+
+def bits_equal(a, b):
+    """Bit-exact comparison of float32 arrays with NaN == NaN (any payload)."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    if a.shape != b.shape:
+        return False
+    na, nb = np.isnan(a), np.isnan(b)
+    if not np.array_equal(na, nb):
+        return False
+    return np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb])
