@@ -1,0 +1,134 @@
+/*
+ * mgm_hip.h -- C ABI of libmgm_hip.so, the MI355X (gfx950) MGM stereo core.
+ *
+ * This is the drop-in boundary for the hot path of gfacciol/mgm:
+ *
+ *   allocate_and_fill_sgm_costvolume()  mgm_costvolume.h:337-424   -> mgm_costvolume_build[_dev]
+ *   compute_mgm_weights()               mgm_weights.h:63-85        -> mgm_weights[_dev]
+ *   mgm()                               mgm_core.cc:408-613        -> mgm_aggregate[_dev]
+ *   subpixel_refinement_sgm()           mgm_refine.h:40-70         -> mgm_refine[_dev]
+ *
+ * which the reference's main() calls at mgm.cc:372-385 (and again for the
+ * right-to-left run at mgm.cc:405-414).  INTEGRATION.md shows the replacement
+ * of those call sites.
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw pointers, ints; every function returns an
+ *     mgm_status (0 = MGM_OK) and never throws or aborts across the boundary;
+ *     mgm_last_error(ctx) gives the text of the last failure on that context.
+ *   - images are the reference's `struct Img` layout (img.h:35-51): planar
+ *     float32, data[x + y*nx + c*nx*ny].
+ *   - cost volumes are the reference's per-pixel `Dvec` order (dvec.cc:49-131)
+ *     made dense: float32 [y][x][o], o = 0..L-1 <-> disparity dmin+o,
+ *     L = dmax-dmin+1 (dvec.cc:60).  Reads outside [dmin,dmax] behave as +INF.
+ *   - weights are 8 planes in the order W,E,S,N,NW,NE,SE,SW (mgm_weights.h:69).
+ *   - one mgm_ctx per host thread; a ctx is bound to one device and owns one
+ *     HIP stream.  The *_dev entry points enqueue on that stream and return
+ *     without synchronising (results are ordered on the stream); entry points
+ *     that take or return HOST buffers synchronise before returning.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute
+ *     entry point fails with MGM_ERR_HIP.
+ */
+#ifndef MGM_HIP_H_
+#define MGM_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgm_ctx mgm_ctx; /* device + stream + workspace */
+typedef struct mgm_img mgm_img; /* device-resident planar float image */
+typedef struct mgm_cv mgm_cv;   /* device-resident dense volume [ny][nx][L] */
+
+typedef enum mgm_status {
+    MGM_OK = 0,
+    MGM_ERR_INVALID = 1,     /* bad argument */
+    MGM_ERR_UNSUPPORTED = 2, /* valid in the reference, not built yet */
+    MGM_ERR_HIP = 3,         /* HIP runtime error / no device */
+    MGM_ERR_NOMEM = 4,
+    MGM_ERR_INTERNAL = 5     /* in-kernel watchdog fired (dataflow hand-off timed out) */
+} mgm_status;
+
+/* ---- context ---------------------------------------------------------- */
+int mgm_ctx_create(int device, mgm_ctx **ctx);
+int mgm_ctx_destroy(mgm_ctx *ctx);
+const char *mgm_last_error(const mgm_ctx *ctx);
+int mgm_ctx_synchronize(mgm_ctx *ctx);
+void *mgm_ctx_stream(mgm_ctx *ctx); /* the hipStream_t everything is enqueued on */
+const char *mgm_version(void);
+
+/* Per-kernel timing with HIP events on the ctx stream.  While enabled every
+ * kernel launch is bracketed by an event pair; mgm_timing_get() synchronises
+ * and reports elapsed milliseconds per launch in launch order. */
+int mgm_timing_enable(mgm_ctx *ctx, int enable);
+int mgm_timing_reset(mgm_ctx *ctx);
+int mgm_timing_count(mgm_ctx *ctx);
+int mgm_timing_get(mgm_ctx *ctx, int idx, const char **kernel_name, float *ms);
+
+/* ---- images (struct Img, img.h:9-59) ----------------------------------- */
+int mgm_img_create(mgm_ctx *ctx, int nx, int ny, int nch, mgm_img **img);
+int mgm_img_upload(mgm_ctx *ctx, const float *host, int nx, int ny, int nch, mgm_img **img);
+int mgm_img_download(mgm_ctx *ctx, const mgm_img *img, float *host);
+int mgm_img_dims(const mgm_img *img, int *nx, int *ny, int *nch);
+void *mgm_img_device_ptr(mgm_img *img);
+int mgm_img_free(mgm_ctx *ctx, mgm_img *img);
+
+/* ---- volumes (costvolume_t, mgm_costvolume.h:311-327) ------------------ */
+int mgm_cv_create(mgm_ctx *ctx, int nx, int ny, int dmin, int dmax, mgm_cv **cv);
+int mgm_cv_upload(mgm_ctx *ctx, const float *dense, int nx, int ny, int dmin, int dmax, mgm_cv **cv);
+int mgm_cv_download(mgm_ctx *ctx, const mgm_cv *cv, float *dense);
+int mgm_cv_dims(const mgm_cv *cv, int *nx, int *ny, int *dmin, int *dmax);
+void *mgm_cv_device_ptr(mgm_cv *cv);
+int mgm_cv_free(mgm_ctx *ctx, mgm_cv *cv);
+
+/* ---- cost volume: allocate_and_fill_sgm_costvolume --------------------- */
+/* prefilter in {"none","census","sobelx","gblur"}, distance in {"ad","sd","census",
+ * "ncc","btad","btsd"}; unknown names silently select the first entry, as the
+ * reference does (mgm_costvolume.h:184-190, 201-207).  census_win is the value
+ * of the reference's CENSUS_NCC_WIN environment parameter (mgm_costvolume.h:61).
+ * Built: none/census x ad/sd/census.  sobelx, gblur, ncc, btad, btsd return
+ * MGM_ERR_UNSUPPORTED. */
+int mgm_costvolume_build_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, int dmin, int dmax,
+                             const char *prefilter, const char *distance, float truncDist, int census_win,
+                             mgm_cv **C);
+/* Host-buffer form taking the reference's per-pixel range images (dminI/dmaxI,
+ * mgm.cc:338-353).  Ranges must be uniform (every pixel the same integer
+ * [dmin,dmax]); ragged ranges return MGM_ERR_UNSUPPORTED. */
+int mgm_costvolume_build(mgm_ctx *ctx, const float *u, const float *v, int nx, int ny, int nch, int vnx, int vny,
+                         const float *dminI, const float *dmaxI, const char *prefilter, const char *distance,
+                         float truncDist, int census_win, mgm_cv **C);
+
+/* ---- edge weights: compute_mgm_weights --------------------------------- */
+int mgm_weights_dev(mgm_ctx *ctx, const mgm_img *u, float aP, float aThresh, mgm_img **w8);
+
+/* ---- aggregation + WTA: mgm() ------------------------------------------ */
+/* C is not modified.  w8 may be NULL (all ones).  As in the reference
+ * (mgm_core.cc:420-423) a single weight != 1.0 anywhere switches the whole run
+ * to the weighted update functions.  P1/P2 are used as given (the caller has
+ * already multiplied by the channel count, mgm.cc:356-357).
+ *   NDIR 1..8, MGM (TSGM) 1..4, use_fh: USE_TRUNCATED_LINEAR_POTENTIALS,
+ *   fix_overcount: TSGM_FIX_OVERCOUNT.
+ * refine: NULL/"none" gives mgm()'s own outputs (integer labels dmin+argmin);
+ *   "vfit" additionally applies subpixel_refinement_sgm in the same kernel.
+ * out/outcost: nx*ny images.  S: NULL, or receives the corrected aggregated
+ *   volume that mgm() returns (costs one extra volume write). */
+int mgm_aggregate_dev(mgm_ctx *ctx, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int NDIR, int MGM,
+                      int use_fh, int fix_overcount, const char *refine, mgm_img *out, mgm_img *outcost,
+                      mgm_cv **S);
+int mgm_aggregate(mgm_ctx *ctx, const mgm_cv *C, const float *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
+                  int fix_overcount, const char *refine, float *out, float *outcost, mgm_cv **S);
+
+/* Test/diagnostic aid: copy pass `pass`'s Lr volume of the LAST mgm_aggregate
+ * call on this ctx into `dense` ([ny][nx][L]). */
+int mgm_debug_download_lr(mgm_ctx *ctx, int pass, float *dense);
+
+/* ---- sub-pixel refinement: subpixel_refinement_sgm ---------------------- */
+/* method in {"none","vfit","parabola","cubic","parabolaOCV"}; unknown => none
+ * (mgm_refine.h:28-35).  Built: none, vfit.  out/outcost are read and updated. */
+int mgm_refine_dev(mgm_ctx *ctx, const mgm_cv *S, const char *method, mgm_img *out, mgm_img *outcost);
+int mgm_refine(mgm_ctx *ctx, const mgm_cv *S, const char *method, float *out, float *outcost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGM_HIP_H_ */

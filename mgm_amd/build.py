@@ -1,0 +1,77 @@
+"""Build libmgm_hip.so for gfx950 with hipcc, in-tree (mgm_amd/lib/).
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build
+container; the resulting .so travels to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(LIBDIR, "libmgm_hip.so")
+
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+# per-translation-unit extras (see the header comment of each file)
+UNITS = {
+    "mgm_pass.hip": ["-fno-honor-nans"],
+    "mgm_cost.hip": [],
+    "mgm_wta.hip": [],
+    "mgm_api.hip": [],
+}
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc = hipcc()
+    headers = [os.path.join(CSRC, "mgm_device.h"), os.path.join(HERE, "..", "include", "mgm_hip.h"),
+               os.path.abspath(__file__)]
+    jobs = []
+    objs = []
+    for src, extra in UNITS.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([cc] + COMMON + extra + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stdout))
+        return r.stdout
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            for out in ex.map(run, jobs):
+                if verbose and out.strip():
+                    print(out)
+    if jobs or force or _stale(LIB, objs):
+        run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

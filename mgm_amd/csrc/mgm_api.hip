@@ -1,0 +1,665 @@
+// mgm_api.hip -- the C ABI of libmgm_hip.so (include/mgm_hip.h): contexts, device
+// containers, and the host-side orchestration of the kernels.  No compute
+// happens on the host and there is no CPU fallback.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mgm_hip.h"
+#include "mgm_device.h"
+
+using namespace mgm;
+
+struct mgm_img {
+    float *d;
+    int nx, ny, nch;
+};
+struct mgm_cv {
+    float *d;
+    int nx, ny, dmin, dmax;
+};
+
+namespace {
+
+struct Buf {  // grow-only device scratch
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Timing {
+    const char *name;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct mgm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // workspace
+    Buf lr, hand, handm, words, tasks, census_u, census_v;
+    unsigned *h_words = nullptr;  // pinned mirror of the control words
+    // cached task table key
+    int tk_nx = -1, tk_ny = -1, tk_ndir = -1;
+    int ntasks = 0;
+    // last aggregate (for mgm_debug_download_lr)
+    long long last_nvol = 0;
+    int last_ndir = 0;
+    bool pending_check = false;
+    // timing
+    bool timing = false;
+    std::vector<Timing> tim;
+};
+
+namespace {
+
+constexpr int kR = 16;       // lines per band (waves per workgroup) of the pass kernel
+constexpr int kCtrlWords = 4 + kMaxDirs * 4096;  // ticket, err, flag, pad, prog[pass][maxbands]
+constexpr int kMaxBands = 4096;
+
+int fail(mgm_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+int hipfail(mgm_ctx *c, hipError_t e, const char *what)
+{
+    return fail(c, MGM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(c, call)                                          \
+    do {                                                         \
+        hipError_t e__ = (call);                                 \
+        if (e__ != hipSuccess) return hipfail((c), e__, #call);  \
+    } while (0)
+
+int reserve(mgm_ctx *c, Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return MGM_OK;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, MGM_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    }
+    b.cap = bytes;
+    return MGM_OK;
+}
+
+struct TimeScope {  // brackets one kernel launch with events when timing is on
+    mgm_ctx *c;
+    Timing t{};
+    bool on;
+    TimeScope(mgm_ctx *ctx, const char *name) : c(ctx), on(ctx->timing)
+    {
+        if (!on) return;
+        t.name = name;
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+        hipEventRecord(t.a, c->stream);
+    }
+    ~TimeScope()
+    {
+        if (!on) return;
+        hipEventRecord(t.b, c->stream);
+        c->tim.push_back(t);
+    }
+};
+
+// name tables with the reference's silent fall-back to entry 0
+int distance_index(const char *n)  // mgm_costvolume.h:170-190
+{
+    static const char *t[] = {"ad", "sd", "census", "ncc", "btad", "btsd", nullptr};
+    int r = 0;
+    for (int i = 0; t[i]; i++)
+        if (n && !strcmp(n, t[i])) r = i;
+    return r;
+}
+int prefilter_index(const char *n)  // mgm_costvolume.h:194-207
+{
+    static const char *t[] = {"none", "census", "sobelx", "gblur", nullptr};
+    int r = 0;
+    for (int i = 0; t[i]; i++)
+        if (n && !strcmp(n, t[i])) r = i;
+    return r;
+}
+int refinement_index(const char *n)  // mgm_refine.h:15-35
+{
+    static const char *t[] = {"none", "vfit", "parabola", "cubic", "parabolaOCV", nullptr};
+    int r = 0;
+    for (int i = 0; t[i]; i++)
+        if (n && !strcmp(n, t[i])) r = i;
+    return r;
+}
+
+// The reference's pass table, mgm_core.cc:463-471, as data.
+struct RefPass {
+    int d[4][2];
+    int inc_x, inc_y, row_major;
+};
+const RefPass kPasses[8] = {
+    {{{-1, 0}, {0, -1}, {-1, -1}, {1, -1}}, 1, 1, 1}, {{{1, 0}, {0, 1}, {1, 1}, {-1, 1}}, 0, 0, 1},
+    {{{0, 1}, {-1, 0}, {-1, 1}, {-1, -1}}, 1, 0, 0},  {{{0, -1}, {1, 0}, {1, -1}, {1, 1}}, 0, 1, 0},
+    {{{-1, -1}, {1, -1}, {0, -1}, {1, 0}}, 0, 1, 1},  {{{1, -1}, {1, 1}, {1, 0}, {0, 1}}, 0, 0, 0},
+    {{{1, 1}, {-1, 1}, {0, 1}, {-1, 0}}, 1, 0, 1},    {{{-1, 1}, {-1, -1}, {-1, 0}, {0, -1}}, 1, 1, 0},
+};
+const int kPassToChannel[4][8] = {  // mgm_core.cc:481-484
+    {0, 1, 2, 3, 4, 5, 6, 7}, {3, 2, 0, 1, 5, 6, 7, 4}, {4, 6, 7, 5, 3, 1, 2, 0}, {5, 7, 4, 6, 1, 2, 0, 3}};
+
+// Canonical geometry of a pass (see PassGeom).  Returns false if the table
+// entry does not reduce to one of the two canonical neighbour orders.
+bool make_geom(int pass, int nx, int ny, PassGeom &g)
+{
+    const RefPass &rp = kPasses[pass];
+    const long long sx = rp.inc_x ? 1 : -1, sy = rp.inc_y ? 1 : -1;
+    g.base = (long long)(rp.inc_y ? 0 : ny - 1) * nx + (rp.inc_x ? 0 : nx - 1);
+    if (rp.row_major) {
+        g.NL = ny;
+        g.LL = nx;
+        g.istep = sx;
+        g.jstep = sy * nx;
+    } else {
+        g.NL = nx;
+        g.LL = ny;
+        g.istep = sy * nx;
+        g.jstep = sx;
+    }
+    int kind[4];
+    for (int k = 0; k < 4; k++) {
+        const int dx = rp.d[k][0], dy = rp.d[k][1];
+        const int di = rp.row_major ? dx * (int)sx : dy * (int)sy;
+        const int dj = rp.row_major ? dy * (int)sy : dx * (int)sx;
+        if (di == -1 && dj == 0) kind[k] = 0;        // inline
+        else if (di == 0 && dj == -1) kind[k] = 1;   // same
+        else if (di == -1 && dj == -1) kind[k] = 2;  // back
+        else if (di == 1 && dj == -1) kind[k] = 3;   // fwd
+        else return false;
+        g.wplane[k] = kPassToChannel[k][pass];
+    }
+    if (kind[0] == 0 && kind[1] == 1 && kind[2] == 2 && kind[3] == 3) g.form = 0;
+    else if (kind[0] == 3 && kind[1] == 2 && kind[2] == 1 && kind[3] == 0) g.form = 1;
+    else return false;
+    g.nbands = (g.NL + kR - 1) / kR;
+    return true;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char *mgm_version(void) { return "mgm-hip 0.1 (gfx950)"; }
+
+int mgm_ctx_create(int device, mgm_ctx **out)
+{
+    if (!out) return MGM_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return MGM_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return MGM_ERR_HIP;
+    mgm_ctx *c = new mgm_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return MGM_ERR_HIP;
+    }
+    if (hipHostMalloc((void **)&c->h_words, 16 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+        hipStreamDestroy(c->stream);
+        delete c;
+        return MGM_ERR_HIP;
+    }
+    memset(c->h_words, 0, 16 * sizeof(unsigned));
+    *out = c;
+    return MGM_OK;
+}
+
+int mgm_ctx_destroy(mgm_ctx *c)
+{
+    if (!c) return MGM_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (Buf *b : {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v})
+        if (b->p) hipFree(b->p);
+    for (auto &t : c->tim) {
+        hipEventDestroy(t.a);
+        hipEventDestroy(t.b);
+    }
+    if (c->h_words) hipHostFree(c->h_words);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return MGM_OK;
+}
+
+const char *mgm_last_error(const mgm_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+void *mgm_ctx_stream(mgm_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int mgm_ctx_synchronize(mgm_ctx *c)
+{
+    if (!c) return MGM_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->pending_check) {
+        c->pending_check = false;
+        if (c->h_words[1] != 0) {
+            c->h_words[1] = 0;
+            return fail(c, MGM_ERR_INTERNAL, "pass kernel watchdog: inter-band hand-off timed out");
+        }
+    }
+    return MGM_OK;
+}
+
+int mgm_timing_enable(mgm_ctx *c, int enable)
+{
+    if (!c) return MGM_ERR_INVALID;
+    c->timing = enable != 0;
+    return MGM_OK;
+}
+int mgm_timing_reset(mgm_ctx *c)
+{
+    if (!c) return MGM_ERR_INVALID;
+    hipStreamSynchronize(c->stream);
+    for (auto &t : c->tim) {
+        hipEventDestroy(t.a);
+        hipEventDestroy(t.b);
+    }
+    c->tim.clear();
+    return MGM_OK;
+}
+int mgm_timing_count(mgm_ctx *c) { return c ? (int)c->tim.size() : 0; }
+int mgm_timing_get(mgm_ctx *c, int idx, const char **name, float *ms)
+{
+    if (!c || idx < 0 || idx >= (int)c->tim.size()) return MGM_ERR_INVALID;
+    HIPCHK(c, hipEventSynchronize(c->tim[idx].b));
+    float t = 0;
+    HIPCHK(c, hipEventElapsedTime(&t, c->tim[idx].a, c->tim[idx].b));
+    if (name) *name = c->tim[idx].name;
+    if (ms) *ms = t;
+    return MGM_OK;
+}
+
+// ---- images ---------------------------------------------------------------
+int mgm_img_create(mgm_ctx *c, int nx, int ny, int nch, mgm_img **out)
+{
+    if (!c || !out || nx <= 0 || ny <= 0 || nch <= 0) return fail(c, MGM_ERR_INVALID, "mgm_img_create: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    mgm_img *im = new mgm_img{nullptr, nx, ny, nch};
+    hipError_t e = hipMalloc((void **)&im->d, sizeof(float) * (size_t)nx * ny * nch);
+    if (e != hipSuccess) {
+        delete im;
+        return fail(c, MGM_ERR_NOMEM, std::string("mgm_img_create: ") + hipGetErrorString(e));
+    }
+    *out = im;
+    return MGM_OK;
+}
+int mgm_img_upload(mgm_ctx *c, const float *host, int nx, int ny, int nch, mgm_img **out)
+{
+    if (!host) return fail(c, MGM_ERR_INVALID, "mgm_img_upload: null host pointer");
+    int r = mgm_img_create(c, nx, ny, nch, out);
+    if (r) return r;
+    HIPCHK(c, hipMemcpyAsync((*out)->d, host, sizeof(float) * (size_t)nx * ny * nch, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MGM_OK;
+}
+int mgm_img_download(mgm_ctx *c, const mgm_img *im, float *host)
+{
+    if (!c || !im || !host) return fail(c, MGM_ERR_INVALID, "mgm_img_download: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(host, im->d, sizeof(float) * (size_t)im->nx * im->ny * im->nch, hipMemcpyDeviceToHost,
+                             c->stream));
+    return mgm_ctx_synchronize(c);
+}
+int mgm_img_dims(const mgm_img *im, int *nx, int *ny, int *nch)
+{
+    if (!im) return MGM_ERR_INVALID;
+    if (nx) *nx = im->nx;
+    if (ny) *ny = im->ny;
+    if (nch) *nch = im->nch;
+    return MGM_OK;
+}
+void *mgm_img_device_ptr(mgm_img *im) { return im ? im->d : nullptr; }
+int mgm_img_free(mgm_ctx *c, mgm_img *im)
+{
+    if (!im) return MGM_OK;
+    if (c) {
+        hipSetDevice(c->device);
+        hipStreamSynchronize(c->stream);
+    }
+    hipFree(im->d);
+    delete im;
+    return MGM_OK;
+}
+
+// ---- volumes --------------------------------------------------------------
+int mgm_cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, mgm_cv **out)
+{
+    if (!c || !out || nx <= 0 || ny <= 0 || dmax < dmin) return fail(c, MGM_ERR_INVALID, "mgm_cv_create: bad arguments");
+    const long long L = (long long)dmax - dmin + 1;
+    if (L > kMaxLPL * 64)
+        return fail(c, MGM_ERR_UNSUPPORTED, "more than 512 disparity labels per pixel are not supported");
+    HIPCHK(c, hipSetDevice(c->device));
+    mgm_cv *cv = new mgm_cv{nullptr, nx, ny, dmin, dmax};
+    hipError_t e = hipMalloc((void **)&cv->d, sizeof(float) * (size_t)nx * ny * (size_t)L);
+    if (e != hipSuccess) {
+        delete cv;
+        return fail(c, MGM_ERR_NOMEM, std::string("mgm_cv_create: ") + hipGetErrorString(e));
+    }
+    *out = cv;
+    return MGM_OK;
+}
+int mgm_cv_upload(mgm_ctx *c, const float *dense, int nx, int ny, int dmin, int dmax, mgm_cv **out)
+{
+    if (!dense) return fail(c, MGM_ERR_INVALID, "mgm_cv_upload: null host pointer");
+    int r = mgm_cv_create(c, nx, ny, dmin, dmax, out);
+    if (r) return r;
+    const size_t n = (size_t)nx * ny * (size_t)(dmax - dmin + 1);
+    HIPCHK(c, hipMemcpyAsync((*out)->d, dense, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MGM_OK;
+}
+int mgm_cv_download(mgm_ctx *c, const mgm_cv *cv, float *dense)
+{
+    if (!c || !cv || !dense) return fail(c, MGM_ERR_INVALID, "mgm_cv_download: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)cv->nx * cv->ny * (size_t)(cv->dmax - cv->dmin + 1);
+    HIPCHK(c, hipMemcpyAsync(dense, cv->d, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    return mgm_ctx_synchronize(c);
+}
+int mgm_cv_dims(const mgm_cv *cv, int *nx, int *ny, int *dmin, int *dmax)
+{
+    if (!cv) return MGM_ERR_INVALID;
+    if (nx) *nx = cv->nx;
+    if (ny) *ny = cv->ny;
+    if (dmin) *dmin = cv->dmin;
+    if (dmax) *dmax = cv->dmax;
+    return MGM_OK;
+}
+void *mgm_cv_device_ptr(mgm_cv *cv) { return cv ? cv->d : nullptr; }
+int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
+{
+    if (!cv) return MGM_OK;
+    if (c) {
+        hipSetDevice(c->device);
+        hipStreamSynchronize(c->stream);
+    }
+    hipFree(cv->d);
+    delete cv;
+    return MGM_OK;
+}
+
+// ---- cost volume ------------------------------------------------------------
+int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int dmin, int dmax, const char *prefilter,
+                             const char *distance, float truncDist, int census_win, mgm_cv **out)
+{
+    if (!c || !u || !v || !out) return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: null argument");
+    if (u->nch != v->nch) return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: channel counts differ");
+    HIPCHK(c, hipSetDevice(c->device));
+    int dist = distance_index(distance), pre = prefilter_index(prefilter);
+    const int costfn = dist;  // the function is picked BEFORE the consistency fix (mgm_costvolume.h:355)
+    if (dist == 2 || pre == 1) {  // 358-362
+        dist = 2;
+        pre = 1;
+    }
+    if (costfn > 2) return fail(c, MGM_ERR_UNSUPPORTED, "distance ncc/btad/btsd is not built yet");
+    if (pre > 1) return fail(c, MGM_ERR_UNSUPPORTED, "prefilter sobelx/gblur is not built yet");
+
+    int r = mgm_cv_create(c, u->nx, u->ny, dmin, dmax, out);
+    if (r) return r;
+    CostParams p{};
+    p.C = (*out)->d;
+    p.nx = u->nx;
+    p.ny = u->ny;
+    p.vnx = v->nx;
+    p.vny = v->ny;
+    p.dmin = dmin;
+    p.L = dmax - dmin + 1;
+    p.costfn = costfn;
+    p.nch = u->nch;
+    p.u = u->d;
+    p.v = v->d;
+    if (pre == 1) {
+        const int wr = census_win / 2, side = 2 * wr + 1;
+        const int nbits = u->nch * (side * side - 1);
+        if (wr < 1 || nbits % 8)  // census_tools.cc:81 asserts this
+            return fail(c, MGM_ERR_INVALID, "census: nch*(win*win-1) must be a positive multiple of 8");
+        const int nwords = (nbits / 8 + 3) / 4;
+        if (nwords > kCensusMaxWords) return fail(c, MGM_ERR_UNSUPPORTED, "census descriptor longer than 256 bits");
+        if ((r = reserve(c, c->census_u, sizeof(uint32_t) * (size_t)u->nx * u->ny * nwords))) return r;
+        if ((r = reserve(c, c->census_v, sizeof(uint32_t) * (size_t)v->nx * v->ny * nwords))) return r;
+        {
+            TimeScope t(c, "k_census");
+            HIPCHK(c, launch_census(u->d, u->nx, u->ny, u->nch, wr, (uint32_t *)c->census_u.p, c->stream));
+        }
+        {
+            TimeScope t(c, "k_census");
+            HIPCHK(c, launch_census(v->d, v->nx, v->ny, v->nch, wr, (uint32_t *)c->census_v.p, c->stream));
+        }
+        p.cu = (const uint32_t *)c->census_u.p;
+        p.cv = (const uint32_t *)c->census_v.p;
+        p.u = (const float *)c->census_u.p;  // -p census with an ad/sd cost: words read as floats
+        p.v = (const float *)c->census_v.p;
+        p.nch = nwords;
+    }
+    p.trunc = truncDist * (float)p.nch;  // mgm_costvolume.h:401,405
+    {
+        TimeScope t(c, "k_cost");
+        HIPCHK(c, launch_cost(p, c->stream));
+    }
+    return MGM_OK;
+}
+
+int mgm_costvolume_build(mgm_ctx *c, const float *u, const float *v, int nx, int ny, int nch, int vnx, int vny,
+                         const float *dminI, const float *dmaxI, const char *prefilter, const char *distance,
+                         float truncDist, int census_win, mgm_cv **out)
+{
+    if (!c || !u || !v || !dminI || !dmaxI || !out) return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: null argument");
+    // Dvec::init receives the float range values converted to int (dvec.cc:55-60)
+    const int dmin = (int)dminI[0], dmax = (int)dmaxI[0];
+    for (long long i = 0; i < (long long)nx * ny; i++)
+        if ((int)dminI[i] != dmin || (int)dmaxI[i] != dmax)
+            return fail(c, MGM_ERR_UNSUPPORTED, "per-pixel (ragged) disparity ranges are not built yet");
+    mgm_img *du = nullptr, *dv = nullptr;
+    int r = mgm_img_upload(c, u, nx, ny, nch, &du);
+    if (!r) r = mgm_img_upload(c, v, vnx, vny, nch, &dv);
+    if (!r) r = mgm_costvolume_build_dev(c, du, dv, dmin, dmax, prefilter, distance, truncDist, census_win, out);
+    if (!r) r = mgm_ctx_synchronize(c);
+    mgm_img_free(c, du);
+    mgm_img_free(c, dv);
+    return r;
+}
+
+// ---- weights ------------------------------------------------------------------
+int mgm_weights_dev(mgm_ctx *c, const mgm_img *u, float aP, float aThresh, mgm_img **w8)
+{
+    if (!c || !u || !w8) return fail(c, MGM_ERR_INVALID, "mgm_weights: null argument");
+    int r = mgm_img_create(c, u->nx, u->ny, 8, w8);
+    if (r) return r;
+    TimeScope t(c, "k_weights");
+    HIPCHK(c, launch_weights(u->d, u->nx, u->ny, u->nch, aP, aThresh, (*w8)->d, c->stream));
+    return MGM_OK;
+}
+
+// ---- aggregation ----------------------------------------------------------------
+int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
+                      int fix_overcount, const char *refine, mgm_img *out, mgm_img *outcost, mgm_cv **S)
+{
+    if (!c || !C || !out || !outcost) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: null argument");
+    if (NDIR < 1 || NDIR > kMaxDirs)  // the reference reads past its 8-entry table for -O 16 (mgm_core.cc:489)
+        return fail(c, MGM_ERR_INVALID, "NDIR must be 1..8");
+    if (MGM < 1 || MGM > 4) return fail(c, MGM_ERR_INVALID, "MGM (TSGM) must be 1..4");
+    const int nx = C->nx, ny = C->ny, L = C->dmax - C->dmin + 1;
+    if (out->nx != nx || out->ny != ny || outcost->nx != nx || outcost->ny != ny)
+        return fail(c, MGM_ERR_INVALID, "mgm_aggregate: output image size mismatch");
+    if (w8 && (w8->nx != nx || w8->ny != ny || w8->nch != 8))
+        return fail(c, MGM_ERR_INVALID, "mgm_aggregate: weights must be nx*ny*8");
+    const int ridx = refinement_index(refine);
+    if (ridx > 1) return fail(c, MGM_ERR_UNSUPPORTED, "fused refinement supports none|vfit only");
+    HIPCHK(c, hipSetDevice(c->device));
+
+    const long long npix = (long long)nx * ny, nvol = npix * L;
+    const int lpl = pass_lpl(L), LP = lpl * 64;
+    int r;
+    if ((r = reserve(c, c->words, sizeof(unsigned) * kCtrlWords))) return r;
+    unsigned *words = (unsigned *)c->words.p;
+    HIPCHK(c, hipMemsetAsync(words, 0, sizeof(unsigned) * kCtrlWords, c->stream));
+
+    // weighted? (mgm_core.cc:420-423: any value != 1.0 switches every update)
+    bool weighted = false;
+    if (w8) {
+        HIPCHK(c, launch_any_not_one(w8->d, npix * 8, words + 2, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_words + 2, words + 2, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        weighted = c->h_words[2] != 0;
+    }
+    const bool fh = use_fh > 0;
+    const int NS = pass_ns(fh, weighted);
+
+    PassParams p{};
+    int maxLL = 0, maxbands = 0;
+    for (int q = 0; q < NDIR; q++) {
+        if (!make_geom(q, nx, ny, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
+        maxLL = std::max(maxLL, p.g[q].LL);
+        maxbands = std::max(maxbands, p.g[q].nbands);
+    }
+    if (maxbands > kMaxBands) return fail(c, MGM_ERR_UNSUPPORTED, "image side exceeds 65536 pixels");
+
+    if ((r = reserve(c, c->lr, sizeof(float) * (size_t)nvol * NDIR))) return r;
+    if ((r = reserve(c, c->hand, sizeof(float) * (size_t)NDIR * 2 * maxLL * NS * LP))) return r;
+    if ((r = reserve(c, c->handm, sizeof(float) * (size_t)NDIR * 2 * maxLL))) return r;
+
+    // task table: ticket -> (pass, band), ordered by band then pass so that
+    // item (p, b) always follows (p, b-1)
+    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != NDIR) {
+        std::vector<int2> tasks;
+        for (int b = 0; b < maxbands; b++)
+            for (int q = 0; q < NDIR; q++)
+                if (b < p.g[q].nbands) tasks.push_back(make_int2(q, b));
+        if ((r = reserve(c, c->tasks, sizeof(int2) * tasks.size()))) return r;
+        HIPCHK(c, hipMemcpyAsync(c->tasks.p, tasks.data(), sizeof(int2) * tasks.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->ntasks = (int)tasks.size();
+        c->tk_nx = nx;
+        c->tk_ny = ny;
+        c->tk_ndir = NDIR;
+    }
+
+    p.C = C->d;
+    p.Lr = (float *)c->lr.p;
+    p.w8 = weighted ? w8->d : nullptr;
+    p.hand = (float *)c->hand.p;
+    p.handm = (float *)c->handm.p;
+    p.ticket = words + 0;
+    p.err = words + 1;
+    p.prog = words + 4;
+    p.tasks = (const int2 *)c->tasks.p;
+    p.npix = npix;
+    p.nvol = nvol;
+    p.L = L;
+    p.MGM = MGM;
+    p.NDIR = NDIR;
+    p.LLmax = maxLL;
+    p.maxbands = kMaxBands;
+    p.P1 = P1;
+    p.P2 = P2;
+    {
+        TimeScope t(c, "k_pass");
+        HIPCHK(c, launch_pass(p, c->ntasks, kR, fh, weighted ? 1 : 0, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_words + 1, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    c->pending_check = true;
+    c->last_nvol = nvol;
+    c->last_ndir = NDIR;
+
+    WtaParams w{};
+    w.C = C->d;
+    w.Lr = (const float *)c->lr.p;
+    w.S = nullptr;
+    if (S) {
+        if ((r = mgm_cv_create(c, nx, ny, C->dmin, C->dmax, S))) return r;
+        w.S = (*S)->d;
+    }
+    w.out = out->d;
+    w.outcost = outcost->d;
+    w.npix = npix;
+    w.nvol = nvol;
+    w.L = L;
+    w.NDIR = NDIR;
+    w.FIX = fix_overcount;
+    w.dmin = C->dmin;
+    w.refine = ridx;
+    {
+        TimeScope t(c, "k_wta");
+        HIPCHK(c, launch_wta(w, c->stream));
+    }
+    return MGM_OK;
+}
+
+int mgm_aggregate(mgm_ctx *c, const mgm_cv *C, const float *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
+                  int fix_overcount, const char *refine, float *out, float *outcost, mgm_cv **S)
+{
+    if (!c || !C || !out || !outcost) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: null argument");
+    mgm_img *dw = nullptr, *dout = nullptr, *dcost = nullptr;
+    int r = MGM_OK;
+    if (w8) r = mgm_img_upload(c, w8, C->nx, C->ny, 8, &dw);
+    if (!r) r = mgm_img_create(c, C->nx, C->ny, 1, &dout);
+    if (!r) r = mgm_img_create(c, C->nx, C->ny, 1, &dcost);
+    if (!r) r = mgm_aggregate_dev(c, C, dw, P1, P2, NDIR, MGM, use_fh, fix_overcount, refine, dout, dcost, S);
+    if (!r) r = mgm_img_download(c, dout, out);
+    if (!r) r = mgm_img_download(c, dcost, outcost);
+    mgm_img_free(c, dw);
+    mgm_img_free(c, dout);
+    mgm_img_free(c, dcost);
+    return r;
+}
+
+int mgm_debug_download_lr(mgm_ctx *c, int pass, float *dense)
+{
+    if (!c || !dense || pass < 0 || pass >= c->last_ndir || !c->lr.p)
+        return fail(c, MGM_ERR_INVALID, "mgm_debug_download_lr: nothing to download");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dense, (const float *)c->lr.p + (size_t)pass * c->last_nvol, sizeof(float) * c->last_nvol,
+                             hipMemcpyDeviceToHost, c->stream));
+    return mgm_ctx_synchronize(c);
+}
+
+// ---- refinement -----------------------------------------------------------------
+int mgm_refine_dev(mgm_ctx *c, const mgm_cv *S, const char *method, mgm_img *out, mgm_img *outcost)
+{
+    if (!c || !S || !out || !outcost) return fail(c, MGM_ERR_INVALID, "mgm_refine: null argument");
+    if (out->nx != S->nx || out->ny != S->ny || outcost->nx != S->nx || outcost->ny != S->ny)
+        return fail(c, MGM_ERR_INVALID, "mgm_refine: image size mismatch");
+    const int m = refinement_index(method);
+    if (m == 0) return MGM_OK;  // "none" and unknown names (mgm_refine.h:28-35)
+    if (m != 1) return fail(c, MGM_ERR_UNSUPPORTED, "refinement parabola/cubic/parabolaOCV is not built yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    TimeScope t(c, "k_refine");
+    HIPCHK(c, launch_refine(S->d, (long long)S->nx * S->ny, S->dmax - S->dmin + 1, S->dmin, m, out->d, outcost->d,
+                            c->stream));
+    return MGM_OK;
+}
+
+int mgm_refine(mgm_ctx *c, const mgm_cv *S, const char *method, float *out, float *outcost)
+{
+    if (!c || !S || !out || !outcost) return fail(c, MGM_ERR_INVALID, "mgm_refine: null argument");
+    mgm_img *dout = nullptr, *dcost = nullptr;
+    int r = mgm_img_upload(c, out, S->nx, S->ny, 1, &dout);
+    if (!r) r = mgm_img_upload(c, outcost, S->nx, S->ny, 1, &dcost);
+    if (!r) r = mgm_refine_dev(c, S, method, dout, dcost);
+    if (!r) r = mgm_img_download(c, dout, out);
+    if (!r) r = mgm_img_download(c, dcost, outcost);
+    mgm_img_free(c, dout);
+    mgm_img_free(c, dcost);
+    return r;
+}
+
+}  // extern "C"

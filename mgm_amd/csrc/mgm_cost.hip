@@ -1,0 +1,177 @@
+// mgm_cost.hip -- K1 census transform, K2 cost-volume fill, K7 edge weights.
+//
+//   K1  census_transform          census_tools.cc:16-57, 76-99, 127-153
+//   K2  allocate_and_fill_sgm_costvolume   mgm_costvolume.h:390-422
+//       with computeC_AD (23-33), computeC_SD (34-44),
+//       computeC_census_on_preprocessed_images (65-78)
+//   K7  compute_mgm_weights       mgm_weights.h:26-85
+//
+// Compiled with default (NaN-honouring) floating point: non-finite pixels and
+// costs follow IEEE rules exactly as on the CPU.
+#include "mgm_device.h"
+
+namespace mgm {
+
+__device__ __forceinline__ bool finite_bits(float x)
+{
+    return (__builtin_bit_cast(unsigned, x) & 0x7f800000u) != 0x7f800000u;
+}
+
+// ---- K1 -----------------------------------------------------------------------
+// One thread per pixel.  Bit order: channel, dy, dx, centre skipped; bit =
+// (centre < neighbour), 0 when the neighbour is outside the image (NaN sample,
+// census_tools.cc:28-33); bits packed MSB-first into bytes (16-25), bytes laid
+// little-endian into 32-bit words (the reference memcpy's them into floats).
+__global__ void __launch_bounds__(256) k_census(const float *__restrict__ u, int nx, int ny, int nch, int wr,
+                                                int nwords, uint32_t *__restrict__ out)
+{
+    const long long npix = (long long)nx * ny;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const int x = (int)(idx % nx), y = (int)(idx / nx);
+    uint32_t word = 0;   // word being assembled
+    uint32_t byte = 0;   // byte being assembled
+    int nbit = 0, nbyte = 0, w = 0;
+    for (int l = 0; l < nch; l++) {
+        const float *pl = u + (long long)l * npix;
+        const float a = pl[idx];
+        for (int j = -wr; j <= wr; j++)
+            for (int i = -wr; i <= wr; i++) {
+                if (!i && !j) continue;
+                const int xx = x + i, yy = y + j;
+                uint32_t bit = 0;
+                if (xx >= 0 && xx < nx && yy >= 0 && yy < ny) bit = a < pl[(long long)yy * nx + xx];
+                byte = byte * 2 + bit;
+                if (++nbit == 8) {
+                    word |= byte << (8 * nbyte);
+                    byte = 0;
+                    nbit = 0;
+                    if (++nbyte == 4) {
+                        out[idx + (long long)w * npix] = word;
+                        word = 0;
+                        nbyte = 0;
+                        w++;
+                    }
+                }
+            }
+    }
+    if (nbyte) out[idx + (long long)w * npix] = word;
+    (void)nwords;
+}
+
+hipError_t launch_census(const float *u, int nx, int ny, int nch, int winradius, uint32_t *out, hipStream_t s)
+{
+    const long long npix = (long long)nx * ny;
+    const int side = 2 * winradius + 1;
+    const int nwords = (nch * (side * side - 1) / 8 + 3) / 4;
+    hipLaunchKernelGGL(k_census, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, u, nx, ny, nch, winradius,
+                       nwords, out);
+    return hipGetLastError();
+}
+
+// ---- K2 -----------------------------------------------------------------------
+// One wavefront per pixel; lane l fills labels o = l, l+64, ... so that every
+// store instruction writes 64 consecutive floats of the pixel's slab.
+__global__ void __launch_bounds__(256) k_cost(const CostParams P)
+{
+    const long long npix = (long long)P.nx * P.ny;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= npix) return;
+    const int lane = threadIdx.x & 63;
+    const int x = (int)(pix % P.nx), y = (int)(pix / P.nx);
+    const long long vpix = (long long)P.vnx * P.vny;
+    float *Cp = P.C + pix * P.L;
+    const bool yin = (y < P.vny);  // q.y = p.y >= 0 always
+    bool anyfinite = false;
+    for (int o = lane; o < P.L; o += 64) {
+        const int qx = x + o + P.dmin;
+        float e = P.trunc;
+        if (yin && qx >= 0 && qx < P.vnx) {
+            const long long q = (long long)y * P.vnx + qx;
+            if (P.costfn == 2) {
+                float r = 0;
+                for (int t = 0; t < P.nch; t++) {
+                    const uint32_t xr = P.cu[pix + (long long)t * npix] ^ P.cv[q + (long long)t * vpix];
+                    r += (float)__builtin_popcount(xr);
+                }
+                e = (float)((double)r * 1.0 / (double)P.nch);
+            } else {
+                float tmp = 0;
+                for (int t = 0; t < P.nch; t++) {
+                    float d = P.u[pix + (long long)t * npix] - P.v[q + (long long)t * vpix];
+                    d = (d > -d) ? d : -d;
+                    if (P.costfn == 0) tmp += d;
+                    else tmp += d * d;
+                }
+                e = tmp;
+            }
+        }
+        e = (e < P.trunc) ? e : P.trunc;
+        Cp[o] = e;
+        anyfinite |= finite_bits(e);
+    }
+    // no valid hypothesis for this pixel => all labels cost 0 (mgm_costvolume.h:414-421)
+    if (__builtin_amdgcn_ballot_w64(anyfinite) == 0ull)
+        for (int o = lane; o < P.L; o += 64) Cp[o] = 0.0f;
+}
+
+hipError_t launch_cost(const CostParams &p, hipStream_t s)
+{
+    const long long npix = (long long)p.nx * p.ny;
+    hipLaunchKernelGGL(k_cost, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---- K7 -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_weights(const float *__restrict__ u, int nx, int ny, int nch, float aP,
+                                                 float aThresh, float *__restrict__ w)
+{
+    const int sx[8] = {-1, 1, 0, 0, -1, 1, 1, -1};
+    const int sy[8] = {0, 0, 1, -1, -1, -1, 1, 1};
+    const long long npix = (long long)nx * ny;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * 8) return;
+    const int o = (int)(idx / npix);
+    const long long p = idx % npix;
+    const int i = (int)(p % nx), j = (int)(p / nx);
+    float wvalue = 1.0f;
+    const int qx = i + sx[o], qy = j + sy[o];
+    if (qx >= 0 && qy >= 0 && qx < nx && qy < ny) {
+        float d = 0;
+        for (int c = 0; c < nch; c++) {
+            const float diff = u[p + c * npix] - u[(long long)qy * nx + qx + c * npix];
+            d += diff * diff;
+        }
+        const float Delta = d / (float)nch;
+        // ws(): fabs(DeltaI) < Thresh*Thresh ? aP3 : 1   (mgm_weights.h:38-41)
+        wvalue = (__builtin_fabsf(Delta) < aThresh * aThresh) ? aP : 1.0f;
+    }
+    w[idx] = wvalue;
+}
+
+hipError_t launch_weights(const float *u, int nx, int ny, int nch, float aP, float aThresh, float *w8, hipStream_t s)
+{
+    const long long n = (long long)nx * ny * 8;
+    hipLaunchKernelGGL(k_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, nx, ny, nch, aP, aThresh,
+                       w8);
+    return hipGetLastError();
+}
+
+// "is any weight != 1.0" (mgm_core.cc:420-422)
+__global__ void __launch_bounds__(256) k_any_not_one(const float *__restrict__ w, long long n, unsigned *flag)
+{
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        bad |= (w[i] != 1.0f);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+hipError_t launch_any_not_one(const float *w, long long n, unsigned *flag, hipStream_t s)
+{
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_any_not_one, dim3((unsigned)blocks), dim3(256), 0, s, w, n, flag);
+    return hipGetLastError();
+}
+
+}  // namespace mgm

@@ -1,0 +1,118 @@
+// mgm_device.h -- shared host/device declarations of libmgm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mgm {
+
+constexpr int kMaxDirs = 8;
+constexpr int kMaxLPL = 8;           // disparities per lane -> L <= 512
+constexpr int kWave = 64;            // CDNA wavefront
+constexpr int kCensusMaxWords = 8;   // 32-bit census words per pixel
+
+// Geometry of one pass in canonical coordinates (i = position along the scan
+// line, j = line index).  Derived on the host from the reference's pass table
+// (mgm_core.cc:463-471): pixel(i,j) = base + i*istep + j*jstep.  In these
+// coordinates every pass has the same four neighbours
+//   inline (i-1,j)   same (i,j-1)   back (i-1,j-1)   fwd (i+1,j-1)
+// and only the ORDER in which they are summed differs:
+//   form 0 (passes 0-3): inline, same, back, fwd
+//   form 1 (passes 4-7): fwd, back, same, inline
+struct PassGeom {
+    int NL, LL;        // number of lines, pixels per line
+    int form;          // 0 / 1
+    int nbands;        // ceil(NL / R)
+    long long base;    // pixel index of (0,0)
+    long long istep;   // pixel-index step along the line
+    long long jstep;   // pixel-index step between lines
+    int wplane[4];     // weight plane of neighbour k (mgm_core.cc:481-484)
+};
+
+struct PassParams {
+    const float *C;     // [npix][L]
+    float *Lr;          // NDIR volumes, pass p at Lr + p*nvol
+    const float *w8;    // 8 planes [npix] or nullptr
+    float *hand;        // hand-off slabs  [pass][2][LLmax][NS*LP]
+    float *handm;       // hand-off minima [pass][2][LLmax]
+    unsigned *prog;     // progress words  [pass][maxbands]
+    unsigned *ticket;   // work-item ticket counter
+    unsigned *err;      // watchdog word
+    const int2 *tasks;  // ticket -> (pass, band)
+    long long npix, nvol;
+    int L, MGM, NDIR;
+    int LLmax, maxbands;
+    float P1, P2;
+    PassGeom g[kMaxDirs];
+};
+
+struct WtaParams {
+    const float *C;
+    const float *Lr;    // NDIR volumes
+    float *S;           // nullptr or corrected volume out
+    float *out, *outcost;
+    long long npix, nvol;
+    int L, NDIR, FIX, dmin, refine;  // refine: 0 none, 1 vfit
+};
+
+// launchers (one per translation unit)
+hipError_t launch_pass(const PassParams &p, int ntasks, int R, bool fh, int wmode, hipStream_t s);
+int pass_ns(bool fh, bool weighted);  // slabs per hand-off slot
+int pass_lpl(int L);                  // disparities per lane the pass kernel is instantiated for
+hipError_t launch_wta(const WtaParams &p, hipStream_t s);
+hipError_t launch_refine(const float *S, long long npix, int L, int dmin, int method, float *out, float *outcost,
+                         hipStream_t s);
+hipError_t launch_census(const float *u, int nx, int ny, int nch, int winradius, uint32_t *out, hipStream_t s);
+struct CostParams {
+    const float *u, *v;          // planar images (float, or census words reinterpreted)
+    const uint32_t *cu, *cv;     // census words (planar) when prefiltered
+    float *C;
+    int nx, ny, vnx, vny, nch;   // nch = channels of the (prefiltered) images
+    int dmin, L;
+    int costfn;                  // 0 ad, 1 sd, 2 census
+    float trunc;                 // truncDist * nch
+};
+hipError_t launch_cost(const CostParams &p, hipStream_t s);
+hipError_t launch_weights(const float *u, int nx, int ny, int nch, float aP, float aThresh, float *w8,
+                          hipStream_t s);
+hipError_t launch_any_not_one(const float *w, long long n, unsigned *flag, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float f_inf() { return __builtin_huge_valf(); }
+
+// DPP lane shifts over the whole wave (gfx9 wave_shr / wave_shl).
+// shr1: lane l receives lane l-1 (lane 0 gets `fill`).
+__device__ __forceinline__ float dpp_shr1(float v, float fill)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill),
+                                                                 __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+// shl1: lane l receives lane l+1 (lane 63 gets `fill`).
+__device__ __forceinline__ float dpp_shl1(float v, float fill)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill),
+                                                                 __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_min_step(float v)
+{
+    float o = __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0x7f800000, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+    return fminf(v, o);
+}
+// wave-wide minimum, result uniform (SGPR).  NaN-free inputs only.
+__device__ __forceinline__ float wave_min(float v)
+{
+    v = dpp_min_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_min_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_min_step<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_min_step<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15
+    v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#endif
+
+}  // namespace mgm
