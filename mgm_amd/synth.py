@@ -31,13 +31,15 @@ def stereo_pair(nx, ny, dmin, dmax, seed=SEED, nch=1):
     base = _smooth_field(rng, ny, nx) * 160.0 + rng.random((ny, nx)).astype(np.float32) * 95.0
     u = np.clip(np.rint(base), 0, 255).astype(np.float32)
     # disparity planes
+    if dmax < dmin:
+        dmin = dmax = 0
     span = dmax - dmin
     gt = np.full((ny, nx), dmin + span // 2, np.int32)
     nplanes = 4
     for k in range(nplanes):
         y0, y1 = sorted(rng.integers(0, ny, 2))
         x0, x1 = sorted(rng.integers(0, nx, 2))
-        gt[y0:y1 + 1, x0:x1 + 1] = dmin + int(rng.integers(span // 8, span - span // 8 + 1))
+        gt[y0:y1 + 1, x0:x1 + 1] = dmin + int(rng.integers(span // 8, max(span // 8, span - span // 8) + 1))
     # slanted ramp in a horizontal band
     y0 = ny // 3
     ramp = (dmin + span // 4 + (np.arange(nx) * (span // 2)) // max(1, nx - 1)).astype(np.int32)

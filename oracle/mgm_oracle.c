@@ -27,8 +27,21 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORC_MAX_CENSUS_WORDS 16
+
+/* number of OpenMP threads used by every loop below (default: 1) */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n < 1 ? 1 : n);
+#else
+    (void)n;
+#endif
+}
 
 /* mgm_costvolume.h:16-17 */
 #define MIN_(a, b) (((a) < (b)) ? (a) : (b))
@@ -479,11 +492,12 @@ int orc_mgm(const float *C, int nx, int ny, int L, int dmin, const float *w8, fl
         }
         /* Slope-2 diagonal schedule of mgm_core.cc:505-511.  Any topological
          * order gives the same result; keeping the diagonals lets OpenMP run
-         * the same parallel loop as the reference. */
-        for (int ii = 0; ii < maxii + 2 * maxjj; ii++) {
+         * the same parallel loop as the reference (one team per pass, one
+         * barrier per diagonal). */
 #pragma omp parallel
-            {
-                float *scratch = (float *)malloc(sizeof(float) * 4 * (size_t)L);
+        {
+            float *scratch = (float *)malloc(sizeof(float) * 4 * (size_t)L);
+            for (int ii = 0; ii < maxii + 2 * maxjj; ii++) {
 #pragma omp for schedule(static, 1)
                 for (int jj = 0; jj < maxjj; jj++) {
                     int x = ii - 2 * jj, y = jj;
@@ -518,9 +532,9 @@ int orc_mgm(const float *C, int nx, int ny, int L, int dmin, const float *w8, fl
                         update_pixel(Lr + pidx * L, C + pidx * L, Ln, mn, D, P1, P2, MGM, mode, L, scratch);
                     }
                     mins[pidx] = slab_min(Lr + pidx * L, L); /* 577 */
-                }
-                free(scratch);
+                } /* implicit barrier: one diagonal completes before the next starts */
             }
+            free(scratch);
         }
         if (Lr_dump) memcpy(Lr_dump + (size_t)pass * nvol, Lr, sizeof(float) * nvol);
 #pragma omp parallel for

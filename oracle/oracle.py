@@ -40,6 +40,25 @@ def build(force=False):
         subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
+def usable_cpus(cap=64):
+    """CPUs this process may really use: affinity mask and cgroup quota, capped."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, cap))
+
+
 def _img(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     if a.ndim == 2:
@@ -55,9 +74,11 @@ def _optp(a):
 class Oracle:
     """The C restatement.  One instance per process is enough (stateless)."""
 
-    def __init__(self):
+    def __init__(self, threads=1):
         build()
         L = self.lib = C.CDLL(ORACLE_SO)
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads(threads)
         L.orc_census_nwords.argtypes = [C.c_int, C.c_int]
         L.orc_census.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _u32p]
         L.orc_distance_index.argtypes = [C.c_char_p]
@@ -68,6 +89,9 @@ class Oracle:
         L.orc_mgm.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float,
                               C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_void_p]
         L.orc_refine.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p]
+
+    def set_threads(self, n):
+        self.lib.orc_set_num_threads(int(n))
 
     def census(self, u, winradius):
         u = _img(u)

@@ -6,6 +6,7 @@ volume, each pass's Lr, the corrected S, the labels and the costs.  This is a
 development aid; the judged parity tests are tests/test_gpu_*.py.
 """
 import argparse
+import faulthandler
 import itertools
 import os
 import sys
@@ -30,6 +31,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--big", action="store_true")
+    ap.add_argument("--case-timeout", type=int, default=60)
+    ap.add_argument("--first", default="")
     args = ap.parse_args()
     orc = Oracle()
     ctx = mgm_amd.Context(0)
@@ -69,16 +72,22 @@ def main():
         cv = ctx.upload_volume(C, dmin)
         combos = [(8, 3, 0, 8.0, 32.0), (4, 2, 0, 8.0, 32.0), (8, 4, 0, 8.0, 32.0), (8, 1, 0, 8.0, 32.0),
                   (8, 3, 1, 2.0, 20000.0), (4, 2, 1, 2.0, 9.0), (8, 4, 1, 1.5, np.inf), (3, 1, 1, 2.0, 9.0)]
+        if args.first == "mgm1":
+            combos = [combos[3]] * 3 + combos
         for (NDIR, MGM, FH, P1, P2) in combos:
             for wmode in (0, 1):
                 w8 = None
                 if wmode:
                     rng = np.random.default_rng(7)
                     w8 = np.where(rng.random((8, ny, nx)) < 0.5, 4.0 if FH == 0 else 0.3, 1.0).astype(np.float32)
+                faulthandler.dump_traceback_later(args.case_timeout, exit=True)
+                print("  start NDIR=%d MGM=%d FH=%d w=%d" % (NDIR, MGM, FH, wmode), flush=True)
                 Sa, oa, ca, lra = orc.mgm(C, dmin, P1, P2, NDIR, MGM, FH, 1, w8, dump_lr=True)
+                print("  oracle done", flush=True)
                 t0 = time.time()
                 Sb, ob, cb = ctx.aggregate(cv, P1, P2, NDIR, MGM, FH, 1, w8, None, want_S=True)
                 dt = time.time() - t0
+                print("  hip done", flush=True)
                 lrd = [ndiff(lra[p], ctx.debug_lr(cv, p)) for p in range(NDIR)]
                 Sd = ndiff(Sa, Sb.download())
                 fin = np.isfinite(ca)
