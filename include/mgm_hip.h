@@ -122,6 +122,11 @@ int mgm_aggregate(mgm_ctx *ctx, const mgm_cv *C, const float *w8, float P1, floa
  * call on this ctx into `dense` ([ny][nx][L]). */
 int mgm_debug_download_lr(mgm_ctx *ctx, int pass, float *dense);
 
+/* Device self-test: compares the kernels' three-operation exact x/3 against IEEE
+ * division for all 2^32 float32 inputs; *nbad receives the number of inputs
+ * whose results differ (NaN == NaN). */
+int mgm_selftest_div3(mgm_ctx *ctx, unsigned long long *nbad);
+
 /* ---- sub-pixel refinement: subpixel_refinement_sgm ---------------------- */
 /* method in {"none","vfit","parabola","cubic","parabolaOCV"}; unknown => none
  * (mgm_refine.h:28-35).  Built: none, vfit.  out/outcost are read and updated. */

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmgm_hip.so")
+LIB_PATH = os.environ.get("MGM_HIP_LIB") or os.path.join(_HERE, "lib", "libmgm_hip.so")
 
 # every symbol include/mgm_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "mgm_cv_create", "mgm_cv_upload", "mgm_cv_download", "mgm_cv_dims", "mgm_cv_device_ptr", "mgm_cv_free",
     "mgm_costvolume_build_dev", "mgm_costvolume_build", "mgm_weights_dev",
     "mgm_aggregate_dev", "mgm_aggregate", "mgm_debug_download_lr", "mgm_refine_dev", "mgm_refine",
+    "mgm_selftest_div3",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -83,6 +84,7 @@ def load_library():
     L.mgm_debug_download_lr.argtypes = [vp, i, fp]
     L.mgm_refine_dev.argtypes = [vp, vp, cp, vp, vp]
     L.mgm_refine.argtypes = [vp, vp, cp, fp, fp]
+    L.mgm_selftest_div3.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
 
@@ -254,6 +256,11 @@ class Context:
         outcost = np.array(outcost, np.float32, copy=True)
         self._chk(self.lib.mgm_refine(self.h, S.h, method.encode(), _ptr(out), _ptr(outcost)))
         return out, outcost
+
+    def selftest_div3(self):
+        n = C.c_ulonglong(0)
+        self._chk(self.lib.mgm_selftest_div3(self.h, C.byref(n)))
+        return n.value
 
     # ---- timing ----
     def timing(self, enable=True):

@@ -19,12 +19,12 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
           "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 # per-translation-unit extras (see the header comment of each file)
-UNITS = {
-    "mgm_pass.hip": ["-fno-honor-nans"],
-    "mgm_cost.hip": [],
-    "mgm_wta.hip": [],
-    "mgm_api.hip": [],
-}
+# (source, object suffix, extra flags)
+UNITS = [("mgm_pass.hip", "", ["-fno-honor-nans"])]
+P2_EXTRA = os.environ.get("MGM_P2_DEFINES", "").split()  # e.g. "-DMGM_P2_MAXD=3" (tuning experiments)
+UNITS += [("mgm_pass2.hip", "_lpl%d" % n, ["-fno-honor-nans", "-DMGM_P2_LPL=%d" % n] + P2_EXTRA) for n in (1, 2, 3, 4, 6, 8)]
+UNITS += [("mgm_pass2_dispatch.hip", "", []), ("mgm_cost.hip", "", []), ("mgm_wta.hip", "", []),
+          ("mgm_api.hip", "", [])]
 
 
 def hipcc():
@@ -44,13 +44,13 @@ def _stale(target, sources):
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
-    headers = [os.path.join(CSRC, "mgm_device.h"), os.path.join(HERE, "..", "include", "mgm_hip.h"),
+    headers = [os.path.join(CSRC, "mgm_device.h"), os.path.join(CSRC, "mgm_pass_common.h"), os.path.join(HERE, "..", "include", "mgm_hip.h"),
                os.path.abspath(__file__)]
     jobs = []
     objs = []
-    for src, extra in UNITS.items():
+    for src, suffix, extra in UNITS:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        o = os.path.join(OBJDIR, src.replace(".hip", suffix + ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
             jobs.append([cc] + COMMON + extra + ["-c", s, "-o", o])
@@ -64,7 +64,7 @@ def build(force=False, verbose=False):
         return r.stdout
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             for out in ex.map(run, jobs):
                 if verbose and out.strip():
                     print(out)

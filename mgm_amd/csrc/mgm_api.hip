@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,10 +42,12 @@ struct mgm_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // workspace
-    Buf lr, hand, handm, words, tasks, census_u, census_v;
+    Buf lr, hand, handm, words, tasks, census_u, census_v, dbg;
+    int debug_stats = 0;  // MGM_HIP_DEBUG_STATS=1: per-workgroup timing summary of K3 on stderr
     unsigned *h_words = nullptr;  // pinned mirror of the control words
     // cached task table key
-    int tk_nx = -1, tk_ny = -1, tk_ndir = -1;
+    int tk_nx = -1, tk_ny = -1, tk_ndir = -1, tk_r = -1;
+    int force_build = 0;  // 0 auto, 1 first build only (MGM_HIP_PASS_BUILD=1)
     int ntasks = 0;
     // last aggregate (for mgm_debug_download_lr)
     long long last_nvol = 0;
@@ -158,7 +161,7 @@ const int kPassToChannel[4][8] = {  // mgm_core.cc:481-484
 
 // Canonical geometry of a pass (see PassGeom).  Returns false if the table
 // entry does not reduce to one of the two canonical neighbour orders.
-bool make_geom(int pass, int nx, int ny, PassGeom &g)
+bool make_geom(int pass, int nx, int ny, int R, PassGeom &g)
 {
     const RefPass &rp = kPasses[pass];
     const long long sx = rp.inc_x ? 1 : -1, sy = rp.inc_y ? 1 : -1;
@@ -189,7 +192,7 @@ bool make_geom(int pass, int nx, int ny, PassGeom &g)
     if (kind[0] == 0 && kind[1] == 1 && kind[2] == 2 && kind[3] == 3) g.form = 0;
     else if (kind[0] == 3 && kind[1] == 2 && kind[2] == 1 && kind[3] == 0) g.form = 1;
     else return false;
-    g.nbands = (g.NL + kR - 1) / kR;
+    g.nbands = (g.NL + R - 1) / R;
     return true;
 }
 
@@ -219,6 +222,8 @@ int mgm_ctx_create(int device, mgm_ctx **out)
         return MGM_ERR_HIP;
     }
     memset(c->h_words, 0, 16 * sizeof(unsigned));
+    if (const char *e = getenv("MGM_HIP_PASS_BUILD")) c->force_build = atoi(e);
+    if (const char *e = getenv("MGM_HIP_DEBUG_STATS")) c->debug_stats = atoi(e);
     *out = c;
     return MGM_OK;
 }
@@ -228,7 +233,7 @@ int mgm_ctx_destroy(mgm_ctx *c)
     if (!c) return MGM_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (Buf *b : {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v})
+    for (Buf *b : {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v, &c->dbg})
         if (b->p) hipFree(b->p);
     for (auto &t : c->tim) {
         hipEventDestroy(t.a);
@@ -524,10 +529,13 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
     const bool fh = use_fh > 0;
     const int NS = pass_ns(fh, weighted);
 
+    // second build (LDS-DMA loaders) whenever the slabs are whole DMA pieces
+    const int R2 = c->force_build == 1 ? 0 : pass2_lines(L);
+    const int R = R2 ? R2 : kR;
     PassParams p{};
     int maxLL = 0, maxbands = 0;
     for (int q = 0; q < NDIR; q++) {
-        if (!make_geom(q, nx, ny, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
+        if (!make_geom(q, nx, ny, R, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
         maxLL = std::max(maxLL, p.g[q].LL);
         maxbands = std::max(maxbands, p.g[q].nbands);
     }
@@ -539,7 +547,7 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
 
     // task table: ticket -> (pass, band), ordered by band then pass so that
     // item (p, b) always follows (p, b-1)
-    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != NDIR) {
+    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != NDIR || c->tk_r != R) {
         std::vector<int2> tasks;
         for (int b = 0; b < maxbands; b++)
             for (int q = 0; q < NDIR; q++)
@@ -551,6 +559,7 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
         c->tk_nx = nx;
         c->tk_ny = ny;
         c->tk_ndir = NDIR;
+        c->tk_r = R;
     }
 
     p.C = C->d;
@@ -571,12 +580,64 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
     p.maxbands = kMaxBands;
     p.P1 = P1;
     p.P2 = P2;
+    p.dbg = nullptr;
+    p.xflags = 0;
+    if (const char *e = getenv("MGM_HIP_XFLAGS")) p.xflags = atoi(e);
+    if (c->debug_stats && R2) {
+        if ((r = reserve(c, c->dbg, sizeof(unsigned long long) * 16 * (size_t)c->ntasks))) return r;
+        HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, sizeof(unsigned long long) * 16 * (size_t)c->ntasks, c->stream));
+        p.dbg = (unsigned long long *)c->dbg.p;
+    }
     {
-        TimeScope t(c, "k_pass");
-        HIPCHK(c, launch_pass(p, c->ntasks, kR, fh, weighted ? 1 : 0, c->stream));
+        TimeScope t(c, R2 ? "k_pass2" : "k_pass");
+        if (R2) HIPCHK(c, launch_pass2(p, c->ntasks, fh, weighted ? 1 : 0, c->stream));
+        else HIPCHK(c, launch_pass(p, c->ntasks, kR, fh, weighted ? 1 : 0, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->h_words + 1, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     c->pending_check = true;
+    if (p.dbg) {  // development aid: where does K3's time go?
+        std::vector<unsigned long long> d((size_t)c->ntasks * 16);
+        std::vector<int2> tk(c->ntasks);
+        HIPCHK(c, hipMemcpyAsync(d.data(), p.dbg, d.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(tk.data(), c->tasks.p, tk.size() * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < c->ntasks; i++) {
+            t0 = std::min(t0, d[i * 16 + 0]);
+            t1 = std::max(t1, d[i * 16 + 2]);
+        }
+        const double tick = 1e-2;  // wall_clock64: 100 MHz -> 0.01 us
+        fprintf(stderr, "[mgm stats] %d workgroups, kernel span %.1f us\n", c->ntasks, (t1 - t0) * tick);
+        for (int q = 0; q < NDIR; q++) {
+            double run = 0, slow = 0, pro = 0, nslow = 0, nspin = 0, steps = 0, first = 1e30, last = 0;
+            double ai = 0, ar = 0, ab = 0, bi = 0, br = 0, bb = 0, cb = 0;
+            int n = 0;
+            for (int i = 0; i < c->ntasks; i++)
+                if (tk[i].x == q) {
+                    n++;
+                    run += (d[i * 16 + 2] - d[i * 16 + 1]) * tick;
+                    pro += (d[i * 16 + 1] - d[i * 16 + 0]) * tick;
+                    slow += d[i * 16 + 6] * tick;
+                    nslow += d[i * 16 + 3];
+                    nspin += d[i * 16 + 4];
+                    steps = (double)d[i * 16 + 7];
+                    ai += d[i * 16 + 8] * tick; ar += d[i * 16 + 9] * tick; ab += d[i * 16 + 10] * tick;
+                    bi += d[i * 16 + 11] * tick; br += d[i * 16 + 12] * tick; bb += d[i * 16 + 13] * tick;
+                    cb += d[i * 16 + 14] * tick;
+                    first = std::min(first, (double)(d[i * 16 + 0] - t0) * tick);
+                    last = std::max(last, (double)(d[i * 16 + 2] - t0) * tick);
+                }
+            fprintf(stderr,
+                    "[mgm stats] pass %d: %d bands x %.0f steps; per band: prologue %.1f us, main loop %.1f us (%.3f us/step), "
+                    "slow-path %.1f us in %.1f polls (%.0f spins); pass active %.1f..%.1f us\n",
+                    q, n, steps, pro / n, run / n, run / n / steps, slow / n, nslow / n, nspin / n, first, last);
+            fprintf(stderr,
+                    "[mgm stats]         loader A: issue %.0f retire %.0f barrier %.0f us | compute wave: barrier-wait %.0f us; "
+                    "kcycles per band: lds-read %.0f combine %.0f store+min %.0f transform %.0f lds-write %.0f\n",
+                    ai / n, ar / n, ab / n, cb / n, nslow / n / 1e3, nspin / n / 1e3, bi / tick / n / 1e3, br / tick / n / 1e3,
+                    bb / tick / n / 1e3);
+        }
+    }
     c->last_nvol = nvol;
     c->last_ndir = NDIR;
 
@@ -630,6 +691,21 @@ int mgm_debug_download_lr(mgm_ctx *c, int pass, float *dense)
     HIPCHK(c, hipMemcpyAsync(dense, (const float *)c->lr.p + (size_t)pass * c->last_nvol, sizeof(float) * c->last_nvol,
                              hipMemcpyDeviceToHost, c->stream));
     return mgm_ctx_synchronize(c);
+}
+
+// ---- self-tests -------------------------------------------------------------------
+int mgm_selftest_div3(mgm_ctx *c, unsigned long long *nbad)
+{
+    if (!c || !nbad) return fail(c, MGM_ERR_INVALID, "mgm_selftest_div3: null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int r;
+    if ((r = reserve(c, c->words, sizeof(unsigned) * kCtrlWords))) return r;
+    unsigned long long *d = (unsigned long long *)c->words.p;
+    HIPCHK(c, hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(c, launch_selftest_div3(d, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nbad, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MGM_OK;
 }
 
 // ---- refinement -----------------------------------------------------------------

@@ -38,6 +38,8 @@ struct PassParams {
     unsigned *ticket;   // work-item ticket counter
     unsigned *err;      // watchdog word
     const int2 *tasks;  // ticket -> (pass, band)
+    int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA
+    unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
     long long npix, nvol;
     int L, MGM, NDIR;
     int LLmax, maxbands;
@@ -58,6 +60,11 @@ struct WtaParams {
 hipError_t launch_pass(const PassParams &p, int ntasks, int R, bool fh, int wmode, hipStream_t s);
 int pass_ns(bool fh, bool weighted);  // slabs per hand-off slot
 int pass_lpl(int L);                  // disparities per lane the pass kernel is instantiated for
+// second build (LDS-DMA loader waves); pass2_lines(L) = lines per band, 0 if L is not supported by it
+int pass2_lines(int L);
+hipError_t launch_pass2(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s);
+template <int LPL>
+hipError_t launch_pass2_lpl(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s);
 hipError_t launch_wta(const WtaParams &p, hipStream_t s);
 hipError_t launch_refine(const float *S, long long npix, int L, int dmin, int method, float *out, float *outcost,
                          hipStream_t s);
@@ -74,6 +81,7 @@ struct CostParams {
 hipError_t launch_cost(const CostParams &p, hipStream_t s);
 hipError_t launch_weights(const float *u, int nx, int ny, int nch, float aP, float aThresh, float *w8,
                           hipStream_t s);
+hipError_t launch_selftest_div3(unsigned long long *nbad, hipStream_t s);
 hipError_t launch_any_not_one(const float *w, long long n, unsigned *flag, hipStream_t s);
 
 // ---------------------------------------------------------------------------

@@ -34,270 +34,9 @@
 // NaN-free (costs are finite or +INF and every pixel has a finite cost, see
 // mgm_costvolume.h:414-421), and it lets v_min_f32 be used without
 // canonicalisation.  Nothing here may rely on NaN semantics.
-#include "mgm_device.h"
+#include "mgm_pass_common.h"
 
 namespace mgm {
-
-constexpr int PF = 4;                    // prefetch depth (steps)
-constexpr int CH = 8;                    // pixels per inter-band progress publication
-constexpr unsigned SPIN_LIMIT = 1u << 22;  // watchdog for the inter-band poll
-
-#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// ---- slab I/O ---------------------------------------------------------------
-template <int LPL>
-__device__ __forceinline__ void load_slab(const float *__restrict__ p, int lane, int L, bool exact, float (&v)[LPL])
-{
-    const float *q = p + lane * LPL;
-    if (exact) {
-#pragma unroll
-        for (int k = 0; k < LPL; k++) v[k] = q[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < LPL; k++) v[k] = (lane * LPL + k < L) ? q[k] : f_inf();
-    }
-}
-template <int LPL>
-__device__ __forceinline__ void store_slab(float *__restrict__ p, int lane, int L, bool exact, const float (&v)[LPL])
-{
-    float *q = p + lane * LPL;
-    if (exact) {
-#pragma unroll
-        for (int k = 0; k < LPL; k++) q[k] = v[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < LPL; k++)
-            if (lane * LPL + k < L) q[k] = v[k];
-    }
-}
-// inter-workgroup hand-off: write-through stores / L1-bypassing loads (sc1)
-template <int LPL>
-__device__ __forceinline__ void store_slab_sc1(float *p, int lane, const float (&v)[LPL])
-{
-    unsigned *q = reinterpret_cast<unsigned *>(p) + lane * LPL;
-#pragma unroll
-    for (int k = 0; k < LPL; k++) __hip_atomic_store(q + k, __builtin_bit_cast(unsigned, v[k]), RLX_AGENT);
-}
-template <int LPL>
-__device__ __forceinline__ void load_slab_sc1(const float *p, int lane, float (&v)[LPL])
-{
-    const unsigned *q = reinterpret_cast<const unsigned *>(p) + lane * LPL;
-#pragma unroll
-    for (int k = 0; k < LPL; k++) v[k] = __builtin_bit_cast(float, __hip_atomic_load(q + k, RLX_AGENT));
-}
-
-// ---- per-slab transforms ------------------------------------------------------
-template <int LPL>
-__device__ __forceinline__ float slab_min(const float (&v)[LPL])
-{
-    float m = v[0];
-#pragma unroll
-    for (int k = 1; k < LPL; k++) m = fminf(m, v[k]);
-    return wave_min(m);
-}
-
-// N[o] = min(L[o-1], L[o+1]) with +INF outside the label range (dvec.cc:129)
-template <int LPL>
-__device__ __forceinline__ void neighbour_min(const float (&Lv)[LPL], float (&N)[LPL])
-{
-    const float left = dpp_shr1(Lv[LPL - 1], f_inf());
-    const float right = dpp_shl1(Lv[0], f_inf());
-#pragma unroll
-    for (int k = 0; k < LPL; k++) {
-        const float lo = k ? Lv[k - 1] : left;
-        const float hi = (k < LPL - 1) ? Lv[k + 1] : right;
-        N[k] = fminf(lo, hi);
-    }
-}
-
-// Exact minConvTruncatedLinear (mgm_core.cc:152-163) on a slab spread over the
-// wave.  The reference runs two SEQUENTIAL fp32 recurrences over o,
-//   fwd: M[o] = min(M[o-1] + P1, M[o])      bwd: M[o] = min(M[o+1] + P1, M[o]),
-// each add rounded, so x + n*P1 in one rounding is not equivalent.  Here every
-// lane runs the recurrence exactly over its own LPL elements given a carry
-// from its neighbour lane; the 64 carries are first GUESSED with a log-step
-// scan (single-rounded ramps) and then iterated to the fixed point
-//   c_l = carry_out(lane l | carry_in = c_{l-1}),
-// which is unique and equals the sequential result (lane 0 has no carry-in, so
-// after n sweeps lanes 0..n-1 are exact; the loop ends when a sweep changes
-// nothing, normally the first).  `valid` masks label slots >= L.
-template <int LPL>
-__device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, float P2, int lane, int L)
-{
-    const float rampP = (float)LPL * P1;
-    // ---------------- forward ----------------
-    {
-        float a = M[0];
-#pragma unroll
-        for (int k = 1; k < LPL; k++) a = fminf(M[k], a + P1);
-        float c = a;  // carry-out ignoring carry-in: exact for lane 0, a guess elsewhere
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const float t = __shfl_up(c, d) + (float)d * rampP;
-            if (lane >= d) c = fminf(c, t);
-        }
-        float f[LPL];
-        for (int it = 0; it < 66; it++) {
-            const float cin = dpp_shr1(c, f_inf());
-            f[0] = fminf(M[0], cin + P1);
-#pragma unroll
-            for (int k = 1; k < LPL; k++) f[k] = fminf(M[k], f[k - 1] + P1);
-            const bool same = (f[LPL - 1] == c);
-            c = f[LPL - 1];
-            if (__builtin_amdgcn_ballot_w64(!same) == 0ull) break;
-        }
-#pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = (lane * LPL + k < L) ? f[k] : f_inf();
-    }
-    // ---------------- backward ----------------
-    {
-        float a = M[LPL - 1];
-#pragma unroll
-        for (int k = LPL - 2; k >= 0; k--) a = fminf(M[k], a + P1);
-        float c = a;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const float t = __shfl_down(c, d) + (float)d * rampP;
-            if (lane + d < 64) c = fminf(c, t);
-        }
-        float f[LPL];
-        for (int it = 0; it < 66; it++) {
-            const float cin = dpp_shl1(c, f_inf());
-            f[LPL - 1] = fminf(M[LPL - 1], cin + P1);
-#pragma unroll
-            for (int k = LPL - 2; k >= 0; k--) f[k] = fminf(M[k], f[k + 1] + P1);
-            const bool same = (f[0] == c);
-            c = f[0];
-            if (__builtin_amdgcn_ballot_w64(!same) == 0ull) break;
-        }
-#pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = f[k];
-    }
-    if (P2 < f_inf()) {
-        const float cap = m + P2;
-#pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = fminf(M[k], cap);
-    }
-}
-
-// ---- the four reference update functions ---------------------------------------
-// Neighbour k's published slab(s) and minimum.
-template <int LPL, int NS>
-struct Nb {
-    float w[NS][LPL];
-    float m;
-};
-
-// unit weights: w[0] = T.  MGM, FH are wave-uniform run-time values.
-template <int LPL>
-__device__ __forceinline__ void combine_unit(const float (&C)[LPL], const Nb<LPL, 1> &n1, const Nb<LPL, 1> &n2,
-                                             const Nb<LPL, 1> &n3, const Nb<LPL, 1> &n4, int MGM, bool FH,
-                                             float (&out)[LPL])
-{
-    if (MGM == 2) {
-        if (!FH) {  // update_cost2: e=0; e+=(t1-m1)/2; e+=(t2-m2)/2
-#pragma unroll
-            for (int k = 0; k < LPL; k++) {
-                float e = 0.0f;
-                e += (n1.w[0][k] - n1.m) * 0.5f;
-                e += (n2.w[0][k] - n2.m) * 0.5f;
-                out[k] = C[k] + e;
-            }
-        } else {  // update_cost2_trunclinear: (M1 - m1 + M2 - m2)/2
-#pragma unroll
-            for (int k = 0; k < LPL; k++) out[k] = C[k] + (((n1.w[0][k] - n1.m) + n2.w[0][k]) - n2.m) * 0.5f;
-        }
-        return;
-    }
-    // update_costW / update_costW_trunclinear with DeltaI = 1
-#pragma unroll
-    for (int k = 0; k < LPL; k++) {
-        float e;
-        if (!FH) {
-            e = 0.0f;
-            e += n1.w[0][k] - n1.m;
-        } else {
-            e = n1.w[0][k] - n1.m;
-        }
-        if (MGM >= 2) e += n2.w[0][k] - n2.m;  // MGM == 2 never reaches here
-        if (MGM >= 3) e += n3.w[0][k] - n3.m;
-        if (MGM >= 4) e += n4.w[0][k] - n4.m;
-        float q;
-        if (MGM == 1) q = e;
-        else if (MGM == 3) q = e / 3.0f;
-        else q = e * 0.25f;
-        out[k] = C[k] + q;
-    }
-}
-
-// weighted Hirschmueller (update_costW): w[0] = L, w[1] = N
-template <int LPL>
-__device__ __forceinline__ float hirsch_w_term(const Nb<LPL, 2> &n, int k, float p1, float p2)
-{
-    const float t = fminf(fminf(n.w[0][k], n.w[1][k] + p1), n.m + p2);
-    return t - n.m;
-}
-template <int LPL>
-__device__ __forceinline__ void combine_whirsch(const float (&C)[LPL], const Nb<LPL, 2> &n1, const Nb<LPL, 2> &n2,
-                                                const Nb<LPL, 2> &n3, const Nb<LPL, 2> &n4, const float (&D)[4],
-                                                float P1, float P2, int MGM, float (&out)[LPL])
-{
-    const float a1 = P1 * D[0], b1 = P2 * D[0], a2 = P1 * D[1], b2 = P2 * D[1];
-    const float a3 = P1 * D[2], b3 = P2 * D[2], a4 = P1 * D[3], b4 = P2 * D[3];
-#pragma unroll
-    for (int k = 0; k < LPL; k++) {
-        float e = 0.0f;
-        e += hirsch_w_term<LPL>(n1, k, a1, b1);
-        if (MGM >= 2) e += hirsch_w_term<LPL>(n2, k, a2, b2);
-        if (MGM >= 3) e += hirsch_w_term<LPL>(n3, k, a3, b3);
-        if (MGM >= 4) e += hirsch_w_term<LPL>(n4, k, a4, b4);
-        out[k] = C[k] + e / (float)MGM;
-    }
-}
-// weighted FH (update_costW_trunclinear): w[0] = L; the min-convolution depends
-// on the consumer's weights, so it runs here, once per neighbour.
-template <int LPL>
-__device__ __forceinline__ void combine_wfh(const float (&C)[LPL], const Nb<LPL, 1> &n1, const Nb<LPL, 1> &n2,
-                                            const Nb<LPL, 1> &n3, const Nb<LPL, 1> &n4, const float (&D)[4], float P1,
-                                            float P2, int MGM, int lane, int L, float (&out)[LPL])
-{
-    float e[LPL], M[LPL];
-#pragma unroll
-    for (int k = 0; k < LPL; k++) M[k] = n1.w[0][k];
-    fh_minconv<LPL>(M, n1.m, P1 * D[0], P2 * D[0], lane, L);
-#pragma unroll
-    for (int k = 0; k < LPL; k++) e[k] = M[k] - n1.m;
-    if (MGM >= 2) {
-#pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = n2.w[0][k];
-        fh_minconv<LPL>(M, n2.m, P1 * D[1], P2 * D[1], lane, L);
-#pragma unroll
-        for (int k = 0; k < LPL; k++) e[k] += M[k] - n2.m;
-    }
-    if (MGM >= 3) {
-#pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = n3.w[0][k];
-        fh_minconv<LPL>(M, n3.m, P1 * D[2], P2 * D[2], lane, L);
-#pragma unroll
-        for (int k = 0; k < LPL; k++) e[k] += M[k] - n3.m;
-    }
-    if (MGM >= 4) {
-#pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = n4.w[0][k];
-        fh_minconv<LPL>(M, n4.m, P1 * D[3], P2 * D[3], lane, L);
-#pragma unroll
-        for (int k = 0; k < LPL; k++) e[k] += M[k] - n4.m;
-    }
-#pragma unroll
-    for (int k = 0; k < LPL; k++) out[k] = C[k] + e[k] / (float)MGM;
-}
 
 // ---- the kernel ------------------------------------------------------------------
 template <int LPL, bool FH, bool WEIGHTED, int R>
@@ -487,6 +226,26 @@ __global__ void __launch_bounds__(R * 64) k_pass(const PassParams P)
             lds_barrier();
         }
     }
+}
+
+// ---- self-test: div3_exact against IEEE division over every fp32 bit pattern ---------
+__global__ void __launch_bounds__(256) k_selftest_div3(unsigned long long *nbad)
+{
+    unsigned long long bad = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += stride) {
+        const float x = __builtin_bit_cast(float, (unsigned)b);
+        const unsigned a = __builtin_bit_cast(unsigned, x / 3.0f);
+        const unsigned q = __builtin_bit_cast(unsigned, div3_exact(x));
+        const bool a_nan = (a & 0x7fffffffu) > 0x7f800000u, q_nan = (q & 0x7fffffffu) > 0x7f800000u;
+        if (a != q && !(a_nan && q_nan)) bad++;
+    }
+    if (bad) atomicAdd(nbad, bad);
+}
+hipError_t launch_selftest_div3(unsigned long long *nbad, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_div3, dim3(4096), dim3(256), 0, s, nbad);
+    return hipGetLastError();
 }
 
 // ---- launcher ------------------------------------------------------------------

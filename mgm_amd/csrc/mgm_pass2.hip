@@ -1,0 +1,580 @@
+// mgm_pass2.hip -- K3, second build: the same recursion and dataflow as
+// mgm_pass.hip (read its header first), with the memory side moved off the
+// compute waves:
+//
+//   * a workgroup = NC compute waves (one scan line each, lock-step on the
+//     slope-2 diagonal) + NL loader waves;
+//   * the loader waves stream every operand that comes from memory -- the C
+//     slab of each line D steps ahead, and the previous band's hand-off slabs,
+//     minima and progress word -- into LDS rings with LDS-DMA
+//     (global_load_lds_dwordx4, no VGPR round trip) and retire them with a
+//     COUNTED s_waitcnt vmcnt(n*(D-1)) followed by the step barrier, so D-1
+//     steps of loads stay in flight across every barrier;
+//   * compute waves only read LDS and issue stores (their Lr slab, and for the
+//     last line of the band the sc1 hand-off), so the compiler has no load to
+//     wait for: the first build lost ~1.5 us per step to vmcnt(0) drains the
+//     compiler placed on in-flight prefetch registers.
+//
+// Used when every slab is a whole number of 16-byte DMA pieces (L == 64*LPL,
+// LPL in {1,2,3,4,6,8}); other label counts take the first build.
+#include <type_traits>
+
+#include "mgm_pass_common.h"
+
+namespace mgm {
+
+typedef __attribute__((address_space(3))) void *lds_vptr;
+typedef const __attribute__((address_space(1))) void *glb_vptr;
+
+// One 16-byte-per-lane LDS-DMA piece: lane l moves src[l*4 .. l*4+3] to
+// dst_base[l*4 ..] (LDS destination = wave-uniform base + 16*lane).
+template <int AUX>
+__device__ __forceinline__ void dma16(const float *src_lane, float *dst_base)
+{
+    __builtin_amdgcn_global_load_lds((glb_vptr)src_lane, (lds_vptr)dst_base, 16, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void dma4(const void *src_lane, void *dst_base)
+{
+    __builtin_amdgcn_global_load_lds((glb_vptr)src_lane, (lds_vptr)dst_base, 4, 0, AUX);
+}
+constexpr int AUX_SC1 = 16;  // agent-scope (L1-bypassing) cache policy bit
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void step_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// LDS read the compiler must not order against pending LDS-DMA itself (it would
+// drain vmcnt): the landing of the word is guaranteed by the counted wait.
+__device__ __forceinline__ unsigned lds_read_u32_opaque(const unsigned *p)
+{
+    unsigned v;
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned *)p;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+
+// Write-through (sc1) slab store in the widest pieces the slab allows: narrow sc1 stores are one
+// fabric write each, so 4 x dword costs ~6x the time of one dwordx4 (MI355X_MICROARCH.md).
+// Inline asm because clang has no 16-byte agent-scope store; the trailing s_nop keeps the data
+// registers intact until the store has read them.  Not counted by the compiler's vmcnt
+// bookkeeping -- compute waves issue no loads, and every wait on these stores is explicit.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_sc1_x4(float *p, float a, float b, float c, float d)
+{
+    const f32x4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_sc1_x2(float *p, float a, float b)
+{
+    const f32x2 v = {a, b};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_sc1_x1(float *p, float a)
+{
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(a) : "memory");
+}
+template <int LPL>
+__device__ __forceinline__ void store_slab_sc1_wide(float *slab, int lane, const float (&v)[LPL])
+{
+    float *p = slab + lane * LPL;
+    if constexpr (LPL == 1) st_sc1_x1(p, v[0]);
+    else if constexpr (LPL == 2) st_sc1_x2(p, v[0], v[1]);
+    else if constexpr (LPL == 3) { st_sc1_x2(p, v[0], v[1]); st_sc1_x1(p + 2, v[2]); }
+    else if constexpr (LPL == 4) st_sc1_x4(p, v[0], v[1], v[2], v[3]);
+    else if constexpr (LPL == 6) { st_sc1_x4(p, v[0], v[1], v[2], v[3]); st_sc1_x2(p + 4, v[4], v[5]); }
+    else { st_sc1_x4(p, v[0], v[1], v[2], v[3]); st_sc1_x4(p + 4, v[4], v[5], v[6], v[7]); }
+}
+template <int LPL>
+constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 1; }
+
+#ifndef MGM_P2_WAVES_PER_EU
+#define MGM_P2_WAVES_PER_EU 4
+#endif
+#ifndef MGM_P2_NC
+#define MGM_P2_NC 14
+#endif
+#ifndef MGM_P2_LDS_KB
+#define MGM_P2_LDS_KB 160
+#endif
+#ifndef MGM_P2_MAXD
+#define MGM_P2_MAXD 2
+#endif
+#ifndef MGM_P2_PUBLAG
+#define MGM_P2_PUBLAG 3
+#endif
+#ifndef MGM_P2_LEAD
+#define MGM_P2_LEAD 4
+#endif
+// ---- geometry of the build --------------------------------------------------------
+template <int LPL, int NS, bool HASM>
+struct Plan {
+    static constexpr int LP = LPL * 64;
+    static constexpr int IPS = (LPL * 16 + 63) / 64;  // DMA pieces per slab
+    static constexpr int NC = (LPL <= 4) ? MGM_P2_NC : 7;    // compute waves = lines per band
+    static constexpr int NL = (LPL <= 4 && MGM_P2_NC > 7) ? 2 : 1;     // loader waves
+    static constexpr int NCA = (NL == 2) ? NC / 2 : NC;  // lines served by loader A
+    // DMA instructions per step: loader A = its C lines + hand-off slabs + minimum + progress word
+    static constexpr int nA = NCA * IPS + NS * IPS + 1 + (HASM ? 1 : 0);
+    static constexpr int nB = (NC - NCA) * IPS;
+    static constexpr int lds_floats(int D)
+    {
+        return NC * 2 * NS * LP      // T ring
+               + NC * 2              // T minima
+               + (D + 1) * NS * LP   // hand-off ring
+               + 2 * (D + 1) + 8     // hand-off minima, progress words, task word
+               + NC * (D + 1) * LP;  // C ring
+    }
+    static constexpr int pick_D()
+    {
+        for (int D = MGM_P2_MAXD; D >= 2; D--)
+            if (lds_floats(D) * 4 <= (LPL <= 4 ? MGM_P2_LDS_KB : 160) * 1024 && nA * (D - 1) <= 63 && nB * (D - 1) <= 63) return D;
+        return 1;
+    }
+    static constexpr int D = pick_D();
+    static_assert(D >= 2, "no feasible pipeline depth");
+};
+
+// unit weights, slabs hold E = T - m (every unit-weight case but FH with MGM == 2)
+template <int LPL, int MGM, bool FH>
+__device__ __forceinline__ void combine_unit_E(const float (&C)[LPL], const float (&e1)[LPL], const float (&e2)[LPL],
+                                               const float (&e3)[LPL], const float (&e4)[LPL], float (&out)[LPL])
+{
+    if constexpr (MGM == 2) {  // update_cost2 (FH with MGM == 2 never gets here)
+#pragma unroll
+        for (int k = 0; k < LPL; k++) {
+            float e = 0.0f;
+            e += e1[k] * 0.5f;
+            e += e2[k] * 0.5f;
+            out[k] = C[k] + e;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < LPL; k++) {
+            float e;
+            if constexpr (!FH) {
+                e = 0.0f;
+                e += e1[k];
+            } else {
+                e = e1[k];
+            }
+            if constexpr (MGM >= 3) e += e2[k];
+            if constexpr (MGM >= 3) e += e3[k];
+            if constexpr (MGM >= 4) e += e4[k];
+            out[k] = C[k] + div_small<MGM>(e);
+        }
+    }
+}
+
+template <int LPL, bool FH, bool WEIGHTED, int MGM>
+__global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::NL) * 64, (LPL <= 4 ? MGM_P2_WAVES_PER_EU : 4))
+    k_pass2(const PassParams P)
+{
+    constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
+    constexpr bool pubE = !WEIGHTED && !(FH && MGM == 2);  // slabs carry E = T - m; minima not needed
+    using PL = Plan<LPL, NS, !pubE>;
+    constexpr int LP = PL::LP, NC = PL::NC, NCA = PL::NCA, D = PL::D, IPS = PL::IPS;
+    constexpr int LPW = NCA;   // C lines per loader wave (NC - NCA == NCA when there are two loaders)
+    constexpr int RD = D + 1;  // ring depth
+    using NbT = Nb<LPL, NS>;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Tring = smem;                          // [NC][2][NS][LP]
+    float *Hring = Tring + NC * 2 * NS * LP;      // [RD][NS][LP]
+    float *Cring = Hring + RD * NS * LP;          // [NC][RD][LP]
+    float *Tm = Cring + NC * RD * LP;             // [NC][2]
+    float *Hm = Tm + NC * 2;                      // [RD]
+    unsigned *Hprog = reinterpret_cast<unsigned *>(Hm + RD);  // [RD]
+    int *s_task = reinterpret_cast<int *>(Hprog + RD);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) *s_task = (int)atomicAdd(P.ticket, 1u);
+    __syncthreads();
+    const int ticket = *s_task;
+    const int2 tk = P.tasks[ticket];
+    const int pass = tk.x, band = tk.y;
+    unsigned long long *dbg = P.dbg ? P.dbg + (long long)ticket * 16 : nullptr;
+    if (dbg && tid == 0) dbg[0] = wall_clock64();
+    const PassGeom &g = P.g[pass];
+    const int NLn = g.NL, LL = g.LL, L = P.L, form = g.form;
+    const float P1 = P.P1, P2 = P.P2;
+    const long long istep = g.istep;
+    const int nsteps = ((LL + 1 + 2 * (NC - 1)) + 2) / 3 * 3;
+    const bool from_global = band > 0;
+
+    constexpr int NSLP = NS * LP;
+    float *hand_out = P.hand + ((long long)(pass * 2 + (band & 1)) * P.LLmax) * NSLP;
+    float *handm_out = P.handm + (long long)(pass * 2 + (band & 1)) * P.LLmax;
+    const float *hand_in = P.hand + ((long long)(pass * 2 + ((band + 1) & 1)) * P.LLmax) * NSLP;
+    const float *handm_in = P.handm + (long long)(pass * 2 + ((band + 1) & 1)) * P.LLmax;
+    unsigned *prog_out = P.prog + pass * P.maxbands + band;
+    const unsigned *prog_in = from_global ? prog_out - 1 : prog_out;
+
+    if (wave >= NC) {
+        // =========================== loader waves ===========================
+        const int wl = wave - NC;
+        const int r0 = wl == 0 ? 0 : NCA;
+        unsigned known = 0;
+        bool dead = false;
+        unsigned long long n_slow = 0, t_slow = 0, n_spin = 0, t_ret = 0, t_bar = 0, t_iss = 0;
+
+        // Per line: the (clamped) source pointer of the NEXT target step and its pixel index.
+        // Target step t wants pixel i = t-1-2r of line r; out-of-range steps re-read an end pixel
+        // (the slot they fill is never consumed) so that every step issues the same DMA count.
+        const float *cptr[LPW];
+        int ci[LPW];
+        const long long cstride = istep * L;
+#pragma unroll
+        for (int q = 0; q < LPW; q++) {
+            const int r = r0 + q;
+            int j = band * NC + r;
+            j = j < NLn ? j : NLn - 1;
+            cptr[q] = P.C + (g.base + (long long)j * g.jstep) * L + lane * 4;
+            ci[q] = -1 - 2 * r;
+        }
+        const float *hptr = hand_in + lane * 4;  // hand-off slab of pixel h = clamp(t, 0, LL-1)
+        const float *hmptr = handm_in;
+        int ht = 0;
+
+        auto issue = [&](int slot) {  // everything the step `ht` needs, into ring slot `slot`
+#pragma unroll
+            for (int q = 0; q < LPW; q++) {
+                float *dst = Cring + ((r0 + q) * RD + slot) * LP;
+#pragma unroll
+                for (int c = 0; c < IPS; c++)
+                    if (c * 64 + lane < ((P.xflags & 2) ? 1 : LPL * 16)) dma16<0>(cptr[q] + c * 256, dst + c * 256);
+                const bool adv = (ci[q] >= 0) && (ci[q] < LL - 1);
+                cptr[q] += adv ? cstride : 0;
+                ci[q]++;
+            }
+            if (wl == 0) {
+                const int h = ht < LL ? ht : LL - 1;
+                if (from_global && !dead && !(P.xflags & 4) && known < (unsigned)h + 1u) {
+                    // slow path: the producer band is not far enough ahead.  Poll the word through
+                    // LDS-DMA as well (no VGPR load, so nothing makes the compiler drain us elsewhere).
+                    // Wait for a LEAD beyond the bare need: the producer publishes one pixel per step, so
+                    // returning at the first sufficient value would put us back here on the next step.
+                    unsigned spins = 0;
+                    const unsigned long long t0 = dbg ? wall_clock64() : 0;
+                    constexpr unsigned LEAD = MGM_P2_LEAD;
+                    const unsigned want = (unsigned)h + 1u + LEAD < (unsigned)LL ? (unsigned)h + 1u + LEAD : (unsigned)LL;
+                    n_slow++;
+                    for (;;) {
+                        n_spin++;
+                        if (lane == 0) dma4<AUX_SC1>(prog_in, Hprog + slot);
+                        wait_vmcnt<0>();
+                        known = __builtin_amdgcn_readfirstlane(lds_read_u32_opaque(Hprog + slot));
+                        if (known >= want) break;
+                        __builtin_amdgcn_s_sleep(8);
+                        if (((++spins) & 255u) == 0) {
+                            if (lane == 0) dma4<AUX_SC1>(P.err, Hprog + slot);
+                            wait_vmcnt<0>();
+                            const unsigned e = __builtin_amdgcn_readfirstlane(lds_read_u32_opaque(Hprog + slot));
+                            if (spins > (SPIN_LIMIT >> 2) || e != 0) {
+                                if (lane == 0) __hip_atomic_store(P.err, 1u, RLX_AGENT);
+                                dead = true;
+                                break;
+                            }
+                        }
+                    }
+                    if (dbg) t_slow += wall_clock64() - t0;
+                }
+#pragma unroll
+                for (int q = 0; q < NS; q++)
+#pragma unroll
+                    for (int c = 0; c < IPS; c++)
+                        if (c * 64 + lane < LPL * 16)
+                            dma16<AUX_SC1>(hptr + q * LP + c * 256, Hring + (slot * NS + q) * LP + c * 256);
+                if constexpr (!pubE)
+                    if (lane == 0) dma4<AUX_SC1>(hmptr, Hm + slot);
+                if (lane == 0) dma4<AUX_SC1>(prog_in, Hprog + slot);
+                const bool adv = ht < LL - 1;
+                hptr += adv ? NSLP : 0;
+                hmptr += adv ? 1 : 0;
+                ht++;
+            }
+        };
+        auto retire = [&]() {  // all but the newest D-1 steps of DMA have landed
+            if (wl == 0) wait_vmcnt<PL::nA *(D - 1)>();
+            else wait_vmcnt<PL::nB *(D - 1)>();
+        };
+
+        int slot = 0;
+        for (int t = 0; t < D; t++) {  // prologue: steps 0..D-1
+            issue(slot);
+            slot = slot + 1 == RD ? 0 : slot + 1;
+        }
+        retire();
+        if (dbg && wl == 0 && lane == 0) {
+            dbg[1] = wall_clock64();
+            dbg[5] = t_slow;
+        }
+        step_barrier();  // B0
+        int uslot = 0;   // slot of the step that is about to run
+        for (int s = 0; s < nsteps; s++) {
+            if (wl == 0 && from_global) {
+                // freshest progress word that has landed: the one issued for step s
+                const unsigned k = __builtin_amdgcn_readfirstlane(lds_read_u32_opaque(Hprog + uslot));
+                known = k > known ? k : known;
+            }
+            const unsigned long long ta = dbg ? wall_clock64() : 0;
+            issue(slot);
+            slot = slot + 1 == RD ? 0 : slot + 1;
+            uslot = uslot + 1 == RD ? 0 : uslot + 1;
+            const unsigned long long tb = dbg ? wall_clock64() : 0;
+            retire();
+            const unsigned long long tc = dbg ? wall_clock64() : 0;
+            step_barrier();
+            if (dbg) {
+                const unsigned long long td = wall_clock64();
+                t_iss += tb - ta;
+                t_ret += tc - tb;
+                t_bar += td - tc;
+            }
+        }
+        if (dbg && wl == 0 && lane == 0) {
+            dbg[2] = wall_clock64();
+            dbg[6] = t_slow;
+            dbg[7] = (unsigned long long)nsteps;
+            dbg[8] = t_iss;
+            dbg[9] = t_ret;
+            dbg[10] = t_bar;
+        }
+        return;
+    }
+
+    // ============================= compute waves =============================
+    const int r = wave;
+    const int j = band * NC + r;
+    const bool line_ok = j < NLn;
+    const bool has_prev = line_ok && (j >= 1);
+    const bool to_lds = (r < NC - 1) && (j + 1 < NLn);
+    const bool to_global = (r == NC - 1) && (band + 1 < g.nbands);
+    float *__restrict__ Lrb = P.Lr + (long long)pass * P.nvol;
+    const long long pix0 = g.base + (long long)j * g.jstep;
+    const float *fwd_src0 = r > 0 ? Tring + (r - 1) * 2 * NSLP + lane * LPL : Hring + lane * LPL;
+    const float *fwd_m0 = r > 0 ? Tm + (r - 1) * 2 : Hm;
+    const float *c_src0 = Cring + r * RD * LP + lane * LPL;
+    float *t_dst0 = Tring + r * 2 * NSLP + lane * LPL;
+
+    // The whole line walk, specialised on the neighbour order of the pass (FORM).
+    auto run = [&](auto formc) {
+        constexpr int FORM = decltype(formc)::value;
+        NbT wA = {}, wB = {}, wC = {}, nb_i = {};
+
+        // one step: X receives the new fwd slab; Y = back, Z = same
+        unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+        const bool prof = dbg && r == NC / 2;
+        auto step = [&](int s, int cslot, NbT &X, const NbT &Y, const NbT &Z) {
+            const int i = s - 1 - 2 * r;
+            const unsigned long long c0 = prof ? clock64() : 0;
+            if (has_prev && i >= -1 && i + 1 < LL) {
+                const int sl = r > 0 ? ((i + 1) & 1) : cslot;
+                const float *src = fwd_src0 + sl * NSLP;
+#pragma unroll
+                for (int q = 0; q < NS; q++)
+#pragma unroll
+                    for (int k = 0; k < LPL; k++) X.w[q][k] = src[q * LP + k];
+                if constexpr (!pubE) X.m = fwd_m0[sl];
+            }
+            if (line_ok && i >= 0 && i < LL) {
+                const long long pix = pix0 + (long long)i * istep;
+                float Cv[LPL], Lv[LPL];
+                {
+                    const float *src = c_src0 + cslot * LP;
+#pragma unroll
+                    for (int k = 0; k < LPL; k++) Cv[k] = src[k];
+                }
+                const bool interior = has_prev && i >= 1 && i <= LL - 2;  // mgm_core.cc:538-541
+                if (prof) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("" : "+v"(Cv[0]), "+v"(X.w[0][0]));
+                    ph[0] += clock64() - c0;  // LDS reads landed
+                }
+                const unsigned long long c1 = prof ? clock64() : 0;
+                if (interior) {
+                    if constexpr (!WEIGHTED) {
+                        if constexpr (pubE) {
+                            if constexpr (FORM == 0)
+                                combine_unit_E<LPL, MGM, FH>(Cv, nb_i.w[0], Z.w[0], Y.w[0], X.w[0], Lv);
+                            else
+                                combine_unit_E<LPL, MGM, FH>(Cv, X.w[0], Y.w[0], Z.w[0], nb_i.w[0], Lv);
+                        } else {
+                            if constexpr (FORM == 0) combine_unit<LPL>(Cv, nb_i, Z, Y, X, MGM, FH, Lv);
+                            else combine_unit<LPL>(Cv, X, Y, Z, nb_i, MGM, FH, Lv);
+                        }
+                    } else {
+                        float Dw[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) Dw[k] = P.w8[(long long)g.wplane[k] * P.npix + pix];
+                        if constexpr (!FH) {
+                            if constexpr (FORM == 0) combine_whirsch<LPL>(Cv, nb_i, Z, Y, X, Dw, P1, P2, MGM, Lv);
+                            else combine_whirsch<LPL>(Cv, X, Y, Z, nb_i, Dw, P1, P2, MGM, Lv);
+                        } else {
+                            if constexpr (FORM == 0)
+                                combine_wfh<LPL>(Cv, nb_i, Z, Y, X, Dw, P1, P2, MGM, lane, L, Lv);
+                            else
+                                combine_wfh<LPL>(Cv, X, Y, Z, nb_i, Dw, P1, P2, MGM, lane, L, Lv);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < LPL; k++) Lv[k] = Cv[k];
+                }
+                if (prof) {
+                    asm volatile("" : "+v"(Lv[0]), "+v"(Lv[LPL - 1]));
+                    ph[1] += clock64() - c1;  // combine
+                }
+                const unsigned long long c2 = prof ? clock64() : 0;
+                if (!(P.xflags & 1)) {
+                    float *q = Lrb + pix * L + lane * LPL;
+#pragma unroll
+                    for (int k = 0; k < LPL; k++) q[k] = Lv[k];
+                }
+                const float m = slab_min<LPL>(Lv);
+                nb_i.m = m;
+                if (prof) {
+                    float mm = m;
+                    asm volatile("" : "+v"(mm));
+                    ph[2] += clock64() - c2;  // store issue + wave min
+                }
+                const unsigned long long c3 = prof ? clock64() : 0;
+                if constexpr (!WEIGHTED) {
+                    if constexpr (!FH) {
+                        float N[LPL];
+                        neighbour_min<LPL>(Lv, N);
+                        const float cap = m + P2;
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) nb_i.w[0][k] = fminf(fminf(Lv[k], N[k] + P1), cap);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) nb_i.w[0][k] = Lv[k];
+                        fh_minconv<LPL>(nb_i.w[0], m, P1, P2, lane, L);
+                    }
+                    if constexpr (pubE) {
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) nb_i.w[0][k] = nb_i.w[0][k] - m;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < LPL; k++) nb_i.w[0][k] = Lv[k];
+                    if constexpr (!FH) neighbour_min<LPL>(Lv, nb_i.w[NS - 1]);
+                }
+                if (prof) {
+                    asm volatile("" : "+v"(nb_i.w[0][0]), "+v"(nb_i.w[0][LPL - 1]));
+                    ph[3] += clock64() - c3;  // publish transform
+                }
+                const unsigned long long c4 = prof ? clock64() : 0;
+                if (to_lds) {
+                    float *dst = t_dst0 + (i & 1) * NSLP;
+#pragma unroll
+                    for (int q = 0; q < NS; q++)
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) dst[q * LP + k] = nb_i.w[q][k];
+                    if constexpr (!pubE)
+                        if (lane == 0) Tm[r * 2 + (i & 1)] = m;
+                }
+                if (prof) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    ph[4] += clock64() - c4;  // LDS write retired
+                }
+                if (to_global) {
+#pragma unroll
+                    for (int q = 0; q < NS; q++)
+                        store_slab_sc1_wide<LPL>(hand_out + ((long long)i * NS + q) * LP, lane, nb_i.w[q]);
+                    if constexpr (!pubE)
+                        if (lane == 0) st_sc1_x1(handm_out + i, m);
+                    // Publish progress PUBLAG steps late, every PUBEVERY pixels: this wave only issues
+                    // stores, and they retire in order, so once at most PUBLAG*SPS newer stores are
+                    // outstanding every store of step i-PUBLAG (hand-off slab, minimum) has reached
+                    // memory.  SPS is a lower bound of the stores issued per step (the Lr slab + the
+                    // hand-off slabs), which only makes the wait conservative.  The word is not written
+                    // every step: write-through stores to one address serialise at ~1.5 us each.
+                    constexpr int SPS = 1 + NS * sc1_store_count<LPL>();
+                    constexpr int PUBLAG = (63 / SPS) < MGM_P2_PUBLAG ? (63 / SPS) : MGM_P2_PUBLAG;
+                    constexpr int PUBEVERY = 4;
+                    if (i == LL - 1) {
+                        wait_vmcnt<0>();
+                        if (lane == 0) __hip_atomic_store(prog_out, (unsigned)LL, RLX_AGENT);
+                    } else if (((i - PUBLAG + 1) % PUBEVERY) == 0 && i - PUBLAG >= 0) {
+                        wait_vmcnt<PUBLAG * SPS>();
+                        if (lane == 0) __hip_atomic_store(prog_out, (unsigned)(i - PUBLAG + 1), RLX_AGENT);
+                    }
+                }
+            }
+        };
+
+        step_barrier();  // B0: the loaders' prologue has landed
+        int cslot = 0;
+        unsigned long long t_cbar = 0;
+        for (int s = 0; s < nsteps; s += 3) {
+            step(s, cslot, wA, wB, wC);
+            cslot = cslot + 1 == RD ? 0 : cslot + 1;
+            const unsigned long long t0 = (dbg && r == NC / 2) ? wall_clock64() : 0;
+            step_barrier();
+            if (dbg && r == NC / 2) t_cbar += wall_clock64() - t0;
+            step(s + 1, cslot, wB, wC, wA);
+            cslot = cslot + 1 == RD ? 0 : cslot + 1;
+            step_barrier();
+            step(s + 2, cslot, wC, wA, wB);
+            cslot = cslot + 1 == RD ? 0 : cslot + 1;
+            step_barrier();
+        }
+        if (dbg && r == NC / 2 && lane == 0) {
+            dbg[14] = t_cbar * 3;
+            dbg[3] = ph[0]; dbg[4] = ph[1]; dbg[11] = ph[2]; dbg[12] = ph[3]; dbg[13] = ph[4];
+        }
+    };
+    if (form == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+}
+
+// ---- launcher (one translation unit per LPL: -DMGM_P2_LPL=n) -----------------------
+template <int LPL, bool FH, bool WEIGHTED, int MGM>
+static hipError_t launch2_one(const PassParams &p, int ntasks, hipStream_t s)
+{
+    constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
+    using PL = Plan<LPL, NS, WEIGHTED || (FH && MGM == 2)>;
+    const size_t shmem = sizeof(float) * (size_t)PL::lds_floats(PL::D);
+    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(ntasks), dim3((PL::NC + PL::NL) * 64), shmem, s, p);
+    return hipGetLastError();
+}
+
+template <int LPL, bool FH, bool WEIGHTED>
+static hipError_t launch2_mgm(const PassParams &p, int ntasks, hipStream_t s)
+{
+    switch (p.MGM) {
+        case 1: return launch2_one<LPL, FH, WEIGHTED, 1>(p, ntasks, s);
+        case 2: return launch2_one<LPL, FH, WEIGHTED, 2>(p, ntasks, s);
+        case 3: return launch2_one<LPL, FH, WEIGHTED, 3>(p, ntasks, s);
+        case 4: return launch2_one<LPL, FH, WEIGHTED, 4>(p, ntasks, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+#ifndef MGM_P2_LPL
+#error "compile with -DMGM_P2_LPL=<1|2|3|4|6|8>"
+#endif
+template <>
+hipError_t launch_pass2_lpl<MGM_P2_LPL>(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s)
+{
+    constexpr int LPL = MGM_P2_LPL;
+    if (!wmode) return fh ? launch2_mgm<LPL, true, false>(p, ntasks, s) : launch2_mgm<LPL, false, false>(p, ntasks, s);
+    return fh ? launch2_mgm<LPL, true, true>(p, ntasks, s) : launch2_mgm<LPL, false, true>(p, ntasks, s);
+}
+
+}  // namespace mgm

@@ -1,0 +1,30 @@
+// mgm_pass2_dispatch.hip -- picks the per-LPL object of the second K3 build
+// (mgm_pass2.hip is compiled once per LPL with -DMGM_P2_LPL=n).
+#include "mgm_device.h"
+
+namespace mgm {
+
+// lines per band of the second build (0 = this L is not supported by it)
+int pass2_lines(int L)
+{
+    if (L % 64) return 0;
+    const int lpl = L / 64;
+    if (lpl == 1 || lpl == 2 || lpl == 3 || lpl == 4) return 14;
+    if (lpl == 6 || lpl == 8) return 7;
+    return 0;
+}
+
+hipError_t launch_pass2(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s)
+{
+    switch (p.L % 64 ? 0 : p.L / 64) {
+        case 1: return launch_pass2_lpl<1>(p, ntasks, fh, wmode, s);
+        case 2: return launch_pass2_lpl<2>(p, ntasks, fh, wmode, s);
+        case 3: return launch_pass2_lpl<3>(p, ntasks, fh, wmode, s);
+        case 4: return launch_pass2_lpl<4>(p, ntasks, fh, wmode, s);
+        case 6: return launch_pass2_lpl<6>(p, ntasks, fh, wmode, s);
+        case 8: return launch_pass2_lpl<8>(p, ntasks, fh, wmode, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mgm

@@ -38,6 +38,9 @@ def main():
     ctx = mgm_amd.Context(0)
     print(mgm_amd.load_library().mgm_version().decode(), flush=True)
     bad = 0
+    nb = ctx.selftest_div3()
+    print('SELFTEST div3: mismatching inputs =', nb, flush=True)
+    bad += nb != 0
 
     # ---- cost volume ----
     for nch, (nx, ny), (dmin, dmax), (pre, dist), win, td in [

@@ -1,0 +1,20 @@
+"""Development aid: run one full-size aggregation with MGM_HIP_DEBUG_STATS=1."""
+import os, sys
+os.environ.setdefault("MGM_HIP_DEBUG_STATS", "1")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import mgm_amd
+from mgm_amd import synth
+cfgs = {"cfg2": (1920, 1080, 128, 4, 2, 0, 8.0, 32.0), "cfg3h": (1920, 1080, 256, 8, 3, 0, 8.0, 32.0),
+        "cfg3": (1920, 1080, 256, 8, 3, 1, 2.0, 20000.0)}
+for name in sys.argv[1:] or ["cfg3h"]:
+    nx, ny, L, NDIR, MGM, FH, P1, P2 = cfgs[name]
+    ctx = mgm_amd.Context(0)
+    cv = ctx.upload_volume(synth.raw_volume(nx, ny, L), 0)
+    ctx.timing(True)
+    for rep in range(2):
+        ctx.timing_reset()
+        _, o, c = ctx.aggregate_dev(cv, P1, P2, NDIR, MGM, FH, 1, None, "vfit")
+        ctx.synchronize()
+        print(name, ctx.timings(), flush=True)
+    ctx.close()
