@@ -56,6 +56,30 @@ static inline float fmin3(float a, float b, float c)
     return m;
 }
 
+/* Check of the HIP kernels' exact division by three (mgm_pass_common.h div3_exact) with C fmaf:
+ * counts inputs in [start, end) (stride `step` over float bit patterns) whose
+ * q = fma(fma(-3, x*c, x), c, x*c) differs from x/3; -0 and +-inf are excluded
+ * (the device finishes with v_div_fixup_f32, tested on the device by mgm_selftest_div3). */
+unsigned long long orc_check_div3(unsigned long long start, unsigned long long end, unsigned long long step)
+{
+    const float c = 1.0f / 3.0f;
+    unsigned long long bad = 0;
+    for (unsigned long long b = start; b < end; b += step) {
+        uint32_t u = (uint32_t)b, a, q;
+        float x, ref, q0, r, qq;
+        memcpy(&x, &u, 4);
+        if (!isfinite(x) || u == 0x80000000u) continue;
+        ref = x / 3.0f;
+        q0 = x * c;
+        r = fmaf(-3.0f, q0, x);
+        qq = fmaf(r, c, q0);
+        memcpy(&a, &ref, 4);
+        memcpy(&q, &qq, 4);
+        if (a != q) bad++;
+    }
+    return bad;
+}
+
 /* ------------------------------------------------------------------------ */
 /* Census transform: census_tools.cc:16-57, 76-99, 127-153.                  */
 /* Bits "centre < neighbour" in order (channel, dy, dx), centre skipped, NaN */

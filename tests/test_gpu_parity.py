@@ -1,0 +1,160 @@
+"""Parity of the HIP path (through the C ABI of libmgm_hip.so) with the CPU oracle and
+with the golden vectors of the compiled reference.  Bit-exact for volumes, labels and
+costs; V-fit refined disparities are compared bit-exactly as well (tolerance allowed by
+the task: 1e-5).  Run on a real MI355X:  python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+
+from helpers import golden_cases, labels_equal, load_golden, ndiff
+from mgm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+VFIT_TOL = 1e-5  # stated tolerance for the floating-point refinement; the tests assert 0 differing bits
+
+
+def test_device_selftest_exact_division_by_three(ctx):
+    assert ctx.selftest_div3() == 0  # all 2^32 inputs
+
+
+# ---- golden vectors of the reference --------------------------------------------
+@pytest.mark.parametrize("name", golden_cases("cv"))
+def test_golden_costvolume(ctx, name):
+    g = load_golden(name)
+    if str(g["prefilter"]) not in ("none", "census") or str(g["distance"]) not in ("ad", "sd", "census"):
+        pytest.skip("mode not built on the device yet")
+    u, v = ctx.upload_image(g["u"]), ctx.upload_image(g["v"])
+    cv = ctx.costvolume_dev(u, v, int(g["dmin"]), int(g["dmax"]), str(g["prefilter"]), str(g["distance"]),
+                            float(g["truncDist"]), int(g["census_win"]))
+    assert ndiff(cv.download(), g["C"]) == 0
+    for h in (cv, u, v):
+        h.free()
+
+
+@pytest.mark.parametrize("name", golden_cases("weights"))
+def test_golden_weights(ctx, name):
+    g = load_golden(name)
+    u = ctx.upload_image(g["u"])
+    w = ctx.weights_dev(u, float(g["aP"]), float(g["aThresh"]))
+    assert ndiff(w.download(), g["w8"]) == 0
+    u.free(), w.free()
+
+
+@pytest.mark.parametrize("name", golden_cases("agg"))
+def test_golden_aggregation(ctx, name):
+    g = load_golden(name)
+    dmin = int(g["dmin"])
+    cv = ctx.upload_volume(g["C"], dmin)
+    args = (float(g["P1"]), float(g["P2"]), int(g["NDIR"]), int(g["MGM"]), int(g["FH"]), int(g["FIX"]), g.get("w8"))
+    S, out, outc = ctx.aggregate(cv, *args, None, want_S=True)
+    assert ndiff(S.download(), g["S"]) == 0
+    assert ndiff(outc, g["outcost"]) == 0
+    assert labels_equal(out, g["out"], outc)
+    # stand-alone refinement on the materialised S, then the fused form
+    ro, rc = ctx.refine(S, "vfit", g["out"], g["outcost"])
+    assert ndiff(ro, g["out_vfit"]) == 0 and ndiff(rc, g["outcost_vfit"]) == 0
+    _, fo, fc = ctx.aggregate(cv, *args, "vfit", want_S=False)
+    fin = np.isfinite(g["outcost"])
+    assert ndiff(fo[fin], g["out_vfit"][fin]) == 0 and ndiff(fc, g["outcost_vfit"]) == 0
+    assert np.nanmax(np.abs(fo[fin] - g["out_vfit"][fin]), initial=0) <= VFIT_TOL
+    S.free(), cv.free()
+
+
+# ---- seeded sweeps against the oracle ----------------------------------------------
+SHAPES = [(40, 37, 12), (70, 35, 64), (35, 70, 100), (50, 40, 128), (130, 70, 151), (45, 33, 192), (64, 48, 256),
+          (48, 40, 300), (40, 36, 384), (40, 36, 512)]
+MODES = [(8, 3, 0, 8.0, 32.0), (4, 2, 0, 8.0, 32.0), (8, 4, 0, 8.0, 32.0), (8, 1, 0, 8.0, 32.0),
+         (8, 3, 1, 2.0, 20000.0), (4, 2, 1, 2.0, 9.0), (8, 4, 1, 1.5, np.inf), (3, 1, 1, 2.0, 9.0)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%dx%dx%d" % s)
+def test_aggregation_modes_vs_oracle(ctx, oracle, shape):
+    nx, ny, L = shape
+    C = synth.raw_volume(nx, ny, L, inf_frac=0.03)
+    dmin = -5
+    cv = ctx.upload_volume(C, dmin)
+    rng = np.random.default_rng(7)
+    for (NDIR, MGM, FH, P1, P2) in MODES:
+        for wmode in (0, 1):
+            w8 = None
+            if wmode:
+                w8 = np.where(rng.random((8, ny, nx)) < 0.5, 0.3 if FH else 4.0, 1.0).astype(np.float32)
+            Sa, oa, ca, lra = oracle.mgm(C, dmin, P1, P2, NDIR, MGM, FH, 1, w8, dump_lr=True)
+            Sb, ob, cb = ctx.aggregate(cv, P1, P2, NDIR, MGM, FH, 1, w8, None, want_S=True)
+            tag = (shape, NDIR, MGM, FH, wmode)
+            for p in range(NDIR):
+                assert ndiff(lra[p], ctx.debug_lr(cv, p)) == 0, tag + ("Lr", p)
+            assert ndiff(Sa, Sb.download()) == 0, tag
+            assert ndiff(ca, cb) == 0 and labels_equal(oa, ob, ca), tag
+            fin = np.isfinite(ca)
+            ora, cra = oracle.refine(Sa, dmin, "vfit", np.where(fin, oa, dmin), ca)
+            _, fo, fc = ctx.aggregate(cv, P1, P2, NDIR, MGM, FH, 1, w8, "vfit", want_S=False)
+            assert ndiff(ora[fin], fo[fin]) == 0 and ndiff(cra, fc) == 0, tag + ("vfit",)
+            Sb.free()
+    cv.free()
+
+
+COSTS = [(1, (40, 23), (-7, 8), "none", "ad", 3, np.inf), (3, (40, 23), (-7, 8), "none", "ad", 3, 25.0),
+         (1, (40, 23), (-7, 8), "none", "census", 3, np.inf), (1, (40, 23), (-7, 8), "none", "census", 5, np.inf),
+         (3, (40, 23), (-30, 40), "none", "census", 3, np.inf), (3, (40, 23), (-30, 40), "none", "census", 5, np.inf),
+         (1, (70, 23), (30, 100), "none", "census", 7, 20.0), (1, (40, 23), (-7, 8), "census", "ad", 3, np.inf),
+         (3, (33, 17), (-70, 70), "none", "sd", 3, 50.0), (1, (1, 1), (0, 0), "none", "ad", 3, np.inf),
+         (1, (5, 3), (-300, 211), "none", "census", 3, np.inf)]
+
+
+@pytest.mark.parametrize("case", COSTS, ids=lambda c: "%dch-%s-%s-w%d" % (c[0], c[3], c[4], c[5]))
+def test_costvolume_vs_oracle(ctx, oracle, case):
+    nch, (nx, ny), (dmin, dmax), pre, dist, win, td = case
+    u, v, _ = synth.stereo_pair(nx, ny, max(dmin, -nx // 4), min(dmax, nx // 4), nch=nch)
+    a = oracle.costvolume(u, v, dmin, dmax, pre, dist, td, win)
+    # host-buffer entry point with per-pixel range images, like the reference's main()
+    dminI = np.full((ny, nx), dmin, np.float32)
+    dmaxI = np.full((ny, nx), dmax, np.float32)
+    cv = ctx.costvolume(u, v, dminI, dmaxI, pre, dist, td, win)
+    assert ndiff(a, cv.download()) == 0
+    cv.free()
+
+
+def test_unsupported_and_invalid_inputs_fail_loudly(ctx):
+    import mgm_amd
+    u, v, _ = synth.stereo_pair(16, 8, -3, 3)
+    du, dv = ctx.upload_image(u), ctx.upload_image(v)
+    for kw in (dict(prefilter="sobelx"), dict(distance="ncc")):
+        with pytest.raises(mgm_amd.MgmError) as e:
+            ctx.costvolume_dev(du, dv, -3, 3, **kw)
+        assert e.value.code == mgm_amd.MGM_ERR_UNSUPPORTED
+    ragged = np.full((8, 16), -3, np.float32)
+    ragged[2, 2] = -2
+    with pytest.raises(mgm_amd.MgmError) as e:
+        ctx.costvolume(u, v, ragged, np.full((8, 16), 3, np.float32))
+    assert e.value.code == mgm_amd.MGM_ERR_UNSUPPORTED
+    cv = ctx.costvolume_dev(du, dv, -3, 3)
+    for bad in (dict(NDIR=9, MGM=2), dict(NDIR=4, MGM=5), dict(NDIR=0, MGM=1)):
+        with pytest.raises(mgm_amd.MgmError) as e:
+            ctx.aggregate(cv, 8.0, 32.0, bad["NDIR"], bad["MGM"])
+        assert e.value.code == mgm_amd.MGM_ERR_INVALID
+    # unknown cost / refinement names fall back silently, as in the reference
+    cv2 = ctx.costvolume_dev(du, dv, -3, 3, "nope", "nope")
+    assert ndiff(cv.download(), cv2.download()) == 0
+    for h in (cv, cv2, du, dv):
+        h.free()
+
+
+def test_both_builds_of_the_pass_kernel_agree(oracle):
+    """K3 exists twice (register-prefetch build, LDS-DMA build); they must agree bit for bit."""
+    import os
+    import mgm_amd
+    C = synth.raw_volume(200, 120, 128, inf_frac=0.01)
+    res = []
+    for build in ("1", "0"):
+        os.environ["MGM_HIP_PASS_BUILD"] = build
+        c = mgm_amd.Context(0)
+        cv = c.upload_volume(C, 0)
+        S, o, oc = c.aggregate(cv, 8.0, 32.0, 8, 3, 0, 1, None, "vfit", want_S=True)
+        res.append((S.download(), o, oc))
+        c.close()
+    os.environ.pop("MGM_HIP_PASS_BUILD")
+    Sa, oa, ca = oracle.mgm(C, 0, 8.0, 32.0, 8, 3)
+    assert ndiff(res[0][0], res[1][0]) == 0 and ndiff(res[0][1], res[1][1]) == 0
+    assert ndiff(res[0][0], Sa) == 0

@@ -1,0 +1,35 @@
+"""Host-side plumbing that needs no device: synthetic inputs, the exact x/3 sequence
+(checked on the CPU with C fmaf over a strided sample of all floats), CPU counting."""
+import ctypes
+
+import numpy as np
+
+from mgm_amd import synth
+from oracle.oracle import usable_cpus
+
+
+def test_synth_is_deterministic_and_in_range():
+    a = synth.stereo_pair(64, 40, -12, 3)
+    b = synth.stereo_pair(64, 40, -12, 3)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    u, v, gt = a
+    assert u.dtype == np.float32 and u.shape == (1, 40, 64) and gt.min() >= -12 and gt.max() <= 3
+    assert np.array_equal(u, np.rint(u)) and u.min() >= 0 and u.max() <= 255
+    C = synth.raw_volume(20, 10, 16, inf_frac=0.2)
+    assert np.isfinite(C).any(axis=2).all()
+
+
+def test_div3_sequence_matches_ieee_division(oracle):
+    """q = fma(fma(-3, x*c, x), c, x*c), c = RN(1/3): equal to x/3 for every finite float
+    but -0 (the kernels finish with v_div_fixup_f32, which repairs -0 and +-inf)."""
+    f = oracle.lib.orc_check_div3
+    f.restype = ctypes.c_ulonglong
+    f.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong]
+    assert f(0, 1 << 32, 61) == 0            # strided sample of all bit patterns
+    assert f(0x3f000000, 0x3f000000 + (1 << 22), 1) == 0   # one binade exhaustively
+    assert f(0, 1 << 16, 1) == 0             # subnormals near zero
+
+
+def test_usable_cpus():
+    assert 1 <= usable_cpus() <= 64
