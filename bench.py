@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""bench.py -- disparity-volumes/s of the MGM hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3]
+
+One "step" = one full pass of the hot path over one synthetic stereo pair whose images are
+already resident in HBM: census transform + W*H*L cost volume (K1, K2), all-direction MGM
+aggregation (K3), ordered sum + over-count fix + WTA + V-fit (K4-K6).  Outputs stay on the
+device.  With N > 1 (launched by torch.distributed.run, one process per GPU) every rank
+processes its own independent pairs -- the reference has no cross-pair coupling, so there
+is no data-path collective -- and the job rate is N*K volumes over the slowest rank's time
+(weak scaling).  torch is used for the process group, the barrier and the max-reduction only.
+
+Rank 0 prints ONE JSON line; see the fields `roofline` and `cpu_baseline` in DESIGN.md.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs: shape, labels, census window, NDIR, TSGM, FH, P1, P2
+WORKLOADS = {
+    "cfg2": dict(nx=1920, ny=1080, dmin=-127, dmax=0, win=3, NDIR=4, MGM=2, FH=0, P1=8.0, P2=32.0,
+                 desc="1920x1080 synthetic pair, 128 disparities, CENSUS 3x3, -O 4 TSGM=2"),
+    "cfg3": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0,
+                 desc="1920x1080 synthetic pair, 256 disparities, CENSUS 5x5, -O 8 TSGM=3, FH truncated-linear V"),
+    "cfg3h": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0,
+                  desc="1920x1080 synthetic pair, 256 disparities, CENSUS 5x5, -O 8 TSGM=3, Hirschmueller V"),
+    "cfg5": dict(nx=1024, ny=1024, dmin=-127, dmax=0, win=3, NDIR=4, MGM=2, FH=0, P1=8.0, P2=32.0,
+                 desc="1024x1024 synthetic pair, 128 disparities, CENSUS 3x3, -O 4 TSGM=2 (throughput mode)"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def run_step(ctx, du, dv, w, out, outc, cv=None):
+    cv = ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", "census", float("inf"), w["win"], into=cv)
+    ctx.aggregate_dev(cv, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, None, "vfit", out, outc, want_S=False)
+    return cv
+
+
+def cpu_baseline(w, seconds_target=15.0):
+    """The CPU oracle (plain-C port of the reference path, 1 thread) timed on a row-band of the same
+    workload; the band height is chosen so that the run takes about `seconds_target` seconds."""
+    from mgm_amd import synth
+    from oracle.oracle import Oracle
+    orc = Oracle(threads=1)
+    nx, L = w["nx"], w["dmax"] - w["dmin"] + 1
+    # calibrate on a thin band, then size the sample
+    rows = 8
+    u, v, _ = synth.stereo_pair(nx, rows, w["dmin"] * 3 // 4, 0)
+    t0 = time.perf_counter()
+    C = orc.costvolume(u, v, w["dmin"], w["dmax"], "none", "census", np.inf, w["win"])
+    S, o, c = orc.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1)
+    orc.refine(S, w["dmin"], "vfit", o, c)
+    per_row = (time.perf_counter() - t0) / rows
+    rows = int(max(16, min(w["ny"], seconds_target / per_row)))
+    u, v, _ = synth.stereo_pair(nx, rows, w["dmin"] * 3 // 4, 0)
+    t0 = time.perf_counter()
+    C = orc.costvolume(u, v, w["dmin"], w["dmax"], "none", "census", np.inf, w["win"])
+    S, o, c = orc.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1)
+    orc.refine(S, w["dmin"], "vfit", o, c)
+    dt = time.perf_counter() - t0
+    vol_per_s = (rows / w["ny"]) / dt  # linear in the number of rows
+    return {"value": vol_per_s, "unit": "disparity-volumes/s", "cores": 1, "kind": "port",
+            "sample": "%dx%dx%d band (%d of %d rows) of the same workload, %.1f s of CPU time, extrapolated "
+                      "linearly in rows; oracle/mgm_oracle.c, 1 thread" % (nx, rows, L, rows, w["ny"], dt),
+            "mcell_updates_per_s": nx * rows * L * w["NDIR"] / dt / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" %
+                 (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: there is no CPU path in mgm_amd")
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import mgm_amd
+    from mgm_amd import synth
+    ctx = mgm_amd.Context(local)
+    nx, ny, L = w["nx"], w["ny"], w["dmax"] - w["dmin"] + 1
+    # every rank gets its own pair (different seed): independent units, no exchange
+    u, v, _ = synth.stereo_pair(nx, ny, w["dmin"] * 3 // 4, 0, seed=synth.SEED + rank)
+    du, dv = ctx.upload_image(u), ctx.upload_image(v)
+    out, outc = ctx.new_image(nx, ny), ctx.new_image(nx, ny)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    cv = None  # the W*H*L volume is allocated once and refilled every step
+    for _ in range(max(1, args.warmup)):
+        cv = run_step(ctx, du, dv, w, out, outc, cv)
+    sync_all()
+    ctx.timing(True)
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(ctx, du, dv, w, out, outc, cv)  # enqueue only: nothing synchronises inside the timed region
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern = {}
+    for name, ms in ctx.timings():
+        kern.setdefault(name, []).append(ms)
+    ctx.timing(False)
+    cv.free()
+
+    if rank == 0:
+        cells = float(nx) * ny * L
+        value = world * args.steps / dt
+        avg = {k: float(np.mean(vs)) for k, vs in kern.items()}
+        per_step = {k: float(np.sum(vs)) / args.steps for k, vs in kern.items()}
+        pass_name = "k_pass2" if "k_pass2" in avg else "k_pass"
+        # Aggregation stage = K3 (pass kernel) + K4-K6 (k_wta): the two launches together do what the
+        # reference's aggregation loop does; SURVEY.md 8(d): 12 B per cell per direction.
+        agg_ms = avg[pass_name] + avg["k_wta"]
+        alg_bytes = 12.0 * w["NDIR"] * cells
+        achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(prof):
+            tj = json.load(open(prof))
+            if tj.get("workload") == args.workload:
+                traffic = tj.get("aggregation_hbm_bytes_per_volume")
+        roofline = {"bound": "hbm", "kernel": "%s+k_wta (8-direction aggregation, one launch each per volume)" % pass_name,
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                    "avg_launch_ms": {k: avg[k] for k in sorted(avg)},
+                    "per_kernel": {
+                        pass_name: {"alg_bytes": 8.0 * w["NDIR"] * cells,
+                                    "GBps": 8.0 * w["NDIR"] * cells / (avg[pass_name] * 1e-3) / 1e9},
+                        "k_wta": {"alg_bytes": (4.0 * w["NDIR"] + 4.0) * cells + 8.0 * nx * ny,
+                                  "GBps": ((4.0 * w["NDIR"] + 4.0) * cells) / (avg["k_wta"] * 1e-3) / 1e9},
+                        "k_cost": {"alg_bytes": 4.0 * cells, "GBps": 4.0 * cells / (avg["k_cost"] * 1e-3) / 1e9}}}
+        res = {"metric": "disparity-volumes/sec (W*H*L cost volume -> 8-dir MGM -> WTA+vfit)", "value": value,
+               "unit": "disparity-volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%s: %s" % (args.workload, w["desc"]), "W": nx, "H": ny, "L": L,
+                          "NDIR": w["NDIR"], "TSGM": w["MGM"], "potential": "FH" if w["FH"] else "Hirschmueller",
+                          "P1": w["P1"], "P2": w["P2"], "census_win": w["win"], "refine": "vfit",
+                          "parallelism": "independent pairs, one per GPU" if world > 1 else "1 GPU"},
+               "roofline": roofline,
+               "kernel_ms_per_step": per_step,
+               "mcell_updates_per_s": world * args.steps * cells * w["NDIR"] / dt / 1e6}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(w)
+            res["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,7 +87,8 @@ int mgm_cv_free(mgm_ctx *ctx, mgm_cv *cv);
  * reference does (mgm_costvolume.h:184-190, 201-207).  census_win is the value
  * of the reference's CENSUS_NCC_WIN environment parameter (mgm_costvolume.h:61).
  * Built: none/census x ad/sd/census.  sobelx, gblur, ncc, btad, btsd return
- * MGM_ERR_UNSUPPORTED. */
+ * MGM_ERR_UNSUPPORTED.  *C must be NULL (a new volume is allocated) or a volume of
+ * the same geometry, which is then refilled in place (no allocation, no sync). */
 int mgm_costvolume_build_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, int dmin, int dmax,
                              const char *prefilter, const char *distance, float truncDist, int census_win,
                              mgm_cv **C);

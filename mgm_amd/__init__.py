@@ -197,11 +197,11 @@ class Context:
 
     # ---- the path ----
     def costvolume_dev(self, u, v, dmin, dmax, prefilter="none", distance="ad", truncDist=float("inf"),
-                       census_win=3):
-        h = C.c_void_p()
+                       census_win=3, into=None):
+        h = C.c_void_p(into.h.value) if into is not None else C.c_void_p()
         self._chk(self.lib.mgm_costvolume_build_dev(self.h, u.h, v.h, dmin, dmax, prefilter.encode(),
                                                     distance.encode(), truncDist, census_win, C.byref(h)))
-        return CostVolume(self, h)
+        return into if into is not None else CostVolume(self, h)
 
     def costvolume(self, u, v, dminI, dmaxI, prefilter="none", distance="ad", truncDist=float("inf"), census_win=3):
         """Host-buffer form with per-pixel range images, like the reference."""

@@ -418,8 +418,13 @@ int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int
     if (costfn > 2) return fail(c, MGM_ERR_UNSUPPORTED, "distance ncc/btad/btsd is not built yet");
     if (pre > 1) return fail(c, MGM_ERR_UNSUPPORTED, "prefilter sobelx/gblur is not built yet");
 
-    int r = mgm_cv_create(c, u->nx, u->ny, dmin, dmax, out);
-    if (r) return r;
+    int r = MGM_OK;
+    if (*out) {  // caller-provided volume to refill (must have the right geometry)
+        if ((*out)->nx != u->nx || (*out)->ny != u->ny || (*out)->dmin != dmin || (*out)->dmax != dmax)
+            return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: *C is non-NULL but has a different geometry");
+    } else if ((r = mgm_cv_create(c, u->nx, u->ny, dmin, dmax, out))) {
+        return r;
+    }
     CostParams p{};
     p.C = (*out)->d;
     p.nx = u->nx;
@@ -474,6 +479,7 @@ int mgm_costvolume_build(mgm_ctx *c, const float *u, const float *v, int nx, int
         if ((int)dminI[i] != dmin || (int)dmaxI[i] != dmax)
             return fail(c, MGM_ERR_UNSUPPORTED, "per-pixel (ragged) disparity ranges are not built yet");
     mgm_img *du = nullptr, *dv = nullptr;
+    *out = nullptr;
     int r = mgm_img_upload(c, u, nx, ny, nch, &du);
     if (!r) r = mgm_img_upload(c, v, vnx, vny, nch, &dv);
     if (!r) r = mgm_costvolume_build_dev(c, du, dv, dmin, dmax, prefilter, distance, truncDist, census_win, out);
