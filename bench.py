@@ -84,6 +84,7 @@ def main():
     w = WORKLOADS[args.workload]
 
     import torch
+    dist = None
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -125,10 +126,8 @@ def main():
         run_step(ctx, du, dv, w, out, outc, cv)  # enqueue only: nothing synchronises inside the timed region
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from mgm_amd import shard
+    dt = shard.max_over_ranks(dt, dist if world > 1 else None, device="cuda")
     kern = {}
     for name, ms in ctx.timings():
         kern.setdefault(name, []).append(ms)
@@ -137,7 +136,7 @@ def main():
 
     if rank == 0:
         cells = float(nx) * ny * L
-        value = world * args.steps / dt
+        value = shard.job_rate([args.steps] * world, dt)  # whole-job aggregate: every rank did K volumes
         avg = {k: float(np.mean(vs)) for k, vs in kern.items()}
         per_step = {k: float(np.sum(vs)) / args.steps for k, vs in kern.items()}
         pass_name = "k_pass2" if "k_pass2" in avg else "k_pass"
