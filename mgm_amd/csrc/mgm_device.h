@@ -103,6 +103,17 @@ __device__ __forceinline__ float dpp_shl1(float v, float fill)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill),
                                                                  __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
+// generic DPP move: lanes without a source (row edge / masked row) receive `fill`
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_mov(float v, float fill)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill),
+                                                                 __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ float dpp_min_step(float v)
 {

@@ -374,6 +374,8 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
 
         // one step: X receives the new fwd slab; Y = back, Z = same
         unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long fh_sweeps = 0, fh_n = 0;
+        unsigned fh_max = 0;
         const bool prof = dbg && r == NC / 2;
         auto step = [&](int s, int cslot, NbT &X, const NbT &Y, const NbT &Z) {
             const int i = s - 1 - 2 * r;
@@ -459,7 +461,9 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
                     } else {
 #pragma unroll
                         for (int k = 0; k < LPL; k++) nb_i.w[0][k] = Lv[k];
-                        fh_minconv<LPL>(nb_i.w[0], m, P1, P2, lane, L);
+                        unsigned sw = 0;
+                        fh_minconv<LPL>(nb_i.w[0], m, P1, P2, lane, L, prof ? &sw : nullptr);
+                        if (prof) { fh_sweeps += sw; fh_max = sw > fh_max ? sw : fh_max; fh_n++; }
                     }
                     if constexpr (pubE) {
 #pragma unroll
@@ -533,6 +537,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
         if (dbg && r == NC / 2 && lane == 0) {
             dbg[14] = t_cbar * 3;
             dbg[3] = ph[0]; dbg[4] = ph[1]; dbg[11] = ph[2]; dbg[12] = ph[3]; dbg[13] = ph[4];
+            dbg[15] = (fh_sweeps << 32) | ((unsigned long long)fh_max << 24) | (fh_n & 0xffffff);
         }
     };
     if (form == 0) run(std::integral_constant<int, 0>{});

@@ -101,58 +101,126 @@ __device__ __forceinline__ void neighbour_min(const float (&Lv)[LPL], float (&N)
 // which is unique and equals the sequential result (lane 0 has no carry-in, so
 // after n sweeps lanes 0..n-1 are exact; the loop ends when a sweep changes
 // nothing, normally the first).  `valid` masks label slots >= L.
-template <int LPL>
-__device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, float P2, int lane, int L)
+// n-fold x (+) P1, exactly, when the additions inside a binade are exact (P1 a multiple of the
+// float grid there, e.g. P1 = 2 and values < 2^24): the only roundings of the sequential chain
+// happen on the steps that land in a higher binade, and each of those is ONE rounding of an
+// exactly known partial sum -- evaluated here in f64 and converted (RNE) to f32.  One loop
+// iteration per binade crossed instead of one per label.  If the premise does not hold the
+// value is merely a guess; the caller's fixed-point sweeps remain the ground truth.
+__device__ __forceinline__ float ramp_exact(float z, int n, double P1d, double invP1d)
 {
+    for (int it = 0; it < 48; it++) {
+        if (__builtin_amdgcn_ballot_w64(n > 0) == 0ull) break;
+        const unsigned zb = __builtin_bit_cast(unsigned, z);
+        if (n > 0 && (zb & 0x7f800000u) != 0x7f800000u) {
+            const double B = (double)__builtin_bit_cast(float, (zb & 0x7f800000u) + 0x00800000u);  // next power of two
+            const double dz = (double)z;
+            double t = __builtin_ceil((B - dz) * invP1d);  // steps until the chain lands at or above B
+            if (dz + (t - 1.0) * P1d >= B) t -= 1.0;
+            if (dz + t * P1d < B) t += 1.0;
+            if (!(t >= 1.0)) t = 1.0;
+            const double step = t < (double)n ? t : (double)n;
+            z = (float)(dz + step * P1d);
+            n -= (int)step;
+        } else {
+            n = 0;
+        }
+    }
+    return z;
+}
+
+// One direction of minConvTruncatedLinear.  FWD: M[o] = min(M[o-1] + P1, M[o]) for rising o.
+template <int LPL, bool FWD>
+__device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, unsigned *sweeps)
+{
+    constexpr int K0 = FWD ? 0 : LPL - 1;      // first label of the lane in scan order
+    constexpr int K1 = FWD ? LPL - 1 : 0;      // last
+    constexpr int DK = FWD ? 1 : -1;
     const float rampP = (float)LPL * P1;
-    // ---------------- forward ----------------
+    auto from_prev = [&](float v, int d) { return FWD ? __shfl_up(v, d) : __shfl_down(v, d); };
+    auto has_prev = [&](int d) { return FWD ? lane >= d : lane + d < 64; };
+    auto carry_in = [&](float c) { return FWD ? dpp_shr1(c, f_inf()) : dpp_shl1(c, f_inf()); };
+
+    float a = M[K0];  // carry-out ignoring carry-in: exact for the first lane, a candidate origin elsewhere
+#pragma unroll
+    for (int q = 1; q < LPL; q++) a = fminf(M[K0 + q * DK], a + P1);  // (compile-time indices: no scratch)
+
+    // cheap guess of the 64 carries: min-plus scan with single-rounded ramps.  Inside each row of
+    // 16 lanes with DPP row shifts (lanes without a source get +INF), across rows through the
+    // row totals read into SGPRs -- no LDS-crossbar permutes on this path.
+    float c = a;
     {
-        float a = M[0];
-#pragma unroll
-        for (int k = 1; k < LPL; k++) a = fminf(M[k], a + P1);
-        float c = a;  // carry-out ignoring carry-in: exact for lane 0, a guess elsewhere
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const float t = __shfl_up(c, d) + (float)d * rampP;
-            if (lane >= d) c = fminf(c, t);
+        const float r1 = rampP, r2 = 2.0f * rampP, r4 = 4.0f * rampP, r8 = 8.0f * rampP, r16 = 16.0f * rampP;
+        if constexpr (FWD) {
+            c = fminf(c, dpp_mov<0x111, 0xf>(c, f_inf()) + r1);  // row_shr:1
+            c = fminf(c, dpp_mov<0x112, 0xf>(c, f_inf()) + r2);  // row_shr:2
+            c = fminf(c, dpp_mov<0x114, 0xf>(c, f_inf()) + r4);  // row_shr:4
+            c = fminf(c, dpp_mov<0x118, 0xf>(c, f_inf()) + r8);  // row_shr:8
+            const float t0 = readlane_f(c, 15);                   // total of row 0 (at its last lane)
+            const float t1 = fminf(readlane_f(c, 31), t0 + r16);  // rows 0..1
+            const float t2 = fminf(readlane_f(c, 47), t1 + r16);  // rows 0..2
+            const int row = lane >> 4;
+            const float tp = row == 1 ? t0 : (row == 2 ? t1 : (row == 3 ? t2 : f_inf()));
+            c = fminf(c, tp + (float)((lane & 15) + 1) * rampP);
+        } else {
+            c = fminf(c, dpp_mov<0x101, 0xf>(c, f_inf()) + r1);  // row_shl:1
+            c = fminf(c, dpp_mov<0x102, 0xf>(c, f_inf()) + r2);  // row_shl:2
+            c = fminf(c, dpp_mov<0x104, 0xf>(c, f_inf()) + r4);  // row_shl:4
+            c = fminf(c, dpp_mov<0x108, 0xf>(c, f_inf()) + r8);  // row_shl:8
+            const float t3 = readlane_f(c, 48);                   // total of row 3 (at its first lane)
+            const float t2 = fminf(readlane_f(c, 32), t3 + r16);  // rows 2..3
+            const float t1 = fminf(readlane_f(c, 16), t2 + r16);  // rows 1..3
+            const int row = lane >> 4;
+            const float tp = row == 2 ? t3 : (row == 1 ? t2 : (row == 0 ? t1 : f_inf()));
+            c = fminf(c, tp + (float)(16 - (lane & 15)) * rampP);
         }
-        float f[LPL];
-        for (int it = 0; it < 66; it++) {
-            const float cin = dpp_shr1(c, f_inf());
-            f[0] = fminf(M[0], cin + P1);
-#pragma unroll
-            for (int k = 1; k < LPL; k++) f[k] = fminf(M[k], f[k - 1] + P1);
-            const bool same = (f[LPL - 1] == c);
-            c = f[LPL - 1];
-            if (__builtin_amdgcn_ballot_w64(!same) == 0ull) break;
-        }
-#pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = (lane * LPL + k < L) ? f[k] : f_inf();
     }
-    // ---------------- backward ----------------
-    {
-        float a = M[LPL - 1];
+    float f[LPL];
+    bool boosted = false;
+    for (int it = 0; it < 70; it++) {
+        // exact in-lane recurrence given the neighbour's carry
+        const float cin = carry_in(c);
+        f[K0] = fminf(M[K0], cin + P1);
 #pragma unroll
-        for (int k = LPL - 2; k >= 0; k--) a = fminf(M[k], a + P1);
-        float c = a;
+        for (int q = 1; q < LPL; q++) f[K0 + q * DK] = fminf(M[K0 + q * DK], f[K0 + (q - 1) * DK] + P1);
+        const bool same = (f[K1] == c);
+        c = f[K1];
+        if (sweeps) (*sweeps)++;
+        if (__builtin_amdgcn_ballot_w64(!same) == 0ull) break;
+        if (!boosted) {
+            // The guess was wrong somewhere: a ramp long enough to cross binades more than once
+            // (e.g. over a stretch of +INF costs).  Plain sweeps would repair one lane per sweep.
+            // Re-derive every carry as the exact image of its winning origin instead.
+            boosted = true;
+            float g = a;
+            int src = lane;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const float t = __shfl_down(c, d) + (float)d * rampP;
-            if (lane + d < 64) c = fminf(c, t);
+            for (int d = 1; d < 64; d <<= 1) {
+                const float t = from_prev(g, d) + (float)d * rampP;
+                const int ts = FWD ? __shfl_up(src, d) : __shfl_down(src, d);
+                if (has_prev(d) && t < g) {
+                    g = t;
+                    src = ts;
+                }
+            }
+            const float origin = __shfl(a, src);
+            const int n = (FWD ? lane - src : src - lane) * LPL;
+            c = ramp_exact(origin, n, (double)P1, 1.0 / (double)P1);
         }
-        float f[LPL];
-        for (int it = 0; it < 66; it++) {
-            const float cin = dpp_shl1(c, f_inf());
-            f[LPL - 1] = fminf(M[LPL - 1], cin + P1);
-#pragma unroll
-            for (int k = LPL - 2; k >= 0; k--) f[k] = fminf(M[k], f[k + 1] + P1);
-            const bool same = (f[0] == c);
-            c = f[0];
-            if (__builtin_amdgcn_ballot_w64(!same) == 0ull) break;
-        }
-#pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = f[k];
     }
+#pragma unroll
+    for (int k = 0; k < LPL; k++) M[k] = f[k];
+}
+
+template <int LPL>
+__device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, float P2, int lane, int L,
+                                           unsigned *sweeps = nullptr)
+{
+    fh_scan<LPL, true>(M, P1, lane, sweeps);
+    // label slots >= L hold +INF on entry; the forward scan has filled them with ramp values
+#pragma unroll
+    for (int k = 0; k < LPL; k++) M[k] = (lane * LPL + k < L) ? M[k] : f_inf();
+    fh_scan<LPL, false>(M, P1, lane, sweeps);
     if (P2 < f_inf()) {
         const float cap = m + P2;
 #pragma unroll

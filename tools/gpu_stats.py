@@ -10,7 +10,12 @@ cfgs = {"cfg2": (1920, 1080, 128, 4, 2, 0, 8.0, 32.0), "cfg3h": (1920, 1080, 256
 for name in sys.argv[1:] or ["cfg3h"]:
     nx, ny, L, NDIR, MGM, FH, P1, P2 = cfgs[name]
     ctx = mgm_amd.Context(0)
-    cv = ctx.upload_volume(synth.raw_volume(nx, ny, L), 0)
+    if os.environ.get("MGM_STATS_REAL", "0") == "1":  # a census cost volume of a synthetic pair instead of random costs
+        u, v, _ = synth.stereo_pair(nx, ny, -(L - 1) * 3 // 4, 0)
+        du, dv = ctx.upload_image(u), ctx.upload_image(v)
+        cv = ctx.costvolume_dev(du, dv, -(L - 1), 0, "none", "census", float("inf"), 5)
+    else:
+        cv = ctx.upload_volume(synth.raw_volume(nx, ny, L), 0)
     ctx.timing(True)
     for rep in range(2):
         ctx.timing_reset()
