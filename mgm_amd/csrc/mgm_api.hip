@@ -551,13 +551,18 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
     if ((r = reserve(c, c->hand, sizeof(float) * (size_t)NDIR * 2 * maxLL * NS * LP))) return r;
     if ((r = reserve(c, c->handm, sizeof(float) * (size_t)NDIR * 2 * maxLL))) return r;
 
-    // task table: ticket -> (pass, band), ordered by band then pass so that
-    // item (p, b) always follows (p, b-1)
+    // task table: ticket -> (pass, band); item (p, b) always follows (p, b-1)
     if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != NDIR || c->tk_r != R) {
+        // Passes with more bands (the column passes of a wide image) have the longer dependency
+        // chain, so tickets are dealt by RELATIVE progress b / nbands(pass): every pass advances at
+        // the rate that lets all of them finish together.  Within a pass the order is still by band.
         std::vector<int2> tasks;
-        for (int b = 0; b < maxbands; b++)
-            for (int q = 0; q < NDIR; q++)
-                if (b < p.g[q].nbands) tasks.push_back(make_int2(q, b));
+        for (int q = 0; q < NDIR; q++)
+            for (int b = 0; b < p.g[q].nbands; b++) tasks.push_back(make_int2(q, b));
+        std::stable_sort(tasks.begin(), tasks.end(), [&](const int2 &a, const int2 &b) {
+            const long long ka = (long long)a.y * p.g[b.x].nbands, kb = (long long)b.y * p.g[a.x].nbands;
+            return ka != kb ? ka < kb : a.x < b.x;
+        });
         if ((r = reserve(c, c->tasks, sizeof(int2) * tasks.size()))) return r;
         HIPCHK(c, hipMemcpyAsync(c->tasks.p, tasks.data(), sizeof(int2) * tasks.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
