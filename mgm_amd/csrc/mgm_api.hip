@@ -161,7 +161,7 @@ const int kPassToChannel[4][8] = {  // mgm_core.cc:481-484
 
 // Canonical geometry of a pass (see PassGeom).  Returns false if the table
 // entry does not reduce to one of the two canonical neighbour orders.
-bool make_geom(int pass, int nx, int ny, int R, PassGeom &g)
+bool make_geom(int pass, int nx, int ny, int R, int MGM, bool slope1_ok, PassGeom &g)
 {
     const RefPass &rp = kPasses[pass];
     const long long sx = rp.inc_x ? 1 : -1, sy = rp.inc_y ? 1 : -1;
@@ -193,6 +193,9 @@ bool make_geom(int pass, int nx, int ny, int R, PassGeom &g)
     else if (kind[0] == 3 && kind[1] == 2 && kind[2] == 1 && kind[3] == 0) g.form = 1;
     else return false;
     g.nbands = (g.NL + R - 1) / R;
+    // form 0 sums inline, same, back, fwd: with MGM <= 3 the fwd neighbour (i+1, j-1) is never read,
+    // so a line only has to stay ONE pixel behind the previous one (second K3 build only)
+    g.slope = (slope1_ok && g.form == 0 && MGM <= 3) ? 1 : 2;
     return true;
 }
 
@@ -541,7 +544,7 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
     PassParams p{};
     int maxLL = 0, maxbands = 0;
     for (int q = 0; q < NDIR; q++) {
-        if (!make_geom(q, nx, ny, R, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
+        if (!make_geom(q, nx, ny, R, MGM, R2 != 0, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
         maxLL = std::max(maxLL, p.g[q].LL);
         maxbands = std::max(maxbands, p.g[q].nbands);
     }

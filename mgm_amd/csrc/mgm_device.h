@@ -22,6 +22,7 @@ struct PassGeom {
     int NL, LL;        // number of lines, pixels per line
     int form;          // 0 / 1
     int nbands;        // ceil(NL / R)
+    int slope;         // pixels of lead a line keeps over the next one: 2, or 1 when no fwd neighbour is used
     long long base;    // pixel index of (0,0)
     long long istep;   // pixel-index step along the line
     long long jstep;   // pixel-index step between lines

@@ -209,7 +209,8 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
     const int NLn = g.NL, LL = g.LL, L = P.L, form = g.form;
     const float P1 = P.P1, P2 = P.P2;
     const long long istep = g.istep;
-    const int nsteps = ((LL + 1 + 2 * (NC - 1)) + 2) / 3 * 3;
+    const int SL = g.slope;  // wave r is at pixel i = s - 1 - SL*r at step s
+    const int nsteps = ((LL + 1 + SL * (NC - 1)) + 2) / 3 * 3;
     const bool from_global = band > 0;
 
     constexpr int NSLP = NS * LP;
@@ -240,11 +241,13 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
             int j = band * NC + r;
             j = j < NLn ? j : NLn - 1;
             cptr[q] = P.C + (g.base + (long long)j * g.jstep) * L + lane * 4;
-            ci[q] = -1 - 2 * r;
+            ci[q] = -1 - SL * r;
         }
-        const float *hptr = hand_in + lane * 4;  // hand-off slab of pixel h = clamp(t, 0, LL-1)
+        // hand-off slab wanted by wave 0 at step t: pixel t (its fwd neighbour) with slope 2, pixel t-1
+        // (its same neighbour) with slope 1; clamped to [0, LL-1]
+        const float *hptr = hand_in + lane * 4;
         const float *hmptr = handm_in;
-        int ht = 0;
+        int ht = SL == 2 ? 0 : -1;
 
         auto issue = [&](int slot) {  // everything the step `ht` needs, into ring slot `slot`
 #pragma unroll
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
                 ci[q]++;
             }
             if (wl == 0) {
-                const int h = ht < LL ? ht : LL - 1;
+                const int h = ht < 0 ? 0 : (ht < LL ? ht : LL - 1);
                 if (from_global && !dead && !(P.xflags & 4) && known < (unsigned)h + 1u) {
                     // slow path: the producer band is not far enough ahead.  Poll the word through
                     // LDS-DMA as well (no VGPR load, so nothing makes the compiler drain us elsewhere).
@@ -298,7 +301,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
                 if constexpr (!pubE)
                     if (lane == 0) dma4<AUX_SC1>(hmptr, Hm + slot);
                 if (lane == 0) dma4<AUX_SC1>(prog_in, Hprog + slot);
-                const bool adv = ht < LL - 1;
+                const bool adv = ht >= 0 && ht < LL - 1;
                 hptr += adv ? NSLP : 0;
                 hmptr += adv ? 1 : 0;
                 ht++;
@@ -368,20 +371,23 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
     float *t_dst0 = Tring + r * 2 * NSLP + lane * LPL;
 
     // The whole line walk, specialised on the neighbour order of the pass (FORM).
-    auto run = [&](auto formc) {
+    auto run = [&](auto formc, auto slopec) {
         constexpr int FORM = decltype(formc)::value;
+        constexpr int SLOPE = decltype(slopec)::value;  // 1 only with FORM == 0 and MGM <= 3
         NbT wA = {}, wB = {}, wC = {}, nb_i = {};
 
-        // one step: X receives the new fwd slab; Y = back, Z = same
+        // one step: X receives the newest slab of the previous line.  Slope 2: that is the fwd
+        // neighbour (i+1), Z = same, Y = back.  Slope 1: it is the same neighbour (i), Z = back.
+        constexpr int NEWOFF = SLOPE == 2 ? 1 : 0;  // index of the slab fetched this step, relative to i
         unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
         unsigned long long fh_sweeps = 0, fh_n = 0;
         unsigned fh_max = 0;
         const bool prof = dbg && r == NC / 2;
         auto step = [&](int s, int cslot, NbT &X, const NbT &Y, const NbT &Z) {
-            const int i = s - 1 - 2 * r;
+            const int i = s - 1 - SLOPE * r;
             const unsigned long long c0 = prof ? clock64() : 0;
-            if (has_prev && i >= -1 && i + 1 < LL) {
-                const int sl = r > 0 ? ((i + 1) & 1) : cslot;
+            if (has_prev && i + NEWOFF >= 0 && i + NEWOFF < LL) {
+                const int sl = r > 0 ? ((i + NEWOFF) & 1) : cslot;
                 const float *src = fwd_src0 + sl * NSLP;
 #pragma unroll
                 for (int q = 0; q < NS; q++)
@@ -404,29 +410,35 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
                     ph[0] += clock64() - c0;  // LDS reads landed
                 }
                 const unsigned long long c1 = prof ? clock64() : 0;
+                // neighbours of the previous line by role
+                const NbT &nb_same = SLOPE == 2 ? Z : X;
+                const NbT &nb_back = SLOPE == 2 ? Y : Z;
+                const NbT &nb_fwd = X;  // only read with SLOPE == 2
                 if (interior) {
                     if constexpr (!WEIGHTED) {
                         if constexpr (pubE) {
                             if constexpr (FORM == 0)
-                                combine_unit_E<LPL, MGM, FH>(Cv, nb_i.w[0], Z.w[0], Y.w[0], X.w[0], Lv);
+                                combine_unit_E<LPL, MGM, FH>(Cv, nb_i.w[0], nb_same.w[0], nb_back.w[0], nb_fwd.w[0], Lv);
                             else
-                                combine_unit_E<LPL, MGM, FH>(Cv, X.w[0], Y.w[0], Z.w[0], nb_i.w[0], Lv);
+                                combine_unit_E<LPL, MGM, FH>(Cv, nb_fwd.w[0], nb_back.w[0], nb_same.w[0], nb_i.w[0], Lv);
                         } else {
-                            if constexpr (FORM == 0) combine_unit<LPL>(Cv, nb_i, Z, Y, X, MGM, FH, Lv);
-                            else combine_unit<LPL>(Cv, X, Y, Z, nb_i, MGM, FH, Lv);
+                            if constexpr (FORM == 0) combine_unit<LPL>(Cv, nb_i, nb_same, nb_back, nb_fwd, MGM, FH, Lv);
+                            else combine_unit<LPL>(Cv, nb_fwd, nb_back, nb_same, nb_i, MGM, FH, Lv);
                         }
                     } else {
                         float Dw[4];
 #pragma unroll
                         for (int k = 0; k < 4; k++) Dw[k] = P.w8[(long long)g.wplane[k] * P.npix + pix];
                         if constexpr (!FH) {
-                            if constexpr (FORM == 0) combine_whirsch<LPL>(Cv, nb_i, Z, Y, X, Dw, P1, P2, MGM, Lv);
-                            else combine_whirsch<LPL>(Cv, X, Y, Z, nb_i, Dw, P1, P2, MGM, Lv);
+                            if constexpr (FORM == 0)
+                                combine_whirsch<LPL>(Cv, nb_i, nb_same, nb_back, nb_fwd, Dw, P1, P2, MGM, Lv);
+                            else
+                                combine_whirsch<LPL>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, Lv);
                         } else {
                             if constexpr (FORM == 0)
-                                combine_wfh<LPL>(Cv, nb_i, Z, Y, X, Dw, P1, P2, MGM, lane, L, Lv);
+                                combine_wfh<LPL>(Cv, nb_i, nb_same, nb_back, nb_fwd, Dw, P1, P2, MGM, lane, L, Lv);
                             else
-                                combine_wfh<LPL>(Cv, X, Y, Z, nb_i, Dw, P1, P2, MGM, lane, L, Lv);
+                                combine_wfh<LPL>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, lane, L, Lv);
                         }
                     }
                 } else {
@@ -540,8 +552,9 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
             dbg[15] = (fh_sweeps << 32) | ((unsigned long long)fh_max << 24) | (fh_n & 0xffffff);
         }
     };
-    if (form == 0) run(std::integral_constant<int, 0>{});
-    else run(std::integral_constant<int, 1>{});
+    if (form != 0) run(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    else if (SL == 2) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    else if constexpr (MGM <= 3) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
 }
 
 // ---- launcher (one translation unit per LPL: -DMGM_P2_LPL=n) -----------------------
