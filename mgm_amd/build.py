@@ -70,7 +70,24 @@ def build(force=False, verbose=False):
                     print(out)
     if jobs or force or _stale(LIB, objs):
         run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB])
+    build_cli(force)
     return LIB
+
+
+def build_cli(force=False):
+    """The host program: src/mgm_main.cc (plain g++) linked against libmgm_hip.so -> mgm_amd/bin/mgm."""
+    src = os.path.join(HERE, "..", "src", "mgm_main.cc")
+    hdrs = [os.path.join(HERE, "..", "src", "npyio.h"), os.path.join(HERE, "..", "include", "mgm_hip.h")]
+    exe = os.path.join(HERE, "bin", "mgm")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    if force or _stale(exe, [src, LIB] + hdrs):
+        rocm = os.path.dirname(os.path.dirname(hipcc()))
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", src, "-L" + LIBDIR, "-lmgm_hip", "-L" + os.path.join(rocm, "lib"),
+               "-lamdhip64", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", exe]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode:
+            raise RuntimeError("g++ failed:\n%s\n%s" % (" ".join(cmd), r.stdout))
+    return exe
 
 
 if __name__ == "__main__":

@@ -1,0 +1,266 @@
+// mgm_main.cc -- the `mgm` command line on top of libmgm_hip.so.
+//
+// A from-scratch restatement of the reference's host program (mgm.cc:266-450): same
+// options, same environment parameters, same stdout, same left->right / right->left
+// orchestration and post-processing -- with the hot path (cost volume, aggregation, WTA,
+// refinement; mgm.cc:372-385 and 405-414) running on the MI355X through the C ABI of
+// include/mgm_hip.h.  Everything here is host glue; no stereo arithmetic of the path is
+// computed on the CPU.  Image files: .npy (h,w[,c]) only in this build (the reference's iio
+// reads the same files; PNG/TIFF need libraries this image lacks).
+//
+// Not supported (exit code 2, message on stderr): ragged ranges (-m/-M files that are not
+// constant, TSGM_ITER > 1), WITH_MGM2=1, costs/prefilters/refinements the library reports as
+// MGM_ERR_UNSUPPORTED.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../include/mgm_hip.h"
+#include "npyio.h"
+
+// ---- environment "smart parameters" (smartparameter.h:26-50): double, read once --------------
+static double env_param(const char *name, double dflt)
+{
+    const char *s = getenv(name);
+    double y;
+    if (s && sscanf(s, "%lf", &y) == 1) return y;
+    return dflt;
+}
+
+// ---- pick_option (mgm.cc:165-179): single-dash name, value = next argv, both removed ----------
+static const char *pick_option(int *argc, char **argv, const char *opt, const char *dflt)
+{
+    for (int i = 0; i < *argc - 1; i++)
+        if (argv[i][0] == '-' && 0 == strcmp(argv[i] + 1, opt)) {
+            const char *r = argv[i + 1];
+            *argc -= 2;
+            for (int j = i; j < *argc; j++) argv[j] = argv[j + 2];
+            return r;
+        }
+    return dflt;
+}
+
+static void remove_nonfinite(HostImg &u, float v)  // img_tools.h:37-41
+{
+    for (float &x : u.data)
+        if (!std::isfinite(x)) x = v;
+}
+
+// median_filter (img_tools.h:203-238): NaN-aware, window clipped at the border, upper median
+static HostImg median_filter(const HostImg &u, int radius)
+{
+    HostImg M = u;
+    std::vector<float> v;
+    for (int k = 0; k < u.nch; k++)
+        for (int y = 0; y < u.ny; y++)
+            for (int x = 0; x < u.nx; x++) {
+                v.clear();
+                for (int j = -radius; j <= radius; j++) {
+                    if (j + y < 0 || j + y >= u.ny) continue;
+                    for (int i = -radius; i <= radius; i++) {
+                        if (i + x < 0 || i + x >= u.nx) continue;
+                        const float s = u.data[(i + x) + (size_t)(j + y) * u.nx + (size_t)k * u.npix()];
+                        if (!std::isnan(s)) v.push_back(s);
+                    }
+                }
+                if (!v.empty()) {
+                    std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+                    M.data[x + (size_t)y * u.nx + (size_t)k * u.npix()] = v[v.size() / 2];
+                }
+            }
+    return M;
+}
+
+// leftright_test (mgm.cc:68-91)
+static void leftright_test(HostImg &dx, const HostImg &Rdx, float threshold)
+{
+    const int nc = dx.nx, nr = dx.ny, Rnc = Rdx.nx;
+    for (int y = 0; y < nr; y++)
+        for (int x = 0; x < nc; x++) {
+            const int i = x + y * nc;
+            const float d = dx.data[i];
+            // round(x + d) converted to int; a NaN disparity lands outside every image
+            const double rr = round((double)(x + d));
+            const int Lx = (rr >= -2147483648.0 && rr <= 2147483647.0) ? (int)rr : -2147483647 - 1;
+            if (Lx < Rnc && Lx >= 0) {
+                const int Lidx = Lx + y * Rnc;
+                const float Rx = Lx + Rdx.data[Lidx];
+                if (fabs(Rx - x) > threshold) dx.data[i] = NAN;
+            } else {
+                dx.data[i] = NAN;
+            }
+        }
+}
+
+struct Opts {
+    int dmin, dmax, NDIR;
+    float P1, P2, aP2, aThresh, truncDist;
+    const char *distance, *prefilter, *refine;
+    int TSGM, FH, FIX, census_win;
+};
+
+static void die(mgm_ctx *ctx, int rc, const char *what)
+{
+    fprintf(stderr, "mgm: %s failed (%d): %s\n", what, rc, ctx ? mgm_last_error(ctx) : "");
+    exit(rc == MGM_ERR_UNSUPPORTED ? 2 : 1);
+}
+
+// One run of the path: mgm.cc:372 + 376-385 (u,v) or 373 + 405-414 (v,u with the negated range).
+static void run_path(mgm_ctx *ctx, const HostImg &u, const HostImg &v, int dmin, int dmax, const Opts &o, HostImg &off,
+                     HostImg &cost)
+{
+    int rc;
+    mgm_img *du = nullptr, *dv = nullptr, *dw = nullptr, *dout = nullptr, *dcost = nullptr;
+    mgm_cv *C = nullptr;
+    bool weighted_msg = false;
+    if ((rc = mgm_img_upload(ctx, u.data.data(), u.nx, u.ny, u.nch, &du))) die(ctx, rc, "upload");
+    if ((rc = mgm_img_upload(ctx, v.data.data(), v.nx, v.ny, v.nch, &dv))) die(ctx, rc, "upload");
+    // compute_mgm_weights(u, aP2, aThresh)   [aP1 is parsed and unused in the reference too, mgm.cc:372]
+    if ((rc = mgm_weights_dev(ctx, du, o.aP2, o.aThresh, &dw))) die(ctx, rc, "mgm_weights");
+    if (o.aP2 != 1.0f) {  // mgm() announces the weighted mode on stdout (mgm_core.cc:420-423)
+        std::vector<float> w((size_t)u.npix() * 8);
+        if ((rc = mgm_img_download(ctx, dw, w.data()))) die(ctx, rc, "download");
+        weighted_msg = std::any_of(w.begin(), w.end(), [](float x) { return x != 1.0f; });
+    }
+    if ((rc = mgm_costvolume_build_dev(ctx, du, dv, dmin, dmax, o.prefilter, o.distance, o.truncDist, o.census_win, &C)))
+        die(ctx, rc, "mgm_costvolume_build");
+    if ((rc = mgm_img_create(ctx, u.nx, u.ny, 1, &dout)) || (rc = mgm_img_create(ctx, u.nx, u.ny, 1, &dcost)))
+        die(ctx, rc, "mgm_img_create");
+    // the reference prints one digit per pass from inside mgm() (mgm_core.cc:491), then
+    // print_solution_energy prints "\n" (mgm_print_energy.h:109-111)
+    rc = mgm_aggregate_dev(ctx, C, dw, o.P1, o.P2, o.NDIR, o.TSGM, o.FH, o.FIX, o.refine, dout, dcost, nullptr);
+    if (rc) die(ctx, rc, "mgm_aggregate");
+    off.nx = cost.nx = u.nx;
+    off.ny = cost.ny = u.ny;
+    off.nch = cost.nch = 1;
+    off.data.resize(u.npix());
+    cost.data.resize(u.npix());
+    if ((rc = mgm_img_download(ctx, dout, off.data.data())) || (rc = mgm_img_download(ctx, dcost, cost.data.data())))
+        die(ctx, rc, "download");
+    if (weighted_msg) printf(" USING IMAGE DEPENDENT WEIGHTS\n");
+    for (int p = 0; p < o.NDIR; p++) printf("%d", p);
+    printf("\n");
+    fflush(stdout);
+    mgm_cv_free(ctx, C);
+    for (mgm_img *im : {du, dv, dw, dout, dcost}) mgm_img_free(ctx, im);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2 || !strcmp(argv[1], "-h")) return 0 * puts("usage:\n\tmgm [-options] u v out [cost [backflow]]");
+    if (!strcmp(argv[1], "-?")) return 0 * puts("Compute stereo disparities by the MGM algorithm.");
+    if (!strcmp(argv[1], "--version")) return 0 * puts("mgm 2.0 (mgm-hip, MI355X)");
+    if (!strcmp(argv[1], "--help"))
+        return 0 * puts("mgm [options] in_u in_v out_disp [out_cost [out_backflow]]   (.npy images)\n"
+                        "options: -r dmin(-30) -R dmax(30) -O NDIR(4) -P1 (8) -P2 (32) -p prefilter(none) -t distance(ad)\n"
+                        "         -truncDist (inf) -s subpix(none) -aP1 (1) -aP2 (1) -aThresh (5) -m FILE -M FILE -l FILE\n"
+                        "environment: CENSUS_NCC_WIN=3 TESTLRRL=1 TESTLRRL_TAU=1.0 MEDIAN=0 TSGM=4 TSGM_ITER=1\n"
+                        "             TSGM_FIX_OVERCOUNT=1 USE_TRUNCATED_LINEAR_POTENTIALS=0 MGM_DEVICE=0");
+    if (argc < 4) {
+        fprintf(stderr, "too few parameters\n   usage: %s  [-r dmin -R dmax] [-m dminImg -M dmaxImg] [-O NDIR: 2, (4), 8] u v out "
+                        "[cost [backflow]]\n", argv[0]);
+        return 1;
+    }
+    // mgm.cc:303-318, in the same order (the order matters for pick_option's argv surgery)
+    const char *min_file = pick_option(&argc, argv, "m", "");
+    const char *max_file = pick_option(&argc, argv, "M", "");
+    Opts o;
+    o.dmin = atoi(pick_option(&argc, argv, "r", "-30"));
+    o.dmax = atoi(pick_option(&argc, argv, "R", "30"));
+    o.NDIR = atoi(pick_option(&argc, argv, "O", "4"));
+    o.P1 = (float)atof(pick_option(&argc, argv, "P1", "8"));
+    o.P2 = (float)atof(pick_option(&argc, argv, "P2", "32"));
+    (void)atof(pick_option(&argc, argv, "aP1", "1"));
+    o.aP2 = (float)atof(pick_option(&argc, argv, "aP2", "1"));
+    o.aThresh = (float)atof(pick_option(&argc, argv, "aThresh", "5"));
+    o.distance = pick_option(&argc, argv, "t", "ad");
+    o.prefilter = pick_option(&argc, argv, "p", "none");
+    o.refine = pick_option(&argc, argv, "s", "none");
+    o.truncDist = (float)atof(pick_option(&argc, argv, "truncDist", "inf"));
+    const char *nolr_file = pick_option(&argc, argv, "l", "");
+    const char *f_u = argc > 1 ? argv[1] : nullptr, *f_v = argc > 2 ? argv[2] : nullptr;
+    const char *f_out = argc > 3 ? argv[3] : nullptr, *f_cost = argc > 4 ? argv[4] : nullptr;
+    const char *f_back = argc > 5 ? argv[5] : nullptr;
+    if (!f_u || !f_v || !f_out) { fprintf(stderr, "too few parameters\n"); return 1; }
+
+    printf("%d %d\n", o.dmin, o.dmax);  // mgm.cc:328
+    fflush(stdout);
+
+    o.TSGM = (int)env_param("TSGM", 4);
+    o.FH = (int)env_param("USE_TRUNCATED_LINEAR_POTENTIALS", 0);
+    o.FIX = (int)env_param("TSGM_FIX_OVERCOUNT", 1);
+    o.census_win = (int)env_param("CENSUS_NCC_WIN", 3);
+    const double TSGM_ITER = env_param("TSGM_ITER", 1), TESTLRRL = env_param("TESTLRRL", 1);
+    const double TAU = env_param("TESTLRRL_TAU", 1.0), MEDIAN = env_param("MEDIAN", 0);
+    if (env_param("WITH_MGM2", 0) != 0) { fprintf(stderr, "mgm: WITH_MGM2=1 is not supported (its result is thread-order dependent)\n"); return 2; }
+    if (TSGM_ITER != 1) { fprintf(stderr, "mgm: TSGM_ITER != 1 needs per-pixel ranges (not built yet)\n"); return 2; }
+
+    try {
+        HostImg u = npy::read(f_u), v = npy::read(f_v);
+        remove_nonfinite(u, 0);
+        remove_nonfinite(v, 0);
+        if (min_file[0]) {  // mgm.cc:342-353: only constant range images are supported
+            HostImg a = npy::read(min_file), b = npy::read(max_file);
+            remove_nonfinite(a, (float)o.dmin);
+            remove_nonfinite(b, (float)o.dmax);
+            for (size_t i = 0; i < a.data.size(); i++)
+                if (b.data[i] < a.data[i] + 1) b.data[i] = ceilf(a.data[i] + 1);
+            for (size_t i = 0; i < a.data.size(); i++)
+                if ((int)a.data[i] != (int)a.data[0] || (int)b.data[i] != (int)b.data[0]) {
+                    fprintf(stderr, "mgm: per-pixel disparity ranges (-m/-M) are not built yet\n");
+                    return 2;
+                }
+            o.dmin = (int)a.data[0];
+            o.dmax = (int)b.data[0];
+        }
+        o.P1 *= u.nch;  // mgm.cc:356-357
+        o.P2 *= u.nch;
+
+        mgm_ctx *ctx = nullptr;
+        int rc = mgm_ctx_create((int)env_param("MGM_DEVICE", 0), &ctx);
+        if (rc) { fprintf(stderr, "mgm: no usable MI355X device (mgm_ctx_create = %d); there is no CPU path\n", rc); return 1; }
+
+        HostImg outoff, outcost, outoffR, outcostR;
+        run_path(ctx, u, v, o.dmin, o.dmax, o, outoff, outcost);
+        if (MEDIAN != 0) outoff = median_filter(outoff, (int)MEDIAN);
+        if (nolr_file[0]) npy::write(nolr_file, outoff);
+        if (TESTLRRL != 0) {
+            run_path(ctx, v, u, -o.dmax, -o.dmin, o, outoffR, outcostR);  // mgm.cc:366, 405
+            if (MEDIAN != 0) outoffR = median_filter(outoffR, (int)MEDIAN);
+            const HostImg tmpL = outoff, tmpR = outoffR;
+            leftright_test(outoffR, tmpL, (float)TAU);
+            leftright_test(outoff, tmpR, (float)TAU);
+        }
+        mgm_ctx_destroy(ctx);
+
+        // back-projected image (mgm.cc:433-443), with the reference's float index arithmetic
+        HostImg syn;
+        syn.nx = u.nx;
+        syn.ny = u.ny;
+        syn.nch = u.nch;
+        syn.data.assign((size_t)u.npix() * u.nch, 0.0f);
+        if (f_back)
+            for (int x = 0; x < u.nx; x++)
+                for (int y = 0; y < u.ny; y++) {
+                    const float qx = outoff.data[x + u.nx * y];
+                    const float px = x + qx, py = (float)y;
+                    const bool inside = px >= 0 && py >= 0 && px < v.nx && py < v.ny;
+                    for (int c = 0; c < u.nch; c++)
+                        syn.data[x + y * u.nx + c * u.npix()] =
+                            inside ? v.data[(size_t)(x + qx + (y + 0.0f) * v.nx + c * v.npix())]
+                                   : u.data[x + y * u.nx + c * u.npix()];
+                }
+        npy::write(f_out, outoff);
+        if (f_cost) npy::write(f_cost, outcost);
+        if (f_back) npy::write(f_back, syn);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "mgm: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

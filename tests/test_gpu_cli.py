@@ -1,0 +1,68 @@
+"""The `mgm` host program (src/mgm_main.cc over libmgm_hip.so) against the REFERENCE'S OWN
+command line (oracle/_ref/mgm, compiled from /root/reference; it travels to the GPU box as a
+built binary): same arguments, same environment, .npy in / .npy out; stdout and every
+output file must be identical (NaN == NaN)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import ndiff
+from mgm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OURS = os.path.join(ROOT, "mgm_amd", "bin", "mgm")
+REF = os.path.join(ROOT, "oracle", "_ref", "mgm")
+
+CASES = [
+    # (name, nch, args, env)
+    ("cfg1-style ad O4 TSGM2", 3, "-r -20 -R 12 -t ad -O 4", dict(TSGM="2")),
+    ("defaults (TSGM=4)", 1, "-r -10 -R 10", {}),
+    ("Makefile test: census FH vfit median", 3, "-P2 20000 -P1 2 -r -20 -R 12 -t census -s vfit -O 8",
+     dict(MEDIAN="1", CENSUS_NCC_WIN="3", USE_TRUNCATED_LINEAR_POTENTIALS="1", TSGM="3")),
+    ("README: census5 vfit O8 TSGM3", 1, "-r -22 -R 19 -s vfit -t census -O 8", dict(MEDIAN="1", CENSUS_NCC_WIN="5", TSGM="3")),
+    ("no LR test, -l, weights", 3, "-r -20 -R 12 -t ad -O 8 -aP2 4 -aThresh 12 -l {tmp}/nolr.npy",
+     dict(TESTLRRL="0", TSGM="3")),
+    ("sd trunc, no overcount fix, tau", 1, "-r -9 -R 14 -t sd -truncDist 300 -O 2",
+     dict(TSGM="1", TSGM_FIX_OVERCOUNT="0", TESTLRRL_TAU="2.5")),
+    ("unknown names fall back silently", 1, "-r -8 -R 8 -t nope -p sobel_x -s bogus -O 4", dict(TSGM="2")),
+]
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference CLI (oracle/_ref/mgm) was not built")
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
+def test_cli_matches_reference(case, tmp_path):
+    name, nch, args, env = case
+    u, v, _ = synth.stereo_pair(112, 72, -16, 8, seed=42, nch=nch)
+    np.save(tmp_path / "u.npy", np.ascontiguousarray(u.transpose(1, 2, 0)) if nch > 1 else u[0])
+    np.save(tmp_path / "v.npy", np.ascontiguousarray(v.transpose(1, 2, 0)) if nch > 1 else v[0])
+    outs = {}
+    for tag, exe in (("ref", REF), ("ours", OURS)):
+        d = tmp_path / tag
+        d.mkdir()
+        a = args.format(tmp=d).split()
+        cmd = [exe] + a + [str(tmp_path / "u.npy"), str(tmp_path / "v.npy"), str(d / "disp.npy"), str(d / "cost.npy"),
+                           str(d / "back.npy")]
+        e = dict(os.environ, OMP_NUM_THREADS="4", **env)
+        r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr)
+        outs[tag] = (r.stdout, {f: np.load(d / f) for f in sorted(os.listdir(d))})
+    assert outs["ref"][0] == outs["ours"][0], "stdout differs"
+    assert outs["ref"][1].keys() == outs["ours"][1].keys()
+    for f in outs["ref"][1]:
+        a, b = outs["ref"][1][f], outs["ours"][1][f]
+        assert a.shape == b.shape, f
+        assert ndiff(a, b) == 0, (name, f)
+
+
+def test_cli_refuses_what_is_not_built(tmp_path):
+    u, v, _ = synth.stereo_pair(32, 16, -4, 4)
+    np.save(tmp_path / "u.npy", u[0])
+    np.save(tmp_path / "v.npy", v[0])
+    base = [OURS, str(tmp_path / "u.npy"), str(tmp_path / "v.npy"), str(tmp_path / "d.npy")]
+    for extra, env in (([], dict(TSGM_ITER="2")), ([], dict(WITH_MGM2="1")), (["-t", "ncc"], {})):
+        r = subprocess.run(base[:1] + extra + base[1:], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert r.returncode == 2 and "not" in r.stderr
