@@ -119,6 +119,20 @@ int mgm_aggregate_dev(mgm_ctx *ctx, const mgm_cv *C, const mgm_img *w8, float P1
 int mgm_aggregate(mgm_ctx *ctx, const mgm_cv *C, const float *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
                   int fix_overcount, const char *refine, float *out, float *outcost, mgm_cv **S);
 
+/* ---- one volume sharded by DIRECTION over several GPUs ---------
+ * Each rank holds the full C (rebuilt from the images: cheaper than broadcasting it) and runs
+ * a contiguous subset of the passes; pass first_pass+k's Lr volume stays in workspace slot k
+ * (mgm_lr_device_ptr).  The ranks then exchange ROW SLABS of those volumes (grouped
+ * send/recv over RCCL -- mgm_amd/dist.py; an all-reduce would change the fp32 summation order)
+ * and every rank finishes its rows with mgm_wta_rows_dev, whose `lr_slabs` is a device buffer
+ * [NDIR][nrows][nx][L] holding ALL passes of rows row0..row0+nrows-1 in pass order;
+ * out_rows / outcost_rows are device buffers of nrows*nx floats. */
+int mgm_aggregate_passes_dev(mgm_ctx *ctx, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int MGM, int use_fh,
+                             int first_pass, int n_passes);
+void *mgm_lr_device_ptr(mgm_ctx *ctx, int slot);
+int mgm_wta_rows_dev(mgm_ctx *ctx, const mgm_cv *C, int row0, int nrows, const void *lr_slabs, int NDIR,
+                     int fix_overcount, const char *refine, void *out_rows, void *outcost_rows);
+
 /* Test/diagnostic aid: copy pass `pass`'s Lr volume of the LAST mgm_aggregate
  * call on this ctx into `dense` ([ny][nx][L]). */
 int mgm_debug_download_lr(mgm_ctx *ctx, int pass, float *dense);

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "mgm_cv_create", "mgm_cv_upload", "mgm_cv_download", "mgm_cv_dims", "mgm_cv_device_ptr", "mgm_cv_free",
     "mgm_costvolume_build_dev", "mgm_costvolume_build", "mgm_weights_dev",
     "mgm_aggregate_dev", "mgm_aggregate", "mgm_debug_download_lr", "mgm_refine_dev", "mgm_refine",
-    "mgm_selftest_div3",
+    "mgm_selftest_div3", "mgm_aggregate_passes_dev", "mgm_lr_device_ptr", "mgm_wta_rows_dev",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -85,6 +85,10 @@ def load_library():
     L.mgm_refine_dev.argtypes = [vp, vp, cp, vp, vp]
     L.mgm_refine.argtypes = [vp, vp, cp, fp, fp]
     L.mgm_selftest_div3.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.mgm_aggregate_passes_dev.argtypes = [vp, vp, vp, f, f, i, i, i, i]
+    L.mgm_lr_device_ptr.argtypes = [vp, i]
+    L.mgm_lr_device_ptr.restype = vp
+    L.mgm_wta_rows_dev.argtypes = [vp, vp, i, i, vp, i, i, cp, vp, vp]
     _lib = L
     return L
 
@@ -256,6 +260,18 @@ class Context:
         outcost = np.array(outcost, np.float32, copy=True)
         self._chk(self.lib.mgm_refine(self.h, S.h, method.encode(), _ptr(out), _ptr(outcost)))
         return out, outcost
+
+    # ---- direction sharding (see mgm_amd/dist.py) ----
+    def aggregate_passes_dev(self, Cv, P1, P2, MGM, use_fh, first_pass, n_passes, w8=None):
+        self._chk(self.lib.mgm_aggregate_passes_dev(self.h, Cv.h, w8.h if w8 is not None else None, P1, P2, MGM, use_fh,
+                                                    first_pass, n_passes))
+
+    def lr_device_ptr(self, slot):
+        return self.lib.mgm_lr_device_ptr(self.h, slot)
+
+    def wta_rows_dev(self, Cv, row0, nrows, lr_slabs_ptr, NDIR, fix_overcount, refine, out_ptr, outcost_ptr):
+        self._chk(self.lib.mgm_wta_rows_dev(self.h, Cv.h, row0, nrows, lr_slabs_ptr, NDIR, fix_overcount,
+                                            refine.encode() if refine else None, out_ptr, outcost_ptr))
 
     def selftest_div3(self):
         n = C.c_ulonglong(0)

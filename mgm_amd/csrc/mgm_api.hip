@@ -504,20 +504,13 @@ int mgm_weights_dev(mgm_ctx *c, const mgm_img *u, float aP, float aThresh, mgm_i
 }
 
 // ---- aggregation ----------------------------------------------------------------
-int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
-                      int fix_overcount, const char *refine, mgm_img *out, mgm_img *outcost, mgm_cv **S)
+// K3 for the passes [first, first+count) of the reference's table; pass p's Lr volume goes to
+// workspace slot p - first.  Shared by mgm_aggregate_dev and the direction-sharded multi-GPU path.
+static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int MGM, int use_fh, int first,
+                      int count)
 {
-    if (!c || !C || !out || !outcost) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: null argument");
-    if (NDIR < 1 || NDIR > kMaxDirs)  // the reference reads past its 8-entry table for -O 16 (mgm_core.cc:489)
-        return fail(c, MGM_ERR_INVALID, "NDIR must be 1..8");
-    if (MGM < 1 || MGM > 4) return fail(c, MGM_ERR_INVALID, "MGM (TSGM) must be 1..4");
     const int nx = C->nx, ny = C->ny, L = C->dmax - C->dmin + 1;
-    if (out->nx != nx || out->ny != ny || outcost->nx != nx || outcost->ny != ny)
-        return fail(c, MGM_ERR_INVALID, "mgm_aggregate: output image size mismatch");
-    if (w8 && (w8->nx != nx || w8->ny != ny || w8->nch != 8))
-        return fail(c, MGM_ERR_INVALID, "mgm_aggregate: weights must be nx*ny*8");
-    const int ridx = refinement_index(refine);
-    if (ridx > 1) return fail(c, MGM_ERR_UNSUPPORTED, "fused refinement supports none|vfit only");
+    const int PEND = first + count;
     HIPCHK(c, hipSetDevice(c->device));
 
     const long long npix = (long long)nx * ny, nvol = npix * L;
@@ -543,24 +536,24 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
     const int R = R2 ? R2 : kR;
     PassParams p{};
     int maxLL = 0, maxbands = 0;
-    for (int q = 0; q < NDIR; q++) {
+    for (int q = 0; q < PEND; q++) {
         if (!make_geom(q, nx, ny, R, MGM, R2 != 0, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
         maxLL = std::max(maxLL, p.g[q].LL);
         maxbands = std::max(maxbands, p.g[q].nbands);
     }
     if (maxbands > kMaxBands) return fail(c, MGM_ERR_UNSUPPORTED, "image side exceeds 65536 pixels");
 
-    if ((r = reserve(c, c->lr, sizeof(float) * (size_t)nvol * NDIR))) return r;
-    if ((r = reserve(c, c->hand, sizeof(float) * (size_t)NDIR * 2 * maxLL * NS * LP))) return r;
-    if ((r = reserve(c, c->handm, sizeof(float) * (size_t)NDIR * 2 * maxLL))) return r;
+    if ((r = reserve(c, c->lr, sizeof(float) * (size_t)nvol * count))) return r;
+    if ((r = reserve(c, c->hand, sizeof(float) * (size_t)PEND * 2 * maxLL * NS * LP))) return r;
+    if ((r = reserve(c, c->handm, sizeof(float) * (size_t)PEND * 2 * maxLL))) return r;
 
     // task table: ticket -> (pass, band); item (p, b) always follows (p, b-1)
-    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != NDIR || c->tk_r != R) {
+    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != PEND * 16 + first || c->tk_r != R) {
         // Passes with more bands (the column passes of a wide image) have the longer dependency
         // chain, so tickets are dealt by RELATIVE progress b / nbands(pass): every pass advances at
         // the rate that lets all of them finish together.  Within a pass the order is still by band.
         std::vector<int2> tasks;
-        for (int q = 0; q < NDIR; q++)
+        for (int q = first; q < PEND; q++)
             for (int b = 0; b < p.g[q].nbands; b++) tasks.push_back(make_int2(q, b));
         std::stable_sort(tasks.begin(), tasks.end(), [&](const int2 &a, const int2 &b) {
             const long long ka = (long long)a.y * p.g[b.x].nbands, kb = (long long)b.y * p.g[a.x].nbands;
@@ -572,7 +565,7 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
         c->ntasks = (int)tasks.size();
         c->tk_nx = nx;
         c->tk_ny = ny;
-        c->tk_ndir = NDIR;
+        c->tk_ndir = PEND * 16 + first;
         c->tk_r = R;
     }
 
@@ -589,7 +582,8 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
     p.nvol = nvol;
     p.L = L;
     p.MGM = MGM;
-    p.NDIR = NDIR;
+    p.NDIR = PEND;
+    p.pass0 = first;
     p.LLmax = maxLL;
     p.maxbands = kMaxBands;
     p.P1 = P1;
@@ -622,7 +616,7 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
         }
         const double tick = 1e-2;  // wall_clock64: 100 MHz -> 0.01 us
         fprintf(stderr, "[mgm stats] %d workgroups, kernel span %.1f us\n", c->ntasks, (t1 - t0) * tick);
-        for (int q = 0; q < NDIR; q++) {
+        for (int q = first; q < PEND; q++) {
             double run = 0, slow = 0, pro = 0, nslow = 0, nspin = 0, steps = 0, first = 1e30, last = 0;
             double ai = 0, ar = 0, ab = 0, bi = 0, br = 0, bb = 0, cb = 0, fsw = 0, fn = 0, fmx = 0;
             int n = 0;
@@ -658,30 +652,92 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
         }
     }
     c->last_nvol = nvol;
-    c->last_ndir = NDIR;
+    c->last_ndir = count;
 
+    return MGM_OK;
+}
+
+// K4-K6 over `npix` pixels starting at pixel `pix0` of C, reading pass p's Lr from lr + p*lr_stride.
+static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const float *lr, long long lr_stride, int NDIR,
+                   int fix_overcount, int ridx, float *out, float *outcost, float *Sout)
+{
+    const int L = C->dmax - C->dmin + 1;
     WtaParams w{};
-    w.C = C->d;
-    w.Lr = (const float *)c->lr.p;
-    w.S = nullptr;
-    if (S) {
-        if ((r = mgm_cv_create(c, nx, ny, C->dmin, C->dmax, S))) return r;
-        w.S = (*S)->d;
-    }
-    w.out = out->d;
-    w.outcost = outcost->d;
+    w.C = C->d + pix0 * L;
+    w.Lr = lr;
+    w.S = Sout;
+    w.out = out;
+    w.outcost = outcost;
     w.npix = npix;
-    w.nvol = nvol;
+    w.nvol = lr_stride;
     w.L = L;
     w.NDIR = NDIR;
     w.FIX = fix_overcount;
     w.dmin = C->dmin;
     w.refine = ridx;
-    {
-        TimeScope t(c, "k_wta");
-        HIPCHK(c, launch_wta(w, c->stream));
-    }
+    TimeScope t(c, "k_wta");
+    HIPCHK(c, launch_wta(w, c->stream));
     return MGM_OK;
+}
+
+int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
+                      int fix_overcount, const char *refine, mgm_img *out, mgm_img *outcost, mgm_cv **S)
+{
+    if (!c || !C || !out || !outcost) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: null argument");
+    if (NDIR < 1 || NDIR > kMaxDirs)  // the reference reads past its 8-entry table for -O 16 (mgm_core.cc:489)
+        return fail(c, MGM_ERR_INVALID, "NDIR must be 1..8");
+    if (MGM < 1 || MGM > 4) return fail(c, MGM_ERR_INVALID, "MGM (TSGM) must be 1..4");
+    const int nx = C->nx, ny = C->ny, L = C->dmax - C->dmin + 1;
+    if (out->nx != nx || out->ny != ny || outcost->nx != nx || outcost->ny != ny)
+        return fail(c, MGM_ERR_INVALID, "mgm_aggregate: output image size mismatch");
+    if (w8 && (w8->nx != nx || w8->ny != ny || w8->nch != 8))
+        return fail(c, MGM_ERR_INVALID, "mgm_aggregate: weights must be nx*ny*8");
+    const int ridx = refinement_index(refine);
+    if (ridx > 1) return fail(c, MGM_ERR_UNSUPPORTED, "fused refinement supports none|vfit only");
+    HIPCHK(c, hipSetDevice(c->device));
+    int r;
+    if ((r = run_passes(c, C, w8, P1, P2, MGM, use_fh, 0, NDIR))) return r;
+    const long long npix = (long long)nx * ny, nvol = npix * L;
+    float *Sout = nullptr;
+    if (S) {
+        if ((r = mgm_cv_create(c, nx, ny, C->dmin, C->dmax, S))) return r;
+        Sout = (*S)->d;
+    }
+    return run_wta(c, C, 0, npix, (const float *)c->lr.p, nvol, NDIR, fix_overcount, ridx, out->d, outcost->d, Sout);
+}
+
+// ---- direction sharding (multi-GPU): run a subset of the passes, sum slabs of Lr volumes ----------
+int mgm_aggregate_passes_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int MGM, int use_fh,
+                             int first_pass, int n_passes)
+{
+    if (!c || !C) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes: null argument");
+    if (first_pass < 0 || n_passes < 1 || first_pass + n_passes > kMaxDirs)
+        return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes: passes must lie in 0..7");
+    if (MGM < 1 || MGM > 4) return fail(c, MGM_ERR_INVALID, "MGM (TSGM) must be 1..4");
+    if (w8 && (w8->nx != C->nx || w8->ny != C->ny || w8->nch != 8))
+        return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes: weights must be nx*ny*8");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_passes(c, C, w8, P1, P2, MGM, use_fh, first_pass, n_passes);
+}
+
+void *mgm_lr_device_ptr(mgm_ctx *c, int slot)
+{
+    if (!c || !c->lr.p || slot < 0 || slot >= c->last_ndir) return nullptr;
+    return (float *)c->lr.p + (size_t)slot * c->last_nvol;
+}
+
+int mgm_wta_rows_dev(mgm_ctx *c, const mgm_cv *C, int row0, int nrows, const void *lr_slabs, int NDIR, int fix_overcount,
+                     const char *refine, void *out_rows, void *outcost_rows)
+{
+    if (!c || !C || !lr_slabs || !out_rows || !outcost_rows) return fail(c, MGM_ERR_INVALID, "mgm_wta_rows: null argument");
+    if (row0 < 0 || nrows < 1 || row0 + nrows > C->ny || NDIR < 1 || NDIR > kMaxDirs)
+        return fail(c, MGM_ERR_INVALID, "mgm_wta_rows: bad row range or NDIR");
+    const int ridx = refinement_index(refine);
+    if (ridx > 1) return fail(c, MGM_ERR_UNSUPPORTED, "fused refinement supports none|vfit only");
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long L = C->dmax - C->dmin + 1, slab = (long long)nrows * C->nx * L;
+    return run_wta(c, C, (long long)row0 * C->nx, (long long)nrows * C->nx, (const float *)lr_slabs, slab, NDIR,
+                   fix_overcount, ridx, (float *)out_rows, (float *)outcost_rows, nullptr);
 }
 
 int mgm_aggregate(mgm_ctx *c, const mgm_cv *C, const float *w8, float P1, float P2, int NDIR, int MGM, int use_fh,

@@ -43,6 +43,7 @@ struct PassParams {
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
     long long npix, nvol;
     int L, MGM, NDIR;
+    int pass0;          // pass p writes its Lr volume to slot p - pass0
     int LLmax, maxbands;
     float P1, P2;
     PassGeom g[kMaxDirs];

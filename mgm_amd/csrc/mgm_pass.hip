@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(R * 64) k_pass(const PassParams P)
     const bool to_global = (r == R - 1) && (band + 1 < g.nbands);
 
     const float *__restrict__ Cb = P.C;
-    float *__restrict__ Lrb = P.Lr + (long long)pass * P.nvol;
+    float *__restrict__ Lrb = P.Lr + (long long)(pass - P.pass0) * P.nvol;
     const long long pix0 = g.base + (long long)j * g.jstep;
     const long long istep = g.istep;
 

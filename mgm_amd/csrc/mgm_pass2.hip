@@ -363,7 +363,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
     const bool has_prev = line_ok && (j >= 1);
     const bool to_lds = (r < NC - 1) && (j + 1 < NLn);
     const bool to_global = (r == NC - 1) && (band + 1 < g.nbands);
-    float *__restrict__ Lrb = P.Lr + (long long)pass * P.nvol;
+    float *__restrict__ Lrb = P.Lr + (long long)(pass - P.pass0) * P.nvol;
     const long long pix0 = g.base + (long long)j * g.jstep;
     const float *fwd_src0 = r > 0 ? Tring + (r - 1) * 2 * NSLP + lane * LPL : Hring + lane * LPL;
     const float *fwd_m0 = r > 0 ? Tm + (r - 1) * 2 : Hm;

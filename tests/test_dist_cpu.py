@@ -53,3 +53,53 @@ def test_single_rank_shortcuts():
     assert shard.pairs_of_rank(5, 1, 0) == [0, 1, 2, 3, 4]
     assert shard.max_over_ranks(1.5) == 1.5
     assert shard.job_rate([3], 1.5) == 2.0
+
+
+# ---- direction sharding: the ordered exchange of Lr slabs (mgm_amd/dist.py) over gloo ----------
+def _dir_worker(rank, world, port, q, NDIR):
+    import numpy as np
+    from mgm_amd import dist as mdist
+    from mgm_amd import synth
+    from oracle.oracle import Oracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = Oracle(threads=1)
+    nx, ny, L = 21, 13, 10                              # 13 rows over 2 ranks: uneven slabs
+    C = synth.raw_volume(nx, ny, L, seed=9, inf_frac=0.05)
+    S, out, outc, lr = orc.mgm(C, -2, 8.0, 32.0, NDIR, 3, 0, 1, None, dump_lr=True)
+    first, count = mdist.passes_of_rank(NDIR, world, rank)
+    mine = [torch.from_numpy(np.ascontiguousarray(lr[p])) for p in range(first, first + count)]  # "my" passes only
+    recv = mdist.exchange_lr(mine, NDIR, ny, dist)
+    r0, nr = mdist.row_slabs(ny, world)[rank]
+    Srows = mdist.ordered_sum_numpy([recv[p].numpy() for p in range(NDIR)], C[r0:r0 + nr], 1)
+    a, b = Srows.view(np.uint32), S[r0:r0 + nr].view(np.uint32)
+    nan = np.isnan(Srows) & np.isnan(S[r0:r0 + nr])
+    q.put((rank, int(np.sum((a != b) & ~nan)), nr))
+    dist.destroy_process_group()
+
+
+def test_direction_sharding_exchange_is_bit_exact():
+    for NDIR in (8, 3):                                 # 3 passes over 2 ranks: uneven pass blocks
+        world, port = 2, _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_dir_worker, args=(r, world, port, q, NDIR)) for r in range(world)]
+        [p.start() for p in ps]
+        res = [q.get(timeout=180) for _ in ps]
+        [p.join(60) for p in ps]
+        assert all(p.exitcode == 0 for p in ps)
+        assert sorted(r[2] for r in res) == [6, 7] and all(r[1] == 0 for r in res), res
+
+
+def test_partitions():
+    from mgm_amd import dist as mdist
+    for ny, world in ((1080, 8), (13, 2), (5, 8)):
+        s = mdist.row_slabs(ny, world)
+        assert sum(n for _, n in s) == ny and all(s[i][0] + s[i][1] == s[i + 1][0] for i in range(world - 1))
+    for NDIR in (8, 4, 3, 1):
+        for world in (1, 2, 4, 8):
+            blocks = [mdist.passes_of_rank(NDIR, world, r) for r in range(world)]
+            flat = [p for f, n in blocks for p in range(f, f + n)]
+            assert flat == list(range(NDIR))
+            assert all(mdist.owner_of_pass(p, NDIR, world) == [r for r, (f, n) in enumerate(blocks) if f <= p < f + n][0]
+                       for p in range(NDIR))
