@@ -32,6 +32,8 @@ WORKLOADS = {
                  desc="1920x1080 synthetic pair, 256 disparities, CENSUS 5x5, -O 8 TSGM=3, FH truncated-linear V"),
     "cfg3h": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0,
                   desc="1920x1080 synthetic pair, 256 disparities, CENSUS 5x5, -O 8 TSGM=3, Hirschmueller V"),
+    "cfg4": dict(nx=4096, ny=4096, dmin=-96, dmax=95, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0,
+                 desc="4096x4096 satellite-style synthetic pair, 192 disparities, CENSUS 5x5, -O 8 TSGM=3"),
     "cfg5": dict(nx=1024, ny=1024, dmin=-127, dmax=0, win=3, NDIR=4, MGM=2, FH=0, P1=8.0, P2=32.0,
                  desc="1024x1024 synthetic pair, 128 disparities, CENSUS 3x3, -O 4 TSGM=2 (throughput mode)"),
 }
@@ -80,6 +82,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="pairs", choices=["pairs", "directions"],
+                    help="N>1: 'pairs' = independent pairs, one per GPU (weak scaling, default); 'directions' = ONE "
+                         "volume per step, its passes sharded over the GPUs with an ordered RCCL exchange (strong)")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
 
@@ -94,17 +99,20 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU path in mgm_amd")
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.mode == "directions":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     import mgm_amd
     from mgm_amd import synth
     ctx = mgm_amd.Context(local)
     nx, ny, L = w["nx"], w["ny"], w["dmax"] - w["dmin"] + 1
-    # every rank gets its own pair (different seed): independent units, no exchange
-    u, v, _ = synth.stereo_pair(nx, ny, w["dmin"] * 3 // 4, 0, seed=synth.SEED + rank)
+    # pairs mode: every rank gets its own pair (different seed): independent units, no exchange.
+    # directions mode: every rank holds the SAME pair and builds the full cost volume itself.
+    u, v, _ = synth.stereo_pair(nx, ny, w["dmin"] * 3 // 4, max(0, w["dmax"] * 3 // 4),
+                                seed=synth.SEED + (rank if args.mode == "pairs" else 0))
     du, dv = ctx.upload_image(u), ctx.upload_image(v)
     out, outc = ctx.new_image(nx, ny), ctx.new_image(nx, ny)
 
@@ -115,15 +123,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.mode == "directions":
+        from mgm_amd import dist as mdist
+
+        def step(cv):
+            cv = ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", "census", float("inf"), w["win"], into=cv)
+            mdist.aggregate_direction_sharded(ctx, cv, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, "vfit", dist)
+            return cv
+    else:
+        def step(cv):
+            return run_step(ctx, du, dv, w, out, outc, cv)
+
     cv = None  # the W*H*L volume is allocated once and refilled every step
     for _ in range(max(1, args.warmup)):
-        cv = run_step(ctx, du, dv, w, out, outc, cv)
+        cv = step(cv)
     sync_all()
     ctx.timing(True)
     ctx.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_step(ctx, du, dv, w, out, outc, cv)  # enqueue only: nothing synchronises inside the timed region
+        step(cv)  # pairs mode: enqueue only, nothing synchronises inside the timed region
     sync_all()
     dt = time.perf_counter() - t0
     from mgm_amd import shard
@@ -136,14 +155,21 @@ def main():
 
     if rank == 0:
         cells = float(nx) * ny * L
-        value = shard.job_rate([args.steps] * world, dt)  # whole-job aggregate: every rank did K volumes
+        if args.mode == "pairs":
+            value = shard.job_rate([args.steps] * world, dt)  # whole-job aggregate: every rank did K volumes
+        else:
+            value = args.steps / dt                            # K volumes, each computed by all ranks together
+        nvol_done = args.steps * (world if args.mode == "pairs" else 1)
         avg = {k: float(np.mean(vs)) for k, vs in kern.items()}
         per_step = {k: float(np.sum(vs)) / args.steps for k, vs in kern.items()}
         pass_name = "k_pass2" if "k_pass2" in avg else "k_pass"
+        # in directions mode rank 0 ran NDIR/world passes and summed ny/world rows per launch
+        frac_pass = (mdist.passes_of_rank(w["NDIR"], world, 0)[1] / w["NDIR"]) if args.mode == "directions" else 1.0
+        frac_rows = (mdist.row_slabs(ny, world)[0][1] / ny) if args.mode == "directions" else 1.0
         # Aggregation stage = K3 (pass kernel) + K4-K6 (k_wta): the two launches together do what the
         # reference's aggregation loop does; SURVEY.md 8(d): 12 B per cell per direction.
         agg_ms = avg[pass_name] + avg["k_wta"]
-        alg_bytes = 12.0 * w["NDIR"] * cells
+        alg_bytes = 12.0 * w["NDIR"] * cells * (1.0 if args.mode == "pairs" else (2.0 / 3.0) * frac_pass + (1.0 / 3.0) * frac_rows)
         achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "r01_traffic.json")
@@ -163,22 +189,28 @@ def main():
                         "k_cost": {"alg_bytes": 4.0 * cells, "GBps": 4.0 * cells / (avg["k_cost"] * 1e-3) / 1e9}}}
         res = {"metric": "disparity-volumes/sec (W*H*L cost volume -> 8-dir MGM -> WTA+vfit)", "value": value,
                "unit": "disparity-volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.mode == "pairs" else "strong",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%s: %s" % (args.workload, w["desc"]), "W": nx, "H": ny, "L": L,
                           "NDIR": w["NDIR"], "TSGM": w["MGM"], "potential": "FH" if w["FH"] else "Hirschmueller",
                           "P1": w["P1"], "P2": w["P2"], "census_win": w["win"], "refine": "vfit",
-                          "parallelism": "independent pairs, one per GPU" if world > 1 else "1 GPU"},
+                          "parallelism": ("independent pairs, one per GPU" if args.mode == "pairs" else
+                                          "one volume, %d-way direction sharding, ordered RCCL slab exchange" % world)
+                          if world > 1 or args.mode == "directions" else "1 GPU"},
                "roofline": roofline,
                "kernel_ms_per_step": per_step,
-               "mcell_updates_per_s": world * args.steps * cells * w["NDIR"] / dt / 1e6}
+               "mcell_updates_per_s": nvol_done * cells * w["NDIR"] / dt / 1e6}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w)
             res["cpu_baseline"]["host_cpus"] = os.cpu_count()
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
     ctx.close()
+    if dist is not None and dist.is_initialized():
+        dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)  # the ONE json line, last thing on stdout
+    if dist is not None:
+        os._exit(0)  # librccl leaves a version banner in the C stdio buffer that would be flushed after the json
 
 
 if __name__ == "__main__":
