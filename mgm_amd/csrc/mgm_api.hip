@@ -50,7 +50,8 @@ struct mgm_ctx {
     int force_build = 0;  // 0 auto, 1 first build only (MGM_HIP_PASS_BUILD=1)
     int ntasks = 0;
     // last aggregate (for mgm_debug_download_lr)
-    long long last_nvol = 0;
+    long long last_nvol = 0;    // floats per volume
+    long long last_stride = 0;  // floats between the Lr volumes of consecutive passes (>= last_nvol)
     int last_ndir = 0;
     bool pending_check = false;
     // timing
@@ -63,6 +64,16 @@ namespace {
 constexpr int kR = 16;       // lines per band (waves per workgroup) of the pass kernel
 constexpr int kCtrlWords = 4 + kMaxDirs * 4096;  // ticket, err, flag, pad, prog[pass][maxbands]
 constexpr int kMaxBands = 4096;
+
+long long lr_pad_floats()
+{
+    static long long pad = -1;
+    if (pad < 0) {
+        const char *e = getenv("MGM_HIP_LR_PAD");  // in 256-byte blocks; default 67 (17 KiB + 256 B)
+        pad = 64ll * (e ? atoll(e) : 67);
+    }
+    return pad;
+}
 
 int fail(mgm_ctx *c, int code, const std::string &msg)
 {
@@ -543,7 +554,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
     }
     if (maxbands > kMaxBands) return fail(c, MGM_ERR_UNSUPPORTED, "image side exceeds 65536 pixels");
 
-    if ((r = reserve(c, c->lr, sizeof(float) * (size_t)nvol * count))) return r;
+    // Consecutive passes' volumes are staggered by an odd number of 256-byte blocks so that the
+    // NDIR slabs of one pixel (read together by k_wta) do not fall on the same HBM channel.
+    const long long lr_stride = nvol + lr_pad_floats();
+    if ((r = reserve(c, c->lr, sizeof(float) * (size_t)lr_stride * count))) return r;
     if ((r = reserve(c, c->hand, sizeof(float) * (size_t)PEND * 2 * maxLL * NS * LP))) return r;
     if ((r = reserve(c, c->handm, sizeof(float) * (size_t)PEND * 2 * maxLL))) return r;
 
@@ -579,7 +593,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
     p.prog = words + 4;
     p.tasks = (const int2 *)c->tasks.p;
     p.npix = npix;
-    p.nvol = nvol;
+    p.nvol = lr_stride;
     p.L = L;
     p.MGM = MGM;
     p.NDIR = PEND;
@@ -652,6 +666,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
         }
     }
     c->last_nvol = nvol;
+    c->last_stride = lr_stride;
     c->last_ndir = count;
 
     return MGM_OK;
@@ -703,7 +718,8 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
         if ((r = mgm_cv_create(c, nx, ny, C->dmin, C->dmax, S))) return r;
         Sout = (*S)->d;
     }
-    return run_wta(c, C, 0, npix, (const float *)c->lr.p, nvol, NDIR, fix_overcount, ridx, out->d, outcost->d, Sout);
+    return run_wta(c, C, 0, npix, (const float *)c->lr.p, c->last_stride, NDIR, fix_overcount, ridx, out->d, outcost->d,
+                   Sout);
 }
 
 // ---- direction sharding (multi-GPU): run a subset of the passes, sum slabs of Lr volumes ----------
@@ -723,7 +739,7 @@ int mgm_aggregate_passes_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, flo
 void *mgm_lr_device_ptr(mgm_ctx *c, int slot)
 {
     if (!c || !c->lr.p || slot < 0 || slot >= c->last_ndir) return nullptr;
-    return (float *)c->lr.p + (size_t)slot * c->last_nvol;
+    return (float *)c->lr.p + (size_t)slot * c->last_stride;
 }
 
 int mgm_wta_rows_dev(mgm_ctx *c, const mgm_cv *C, int row0, int nrows, const void *lr_slabs, int NDIR, int fix_overcount,
@@ -763,7 +779,7 @@ int mgm_debug_download_lr(mgm_ctx *c, int pass, float *dense)
     if (!c || !dense || pass < 0 || pass >= c->last_ndir || !c->lr.p)
         return fail(c, MGM_ERR_INVALID, "mgm_debug_download_lr: nothing to download");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(dense, (const float *)c->lr.p + (size_t)pass * c->last_nvol, sizeof(float) * c->last_nvol,
+    HIPCHK(c, hipMemcpyAsync(dense, (const float *)c->lr.p + (size_t)pass * c->last_stride, sizeof(float) * c->last_nvol,
                              hipMemcpyDeviceToHost, c->stream));
     return mgm_ctx_synchronize(c);
 }

@@ -38,11 +38,11 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
     constexpr int LP = LPL * 64;
     __shared__ float sS[4][LP];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long pix = (long long)blockIdx.x * 4 + wv;
-    if (pix >= P.npix) return;
     const int L = P.L;
     const bool exact = (L == LP);
     const int o0 = lane * LPL;
+    // grid-stride over pixels: a bounded number of workgroups, each wave streams many pixels
+    for (long long pix = (long long)blockIdx.x * 4 + wv; pix < P.npix; pix += (long long)gridDim.x * 4) {
 
     float c[LPL], S[LPL];
     {
@@ -50,14 +50,24 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
 #pragma unroll
         for (int k = 0; k < LPL; k++) c[k] = (exact || o0 + k < L) ? q[k] : f_inf();
     }
+    // all NDIR slabs are requested before the first one is consumed (independent loads in flight),
+    // then summed in pass order: S = ((0 + L0) + L1) + ...
+    float l[kMaxDirs][LPL];
+#pragma unroll
+    for (int p = 0; p < kMaxDirs; p++) {
+        if (p < P.NDIR) {
+            const float *q = P.Lr + (long long)p * P.nvol + pix * L + o0;
+#pragma unroll
+            for (int k = 0; k < LPL; k++) l[p][k] = (exact || o0 + k < L) ? q[k] : f_inf();
+        }
+    }
 #pragma unroll
     for (int k = 0; k < LPL; k++) S[k] = 0.0f;
-    for (int p = 0; p < P.NDIR; p++) {
-        const float *q = P.Lr + (long long)p * P.nvol + pix * L + o0;
 #pragma unroll
-        for (int k = 0; k < LPL; k++) {
-            const float l = (exact || o0 + k < L) ? q[k] : f_inf();
-            S[k] = S[k] + l;
+    for (int p = 0; p < kMaxDirs; p++) {
+        if (p < P.NDIR) {
+#pragma unroll
+            for (int k = 0; k < LPL; k++) S[k] = S[k] + l[p][k];
         }
     }
     if (P.FIX == 1) {
@@ -113,11 +123,14 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
         P.out[pix] = outv;
         P.outcost[pix] = outc;
     }
+    }  // pixel loop
 }
 
 hipError_t launch_wta(const WtaParams &p, hipStream_t s)
 {
-    const dim3 grid((unsigned)((p.npix + 3) / 4)), block(256);
+    long long nb = (p.npix + 3) / 4;
+    if (nb > 256 * 16) nb = 256 * 16;  // 16 workgroups of 4 waves per CU, grid-stride beyond
+    const dim3 grid((unsigned)nb), block(256);
     switch (pass_lpl(p.L)) {
         case 1: hipLaunchKernelGGL(k_wta<1>, grid, block, 0, s, p); break;
         case 2: hipLaunchKernelGGL(k_wta<2>, grid, block, 0, s, p); break;

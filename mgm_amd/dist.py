@@ -104,8 +104,8 @@ def aggregate_direction_sharded(ctx, cv, P1, P2, NDIR, MGM, use_fh, fix_overcoun
     first, count = passes_of_rank(NDIR, world, rank)
     ctx.aggregate_passes_dev(cv, P1, P2, MGM, use_fh, first, count, w8)
     ctx.synchronize()  # Lr volumes complete before RCCL reads them (different streams)
-    if world == 1:
-        # nothing to exchange: the workspace already is [NDIR][ny][nx][L] in pass order
+    if world == 1 and ctx.lr_device_ptr(1) in (None, ctx.lr_device_ptr(0) + 4 * ny * nx * L):
+        # nothing to exchange and the workspace is contiguous [NDIR][ny][nx][L] in pass order
         recv = device_view(ctx.lr_device_ptr(0), (NDIR, ny, nx, L))
     else:
         lr_local = [device_view(ctx.lr_device_ptr(k), (ny, nx, L)) for k in range(count)]
