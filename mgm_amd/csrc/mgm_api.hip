@@ -21,6 +21,10 @@ struct mgm_img {
 struct mgm_cv {
     float *d;
     int nx, ny, dmin, dmax;
+    // compact (one byte per cost) copy used by K3 / k_wta when every cost is an integer 0..254 or +INF
+    uint8_t *d8 = nullptr;
+    unsigned *bad8 = nullptr;  // device word: 1 = not representable
+    int c8_state = 0;          // 0 none, 1 written (validity not read back yet), 2 valid, -1 invalid
 };
 
 namespace {
@@ -367,7 +371,11 @@ int mgm_cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, mgm_cv **out)
     if (L > kMaxLPL * 64)
         return fail(c, MGM_ERR_UNSUPPORTED, "more than 512 disparity labels per pixel are not supported");
     HIPCHK(c, hipSetDevice(c->device));
-    mgm_cv *cv = new mgm_cv{nullptr, nx, ny, dmin, dmax};
+    mgm_cv *cv = new mgm_cv();
+    cv->nx = nx;
+    cv->ny = ny;
+    cv->dmin = dmin;
+    cv->dmax = dmax;
     hipError_t e = hipMalloc((void **)&cv->d, sizeof(float) * (size_t)nx * ny * (size_t)L);
     if (e != hipSuccess) {
         delete cv;
@@ -384,6 +392,7 @@ int mgm_cv_upload(mgm_ctx *c, const float *dense, int nx, int ny, int dmin, int 
     const size_t n = (size_t)nx * ny * (size_t)(dmax - dmin + 1);
     HIPCHK(c, hipMemcpyAsync((*out)->d, dense, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    (*out)->c8_state = 0;
     return MGM_OK;
 }
 int mgm_cv_download(mgm_ctx *c, const mgm_cv *cv, float *dense)
@@ -403,7 +412,12 @@ int mgm_cv_dims(const mgm_cv *cv, int *nx, int *ny, int *dmin, int *dmax)
     if (dmax) *dmax = cv->dmax;
     return MGM_OK;
 }
-void *mgm_cv_device_ptr(mgm_cv *cv) { return cv ? cv->d : nullptr; }
+void *mgm_cv_device_ptr(mgm_cv *cv)
+{
+    if (!cv) return nullptr;
+    cv->c8_state = 0;  // the caller may write through the pointer: re-derive the compact copy at the next use
+    return cv->d;
+}
 int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
 {
     if (!cv) return MGM_OK;
@@ -412,7 +426,49 @@ int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
         hipStreamSynchronize(c->stream);
     }
     hipFree(cv->d);
+    if (cv->d8) hipFree(cv->d8);
+    if (cv->bad8) hipFree(cv->bad8);
     delete cv;
+    return MGM_OK;
+}
+
+// ---- compact costs -----------------------------------------------------------
+static int c8_alloc(mgm_ctx *c, mgm_cv *cv)
+{
+    const size_t n = (size_t)cv->nx * cv->ny * (size_t)(cv->dmax - cv->dmin + 1);
+    if (!cv->d8 && hipMalloc((void **)&cv->d8, n + 64) != hipSuccess) {
+        cv->d8 = nullptr;
+        return fail(c, MGM_ERR_NOMEM, "hipMalloc of the compact cost volume failed");
+    }
+    if (!cv->bad8 && hipMalloc((void **)&cv->bad8, 64) != hipSuccess) {
+        cv->bad8 = nullptr;
+        return fail(c, MGM_ERR_NOMEM, "hipMalloc failed");
+    }
+    return MGM_OK;
+}
+// Decide (once per filling of the volume) whether the compact copy can stand in for C.
+// Costs one 4-byte device->host read; MGM_HIP_C8=0 disables the compact path.
+static int c8_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *use)
+{
+    mgm_cv *cv = const_cast<mgm_cv *>(ccv);
+    *use = false;
+    static const bool enabled = !(getenv("MGM_HIP_C8") && atoi(getenv("MGM_HIP_C8")) == 0);
+    const int L = cv->dmax - cv->dmin + 1;
+    if (!enabled || !c8_supported(L)) return MGM_OK;
+    if (cv->c8_state == 0) {  // uploaded / externally written volume: make the compact copy now
+        int r = c8_alloc(c, cv);
+        if (r) return r;
+        HIPCHK(c, hipMemsetAsync(cv->bad8, 0, 4, c->stream));
+        TimeScope t(c, "k_compact");
+        HIPCHK(c, launch_compact(cv->d, (long long)cv->nx * cv->ny * L, cv->d8, cv->bad8, c->stream));
+        cv->c8_state = 1;
+    }
+    if (cv->c8_state == 1) {
+        HIPCHK(c, hipMemcpyAsync(c->h_words + 3, cv->bad8, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        cv->c8_state = c->h_words[3] ? -1 : 2;
+    }
+    *use = cv->c8_state == 2;
     return MGM_OK;
 }
 
@@ -441,6 +497,16 @@ int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int
     }
     CostParams p{};
     p.C = (*out)->d;
+    p.C8 = nullptr;
+    p.bad8 = nullptr;
+    (*out)->c8_state = 0;
+    if (c8_supported(dmax - dmin + 1) && !(getenv("MGM_HIP_C8") && atoi(getenv("MGM_HIP_C8")) == 0)) {
+        if ((r = c8_alloc(c, *out))) return r;
+        HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
+        p.C8 = (*out)->d8;
+        p.bad8 = (*out)->bad8;
+        (*out)->c8_state = 1;
+    }
     p.nx = u->nx;
     p.ny = u->ny;
     p.vnx = v->nx;
@@ -542,8 +608,12 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
     const bool fh = use_fh > 0;
     const int NS = pass_ns(fh, weighted);
 
+    // compact costs (one byte per label) when the volume allows it
+    bool use_c8 = false;
+    if ((r = c8_resolve(c, C, &use_c8))) return r;
+    if (c->force_build == 1) use_c8 = false;
     // second build (LDS-DMA loaders) whenever the slabs are whole DMA pieces
-    const int R2 = c->force_build == 1 ? 0 : pass2_lines(L);
+    const int R2 = c->force_build == 1 ? 0 : pass2_lines(L, use_c8);
     const int R = R2 ? R2 : kR;
     PassParams p{};
     int maxLL = 0, maxbands = 0;
@@ -584,6 +654,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
     }
 
     p.C = C->d;
+    p.C8 = use_c8 ? C->d8 : nullptr;
     p.Lr = (float *)c->lr.p;
     p.w8 = weighted ? w8->d : nullptr;
     p.hand = (float *)c->hand.p;
@@ -679,6 +750,7 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
     const int L = C->dmax - C->dmin + 1;
     WtaParams w{};
     w.C = C->d + pix0 * L;
+    w.C8 = (C->c8_state == 2 && c->force_build != 1) ? C->d8 + pix0 * L : nullptr;
     w.Lr = lr;
     w.S = Sout;
     w.out = out;

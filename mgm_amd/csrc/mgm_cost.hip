@@ -81,8 +81,9 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
     const int x = (int)(pix % P.nx), y = (int)(pix / P.nx);
     const long long vpix = (long long)P.vnx * P.vny;
     float *Cp = P.C + pix * P.L;
+    uint8_t *Cp8 = P.C8 ? P.C8 + pix * P.L : nullptr;
     const bool yin = (y < P.vny);  // q.y = p.y >= 0 always
-    bool anyfinite = false;
+    bool anyfinite = false, bad8 = false;
     for (int o = lane; o < P.L; o += 64) {
         const int qx = x + o + P.dmin;
         float e = P.trunc;
@@ -109,10 +110,46 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
         e = (e < P.trunc) ? e : P.trunc;
         Cp[o] = e;
         anyfinite |= finite_bits(e);
+        if (Cp8) {
+            const unsigned b = c8_encode(e);
+            bad8 |= b > 255u;
+            Cp8[o] = (uint8_t)b;
+        }
     }
     // no valid hypothesis for this pixel => all labels cost 0 (mgm_costvolume.h:414-421)
     if (__builtin_amdgcn_ballot_w64(anyfinite) == 0ull)
-        for (int o = lane; o < P.L; o += 64) Cp[o] = 0.0f;
+        for (int o = lane; o < P.L; o += 64) {
+            Cp[o] = 0.0f;
+            if (Cp8) Cp8[o] = 0;
+        }
+    else if (Cp8 && __builtin_amdgcn_ballot_w64(bad8) != 0ull && lane == 0)
+        atomicOr(P.bad8, 1u);
+}
+
+// compact copy of an existing fp32 volume (uploaded by the caller)
+__global__ void __launch_bounds__(256) k_compact(const float *__restrict__ C, long long n, uint8_t *__restrict__ C8,
+                                                 unsigned *bad8)
+{
+    bool bad = false;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+        unsigned w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned b = (i + k < n) ? c8_encode(C[i + k]) : 0u;
+            bad |= b > 255u;
+            w |= (b & 255u) << (8 * k);
+        }
+        if (i + 3 < n) *reinterpret_cast<unsigned *>(C8 + i) = w;
+        else
+            for (int k = 0; k < 4 && i + k < n; k++) C8[i + k] = (uint8_t)(w >> (8 * k));
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(bad8, 1u);
+}
+
+hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compact, dim3(256 * 16), dim3(256), 0, s, C, n, C8, bad8);
+    return hipGetLastError();
 }
 
 hipError_t launch_cost(const CostParams &p, hipStream_t s)

@@ -31,6 +31,7 @@ struct PassGeom {
 
 struct PassParams {
     const float *C;     // [npix][L]
+    const uint8_t *C8;  // [npix][L] compact costs (integers 0..254, 255 = +INF) or nullptr
     float *Lr;          // NDIR volumes, pass p at Lr + p*nvol
     const float *w8;    // 8 planes [npix] or nullptr
     float *hand;        // hand-off slabs  [pass][2][LLmax][NS*LP]
@@ -51,6 +52,7 @@ struct PassParams {
 
 struct WtaParams {
     const float *C;
+    const uint8_t *C8;  // compact copy of C (see PassParams) or nullptr
     const float *Lr;    // NDIR volumes
     float *S;           // nullptr or corrected volume out
     float *out, *outcost;
@@ -63,10 +65,13 @@ hipError_t launch_pass(const PassParams &p, int ntasks, int R, bool fh, int wmod
 int pass_ns(bool fh, bool weighted);  // slabs per hand-off slot
 int pass_lpl(int L);                  // disparities per lane the pass kernel is instantiated for
 // second build (LDS-DMA loader waves); pass2_lines(L) = lines per band, 0 if L is not supported by it
-int pass2_lines(int L);
+int pass2_lines(int L, bool c8);
 hipError_t launch_pass2(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s);
 template <int LPL>
 hipError_t launch_pass2_lpl(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s);
+// compact-cost support: labels per lane for which the C8 forms of K3 / k_wta exist
+inline bool c8_supported(int L) { return L == 64 || L == 128 || L == 256 || L == 512; }
+hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s);
 hipError_t launch_wta(const WtaParams &p, hipStream_t s);
 hipError_t launch_refine(const float *S, long long npix, int L, int dmin, int method, float *out, float *outcost,
                          hipStream_t s);
@@ -75,6 +80,8 @@ struct CostParams {
     const float *u, *v;          // planar images (float, or census words reinterpreted)
     const uint32_t *cu, *cv;     // census words (planar) when prefiltered
     float *C;
+    uint8_t *C8;                 // compact copy, written alongside C
+    unsigned *bad8;              // set to 1 if some cost is not representable in the compact form
     int nx, ny, vnx, vny, nch;   // nch = channels of the (prefiltered) images
     int dmin, L;
     int costfn;                  // 0 ad, 1 sd, 2 census
@@ -91,6 +98,18 @@ hipError_t launch_any_not_one(const float *w, long long n, unsigned *flag, hipSt
 // ---------------------------------------------------------------------------
 #ifdef __HIPCC__
 __device__ __forceinline__ float f_inf() { return __builtin_huge_valf(); }
+
+// Compact cost: an fp32 cost that is an integer in [0, 254] or +INF is stored as one byte
+// (255 = +INF).  Census costs with one descriptor word and AD costs of 8-bit images qualify; the
+// conversion back is exact.  Returns 256 if x is not representable.
+__device__ __forceinline__ unsigned c8_encode(float x)
+{
+    if (x == __builtin_huge_valf()) return 255u;
+    const float r = __builtin_rintf(x);
+    const bool neg0 = __builtin_bit_cast(unsigned, x) == 0x80000000u;  // -0 would come back as +0
+    return (x >= 0.0f && x <= 254.0f && r == x && !neg0) ? (unsigned)r : 256u;
+}
+__device__ __forceinline__ float c8_decode(unsigned b) { return b == 255u ? __builtin_huge_valf() : (float)b; }
 
 // DPP lane shifts over the whole wave (gfx9 wave_shr / wave_shl).
 // shr1: lane l receives lane l-1 (lane 0 gets `fill`).

@@ -116,23 +116,29 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 
 #define MGM_P2_LEAD 4
 #endif
 // ---- geometry of the build --------------------------------------------------------
-template <int LPL, int NS, bool HASM>
+template <int LPL, int NS, bool HASM, bool C8>
 struct Plan {
     static constexpr int LP = LPL * 64;
-    static constexpr int IPS = (LPL * 16 + 63) / 64;  // DMA pieces per slab
-    static constexpr int NC = (LPL <= 4) ? MGM_P2_NC : 7;    // compute waves = lines per band
-    static constexpr int NL = (LPL <= 4 && MGM_P2_NC > 7) ? 2 : 1;     // loader waves
-    static constexpr int NCA = (NL == 2) ? NC / 2 : NC;  // lines served by loader A
-    // DMA instructions per step: loader A = its C lines + hand-off slabs + minimum + progress word
-    static constexpr int nA = NCA * IPS + NS * IPS + 1 + (HASM ? 1 : 0);
+    static constexpr int IPS = (LPL * 16 + 63) / 64;  // DMA pieces per fp32 slab
+    // compact costs: a slab is LP bytes = LPS lanes of one DMA piece, so one 64-lane piece carries the
+    // slabs of LPD different lines (every lane has its own source address)
+    static constexpr int LPS = LPL * 4;
+    static constexpr int LPD = C8 ? 64 / LPS : 1;
+    static constexpr int NL = (!C8 && LPL <= 4 && MGM_P2_NC > 7) ? 2 : 1;              // loader waves
+    static constexpr int NC = (LPL <= 4) ? (C8 ? 15 : MGM_P2_NC) : 7;                 // compute waves = lines per band
+    static constexpr int NCA = (NL == 2) ? NC / 2 : NC;                               // lines served by loader A
+    static constexpr int NDMA = C8 ? (NC + LPD - 1) / LPD : NCA * IPS;                // C pieces per step (loader A)
+    // DMA instructions per step: loader A = its C pieces + hand-off slabs [+ minimum] + progress word
+    static constexpr int nA = NDMA + NS * IPS + 1 + (HASM ? 1 : 0);
     static constexpr int nB = (NC - NCA) * IPS;
+    static constexpr int cring_floats(int D) { return C8 ? (D + 1) * NDMA * 256 : NC * (D + 1) * LP; }
     static constexpr int lds_floats(int D)
     {
         return NC * 2 * NS * LP      // T ring
                + NC * 2              // T minima
                + (D + 1) * NS * LP   // hand-off ring
                + 2 * (D + 1) + 8     // hand-off minima, progress words, task word
-               + NC * (D + 1) * LP;  // C ring
+               + cring_floats(D);    // C ring
     }
     static constexpr int pick_D()
     {
@@ -142,6 +148,7 @@ struct Plan {
     }
     static constexpr int D = pick_D();
     static_assert(D >= 2, "no feasible pipeline depth");
+    static_assert(!C8 || (64 % LPS == 0), "compact slabs must tile a DMA piece");
 };
 
 // unit weights, slabs hold E = T - m (every unit-weight case but FH with MGM == 2)
@@ -175,14 +182,15 @@ __device__ __forceinline__ void combine_unit_E(const float (&C)[LPL], const floa
     }
 }
 
-template <int LPL, bool FH, bool WEIGHTED, int MGM>
-__global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::NL) * 64, (LPL <= 4 ? MGM_P2_WAVES_PER_EU : 4))
-    k_pass2(const PassParams P)
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8>
+__global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, true, C8>::NL) * 64,
+                                  (LPL <= 4 ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
 {
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
     constexpr bool pubE = !WEIGHTED && !(FH && MGM == 2);  // slabs carry E = T - m; minima not needed
-    using PL = Plan<LPL, NS, !pubE>;
+    using PL = Plan<LPL, NS, !pubE, C8>;
     constexpr int LP = PL::LP, NC = PL::NC, NCA = PL::NCA, D = PL::D, IPS = PL::IPS;
+    constexpr int LPS = PL::LPS, LPD = PL::LPD, NDMA = PL::NDMA;
     constexpr int LPW = NCA;   // C lines per loader wave (NC - NCA == NCA when there are two loaders)
     constexpr int RD = D + 1;  // ring depth
     using NbT = Nb<LPL, NS>;
@@ -190,8 +198,8 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Tring = smem;                          // [NC][2][NS][LP]
     float *Hring = Tring + NC * 2 * NS * LP;      // [RD][NS][LP]
-    float *Cring = Hring + RD * NS * LP;          // [NC][RD][LP]
-    float *Tm = Cring + NC * RD * LP;             // [NC][2]
+    float *Cring = Hring + RD * NS * LP;          // fp32: [NC][RD][LP]; compact: [RD][NDMA][1 KiB]
+    float *Tm = Cring + PL::cring_floats(D);      // [NC][2]
     float *Hm = Tm + NC * 2;                      // [RD]
     unsigned *Hprog = reinterpret_cast<unsigned *>(Hm + RD);  // [RD]
     int *s_task = reinterpret_cast<int *>(Hprog + RD);
@@ -229,18 +237,25 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
         bool dead = false;
         unsigned long long n_slow = 0, t_slow = 0, n_spin = 0, t_ret = 0, t_bar = 0, t_iss = 0;
 
-        // Per line: the (clamped) source pointer of the NEXT target step and its pixel index.
-        // Target step t wants pixel i = t-1-2r of line r; out-of-range steps re-read an end pixel
+        // Per C piece: the (clamped) source pointer of the NEXT target step and its pixel index.
+        // Target step t wants pixel i = t-1-SL*r of line r; out-of-range steps re-read an end pixel
         // (the slot they fill is never consumed) so that every step issues the same DMA count.
-        const float *cptr[LPW];
-        int ci[LPW];
-        const long long cstride = istep * L;
+        // fp32 costs: one piece = one line's slab (lane l moves bytes 16l..16l+15 of it).
+        // compact costs: one piece = the slabs of LPD lines; lane l serves line q*LPD + l/LPS.
+        constexpr int NPIECE = C8 ? NDMA : LPW;
+        const float *cptr[NPIECE];
+        int ci[NPIECE];
+        const long long cstride = C8 ? (istep * L) / 4 : istep * L;  // in floats (compact: L bytes per pixel)
 #pragma unroll
-        for (int q = 0; q < LPW; q++) {
-            const int r = r0 + q;
+        for (int q = 0; q < NPIECE; q++) {
+            int r = C8 ? q * LPD + lane / LPS : r0 + q;
+            r = r < NC ? r : NC - 1;
             int j = band * NC + r;
             j = j < NLn ? j : NLn - 1;
-            cptr[q] = P.C + (g.base + (long long)j * g.jstep) * L + lane * 4;
+            if constexpr (C8)
+                cptr[q] = reinterpret_cast<const float *>(P.C8 + (g.base + (long long)j * g.jstep) * L + (lane % LPS) * 16);
+            else
+                cptr[q] = P.C + (g.base + (long long)j * g.jstep) * L + lane * 4;
             ci[q] = -1 - SL * r;
         }
         // hand-off slab wanted by wave 0 at step t: pixel t (its fwd neighbour) with slope 2, pixel t-1
@@ -251,11 +266,15 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
 
         auto issue = [&](int slot) {  // everything the step `ht` needs, into ring slot `slot`
 #pragma unroll
-            for (int q = 0; q < LPW; q++) {
-                float *dst = Cring + ((r0 + q) * RD + slot) * LP;
+            for (int q = 0; q < NPIECE; q++) {
+                if constexpr (C8) {
+                    dma16<0>(cptr[q], Cring + (slot * NDMA + q) * 256);
+                } else {
+                    float *dst = Cring + ((r0 + q) * RD + slot) * LP;
 #pragma unroll
-                for (int c = 0; c < IPS; c++)
-                    if (c * 64 + lane < ((P.xflags & 2) ? 1 : LPL * 16)) dma16<0>(cptr[q] + c * 256, dst + c * 256);
+                    for (int c = 0; c < IPS; c++)
+                        if (c * 64 + lane < ((P.xflags & 2) ? 1 : LPL * 16)) dma16<0>(cptr[q] + c * 256, dst + c * 256);
+                }
                 const bool adv = (ci[q] >= 0) && (ci[q] < LL - 1);
                 cptr[q] += adv ? cstride : 0;
                 ci[q]++;
@@ -367,7 +386,9 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
     const long long pix0 = g.base + (long long)j * g.jstep;
     const float *fwd_src0 = r > 0 ? Tring + (r - 1) * 2 * NSLP + lane * LPL : Hring + lane * LPL;
     const float *fwd_m0 = r > 0 ? Tm + (r - 1) * 2 : Hm;
-    const float *c_src0 = Cring + r * RD * LP + lane * LPL;
+    // fp32: own ring [RD][LP]; compact: byte (r%LPD)*LPS*16 + lane*LPL of piece r/LPD of the step's slot
+    const float *c_src0 = C8 ? Cring + (r / LPD) * 256 : Cring + r * RD * LP + lane * LPL;
+    const int c8_byte = (r % LPD) * LPS * 16 + lane * LPL;
     float *t_dst0 = Tring + r * 2 * NSLP + lane * LPL;
 
     // The whole line walk, specialised on the neighbour order of the pass (FORM).
@@ -398,7 +419,23 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
             if (line_ok && i >= 0 && i < LL) {
                 const long long pix = pix0 + (long long)i * istep;
                 float Cv[LPL], Lv[LPL];
-                {
+                if constexpr (C8) {
+                    const unsigned char *src = reinterpret_cast<const unsigned char *>(c_src0 + cslot * NDMA * 256) + c8_byte;
+                    if constexpr (LPL == 1) {
+                        Cv[0] = c8_decode(*src);
+                    } else if constexpr (LPL == 2) {
+                        const unsigned w = *reinterpret_cast<const unsigned short *>(src);
+                        Cv[0] = c8_decode(w & 255u);
+                        Cv[1] = c8_decode(w >> 8);
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < LPL / 4; h++) {
+                            const unsigned w = reinterpret_cast<const unsigned *>(src)[h];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) Cv[h * 4 + k] = c8_decode((w >> (8 * k)) & 255u);
+                        }
+                    }
+                } else {
                     const float *src = c_src0 + cslot * LP;
 #pragma unroll
                     for (int k = 0; k < LPL; k++) Cv[k] = src[k];
@@ -558,18 +595,27 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true>::NC + Plan<LPL, 1, true>::
 }
 
 // ---- launcher (one translation unit per LPL: -DMGM_P2_LPL=n) -----------------------
-template <int LPL, bool FH, bool WEIGHTED, int MGM>
-static hipError_t launch2_one(const PassParams &p, int ntasks, hipStream_t s)
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8>
+static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 {
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
-    using PL = Plan<LPL, NS, WEIGHTED || (FH && MGM == 2)>;
+    using PL = Plan<LPL, NS, WEIGHTED || (FH && MGM == 2), C8>;
     const size_t shmem = sizeof(float) * (size_t)PL::lds_floats(PL::D);
-    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM>;
+    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(ntasks), dim3((PL::NC + PL::NL) * 64), shmem, s, p);
     return hipGetLastError();
+}
+
+template <int LPL, bool FH, bool WEIGHTED, int MGM>
+static hipError_t launch2_one(const PassParams &p, int ntasks, hipStream_t s)
+{
+    if constexpr (LPL == 1 || LPL == 2 || LPL == 4 || LPL == 8) {
+        if (p.C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true>(p, ntasks, s);
+    }
+    return launch2_c8<LPL, FH, WEIGHTED, MGM, false>(p, ntasks, s);
 }
 
 template <int LPL, bool FH, bool WEIGHTED>

@@ -5,10 +5,11 @@
 namespace mgm {
 
 // lines per band of the second build (0 = this L is not supported by it)
-int pass2_lines(int L)
+int pass2_lines(int L, bool c8)
 {
     if (L % 64) return 0;
     const int lpl = L / 64;
+    if (c8 && c8_supported(L)) return lpl <= 4 ? 15 : 7;  // one loader wave is enough for compact costs
     if (lpl == 1 || lpl == 2 || lpl == 3 || lpl == 4) return 14;
     if (lpl == 6 || lpl == 8) return 7;
     return 0;

@@ -45,7 +45,11 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
     for (long long pix = (long long)blockIdx.x * 4 + wv; pix < P.npix; pix += (long long)gridDim.x * 4) {
 
     float c[LPL], S[LPL];
-    {
+    if (P.C8 && exact) {  // compact costs: one byte per label (wave-uniform branch)
+        const uint8_t *q = P.C8 + pix * L + o0;
+#pragma unroll
+        for (int k = 0; k < LPL; k++) c[k] = c8_decode(q[k]);
+    } else {
         const float *q = P.C + pix * L + o0;
 #pragma unroll
         for (int k = 0; k < LPL; k++) c[k] = (exact || o0 + k < L) ? q[k] : f_inf();
