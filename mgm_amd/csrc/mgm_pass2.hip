@@ -46,10 +46,10 @@ __device__ __forceinline__ void wait_vmcnt()
     static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void step_barrier()
+__device__ __forceinline__ void step_barrier(bool skip = false)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!skip) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 // LDS read the compiler must not order against pending LDS-DMA itself (it would
@@ -106,6 +106,9 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 
 #ifndef MGM_P2_LDS_KB
 #define MGM_P2_LDS_KB 160
 #endif
+#ifndef MGM_P2_C8_NL
+#define MGM_P2_C8_NL 1
+#endif
 #ifndef MGM_P2_MAXD
 #define MGM_P2_MAXD 2
 #endif
@@ -124,13 +127,14 @@ struct Plan {
     // slabs of LPD different lines (every lane has its own source address)
     static constexpr int LPS = LPL * 4;
     static constexpr int LPD = C8 ? 64 / LPS : 1;
-    static constexpr int NL = (!C8 && LPL <= 4 && MGM_P2_NC > 7) ? 2 : 1;              // loader waves
-    static constexpr int NC = (LPL <= 4) ? (C8 ? 15 : MGM_P2_NC) : 7;                 // compute waves = lines per band
+    static constexpr int NL = (LPL <= 4 && MGM_P2_NC > 7) ? (C8 ? MGM_P2_C8_NL : 2) : 1;  // loader waves
+    static constexpr int NC = (LPL <= 4) ? (C8 ? 16 - MGM_P2_C8_NL : MGM_P2_NC) : 7;   // compute waves = lines per band
     static constexpr int NCA = (NL == 2) ? NC / 2 : NC;                               // lines served by loader A
     static constexpr int NDMA = C8 ? (NC + LPD - 1) / LPD : NCA * IPS;                // C pieces per step (loader A)
     // DMA instructions per step: loader A = its C pieces + hand-off slabs [+ minimum] + progress word
-    static constexpr int nA = NDMA + NS * IPS + 1 + (HASM ? 1 : 0);
-    static constexpr int nB = (NC - NCA) * IPS;
+    // compact costs with two loaders: A = hand-off only, B = all C pieces
+    static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + NS * IPS + 1 + (HASM ? 1 : 0);
+    static constexpr int nB = (C8 && NL == 2) ? NDMA : (NC - NCA) * IPS;
     static constexpr int cring_floats(int D) { return C8 ? (D + 1) * NDMA * 256 : NC * (D + 1) * LP; }
     static constexpr int lds_floats(int D)
     {
@@ -265,8 +269,10 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
         int ht = SL == 2 ? 0 : -1;
 
         auto issue = [&](int slot) {  // everything the step `ht` needs, into ring slot `slot`
+            const bool c_duty = !(C8 && PL::NL == 2) || wl == 1;  // with compact costs and two loaders, B fetches C
 #pragma unroll
             for (int q = 0; q < NPIECE; q++) {
+                if (!c_duty) break;
                 if constexpr (C8) {
                     dma16<0>(cptr[q], Cring + (slot * NDMA + q) * 256);
                 } else {
@@ -341,7 +347,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             dbg[1] = wall_clock64();
             dbg[5] = t_slow;
         }
-        step_barrier();  // B0
+        step_barrier((P.xflags & 8) != 0);  // B0
         int uslot = 0;   // slot of the step that is about to run
         for (int s = 0; s < nsteps; s++) {
             if (wl == 0 && from_global) {
@@ -356,7 +362,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             const unsigned long long tb = dbg ? wall_clock64() : 0;
             retire();
             const unsigned long long tc = dbg ? wall_clock64() : 0;
-            step_barrier();
+            step_barrier((P.xflags & 8) != 0);
             if (dbg) {
                 const unsigned long long td = wall_clock64();
                 t_iss += tb - ta;
@@ -567,21 +573,21 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             }
         };
 
-        step_barrier();  // B0: the loaders' prologue has landed
+        step_barrier((P.xflags & 8) != 0);  // B0: the loaders' prologue has landed
         int cslot = 0;
         unsigned long long t_cbar = 0;
         for (int s = 0; s < nsteps; s += 3) {
             step(s, cslot, wA, wB, wC);
             cslot = cslot + 1 == RD ? 0 : cslot + 1;
             const unsigned long long t0 = (dbg && r == NC / 2) ? wall_clock64() : 0;
-            step_barrier();
+            step_barrier((P.xflags & 8) != 0);
             if (dbg && r == NC / 2) t_cbar += wall_clock64() - t0;
             step(s + 1, cslot, wB, wC, wA);
             cslot = cslot + 1 == RD ? 0 : cslot + 1;
-            step_barrier();
+            step_barrier((P.xflags & 8) != 0);
             step(s + 2, cslot, wC, wA, wB);
             cslot = cslot + 1 == RD ? 0 : cslot + 1;
-            step_barrier();
+            step_barrier((P.xflags & 8) != 0);
         }
         if (dbg && r == NC / 2 && lane == 0) {
             dbg[14] = t_cbar * 3;

@@ -2,6 +2,10 @@
 // (mgm_pass2.hip is compiled once per LPL with -DMGM_P2_LPL=n).
 #include "mgm_device.h"
 
+#ifndef MGM_P2_C8_NL
+#define MGM_P2_C8_NL 1
+#endif
+
 namespace mgm {
 
 // lines per band of the second build (0 = this L is not supported by it)
@@ -9,7 +13,7 @@ int pass2_lines(int L, bool c8)
 {
     if (L % 64) return 0;
     const int lpl = L / 64;
-    if (c8 && c8_supported(L)) return lpl <= 4 ? 15 : 7;  // one loader wave is enough for compact costs
+    if (c8 && c8_supported(L)) return lpl <= 4 ? 16 - MGM_P2_C8_NL : 7;  // compact costs need fewer loader waves
     if (lpl == 1 || lpl == 2 || lpl == 3 || lpl == 4) return 14;
     if (lpl == 6 || lpl == 8) return 7;
     return 0;

@@ -9,6 +9,8 @@
 //
 // Compiled with default floating point: S may hold NaN (inf - inf) and the
 // refinement must propagate NaN/inf exactly as IEEE arithmetic does on the CPU.
+#include <cstdlib>
+
 #include "mgm_device.h"
 
 namespace mgm {
@@ -32,116 +34,141 @@ __device__ __forceinline__ void vfit(float v0, float v1, float v2, float &v_min,
     v_min = v2 + (x_min - 1.0f) * slope;
 }
 
-template <int LPL>
+// PPW pixels per wave and iteration: all their slabs are requested before the first is consumed.
+// One KiB per stream per wave leaves HBM at ~4.7 TB/s, two at ~6 TB/s (tools/microbench/bw.hip).
+template <int LPL, int PPW, bool EXACT>
 __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
 {
     constexpr int LP = LPL * 64;
     __shared__ float sS[4][LP];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int L = P.L;
-    const bool exact = (L == LP);
+    constexpr bool exact = EXACT;  // L == 64*LPL: no label slot is padding, loads need no guard
     const int o0 = lane * LPL;
-    // grid-stride over pixels: a bounded number of workgroups, each wave streams many pixels
-    for (long long pix = (long long)blockIdx.x * 4 + wv; pix < P.npix; pix += (long long)gridDim.x * 4) {
-
-    float c[LPL], S[LPL];
-    if (P.C8 && exact) {  // compact costs: one byte per label (wave-uniform branch)
-        const uint8_t *q = P.C8 + pix * L + o0;
+    const bool c8 = P.C8 && exact;  // compact costs: one byte per label (wave-uniform)
+    // grid-stride over groups of PPW consecutive pixels
+    for (long long pix0 = ((long long)blockIdx.x * 4 + wv) * PPW; pix0 < P.npix; pix0 += (long long)gridDim.x * 4 * PPW) {
+        float c[PPW][LPL], l[kMaxDirs][PPW][LPL];
 #pragma unroll
-        for (int k = 0; k < LPL; k++) c[k] = c8_decode(q[k]);
-    } else {
-        const float *q = P.C + pix * L + o0;
+        for (int u = 0; u < PPW; u++) {
+            const long long pix = pix0 + u < P.npix ? pix0 + u : P.npix - 1;
+            if (c8) {
+                const uint8_t *q = P.C8 + pix * L + o0;
 #pragma unroll
-        for (int k = 0; k < LPL; k++) c[k] = (exact || o0 + k < L) ? q[k] : f_inf();
-    }
-    // all NDIR slabs are requested before the first one is consumed (independent loads in flight),
-    // then summed in pass order: S = ((0 + L0) + L1) + ...
-    float l[kMaxDirs][LPL];
+                for (int k = 0; k < LPL; k++) c[u][k] = c8_decode(q[k]);
+            } else {
+                const float *q = P.C + pix * L + o0;
 #pragma unroll
-    for (int p = 0; p < kMaxDirs; p++) {
-        if (p < P.NDIR) {
-            const float *q = P.Lr + (long long)p * P.nvol + pix * L + o0;
+                for (int k = 0; k < LPL; k++) c[u][k] = (exact || o0 + k < L) ? q[k] : f_inf();
+            }
+        }
 #pragma unroll
-            for (int k = 0; k < LPL; k++) l[p][k] = (exact || o0 + k < L) ? q[k] : f_inf();
+        for (int p = 0; p < kMaxDirs; p++) {
+            if (p < P.NDIR) {
+#pragma unroll
+                for (int u = 0; u < PPW; u++) {
+                    const long long pix = pix0 + u < P.npix ? pix0 + u : P.npix - 1;
+                    const float *q = P.Lr + (long long)p * P.nvol + pix * L + o0;
+#pragma unroll
+                    for (int k = 0; k < LPL; k++) l[p][u][k] = (exact || o0 + k < L) ? q[k] : f_inf();
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PPW; u++) {
+            const long long pix = pix0 + u;
+            if (pix >= P.npix) break;
+            // S = ((0 + L0) + L1) + ... in pass order (mgm_core.cc:582-587)
+            float S[LPL];
+#pragma unroll
+            for (int k = 0; k < LPL; k++) S[k] = 0.0f;
+#pragma unroll
+            for (int p = 0; p < kMaxDirs; p++) {
+                if (p < P.NDIR) {
+#pragma unroll
+                    for (int k = 0; k < LPL; k++) S[k] = S[k] + l[p][u][k];
+                }
+            }
+            if (P.FIX == 1) {
+                const float f = (float)(P.NDIR - 1);
+#pragma unroll
+                for (int k = 0; k < LPL; k++) S[k] = S[k] - f * c[u][k];
+            }
+            if (P.S) {
+                float *q = P.S + pix * L + o0;
+#pragma unroll
+                for (int k = 0; k < LPL; k++)
+                    if (exact || o0 + k < L) q[k] = S[k];
+            }
+            // first strict minimum among finite entries, ascending o
+            float best = f_inf();
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < LPL; k++) {
+                const float v = S[k];
+                if ((exact || o0 + k < L) && finite_bits(v) && best > v) {
+                    best = v;
+                    bi = o0 + k;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float ov = __shfl_xor(best, d);
+                const int oi = __shfl_xor(bi, d);
+                if (ov < best || (ov == best && oi < bi)) {
+                    best = ov;
+                    bi = oi;
+                }
+            }
+            float outv, outc = best;
+            if (bi == 0x7fffffff) {
+                outv = __builtin_nanf("");  // the reference leaves minP uninitialised here
+            } else {
+                outv = (float)(bi + P.dmin);
+                if (P.refine == 1 && bi - 1 >= 0 && bi + 2 <= L - 1) {  // mgm_refine.h:58
+#pragma unroll
+                    for (int k = 0; k < LPL; k++) sS[wv][o0 + k] = S[k];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const float v0 = sS[wv][bi - 1], v1 = sS[wv][bi], v2 = sS[wv][bi + 1];
+                    float vmin, dx;
+                    vfit(v0, v1, v2, vmin, dx);
+                    outv = (float)(bi + P.dmin) + dx;
+                    outc = vmin;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next pixel overwrites sS
+                }
+            }
+            if (lane == 0) {
+                P.out[pix] = outv;
+                P.outcost[pix] = outc;
+            }
         }
     }
-#pragma unroll
-    for (int k = 0; k < LPL; k++) S[k] = 0.0f;
-#pragma unroll
-    for (int p = 0; p < kMaxDirs; p++) {
-        if (p < P.NDIR) {
-#pragma unroll
-            for (int k = 0; k < LPL; k++) S[k] = S[k] + l[p][k];
-        }
-    }
-    if (P.FIX == 1) {
-        const float f = (float)(P.NDIR - 1);
-#pragma unroll
-        for (int k = 0; k < LPL; k++) S[k] = S[k] - f * c[k];
-    }
-    if (P.S) {
-        float *q = P.S + pix * L + o0;
-#pragma unroll
-        for (int k = 0; k < LPL; k++)
-            if (exact || o0 + k < L) q[k] = S[k];
-    }
-
-    // first strict minimum among finite entries, ascending o
-    float best = f_inf();
-    int bi = 0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < LPL; k++) {
-        const float v = S[k];
-        if ((exact || o0 + k < L) && finite_bits(v) && best > v) {
-            best = v;
-            bi = o0 + k;
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const float ov = __shfl_xor(best, d);
-        const int oi = __shfl_xor(bi, d);
-        if (ov < best || (ov == best && oi < bi)) {
-            best = ov;
-            bi = oi;
-        }
-    }
-    float outv, outc = best;
-    if (bi == 0x7fffffff) {
-        outv = __builtin_nanf("");  // the reference leaves minP uninitialised here
-    } else {
-        outv = (float)(bi + P.dmin);
-        if (P.refine == 1 && bi - 1 >= 0 && bi + 2 <= L - 1) {  // mgm_refine.h:58
-#pragma unroll
-            for (int k = 0; k < LPL; k++) sS[wv][o0 + k] = S[k];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const float v0 = sS[wv][bi - 1], v1 = sS[wv][bi], v2 = sS[wv][bi + 1];
-            float vmin, dx;
-            vfit(v0, v1, v2, vmin, dx);
-            outv = (float)(bi + P.dmin) + dx;
-            outc = vmin;
-        }
-    }
-    if (lane == 0) {
-        P.out[pix] = outv;
-        P.outcost[pix] = outc;
-    }
-    }  // pixel loop
 }
 
 hipError_t launch_wta(const WtaParams &p, hipStream_t s)
 {
-    long long nb = (p.npix + 3) / 4;
-    if (nb > 256 * 16) nb = 256 * 16;  // 16 workgroups of 4 waves per CU, grid-stride beyond
+    long long nb = (p.npix + 3) / 4;  // (an upper bound: waves take several pixels per iteration)
+    static int per_cu = 0;
+    if (!per_cu) {
+        const char *e = getenv("MGM_HIP_WTA_WG_PER_CU");
+        per_cu = e ? atoi(e) : 16;
+        if (per_cu < 1) per_cu = 16;
+    }
+    if (nb > 256ll * per_cu) nb = 256ll * per_cu;  // a bounded grid (workgroups of 4 waves), grid-stride beyond
     const dim3 grid((unsigned)nb), block(256);
     switch (pass_lpl(p.L)) {
-        case 1: hipLaunchKernelGGL(k_wta<1>, grid, block, 0, s, p); break;
-        case 2: hipLaunchKernelGGL(k_wta<2>, grid, block, 0, s, p); break;
-        case 3: hipLaunchKernelGGL(k_wta<3>, grid, block, 0, s, p); break;
-        case 4: hipLaunchKernelGGL(k_wta<4>, grid, block, 0, s, p); break;
-        case 6: hipLaunchKernelGGL(k_wta<6>, grid, block, 0, s, p); break;
-        case 8: hipLaunchKernelGGL(k_wta<8>, grid, block, 0, s, p); break;
+#define WTA_CASE(LPL, PPW)                                                                  \
+    case LPL:                                                                               \
+        if (p.L == 64 * LPL) hipLaunchKernelGGL((k_wta<LPL, PPW, true>), grid, block, 0, s, p);  \
+        else hipLaunchKernelGGL((k_wta<LPL, 1, false>), grid, block, 0, s, p);               \
+        break;
+        WTA_CASE(1, 4)
+        WTA_CASE(2, 4)
+        WTA_CASE(3, 2)
+        WTA_CASE(4, 2)
+        WTA_CASE(6, 1)
+        WTA_CASE(8, 1)
+#undef WTA_CASE
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
