@@ -703,11 +703,20 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
         fprintf(stderr, "[mgm stats] %d workgroups, kernel span %.1f us\n", c->ntasks, (t1 - t0) * tick);
         for (int q = first; q < PEND; q++) {
             double run = 0, slow = 0, pro = 0, nslow = 0, nspin = 0, steps = 0, first = 1e30, last = 0;
-            double ai = 0, ar = 0, ab = 0, bi = 0, br = 0, bb = 0, cb = 0, fsw = 0, fn = 0, fmx = 0;
+            double ai = 0, ar = 0, ab = 0, bi = 0, br = 0, bb = 0, cb = 0, fsw = 0, fn = 0, fmx = 0, frep = 0;
             int n = 0;
+            double fa = 0, fb = 0, fc = 0;
+            bool dec = false;
             for (int i = 0; i < c->ntasks; i++)
                 if (tk[i].x == q) {
                     n++;
+                    if (d[i * 16 + 1] >> 63) {  // barrier-free build: failed polls of the profiled wave by cause
+                        dec = true;
+                        fa += (double)((d[i * 16 + 1] >> 42) & 0x1fffff);
+                        fb += (double)((d[i * 16 + 1] >> 21) & 0x1fffff);
+                        fc += (double)(d[i * 16 + 1] & 0x1fffff);
+                        d[i * 16 + 1] = d[i * 16 + 0];
+                    }
                     run += (d[i * 16 + 2] - d[i * 16 + 1]) * tick;
                     pro += (d[i * 16 + 1] - d[i * 16 + 0]) * tick;
                     slow += d[i * 16 + 6] * tick;
@@ -717,8 +726,9 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
                     ai += d[i * 16 + 8] * tick; ar += d[i * 16 + 9] * tick; ab += d[i * 16 + 10] * tick;
                     bi += d[i * 16 + 11] * tick; br += d[i * 16 + 12] * tick; bb += d[i * 16 + 13] * tick;
                     cb += d[i * 16 + 14] * tick;
-                    fsw += (double)(d[i * 16 + 15] >> 32); fn += (double)(d[i * 16 + 15] & 0xffffff);
-                    fmx = std::max(fmx, (double)((d[i * 16 + 15] >> 24) & 0xff));
+                    fsw += (double)(d[i * 16 + 15] >> 44); fn += (double)((d[i * 16 + 15] >> 18) & 0x3ffff);
+                    frep += (double)(d[i * 16 + 15] & 0x3ffff);
+                    fmx = std::max(fmx, (double)((d[i * 16 + 15] >> 36) & 0xff));
                     first = std::min(first, (double)(d[i * 16 + 0] - t0) * tick);
                     last = std::max(last, (double)(d[i * 16 + 2] - t0) * tick);
                 }
@@ -731,9 +741,12 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
                     "kcycles per band: lds-read %.0f combine %.0f store+min %.0f transform %.0f lds-write %.0f\n",
                     ai / n, ar / n, ab / n, cb / n, nslow / n / 1e3, nspin / n / 1e3, bi / tick / n / 1e3, br / tick / n / 1e3,
                     bb / tick / n / 1e3);
+            if (dec)
+                fprintf(stderr, "[mgm stats]         failed polls per band: previous line %.0f, next line %.0f, DMA %.0f\n", fa / n,
+                        fb / n, fc / n);
             if (fn > 0)
-                fprintf(stderr, "[mgm stats]         FH min-convolution: %.2f sweeps per slab (fwd+bwd, minimum 2), worst %.0f\n",
-                        fsw / fn, fmx);
+                fprintf(stderr, "[mgm stats]         FH min-convolution: %.3f sweeps per slab (fwd+bwd, minimum 2), worst %.0f, %.2f%% of slabs repaired\n",
+                        fsw / fn, fmx, 100.0 * frep / fn);
         }
     }
     c->last_nvol = nvol;

@@ -135,22 +135,53 @@ __device__ __forceinline__ float readlane_f(float v, int l)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ float dpp_min_step(float v)
-{
-    float o = __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0x7f800000, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
-    return fminf(v, o);
-}
+// Fused DPP arithmetic, written as inline assembly: the compiler keeps a DPP move, its fill value and
+// the arithmetic apart (four issue slots where one or two do), and with four waves per SIMD every
+// VALU slot of the scan-line kernels costs 16 cycles of the SIMD.  The s_nop ahead of each DPP
+// instruction covers the "VALU writes a VGPR, DPP reads it" hazard (2 wait states), which the
+// compiler's hazard recogniser does not see through inline assembly.
+//   MGM_DPP_MIN(name, ctrl):  c = min(c, t[source lane]);  lanes without a source lane keep c
+//   MGM_DPP_ADD(name, ctrl):  t = c[source lane] + addend; lanes without a source lane read 0,
+//                             so `addend` must be +INF there
+#define MGM_DPP_MIN(name, ctrl)                                                                            \
+    __device__ __forceinline__ float name(float c, float t)                                                \
+    {                                                                                                      \
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %1, %0 " ctrl " bank_mask:0xf" : "+v"(c) : "v"(t));              \
+        return c;                                                                                          \
+    }
+#define MGM_DPP_ADD(name, ctrl)                                                                            \
+    __device__ __forceinline__ float name(float c, float addend)                                           \
+    {                                                                                                      \
+        float t;                                                                                           \
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 " ctrl " bank_mask:0xf bound_ctrl:0" : "=v"(t) : "v"(c), "v"(addend)); \
+        return t;                                                                                          \
+    }
+MGM_DPP_MIN(dpp_min_row_shr1, "row_shr:1 row_mask:0xf")
+MGM_DPP_MIN(dpp_min_row_shr2, "row_shr:2 row_mask:0xf")
+MGM_DPP_MIN(dpp_min_row_shr4, "row_shr:4 row_mask:0xf")
+MGM_DPP_MIN(dpp_min_row_shr8, "row_shr:8 row_mask:0xf")
+MGM_DPP_MIN(dpp_min_row_shl1, "row_shl:1 row_mask:0xf")
+MGM_DPP_MIN(dpp_min_row_shl2, "row_shl:2 row_mask:0xf")
+MGM_DPP_MIN(dpp_min_row_shl4, "row_shl:4 row_mask:0xf")
+MGM_DPP_MIN(dpp_min_row_shl8, "row_shl:8 row_mask:0xf")
+MGM_DPP_MIN(dpp_min_bcast15, "row_bcast:15 row_mask:0xa")
+MGM_DPP_MIN(dpp_min_bcast31, "row_bcast:31 row_mask:0xc")
+MGM_DPP_ADD(dpp_add_bcast15, "row_bcast:15 row_mask:0xf")
+MGM_DPP_ADD(dpp_add_bcast31, "row_bcast:31 row_mask:0xf")
+MGM_DPP_ADD(dpp_add_wave_shr1, "wave_shr:1 row_mask:0xf")
+MGM_DPP_ADD(dpp_add_wave_shl1, "wave_shl:1 row_mask:0xf")
+#undef MGM_DPP_MIN
+#undef MGM_DPP_ADD
+
 // wave-wide minimum, result uniform (SGPR).  NaN-free inputs only.
 __device__ __forceinline__ float wave_min(float v)
 {
-    v = dpp_min_step<0x111, 0xf>(v);  // row_shr:1
-    v = dpp_min_step<0x112, 0xf>(v);  // row_shr:2
-    v = dpp_min_step<0x114, 0xf>(v);  // row_shr:4
-    v = dpp_min_step<0x118, 0xf>(v);  // row_shr:8
-    v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15
-    v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31
+    v = dpp_min_row_shr1(v, v);
+    v = dpp_min_row_shr2(v, v);
+    v = dpp_min_row_shr4(v, v);
+    v = dpp_min_row_shr8(v, v);  // lane 15 of every row: the row's minimum
+    v = dpp_min_bcast15(v, v);   // rows 1 and 3 take in the row before them
+    v = dpp_min_bcast31(v, v);   // rows 2 and 3 take in lane 31
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 #endif

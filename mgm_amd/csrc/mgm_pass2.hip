@@ -38,7 +38,10 @@ __device__ __forceinline__ void dma4(const void *src_lane, void *dst_base)
 {
     __builtin_amdgcn_global_load_lds((glb_vptr)src_lane, (lds_vptr)dst_base, 4, 0, AUX);
 }
-constexpr int AUX_SC1 = 16;  // agent-scope (L1-bypassing) cache policy bit
+#ifndef MGM_P2_EXP
+#define MGM_P2_EXP 0   // timing experiments (wrong results): 1 plain loads for the hand-off, 2 no progress/minimum DMA, 4 no hand-off slab DMA
+#endif
+constexpr int AUX_SC1 = (MGM_P2_EXP & 1) ? 0 : 16;  // agent-scope (L1-bypassing) cache policy bit
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
@@ -106,6 +109,15 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 
 #ifndef MGM_P2_LDS_KB
 #define MGM_P2_LDS_KB 160
 #endif
+#ifndef MGM_P2_DECOUPLED
+#define MGM_P2_DECOUPLED 0   // 1: waves synchronise point-to-point through LDS step counters; 0: one s_barrier per step
+#endif
+#ifndef MGM_P2_RT
+#define MGM_P2_RT 4          // decoupled: slots per line of the LDS ring between consecutive lines (power of two)
+#endif
+#ifndef MGM_P2_RC
+#define MGM_P2_RC 6          // decoupled: steps of C / hand-off data the LDS rings hold
+#endif
 #ifndef MGM_P2_C8_NL
 #define MGM_P2_C8_NL 1
 #endif
@@ -133,26 +145,41 @@ struct Plan {
     static constexpr int NDMA = C8 ? (NC + LPD - 1) / LPD : NCA * IPS;                // C pieces per step (loader A)
     // DMA instructions per step: loader A = its C pieces + hand-off slabs [+ minimum] + progress word
     // compact costs with two loaders: A = hand-off only, B = all C pieces
-    static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + NS * IPS + 1 + (HASM ? 1 : 0);
+    static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + ((MGM_P2_EXP & 4) ? 0 : NS * IPS) + ((MGM_P2_EXP & 2) ? 0 : 1 + (HASM ? 1 : 0));
     static constexpr int nB = (C8 && NL == 2) ? NDMA : (NC - NCA) * IPS;
-    static constexpr int cring_floats(int D) { return C8 ? (D + 1) * NDMA * 256 : NC * (D + 1) * LP; }
-    static constexpr int lds_floats(int D)
+    static constexpr bool DEC = MGM_P2_DECOUPLED != 0;
+    // Ring geometry: RT = T-ring slots per line (2 with barriers), RDEPTH = steps of C / hand-off data the rings
+    // hold, D = steps of DMA kept in flight (D <= RDEPTH-1).  The largest of a few candidates that fits in LDS.
+    static constexpr int cring_floats(int rdepth) { return C8 ? rdepth * NDMA * 256 : NC * rdepth * LP; }
+    static constexpr int lds_floats3(int rt, int rdepth)
     {
-        return NC * 2 * NS * LP      // T ring
-               + NC * 2              // T minima
-               + (D + 1) * NS * LP   // hand-off ring
-               + 2 * (D + 1) + 8     // hand-off minima, progress words, task word
-               + cring_floats(D);    // C ring
+        return NC * rt * NS * LP       // T ring
+               + NC * rt               // T minima
+               + rdepth * NS * LP      // hand-off ring
+               + 2 * rdepth + 8 + 32   // hand-off minima, progress words, task word, step counters
+               + cring_floats(rdepth); // C ring
     }
-    static constexpr int pick_D()
+    static constexpr bool fits(int rt, int rdepth, int d)
     {
-        for (int D = MGM_P2_MAXD; D >= 2; D--)
-            if (lds_floats(D) * 4 <= (LPL <= 4 ? MGM_P2_LDS_KB : 160) * 1024 && nA * (D - 1) <= 63 && nB * (D - 1) <= 63) return D;
-        return 1;
+        return d >= 2 && d <= rdepth - 1 && lds_floats3(rt, rdepth) * 4 <= (LPL <= 4 ? MGM_P2_LDS_KB : 160) * 1024 &&
+               nA * (d - 1) <= 63 && nB * (d - 1) <= 63;
     }
-    static constexpr int D = pick_D();
+    static constexpr int pick(int what)  // 0: RT, 1: RDEPTH, 2: D
+    {
+        const int rts[2] = {DEC ? MGM_P2_RT : 2, 2};
+        const int rds[3] = {DEC ? MGM_P2_RC : MGM_P2_MAXD + 1, 4, 3};
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 3; b++)
+                for (int d = MGM_P2_MAXD; d >= 2; d--)
+                    if (fits(rts[a], rds[b], d)) return what == 0 ? rts[a] : (what == 1 ? rds[b] : d);
+        return 0;
+    }
+    static constexpr int RT = pick(0), RDEPTH = pick(1), D = pick(2);
+    static constexpr int rd(int) { return RDEPTH; }
+    static constexpr int lds_floats(int) { return lds_floats3(RT, RDEPTH); }
     static_assert(D >= 2, "no feasible pipeline depth");
     static_assert(!C8 || (64 % LPS == 0), "compact slabs must tile a DMA piece");
+    static_assert((RT & (RT - 1)) == 0, "RT must be a power of two");
 };
 
 // unit weights, slabs hold E = T - m (every unit-weight case but FH with MGM == 2)
@@ -196,21 +223,27 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     constexpr int LP = PL::LP, NC = PL::NC, NCA = PL::NCA, D = PL::D, IPS = PL::IPS;
     constexpr int LPS = PL::LPS, LPD = PL::LPD, NDMA = PL::NDMA;
     constexpr int LPW = NCA;   // C lines per loader wave (NC - NCA == NCA when there are two loaders)
-    constexpr int RD = D + 1;  // ring depth
+    constexpr int RD = PL::rd(D);  // C / hand-off ring depth (steps)
+    constexpr int RT = PL::RT;     // T-ring slots per line
+    constexpr bool DEC = PL::DEC;
     using NbT = Nb<LPL, NS>;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Tring = smem;                          // [NC][2][NS][LP]
-    float *Hring = Tring + NC * 2 * NS * LP;      // [RD][NS][LP]
+    float *Tring = smem;                          // [NC][RT][NS][LP]
+    float *Hring = Tring + NC * RT * NS * LP;     // [RD][NS][LP]
     float *Cring = Hring + RD * NS * LP;          // fp32: [NC][RD][LP]; compact: [RD][NDMA][1 KiB]
-    float *Tm = Cring + PL::cring_floats(D);      // [NC][2]
-    float *Hm = Tm + NC * 2;                      // [RD]
+    float *Tm = Cring + PL::cring_floats(RD);     // [NC][RT]
+    float *Hm = Tm + NC * RT;                     // [RD]
     unsigned *Hprog = reinterpret_cast<unsigned *>(Hm + RD);  // [RD]
     int *s_task = reinterpret_cast<int *>(Hprog + RD);
+    // decoupled mode: stepdone[r] = steps compute wave r has completed; landed[w] = steps whose DMA of loader w has landed
+    unsigned *stepdone = reinterpret_cast<unsigned *>(s_task + 4);
+    unsigned *landed = stepdone + NC;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) *s_task = (int)atomicAdd(P.ticket, 1u);
+    if (tid < NC + 2) stepdone[tid] = 0;
     __syncthreads();
     const int ticket = *s_task;
     const int2 tk = P.tasks[ticket];
@@ -317,15 +350,19 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     }
                     if (dbg) t_slow += wall_clock64() - t0;
                 }
+                if constexpr (!(MGM_P2_EXP & 4)) {
 #pragma unroll
                 for (int q = 0; q < NS; q++)
 #pragma unroll
                     for (int c = 0; c < IPS; c++)
                         if (c * 64 + lane < LPL * 16)
                             dma16<AUX_SC1>(hptr + q * LP + c * 256, Hring + (slot * NS + q) * LP + c * 256);
+                }
+                if constexpr (!(MGM_P2_EXP & 2)) {
                 if constexpr (!pubE)
                     if (lane == 0) dma4<AUX_SC1>(hmptr, Hm + slot);
                 if (lane == 0) dma4<AUX_SC1>(prog_in, Hprog + slot);
+                }
                 const bool adv = ht >= 0 && ht < LL - 1;
                 hptr += adv ? NSLP : 0;
                 hmptr += adv ? 1 : 0;
@@ -337,6 +374,50 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             else wait_vmcnt<PL::nB *(D - 1)>();
         };
 
+        if constexpr (DEC) {
+            // ---- decoupled: no barriers.  Target step t goes to ring slot t % RD once every compute wave
+            // is done with step t-RD; after the counted wait the steps that have landed are published.
+            int slot = 0, lslot = (RD - (D % RD)) % RD;  // lslot = slot of target step t-D
+            for (int t = 0; t < nsteps; t++) {
+                if (t >= RD) {
+                    unsigned spins = 0;
+                    const unsigned long long tbp = dbg ? wall_clock64() : 0;
+                    for (;;) {
+                        unsigned v = lane < NC ? __hip_atomic_load(stepdone + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                               : 0x7fffffffu;
+                        const float vm = wave_min((float)v);  // (< 2^24: exact)
+                        if ((int)vm >= t - RD + 1 || dead) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (SPIN_LIMIT << 2)) {
+                            if (lane == 0) __hip_atomic_store(P.err, 2u, RLX_AGENT);
+                            dead = true;
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                    if (dbg) t_bar += wall_clock64() - tbp;
+                }
+                if (wl == 0 && from_global && t >= D) {
+                    // freshest progress word that has landed: the one issued with target step t-D
+                    const unsigned k = __builtin_amdgcn_readfirstlane(lds_read_u32_opaque(Hprog + lslot));
+                    known = k > known ? k : known;
+                }
+                const unsigned long long ta = dbg ? wall_clock64() : 0;
+                issue(slot);
+                slot = slot + 1 == RD ? 0 : slot + 1;
+                lslot = lslot + 1 == RD ? 0 : lslot + 1;
+                const unsigned long long tb = dbg ? wall_clock64() : 0;
+                retire();  // targets <= t-D+1 have landed
+                if (t - D + 2 > 0 && lane == 0)
+                    __hip_atomic_store(landed + wl, (unsigned)(t - D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (dbg) {
+                    const unsigned long long tc = wall_clock64();
+                    t_iss += tb - ta;
+                    t_ret += tc - tb;
+                }
+            }
+            wait_vmcnt<0>();
+            if (lane == 0) __hip_atomic_store(landed + wl, (unsigned)nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
         int slot = 0;
         for (int t = 0; t < D; t++) {  // prologue: steps 0..D-1
             issue(slot);
@@ -370,6 +451,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                 t_bar += td - tc;
             }
         }
+        }
         if (dbg && wl == 0 && lane == 0) {
             dbg[2] = wall_clock64();
             dbg[6] = t_slow;
@@ -390,12 +472,12 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     const bool to_global = (r == NC - 1) && (band + 1 < g.nbands);
     float *__restrict__ Lrb = P.Lr + (long long)(pass - P.pass0) * P.nvol;
     const long long pix0 = g.base + (long long)j * g.jstep;
-    const float *fwd_src0 = r > 0 ? Tring + (r - 1) * 2 * NSLP + lane * LPL : Hring + lane * LPL;
-    const float *fwd_m0 = r > 0 ? Tm + (r - 1) * 2 : Hm;
+    const float *fwd_src0 = r > 0 ? Tring + (r - 1) * RT * NSLP + lane * LPL : Hring + lane * LPL;
+    const float *fwd_m0 = r > 0 ? Tm + (r - 1) * RT : Hm;
     // fp32: own ring [RD][LP]; compact: byte (r%LPD)*LPS*16 + lane*LPL of piece r/LPD of the step's slot
     const float *c_src0 = C8 ? Cring + (r / LPD) * 256 : Cring + r * RD * LP + lane * LPL;
     const int c8_byte = (r % LPD) * LPS * 16 + lane * LPL;
-    float *t_dst0 = Tring + r * 2 * NSLP + lane * LPL;
+    float *t_dst0 = Tring + r * RT * NSLP + lane * LPL;
 
     // The whole line walk, specialised on the neighbour order of the pass (FORM).
     auto run = [&](auto formc, auto slopec) {
@@ -407,14 +489,14 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
         // neighbour (i+1), Z = same, Y = back.  Slope 1: it is the same neighbour (i), Z = back.
         constexpr int NEWOFF = SLOPE == 2 ? 1 : 0;  // index of the slab fetched this step, relative to i
         unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
-        unsigned long long fh_sweeps = 0, fh_n = 0;
+        unsigned long long fh_sweeps = 0, fh_n = 0, fh_rep = 0;
         unsigned fh_max = 0;
         const bool prof = dbg && r == NC / 2;
         auto step = [&](int s, int cslot, NbT &X, const NbT &Y, const NbT &Z) {
             const int i = s - 1 - SLOPE * r;
             const unsigned long long c0 = prof ? clock64() : 0;
             if (has_prev && i + NEWOFF >= 0 && i + NEWOFF < LL) {
-                const int sl = r > 0 ? ((i + NEWOFF) & 1) : cslot;
+                const int sl = r > 0 ? ((i + NEWOFF) & (RT - 1)) : cslot;
                 const float *src = fwd_src0 + sl * NSLP;
 #pragma unroll
                 for (int q = 0; q < NS; q++)
@@ -479,9 +561,9 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                                 combine_whirsch<LPL>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, Lv);
                         } else {
                             if constexpr (FORM == 0)
-                                combine_wfh<LPL>(Cv, nb_i, nb_same, nb_back, nb_fwd, Dw, P1, P2, MGM, lane, L, Lv);
+                                combine_wfh<LPL, true>(Cv, nb_i, nb_same, nb_back, nb_fwd, Dw, P1, P2, MGM, lane, L, Lv);
                             else
-                                combine_wfh<LPL>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, lane, L, Lv);
+                                combine_wfh<LPL, true>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, lane, L, Lv);
                         }
                     }
                 } else {
@@ -517,8 +599,8 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 #pragma unroll
                         for (int k = 0; k < LPL; k++) nb_i.w[0][k] = Lv[k];
                         unsigned sw = 0;
-                        fh_minconv<LPL>(nb_i.w[0], m, P1, P2, lane, L, prof ? &sw : nullptr);
-                        if (prof) { fh_sweeps += sw; fh_max = sw > fh_max ? sw : fh_max; fh_n++; }
+                        fh_minconv<LPL, true>(nb_i.w[0], m, P1, P2, lane, L, sw);
+                        if (prof) { fh_sweeps += sw; fh_max = sw > fh_max ? sw : fh_max; fh_n++; fh_rep += sw > 2; }
                     }
                     if constexpr (pubE) {
 #pragma unroll
@@ -535,13 +617,13 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                 }
                 const unsigned long long c4 = prof ? clock64() : 0;
                 if (to_lds) {
-                    float *dst = t_dst0 + (i & 1) * NSLP;
+                    float *dst = t_dst0 + (i & (RT - 1)) * NSLP;
 #pragma unroll
                     for (int q = 0; q < NS; q++)
 #pragma unroll
                         for (int k = 0; k < LPL; k++) dst[q * LP + k] = nb_i.w[q][k];
                     if constexpr (!pubE)
-                        if (lane == 0) Tm[r * 2 + (i & 1)] = m;
+                        if (lane == 0) Tm[r * RT + (i & (RT - 1))] = m;
                 }
                 if (prof) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -573,9 +655,58 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             }
         };
 
-        step_barrier((P.xflags & 8) != 0);  // B0: the loaders' prologue has landed
         int cslot = 0;
         unsigned long long t_cbar = 0;
+        if constexpr (DEC) {
+            // ---- decoupled: before step s this wave needs (a) the previous line's wave to have finished step
+            // s-1 (its slab for this step is in the ring), (b) the DMA of step s to have landed, (c) room in
+            // its own ring slot: the next line's wave must have fetched the slab written RT steps ago.
+            const unsigned *f_prev = r > 0 ? stepdone + (r - 1) : nullptr;
+            const unsigned *f_next = to_lds ? stepdone + (r + 1) : nullptr;
+            const unsigned *f_land = landed + ((C8 || r < NCA) ? 0 : 1);
+            bool wdead = false;
+            unsigned long long fa = 0, fb = 0, fc = 0;  // polls that failed on (a), (b), (c)
+            auto wait_ready = [&](int s) {
+                const unsigned np = (unsigned)s, nl = (unsigned)s + 1u;
+                const int nn = s - RT + 2;
+                unsigned spins = 0;
+                for (;;) {
+                    const unsigned a = f_prev ? __hip_atomic_load(f_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : np;
+                    const unsigned b = f_next ? __hip_atomic_load(f_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffffu;
+                    const unsigned c = __hip_atomic_load(f_land, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((a >= np && (int)b >= nn && c >= nl) || wdead) break;
+                    if (prof) { fa += a < np; fb += (int)b < nn; fc += c < nl; }
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (SPIN_LIMIT << 2)) {
+                        if (lane == 0) __hip_atomic_store(P.err, 3u, RLX_AGENT);
+                        wdead = true;
+                    }
+                }
+                asm volatile("" ::: "memory");  // LDS is in order per wave: the data reads below follow the flag reads
+            };
+            auto done = [&](int s) {
+                asm volatile("" ::: "memory");  // ... and the counter store follows this step's slab stores
+                if (lane == 0) __hip_atomic_store(stepdone + r, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            for (int s = 0; s < nsteps; s += 3) {
+                const unsigned long long t0 = prof ? wall_clock64() : 0;
+                wait_ready(s);
+                if (prof) t_cbar += wall_clock64() - t0;
+                step(s, cslot, wA, wB, wC);
+                done(s);
+                cslot = cslot + 1 == RD ? 0 : cslot + 1;
+                wait_ready(s + 1);
+                step(s + 1, cslot, wB, wC, wA);
+                done(s + 1);
+                cslot = cslot + 1 == RD ? 0 : cslot + 1;
+                wait_ready(s + 2);
+                step(s + 2, cslot, wC, wA, wB);
+                done(s + 2);
+                cslot = cslot + 1 == RD ? 0 : cslot + 1;
+            }
+            if (prof && lane == 0) dbg[1] = (1ull << 63) | (fa << 42) | (fb << 21) | fc;
+        } else {
+        step_barrier((P.xflags & 8) != 0);  // B0: the loaders' prologue has landed
         for (int s = 0; s < nsteps; s += 3) {
             step(s, cslot, wA, wB, wC);
             cslot = cslot + 1 == RD ? 0 : cslot + 1;
@@ -589,10 +720,11 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             cslot = cslot + 1 == RD ? 0 : cslot + 1;
             step_barrier((P.xflags & 8) != 0);
         }
+        }
         if (dbg && r == NC / 2 && lane == 0) {
             dbg[14] = t_cbar * 3;
             dbg[3] = ph[0]; dbg[4] = ph[1]; dbg[11] = ph[2]; dbg[12] = ph[3]; dbg[13] = ph[4];
-            dbg[15] = (fh_sweeps << 32) | ((unsigned long long)fh_max << 24) | (fh_n & 0xffffff);
+            dbg[15] = ((fh_sweeps & 0xfffff) << 44) | ((unsigned long long)(fh_max & 0xff) << 36) | ((fh_n & 0x3ffff) << 18) | (fh_rep & 0x3ffff);
         }
     };
     if (form != 0) run(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});

@@ -101,131 +101,137 @@ __device__ __forceinline__ void neighbour_min(const float (&Lv)[LPL], float (&N)
 // which is unique and equals the sequential result (lane 0 has no carry-in, so
 // after n sweeps lanes 0..n-1 are exact; the loop ends when a sweep changes
 // nothing, normally the first).  `valid` masks label slots >= L.
-// n-fold x (+) P1, exactly, when the additions inside a binade are exact (P1 a multiple of the
-// float grid there, e.g. P1 = 2 and values < 2^24): the only roundings of the sequential chain
-// happen on the steps that land in a higher binade, and each of those is ONE rounding of an
-// exactly known partial sum -- evaluated here in f64 and converted (RNE) to f32.  One loop
-// iteration per binade crossed instead of one per label.  If the premise does not hold the
-// value is merely a guess; the caller's fixed-point sweeps remain the ground truth.
-__device__ __forceinline__ float ramp_exact(float z, int n, double P1d, double invP1d)
+// Repair of a rejected carry guess: all 64 carries at once, exactly, when the additions inside a
+// binade are exact (P1 a multiple of twice the float grid there, e.g. P1 = 2 and values < 2^23).
+// Then the only roundings of a sequential chain z (+) P1 (+) P1 ... happen on the steps that land in
+// a higher binade, each one RNE rounding of an exactly known sum to that binade's grid; and since
+// the steps that follow add multiples of the grid, the roundings commute with them: the chain equals
+// the EXACT sum z' + (n-1)*P1, z' = z (+) P1, rounded successively to the grid of every binade from
+// z' upwards (a grid at or below that of z' changes nothing, so starting at P1's binade serves every
+// origin).  Successive rounding is monotone, so the winning origin is the one with the smallest
+// exact sum: a min-plus scan in f64, which holds these sums exactly.  If the premise does not hold
+// the result is merely another guess; the caller's fixed-point sweeps remain the ground truth.
+template <int LPL, bool FWD>
+__device__ __forceinline__ float fh_repair(float a, float P1, int lane)
 {
-    for (int it = 0; it < 48; it++) {
-        if (__builtin_amdgcn_ballot_w64(n > 0) == 0ull) break;
-        const unsigned zb = __builtin_bit_cast(unsigned, z);
-        if (n > 0 && (zb & 0x7f800000u) != 0x7f800000u) {
-            const double B = (double)__builtin_bit_cast(float, (zb & 0x7f800000u) + 0x00800000u);  // next power of two
-            const double dz = (double)z;
-            double t = __builtin_ceil((B - dz) * invP1d);  // steps until the chain lands at or above B
-            if (dz + (t - 1.0) * P1d >= B) t -= 1.0;
-            if (dz + t * P1d < B) t += 1.0;
-            if (!(t >= 1.0)) t = 1.0;
-            const double step = t < (double)n ? t : (double)n;
-            z = (float)(dz + step * P1d);
-            n -= (int)step;
-        } else {
-            n = 0;
+    auto from_prev = [&](double v, int d) { return FWD ? __shfl_up(v, d) : __shfl_down(v, d); };
+    auto has_prev = [&](int d) { return FWD ? lane >= d : lane + d < 64; };
+    const double P1d = (double)P1, Rd = (double)LPL * (double)P1;
+    const double inf = (double)f_inf();
+    const double b = (double)(a + P1);  // first step of every chain that starts at this lane's carry-out
+    const double pb = from_prev(b, 1);           // (a shuffle must not sit under a divergent condition)
+    double s = has_prev(1) ? pb + Rd : inf;      // = origin' + LPL*P1; the surplus P1 comes off below
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double t = from_prev(s, d) + (double)d * Rd;
+        if (has_prev(d)) s = t < s ? t : s;
+    }
+    s -= P1d;
+    if (P1 > 0.0f) {
+        double B = (double)__builtin_bit_cast(float, (__builtin_bit_cast(unsigned, P1) & 0x7f800000u) + 0x00800000u);
+        for (int it = 0; it < 64; it++) {
+            const bool reach = s < inf && s >= B;  // the chain lands in the binade [B, 2B)
+            if (__builtin_amdgcn_ballot_w64(reach) == 0ull) break;
+            const double magic = B * 805306368.0;  // 1.5 * 2^52 * (B * 2^-23): rounds to multiples of the binade's grid
+            const double r = (s + magic) - magic;
+            s = reach ? r : s;
+            B += B;
         }
     }
-    return z;
+    return fminf(a, (float)s);
 }
 
 // One direction of minConvTruncatedLinear.  FWD: M[o] = min(M[o-1] + P1, M[o]) for rising o.
+// Written for the VALU issue budget (four waves share a SIMD: every slot costs 16 cycles): the
+// guess is a min-plus scan of fused DPP instructions, 2 slots per log-step.
 template <int LPL, bool FWD>
-__device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, unsigned *sweeps)
+__device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, unsigned &sweeps)
 {
     constexpr int K0 = FWD ? 0 : LPL - 1;      // first label of the lane in scan order
     constexpr int K1 = FWD ? LPL - 1 : 0;      // last
     constexpr int DK = FWD ? 1 : -1;
     const float rampP = (float)LPL * P1;
-    auto from_prev = [&](float v, int d) { return FWD ? __shfl_up(v, d) : __shfl_down(v, d); };
-    auto has_prev = [&](int d) { return FWD ? lane >= d : lane + d < 64; };
-    auto carry_in = [&](float c) { return FWD ? dpp_shr1(c, f_inf()) : dpp_shl1(c, f_inf()); };
 
     float a = M[K0];  // carry-out ignoring carry-in: exact for the first lane, a candidate origin elsewhere
 #pragma unroll
     for (int q = 1; q < LPL; q++) a = fminf(M[K0 + q * DK], a + P1);  // (compile-time indices: no scratch)
 
     // cheap guess of the 64 carries: min-plus scan with single-rounded ramps.  Inside each row of
-    // 16 lanes with DPP row shifts (lanes without a source get +INF), across rows through the
-    // row totals read into SGPRs -- no LDS-crossbar permutes on this path.
+    // 16 lanes with DPP row shifts; across rows FWD with the row broadcasts, BWD through the row
+    // totals read into SGPRs -- no LDS-crossbar permutes on this path.  The per-lane constants
+    // depend on (lane, P1) only: with unit weights they are hoisted out of the line walk.
+    const int li = lane & 15, row = lane >> 4;
+    const float r1 = rampP, r2 = 2.0f * rampP, r4 = 4.0f * rampP, r8 = 8.0f * rampP, r16 = 16.0f * rampP;
     float c = a;
-    {
-        const float r1 = rampP, r2 = 2.0f * rampP, r4 = 4.0f * rampP, r8 = 8.0f * rampP, r16 = 16.0f * rampP;
-        if constexpr (FWD) {
-            c = fminf(c, dpp_mov<0x111, 0xf>(c, f_inf()) + r1);  // row_shr:1
-            c = fminf(c, dpp_mov<0x112, 0xf>(c, f_inf()) + r2);  // row_shr:2
-            c = fminf(c, dpp_mov<0x114, 0xf>(c, f_inf()) + r4);  // row_shr:4
-            c = fminf(c, dpp_mov<0x118, 0xf>(c, f_inf()) + r8);  // row_shr:8
-            const float t0 = readlane_f(c, 15);                   // total of row 0 (at its last lane)
-            const float t1 = fminf(readlane_f(c, 31), t0 + r16);  // rows 0..1
-            const float t2 = fminf(readlane_f(c, 47), t1 + r16);  // rows 0..2
-            const int row = lane >> 4;
-            const float tp = row == 1 ? t0 : (row == 2 ? t1 : (row == 3 ? t2 : f_inf()));
-            c = fminf(c, tp + (float)((lane & 15) + 1) * rampP);
-        } else {
-            c = fminf(c, dpp_mov<0x101, 0xf>(c, f_inf()) + r1);  // row_shl:1
-            c = fminf(c, dpp_mov<0x102, 0xf>(c, f_inf()) + r2);  // row_shl:2
-            c = fminf(c, dpp_mov<0x104, 0xf>(c, f_inf()) + r4);  // row_shl:4
-            c = fminf(c, dpp_mov<0x108, 0xf>(c, f_inf()) + r8);  // row_shl:8
-            const float t3 = readlane_f(c, 48);                   // total of row 3 (at its first lane)
-            const float t2 = fminf(readlane_f(c, 32), t3 + r16);  // rows 2..3
-            const float t1 = fminf(readlane_f(c, 16), t2 + r16);  // rows 1..3
-            const int row = lane >> 4;
-            const float tp = row == 2 ? t3 : (row == 1 ? t2 : (row == 0 ? t1 : f_inf()));
-            c = fminf(c, tp + (float)(16 - (lane & 15)) * rampP);
-        }
+    if constexpr (FWD) {
+        c = dpp_min_row_shr1(c, c + r1);
+        c = dpp_min_row_shr2(c, c + r2);
+        c = dpp_min_row_shr4(c, c + r4);
+        c = dpp_min_row_shr8(c, c + r8);
+        // lane 15 of the row before (rows 1..3), then lane 31 (rows 2..3), at their distance in lanes
+        const float offA = row >= 1 ? (float)(li + 1) * rampP : f_inf();
+        const float offB = row >= 2 ? (float)(li + 1 + (row == 3 ? 16 : 0)) * rampP : f_inf();
+        c = fminf(c, dpp_add_bcast15(c, offA));
+        c = fminf(c, dpp_add_bcast31(c, offB));
+    } else {
+        c = dpp_min_row_shl1(c, c + r1);
+        c = dpp_min_row_shl2(c, c + r2);
+        c = dpp_min_row_shl4(c, c + r4);
+        c = dpp_min_row_shl8(c, c + r8);
+        const float t3 = readlane_f(c, 48);                   // total of row 3 (at its first lane)
+        const float t2 = fminf(readlane_f(c, 32), t3 + r16);  // rows 2..3
+        const float t1 = fminf(readlane_f(c, 16), t2 + r16);  // rows 1..3
+        const float tp = row == 0 ? t1 : (row == 1 ? t2 : t3);
+        const float offD = row <= 2 ? (float)(16 - li) * rampP : f_inf();
+        c = fminf(c, tp + offD);
     }
+    const float p1edge = (FWD ? lane == 0 : lane == 63) ? f_inf() : P1;  // no carry into the first lane
     float f[LPL];
     bool boosted = false;
     for (int it = 0; it < 70; it++) {
         // exact in-lane recurrence given the neighbour's carry
-        const float cin = carry_in(c);
-        f[K0] = fminf(M[K0], cin + P1);
+        const float cin = FWD ? dpp_add_wave_shr1(c, p1edge) : dpp_add_wave_shl1(c, p1edge);  // carry + P1
+        f[K0] = fminf(M[K0], cin);
 #pragma unroll
         for (int q = 1; q < LPL; q++) f[K0 + q * DK] = fminf(M[K0 + q * DK], f[K0 + (q - 1) * DK] + P1);
         const bool same = (f[K1] == c);
         c = f[K1];
-        if (sweeps) (*sweeps)++;
+        sweeps++;
         if (__builtin_amdgcn_ballot_w64(!same) == 0ull) break;
         if (!boosted) {
             // The guess was wrong somewhere: a ramp long enough to cross binades more than once
             // (e.g. over a stretch of +INF costs).  Plain sweeps would repair one lane per sweep.
             // Re-derive every carry as the exact image of its winning origin instead.
             boosted = true;
-            float g = a;
-            int src = lane;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float t = from_prev(g, d) + (float)d * rampP;
-                const int ts = FWD ? __shfl_up(src, d) : __shfl_down(src, d);
-                if (has_prev(d) && t < g) {
-                    g = t;
-                    src = ts;
-                }
-            }
-            const float origin = __shfl(a, src);
-            const int n = (FWD ? lane - src : src - lane) * LPL;
-            c = ramp_exact(origin, n, (double)P1, 1.0 / (double)P1);
+            c = fh_repair<LPL, FWD>(a, P1, lane);
         }
     }
 #pragma unroll
     for (int k = 0; k < LPL; k++) M[k] = f[k];
 }
 
-template <int LPL>
-__device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, float P2, int lane, int L,
-                                           unsigned *sweeps = nullptr)
+// FULL: L == 64*LPL, no label slot of the wave is padding
+template <int LPL, bool FULL = false>
+__device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, float P2, int lane, int L, unsigned &sweeps)
 {
     fh_scan<LPL, true>(M, P1, lane, sweeps);
-    // label slots >= L hold +INF on entry; the forward scan has filled them with ramp values
+    if constexpr (!FULL) {
+        // label slots >= L hold +INF on entry; the forward scan has filled them with ramp values
 #pragma unroll
-    for (int k = 0; k < LPL; k++) M[k] = (lane * LPL + k < L) ? M[k] : f_inf();
+        for (int k = 0; k < LPL; k++) M[k] = (lane * LPL + k < L) ? M[k] : f_inf();
+    }
     fh_scan<LPL, false>(M, P1, lane, sweeps);
     if (P2 < f_inf()) {
         const float cap = m + P2;
 #pragma unroll
         for (int k = 0; k < LPL; k++) M[k] = fminf(M[k], cap);
     }
+}
+template <int LPL, bool FULL = false>
+__device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, float P2, int lane, int L)
+{
+    unsigned sweeps = 0;
+    fh_minconv<LPL, FULL>(M, m, P1, P2, lane, L, sweeps);
 }
 
 // ---- exact small-integer division -------------------------------------------------
@@ -329,7 +335,7 @@ __device__ __forceinline__ void combine_whirsch(const float (&C)[LPL], const Nb<
 }
 // weighted FH (update_costW_trunclinear): w[0] = L; the min-convolution depends
 // on the consumer's weights, so it runs here, once per neighbour.
-template <int LPL>
+template <int LPL, bool FULL = false>
 __device__ __forceinline__ void combine_wfh(const float (&C)[LPL], const Nb<LPL, 1> &n1, const Nb<LPL, 1> &n2,
                                             const Nb<LPL, 1> &n3, const Nb<LPL, 1> &n4, const float (&D)[4], float P1,
                                             float P2, int MGM, int lane, int L, float (&out)[LPL])
@@ -337,27 +343,27 @@ __device__ __forceinline__ void combine_wfh(const float (&C)[LPL], const Nb<LPL,
     float e[LPL], M[LPL];
 #pragma unroll
     for (int k = 0; k < LPL; k++) M[k] = n1.w[0][k];
-    fh_minconv<LPL>(M, n1.m, P1 * D[0], P2 * D[0], lane, L);
+    fh_minconv<LPL, FULL>(M, n1.m, P1 * D[0], P2 * D[0], lane, L);
 #pragma unroll
     for (int k = 0; k < LPL; k++) e[k] = M[k] - n1.m;
     if (MGM >= 2) {
 #pragma unroll
         for (int k = 0; k < LPL; k++) M[k] = n2.w[0][k];
-        fh_minconv<LPL>(M, n2.m, P1 * D[1], P2 * D[1], lane, L);
+        fh_minconv<LPL, FULL>(M, n2.m, P1 * D[1], P2 * D[1], lane, L);
 #pragma unroll
         for (int k = 0; k < LPL; k++) e[k] += M[k] - n2.m;
     }
     if (MGM >= 3) {
 #pragma unroll
         for (int k = 0; k < LPL; k++) M[k] = n3.w[0][k];
-        fh_minconv<LPL>(M, n3.m, P1 * D[2], P2 * D[2], lane, L);
+        fh_minconv<LPL, FULL>(M, n3.m, P1 * D[2], P2 * D[2], lane, L);
 #pragma unroll
         for (int k = 0; k < LPL; k++) e[k] += M[k] - n3.m;
     }
     if (MGM >= 4) {
 #pragma unroll
         for (int k = 0; k < LPL; k++) M[k] = n4.w[0][k];
-        fh_minconv<LPL>(M, n4.m, P1 * D[3], P2 * D[3], lane, L);
+        fh_minconv<LPL, FULL>(M, n4.m, P1 * D[3], P2 * D[3], lane, L);
 #pragma unroll
         for (int k = 0; k < LPL; k++) e[k] += M[k] - n4.m;
     }
