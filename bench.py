@@ -40,10 +40,13 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def run_step(ctx, du, dv, w, out, outc, cv=None):
-    cv = ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", "census", float("inf"), w["win"], into=cv)
-    ctx.aggregate_dev(cv, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, None, "vfit", out, outc, want_S=False)
-    return cv
+def run_step(ctx, dus, dvs, w, outs, outcs, cvs=None):
+    """One step = one batch: the cost volume of every pair, ONE pass launch over the batch, WTA+vfit per volume."""
+    cvs = cvs or [None] * len(dus)
+    cvs = [ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", "census", float("inf"), w["win"], into=cv)
+           for du, dv, cv in zip(dus, dvs, cvs)]
+    ctx.aggregate_batch_dev(cvs, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, None, "vfit", outs, outcs, want_S=False)
+    return cvs
 
 
 def cpu_baseline(w, seconds_target=15.0):
@@ -82,6 +85,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=4, choices=[1, 2, 3, 4],
+                    help="pairs per step and GPU: their volumes share ONE launch of the pass kernel (pairs mode)")
     ap.add_argument("--mode", default="pairs", choices=["pairs", "directions"],
                     help="N>1: 'pairs' = independent pairs, one per GPU (weak scaling, default); 'directions' = ONE "
                          "volume per step, its passes sharded over the GPUs with an ordered RCCL exchange (strong)")
@@ -111,10 +116,16 @@ def main():
     nx, ny, L = w["nx"], w["ny"], w["dmax"] - w["dmin"] + 1
     # pairs mode: every rank gets its own pair (different seed): independent units, no exchange.
     # directions mode: every rank holds the SAME pair and builds the full cost volume itself.
-    u, v, _ = synth.stereo_pair(nx, ny, w["dmin"] * 3 // 4, max(0, w["dmax"] * 3 // 4),
-                                seed=synth.SEED + (rank if args.mode == "pairs" else 0))
-    du, dv = ctx.upload_image(u), ctx.upload_image(v)
-    out, outc = ctx.new_image(nx, ny), ctx.new_image(nx, ny)
+    B = args.batch if args.mode == "pairs" else 1
+    dus, dvs, outs, outcs = [], [], [], []
+    for b in range(B):
+        u, v, _ = synth.stereo_pair(nx, ny, w["dmin"] * 3 // 4, max(0, w["dmax"] * 3 // 4),
+                                    seed=synth.SEED + ((rank * B + b) if args.mode == "pairs" else 0))
+        dus.append(ctx.upload_image(u))
+        dvs.append(ctx.upload_image(v))
+        outs.append(ctx.new_image(nx, ny))
+        outcs.append(ctx.new_image(nx, ny))
+    du, dv = dus[0], dvs[0]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -131,8 +142,8 @@ def main():
             mdist.aggregate_direction_sharded(ctx, cv, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, "vfit", dist)
             return cv
     else:
-        def step(cv):
-            return run_step(ctx, du, dv, w, out, outc, cv)
+        def step(cvs):
+            return run_step(ctx, dus, dvs, w, outs, outcs, cvs)
 
     cv = None  # the W*H*L volume is allocated once and refilled every step
     for _ in range(max(1, args.warmup)):
@@ -151,15 +162,16 @@ def main():
     for name, ms in ctx.timings():
         kern.setdefault(name, []).append(ms)
     ctx.timing(False)
-    cv.free()
+    for x in (cv if isinstance(cv, list) else [cv]):
+        x.free()
 
     if rank == 0:
         cells = float(nx) * ny * L
         if args.mode == "pairs":
-            value = shard.job_rate([args.steps] * world, dt)  # whole-job aggregate: every rank did K volumes
+            value = shard.job_rate([args.steps * B] * world, dt)  # whole-job aggregate: every rank did K batches of B volumes
         else:
             value = args.steps / dt                            # K volumes, each computed by all ranks together
-        nvol_done = args.steps * (world if args.mode == "pairs" else 1)
+        nvol_done = args.steps * (world * B if args.mode == "pairs" else 1)
         avg = {k: float(np.mean(vs)) for k, vs in kern.items()}
         per_step = {k: float(np.sum(vs)) / args.steps for k, vs in kern.items()}
         pass_name = "k_pass2" if "k_pass2" in avg else "k_pass"
@@ -168,8 +180,9 @@ def main():
         frac_rows = (mdist.row_slabs(ny, world)[0][1] / ny) if args.mode == "directions" else 1.0
         # Aggregation stage = K3 (pass kernel) + K4-K6 (k_wta): the two launches together do what the
         # reference's aggregation loop does; SURVEY.md 8(d): 12 B per cell per direction.
-        agg_ms = avg[pass_name] + avg["k_wta"]
-        alg_bytes = 12.0 * w["NDIR"] * cells * (1.0 if args.mode == "pairs" else (2.0 / 3.0) * frac_pass + (1.0 / 3.0) * frac_rows)
+        # With a batch of B volumes per step the pass kernel is launched once (over all of them) and k_wta B times.
+        agg_ms = avg[pass_name] + B * avg["k_wta"]
+        alg_bytes = 12.0 * w["NDIR"] * cells * (float(B) if args.mode == "pairs" else (2.0 / 3.0) * frac_pass + (1.0 / 3.0) * frac_rows)
         achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "r01_traffic.json")
@@ -177,13 +190,13 @@ def main():
             tj = json.load(open(prof))
             if tj.get("workload") == args.workload:
                 traffic = tj.get("aggregation_hbm_bytes_per_volume")
-        roofline = {"bound": "hbm", "kernel": "%s+k_wta (8-direction aggregation, one launch each per volume)" % pass_name,
+        roofline = {"bound": "hbm", "kernel": "%s (one launch per batch of %d volumes) + k_wta (one launch per volume): the 8-direction aggregation" % (pass_name, B),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                    "traffic": (traffic * B if traffic is not None else None), "algorithmic_bytes_per_launch": alg_bytes,
                     "avg_launch_ms": {k: avg[k] for k in sorted(avg)},
                     "per_kernel": {
-                        pass_name: {"alg_bytes": 8.0 * w["NDIR"] * cells,
-                                    "GBps": 8.0 * w["NDIR"] * cells / (avg[pass_name] * 1e-3) / 1e9},
+                        pass_name: {"alg_bytes": 8.0 * w["NDIR"] * cells * B,
+                                    "GBps": 8.0 * w["NDIR"] * cells * B / (avg[pass_name] * 1e-3) / 1e9},
                         "k_wta": {"alg_bytes": (4.0 * w["NDIR"] + 4.0) * cells + 8.0 * nx * ny,
                                   "GBps": ((4.0 * w["NDIR"] + 4.0) * cells) / (avg["k_wta"] * 1e-3) / 1e9},
                         "k_cost": {"alg_bytes": 4.0 * cells, "GBps": 4.0 * cells / (avg["k_cost"] * 1e-3) / 1e9}}}
@@ -191,7 +204,7 @@ def main():
                "unit": "disparity-volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.mode == "pairs" else "strong",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%s: %s" % (args.workload, w["desc"]), "W": nx, "H": ny, "L": L,
+               "config": {"workload": "%s: %s" % (args.workload, w["desc"]), "W": nx, "H": ny, "L": L, "pairs_per_step": B,
                           "NDIR": w["NDIR"], "TSGM": w["MGM"], "potential": "FH" if w["FH"] else "Hirschmueller",
                           "P1": w["P1"], "P2": w["P2"], "census_win": w["win"], "refine": "vfit",
                           "parallelism": ("independent pairs, one per GPU" if args.mode == "pairs" else

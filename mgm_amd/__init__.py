@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "mgm_costvolume_build_dev", "mgm_costvolume_build", "mgm_weights_dev",
     "mgm_aggregate_dev", "mgm_aggregate", "mgm_debug_download_lr", "mgm_refine_dev", "mgm_refine",
     "mgm_selftest_div3", "mgm_aggregate_passes_dev", "mgm_lr_device_ptr", "mgm_wta_rows_dev",
+    "mgm_aggregate_batch_dev",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -81,6 +82,7 @@ def load_library():
     L.mgm_weights_dev.argtypes = [vp, vp, f, f, pp]
     L.mgm_aggregate_dev.argtypes = [vp, vp, vp, f, f, i, i, i, i, cp, vp, vp, pp]
     L.mgm_aggregate.argtypes = [vp, vp, fp, f, f, i, i, i, i, cp, fp, fp, pp]
+    L.mgm_aggregate_batch_dev.argtypes = [vp, i, pp, pp, f, f, i, i, i, i, cp, pp, pp, pp]
     L.mgm_debug_download_lr.argtypes = [vp, i, fp]
     L.mgm_refine_dev.argtypes = [vp, vp, cp, vp, vp]
     L.mgm_refine.argtypes = [vp, vp, cp, fp, fp]
@@ -236,6 +238,21 @@ class Context:
                                              use_fh, fix_overcount, refine.encode() if refine else None, out.h,
                                              outcost.h, C.byref(S) if want_S else None))
         return (CostVolume(self, S) if want_S else None), out, outcost
+
+    def aggregate_batch_dev(self, Cvs, P1, P2, NDIR, MGM, use_fh=0, fix_overcount=1, w8s=None, refine=None, outs=None,
+                            outcosts=None, want_S=False):
+        """mgm() over several volumes of identical geometry in one pass launch: ([S...] or None, [out...], [outcost...])."""
+        n = len(Cvs)
+        nx, ny, _, _ = Cvs[0].dims
+        outs = outs or [self.new_image(nx, ny) for _ in range(n)]
+        outcosts = outcosts or [self.new_image(nx, ny) for _ in range(n)]
+        arr = lambda hs: (C.c_void_p * n)(*hs)
+        S = (C.c_void_p * n)()
+        self._chk(self.lib.mgm_aggregate_batch_dev(
+            self.h, n, arr([cv.h for cv in Cvs]), arr([w.h for w in w8s]) if w8s is not None else None, P1, P2, NDIR, MGM,
+            use_fh, fix_overcount, refine.encode() if refine else None, arr([o.h for o in outs]),
+            arr([o.h for o in outcosts]), S if want_S else None))
+        return ([CostVolume(self, C.c_void_p(h)) for h in S] if want_S else None), outs, outcosts
 
     def aggregate(self, Cv, P1, P2, NDIR, MGM, use_fh=0, fix_overcount=1, w8=None, refine=None, want_S=True):
         """mgm(): returns (S or None, out, outcost) with host arrays for out/outcost."""

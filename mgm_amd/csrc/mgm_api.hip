@@ -66,7 +66,7 @@ struct mgm_ctx {
 namespace {
 
 constexpr int kR = 16;       // lines per band (waves per workgroup) of the pass kernel
-constexpr int kCtrlWords = 4 + kMaxDirs * 4096;  // ticket, err, flag, pad, prog[pass][maxbands]
+constexpr int kCtrlWords = 4 + kMaxBatch * kMaxDirs * 4096;  // ticket, err, flag, pad, prog[volume*8 + pass][maxbands]
 constexpr int kMaxBands = 4096;
 
 long long lr_pad_floats()
@@ -583,9 +583,12 @@ int mgm_weights_dev(mgm_ctx *c, const mgm_img *u, float aP, float aThresh, mgm_i
 // ---- aggregation ----------------------------------------------------------------
 // K3 for the passes [first, first+count) of the reference's table; pass p's Lr volume goes to
 // workspace slot p - first.  Shared by mgm_aggregate_dev and the direction-sharded multi-GPU path.
-static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int MGM, int use_fh, int first,
-                      int count)
+// K3 over `nb` cost volumes of identical geometry in one launch (see PassVolume).  Volume v's Lr volumes
+// end up at lr + v*count*lr_stride.
+static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int nb, float P1, float P2, int MGM,
+                      int use_fh, int first, int count)
 {
+    const mgm_cv *C = Cs[0];
     const int nx = C->nx, ny = C->ny, L = C->dmax - C->dmin + 1;
     const int PEND = first + count;
     HIPCHK(c, hipSetDevice(c->device));
@@ -599,18 +602,29 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
 
     // weighted? (mgm_core.cc:420-423: any value != 1.0 switches every update)
     bool weighted = false;
-    if (w8) {
-        HIPCHK(c, launch_any_not_one(w8->d, npix * 8, words + 2, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_words + 2, words + 2, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        weighted = c->h_words[2] != 0;
+    for (int v = 0; v < nb; v++) {
+        bool wv = false;
+        if (w8s && w8s[v]) {
+            HIPCHK(c, hipMemsetAsync(words + 2, 0, sizeof(unsigned), c->stream));
+            HIPCHK(c, launch_any_not_one(w8s[v]->d, npix * 8, words + 2, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_words + 2, words + 2, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            wv = c->h_words[2] != 0;
+        }
+        if (v && wv != weighted)
+            return fail(c, MGM_ERR_UNSUPPORTED, "batched volumes must be all weighted or all unweighted");
+        weighted = wv;
     }
     const bool fh = use_fh > 0;
     const int NS = pass_ns(fh, weighted);
 
     // compact costs (one byte per label) when the volume allows it
-    bool use_c8 = false;
-    if ((r = c8_resolve(c, C, &use_c8))) return r;
+    bool use_c8 = true;
+    for (int v = 0; v < nb; v++) {
+        bool u = false;
+        if ((r = c8_resolve(c, Cs[v], &u))) return r;
+        use_c8 = use_c8 && u;
+    }
     if (c->force_build == 1) use_c8 = false;
     // second build (LDS-DMA loaders) whenever the slabs are whole DMA pieces
     const int R2 = c->force_build == 1 ? 0 : pass2_lines(L, use_c8);
@@ -627,20 +641,21 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
     // Consecutive passes' volumes are staggered by an odd number of 256-byte blocks so that the
     // NDIR slabs of one pixel (read together by k_wta) do not fall on the same HBM channel.
     const long long lr_stride = nvol + lr_pad_floats();
-    if ((r = reserve(c, c->lr, sizeof(float) * (size_t)lr_stride * count))) return r;
-    if ((r = reserve(c, c->hand, sizeof(float) * (size_t)PEND * 2 * maxLL * NS * LP))) return r;
-    if ((r = reserve(c, c->handm, sizeof(float) * (size_t)PEND * 2 * maxLL))) return r;
+    if ((r = reserve(c, c->lr, sizeof(float) * (size_t)lr_stride * count * nb))) return r;
+    if ((r = reserve(c, c->hand, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * LP))) return r;
+    if ((r = reserve(c, c->handm, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL))) return r;
 
     // task table: ticket -> (pass, band); item (p, b) always follows (p, b-1)
-    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != PEND * 16 + first || c->tk_r != R) {
+    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != (PEND * 16 + first) * kMaxBatch + nb - 1 || c->tk_r != R) {
         // Passes with more bands (the column passes of a wide image) have the longer dependency
         // chain, so tickets are dealt by RELATIVE progress b / nbands(pass): every pass advances at
         // the rate that lets all of them finish together.  Within a pass the order is still by band.
         std::vector<int2> tasks;
-        for (int q = first; q < PEND; q++)
-            for (int b = 0; b < p.g[q].nbands; b++) tasks.push_back(make_int2(q, b));
+        for (int v = 0; v < nb; v++)
+            for (int q = first; q < PEND; q++)
+                for (int b = 0; b < p.g[q].nbands; b++) tasks.push_back(make_int2(v * kMaxDirs + q, b));
         std::stable_sort(tasks.begin(), tasks.end(), [&](const int2 &a, const int2 &b) {
-            const long long ka = (long long)a.y * p.g[b.x].nbands, kb = (long long)b.y * p.g[a.x].nbands;
+            const long long ka = (long long)a.y * p.g[b.x % kMaxDirs].nbands, kb = (long long)b.y * p.g[a.x % kMaxDirs].nbands;
             return ka != kb ? ka < kb : a.x < b.x;
         });
         if ((r = reserve(c, c->tasks, sizeof(int2) * tasks.size()))) return r;
@@ -649,14 +664,16 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
         c->ntasks = (int)tasks.size();
         c->tk_nx = nx;
         c->tk_ny = ny;
-        c->tk_ndir = PEND * 16 + first;
+        c->tk_ndir = (PEND * 16 + first) * kMaxBatch + nb - 1;
         c->tk_r = R;
     }
 
-    p.C = C->d;
-    p.C8 = use_c8 ? C->d8 : nullptr;
-    p.Lr = (float *)c->lr.p;
-    p.w8 = weighted ? w8->d : nullptr;
+    for (int v = 0; v < nb; v++) {
+        p.vol[v].C = Cs[v]->d;
+        p.vol[v].C8 = use_c8 ? Cs[v]->d8 : nullptr;
+        p.vol[v].Lr = (float *)c->lr.p + (size_t)v * count * lr_stride;
+        p.vol[v].w8 = weighted ? w8s[v]->d : nullptr;
+    }
     p.hand = (float *)c->hand.p;
     p.handm = (float *)c->handm.p;
     p.ticket = words + 0;
@@ -708,7 +725,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
             double fa = 0, fb = 0, fc = 0;
             bool dec = false;
             for (int i = 0; i < c->ntasks; i++)
-                if (tk[i].x == q) {
+                if (tk[i].x % kMaxDirs == q) {
                     n++;
                     if (d[i * 16 + 1] >> 63) {  // barrier-free build: failed polls of the profiled wave by cause
                         dec = true;
@@ -780,31 +797,52 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
     return MGM_OK;
 }
 
-int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
-                      int fix_overcount, const char *refine, mgm_img *out, mgm_img *outcost, mgm_cv **S)
+int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm_img *const *w8, float P1, float P2, int NDIR,
+                            int MGM, int use_fh, int fix_overcount, const char *refine, mgm_img *const *out,
+                            mgm_img *const *outcost, mgm_cv **S)
 {
-    if (!c || !C || !out || !outcost) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: null argument");
+    if (!c || !C || !out || !outcost || n < 1) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: null argument");
+    if (n > kMaxBatch) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: at most 4 volumes per call");
     if (NDIR < 1 || NDIR > kMaxDirs)  // the reference reads past its 8-entry table for -O 16 (mgm_core.cc:489)
         return fail(c, MGM_ERR_INVALID, "NDIR must be 1..8");
     if (MGM < 1 || MGM > 4) return fail(c, MGM_ERR_INVALID, "MGM (TSGM) must be 1..4");
-    const int nx = C->nx, ny = C->ny, L = C->dmax - C->dmin + 1;
-    if (out->nx != nx || out->ny != ny || outcost->nx != nx || outcost->ny != ny)
-        return fail(c, MGM_ERR_INVALID, "mgm_aggregate: output image size mismatch");
-    if (w8 && (w8->nx != nx || w8->ny != ny || w8->nch != 8))
-        return fail(c, MGM_ERR_INVALID, "mgm_aggregate: weights must be nx*ny*8");
+    for (int v = 0; v < n; v++)
+        if (!C[v] || !out[v] || !outcost[v]) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: null argument");
+    const int nx = C[0]->nx, ny = C[0]->ny, L = C[0]->dmax - C[0]->dmin + 1;
+    for (int v = 0; v < n; v++) {
+        if (C[v]->nx != nx || C[v]->ny != ny || C[v]->dmax - C[v]->dmin + 1 != L)
+            return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: the volumes must have the same size and label count");
+        if (out[v]->nx != nx || out[v]->ny != ny || outcost[v]->nx != nx || outcost[v]->ny != ny)
+            return fail(c, MGM_ERR_INVALID, "mgm_aggregate: output image size mismatch");
+        if (w8 && w8[v] && (w8[v]->nx != nx || w8[v]->ny != ny || w8[v]->nch != 8))
+            return fail(c, MGM_ERR_INVALID, "mgm_aggregate: weights must be nx*ny*8");
+        if (w8 && (w8[v] == nullptr) != (w8[0] == nullptr))
+            return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: weights for all volumes or for none");
+    }
     const int ridx = refinement_index(refine);
     if (ridx > 1) return fail(c, MGM_ERR_UNSUPPORTED, "fused refinement supports none|vfit only");
     HIPCHK(c, hipSetDevice(c->device));
     int r;
-    if ((r = run_passes(c, C, w8, P1, P2, MGM, use_fh, 0, NDIR))) return r;
-    const long long npix = (long long)nx * ny, nvol = npix * L;
-    float *Sout = nullptr;
-    if (S) {
-        if ((r = mgm_cv_create(c, nx, ny, C->dmin, C->dmax, S))) return r;
-        Sout = (*S)->d;
+    if ((r = run_passes(c, C, (w8 && w8[0]) ? w8 : nullptr, n, P1, P2, MGM, use_fh, 0, NDIR))) return r;
+    const long long npix = (long long)nx * ny;
+    for (int v = 0; v < n; v++) {
+        float *Sout = nullptr;
+        if (S) {
+            if ((r = mgm_cv_create(c, nx, ny, C[v]->dmin, C[v]->dmax, &S[v]))) return r;
+            Sout = S[v]->d;
+        }
+        const float *lr = (const float *)c->lr.p + (size_t)v * NDIR * c->last_stride;
+        if ((r = run_wta(c, C[v], 0, npix, lr, c->last_stride, NDIR, fix_overcount, ridx, out[v]->d, outcost[v]->d, Sout)))
+            return r;
     }
-    return run_wta(c, C, 0, npix, (const float *)c->lr.p, c->last_stride, NDIR, fix_overcount, ridx, out->d, outcost->d,
-                   Sout);
+    return MGM_OK;
+}
+
+int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
+                      int fix_overcount, const char *refine, mgm_img *out, mgm_img *outcost, mgm_cv **S)
+{
+    return mgm_aggregate_batch_dev(c, 1, &C, w8 ? &w8 : nullptr, P1, P2, NDIR, MGM, use_fh, fix_overcount, refine, &out,
+                                   &outcost, S);
 }
 
 // ---- direction sharding (multi-GPU): run a subset of the passes, sum slabs of Lr volumes ----------
@@ -818,7 +856,7 @@ int mgm_aggregate_passes_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, flo
     if (w8 && (w8->nx != C->nx || w8->ny != C->ny || w8->nch != 8))
         return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes: weights must be nx*ny*8");
     HIPCHK(c, hipSetDevice(c->device));
-    return run_passes(c, C, w8, P1, P2, MGM, use_fh, first_pass, n_passes);
+    return run_passes(c, &C, w8 ? &w8 : nullptr, 1, P1, P2, MGM, use_fh, first_pass, n_passes);
 }
 
 void *mgm_lr_device_ptr(mgm_ctx *c, int slot)

@@ -29,17 +29,25 @@ struct PassGeom {
     int wplane[4];     // weight plane of neighbour k (mgm_core.cc:481-484)
 };
 
-struct PassParams {
+// One launch of the pass kernel may aggregate several cost volumes of identical geometry (the
+// left->right and right->left volumes of a stereo pair, say): work items are then (volume, pass,
+// band), and the long dependency chains of one volume's column passes are hidden behind the other
+// volumes' work.
+constexpr int kMaxBatch = 4;
+struct PassVolume {
     const float *C;     // [npix][L]
-    const uint8_t *C8;  // [npix][L] compact costs (integers 0..254, 255 = +INF) or nullptr
-    float *Lr;          // NDIR volumes, pass p at Lr + p*nvol
-    const float *w8;    // 8 planes [npix] or nullptr
-    float *hand;        // hand-off slabs  [pass][2][LLmax][NS*LP]
-    float *handm;       // hand-off minima [pass][2][LLmax]
-    unsigned *prog;     // progress words  [pass][maxbands]
+    const uint8_t *C8;  // [npix][L] compact costs (integers 0..254, 255 = +INF) or nullptr (all volumes alike)
+    float *Lr;          // NDIR volumes, pass p at Lr + (p - pass0)*nvol
+    const float *w8;    // 8 planes [npix] or nullptr (all volumes alike)
+};
+struct PassParams {
+    PassVolume vol[kMaxBatch];
+    float *hand;        // hand-off slabs  [volume*8 + pass][2][LLmax][NS*LP]
+    float *handm;       // hand-off minima [volume*8 + pass][2][LLmax]
+    unsigned *prog;     // progress words  [volume*8 + pass][maxbands]
     unsigned *ticket;   // work-item ticket counter
     unsigned *err;      // watchdog word
-    const int2 *tasks;  // ticket -> (pass, band)
+    const int2 *tasks;  // ticket -> (volume*8 + pass, band)
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
     long long npix, nvol;

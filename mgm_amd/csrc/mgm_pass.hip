@@ -55,7 +55,9 @@ __global__ void __launch_bounds__(R * 64) k_pass(const PassParams P)
     if (tid == 0) *s_task = (int)atomicAdd(P.ticket, 1u);
     __syncthreads();
     const int2 tk = P.tasks[*s_task];
-    const int pass = tk.x, band = tk.y;
+    const int vp = tk.x, band = tk.y;  // vp = volume*8 + pass
+    const int pass = vp & (kMaxDirs - 1);
+    const PassVolume &V = P.vol[vp / kMaxDirs];
     const PassGeom &g = P.g[pass];
     const int NL = g.NL, LL = g.LL, L = P.L, MGM = P.MGM, form = g.form;
     const float P1 = P.P1, P2 = P.P2;
@@ -67,16 +69,16 @@ __global__ void __launch_bounds__(R * 64) k_pass(const PassParams P)
     const bool to_lds = (r < R - 1) && (j + 1 < NL);
     const bool to_global = (r == R - 1) && (band + 1 < g.nbands);
 
-    const float *__restrict__ Cb = P.C;
-    float *__restrict__ Lrb = P.Lr + (long long)(pass - P.pass0) * P.nvol;
+    const float *__restrict__ Cb = V.C;
+    float *__restrict__ Lrb = V.Lr + (long long)(pass - P.pass0) * P.nvol;
     const long long pix0 = g.base + (long long)j * g.jstep;
     const long long istep = g.istep;
 
-    float *hand_out = P.hand + ((long long)(pass * 2 + (band & 1)) * P.LLmax) * (NS * LP);
-    float *handm_out = P.handm + (long long)(pass * 2 + (band & 1)) * P.LLmax;
-    const float *hand_in = P.hand + ((long long)(pass * 2 + ((band + 1) & 1)) * P.LLmax) * (NS * LP);
-    const float *handm_in = P.handm + (long long)(pass * 2 + ((band + 1) & 1)) * P.LLmax;
-    unsigned *prog_out = P.prog + pass * P.maxbands + band;
+    float *hand_out = P.hand + ((long long)(vp * 2 + (band & 1)) * P.LLmax) * (NS * LP);
+    float *handm_out = P.handm + (long long)(vp * 2 + (band & 1)) * P.LLmax;
+    const float *hand_in = P.hand + ((long long)(vp * 2 + ((band + 1) & 1)) * P.LLmax) * (NS * LP);
+    const float *handm_in = P.handm + (long long)(vp * 2 + ((band + 1) & 1)) * P.LLmax;
+    unsigned *prog_out = P.prog + vp * P.maxbands + band;
     const unsigned *prog_in = prog_out - 1;  // only dereferenced when band > 0
 
     float Cpf[PF][LPL];
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(R * 64) k_pass(const PassParams P)
                     } else {
                         float D[4];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) D[k] = P.w8[(long long)g.wplane[k] * P.npix + pix];
+                        for (int k = 0; k < 4; k++) D[k] = V.w8[(long long)g.wplane[k] * P.npix + pix];
                         if constexpr (!FH) {
                             if (form == 0) combine_whirsch<LPL>(Cpf[u], nb_i, nb_s, nb_b, nb_f, D, P1, P2, MGM, Lv);
                             else combine_whirsch<LPL>(Cpf[u], nb_f, nb_b, nb_s, nb_i, D, P1, P2, MGM, Lv);

@@ -38,6 +38,9 @@ __device__ __forceinline__ void dma4(const void *src_lane, void *dst_base)
 {
     __builtin_amdgcn_global_load_lds((glb_vptr)src_lane, (lds_vptr)dst_base, 4, 0, AUX);
 }
+#ifndef MGM_P2_NT_STORE
+#define MGM_P2_NT_STORE 0   // 1: the Lr slabs are written with the non-temporal hint
+#endif
 #ifndef MGM_P2_EXP
 #define MGM_P2_EXP 0   // timing experiments (wrong results): 1 plain loads for the hand-off, 2 no progress/minimum DMA, 4 no hand-off slab DMA
 #endif
@@ -127,8 +130,11 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 
 #ifndef MGM_P2_PUBLAG
 #define MGM_P2_PUBLAG 3
 #endif
+#ifndef MGM_P2_PUBEVERY
+#define MGM_P2_PUBEVERY 4
+#endif
 #ifndef MGM_P2_LEAD
-#define MGM_P2_LEAD 4
+#define MGM_P2_LEAD 2
 #endif
 // ---- geometry of the build --------------------------------------------------------
 template <int LPL, int NS, bool HASM, bool C8>
@@ -247,7 +253,9 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     __syncthreads();
     const int ticket = *s_task;
     const int2 tk = P.tasks[ticket];
-    const int pass = tk.x, band = tk.y;
+    const int vp = tk.x, band = tk.y;  // vp = volume*8 + pass
+    const int pass = vp & (kMaxDirs - 1);
+    const PassVolume &V = P.vol[vp / kMaxDirs];
     unsigned long long *dbg = P.dbg ? P.dbg + (long long)ticket * 16 : nullptr;
     if (dbg && tid == 0) dbg[0] = wall_clock64();
     const PassGeom &g = P.g[pass];
@@ -259,11 +267,11 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     const bool from_global = band > 0;
 
     constexpr int NSLP = NS * LP;
-    float *hand_out = P.hand + ((long long)(pass * 2 + (band & 1)) * P.LLmax) * NSLP;
-    float *handm_out = P.handm + (long long)(pass * 2 + (band & 1)) * P.LLmax;
-    const float *hand_in = P.hand + ((long long)(pass * 2 + ((band + 1) & 1)) * P.LLmax) * NSLP;
-    const float *handm_in = P.handm + (long long)(pass * 2 + ((band + 1) & 1)) * P.LLmax;
-    unsigned *prog_out = P.prog + pass * P.maxbands + band;
+    float *hand_out = P.hand + ((long long)(vp * 2 + (band & 1)) * P.LLmax) * NSLP;
+    float *handm_out = P.handm + (long long)(vp * 2 + (band & 1)) * P.LLmax;
+    const float *hand_in = P.hand + ((long long)(vp * 2 + ((band + 1) & 1)) * P.LLmax) * NSLP;
+    const float *handm_in = P.handm + (long long)(vp * 2 + ((band + 1) & 1)) * P.LLmax;
+    unsigned *prog_out = P.prog + vp * P.maxbands + band;
     const unsigned *prog_in = from_global ? prog_out - 1 : prog_out;
 
     if (wave >= NC) {
@@ -290,9 +298,9 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             int j = band * NC + r;
             j = j < NLn ? j : NLn - 1;
             if constexpr (C8)
-                cptr[q] = reinterpret_cast<const float *>(P.C8 + (g.base + (long long)j * g.jstep) * L + (lane % LPS) * 16);
+                cptr[q] = reinterpret_cast<const float *>(V.C8 + (g.base + (long long)j * g.jstep) * L + (lane % LPS) * 16);
             else
-                cptr[q] = P.C + (g.base + (long long)j * g.jstep) * L + lane * 4;
+                cptr[q] = V.C + (g.base + (long long)j * g.jstep) * L + lane * 4;
             ci[q] = -1 - SL * r;
         }
         // hand-off slab wanted by wave 0 at step t: pixel t (its fwd neighbour) with slope 2, pixel t-1
@@ -470,7 +478,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     const bool has_prev = line_ok && (j >= 1);
     const bool to_lds = (r < NC - 1) && (j + 1 < NLn);
     const bool to_global = (r == NC - 1) && (band + 1 < g.nbands);
-    float *__restrict__ Lrb = P.Lr + (long long)(pass - P.pass0) * P.nvol;
+    float *__restrict__ Lrb = V.Lr + (long long)(pass - P.pass0) * P.nvol;
     const long long pix0 = g.base + (long long)j * g.jstep;
     const float *fwd_src0 = r > 0 ? Tring + (r - 1) * RT * NSLP + lane * LPL : Hring + lane * LPL;
     const float *fwd_m0 = r > 0 ? Tm + (r - 1) * RT : Hm;
@@ -553,7 +561,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     } else {
                         float Dw[4];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) Dw[k] = P.w8[(long long)g.wplane[k] * P.npix + pix];
+                        for (int k = 0; k < 4; k++) Dw[k] = V.w8[(long long)g.wplane[k] * P.npix + pix];
                         if constexpr (!FH) {
                             if constexpr (FORM == 0)
                                 combine_whirsch<LPL>(Cv, nb_i, nb_same, nb_back, nb_fwd, Dw, P1, P2, MGM, Lv);
@@ -577,8 +585,13 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                 const unsigned long long c2 = prof ? clock64() : 0;
                 if (!(P.xflags & 1)) {
                     float *q = Lrb + pix * L + lane * LPL;
+#if MGM_P2_NT_STORE
+#pragma unroll
+                    for (int k = 0; k < LPL; k++) __builtin_nontemporal_store(Lv[k], q + k);
+#else
 #pragma unroll
                     for (int k = 0; k < LPL; k++) q[k] = Lv[k];
+#endif
                 }
                 const float m = slab_min<LPL>(Lv);
                 nb_i.m = m;
@@ -643,7 +656,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     // every step: write-through stores to one address serialise at ~1.5 us each.
                     constexpr int SPS = 1 + NS * sc1_store_count<LPL>();
                     constexpr int PUBLAG = (63 / SPS) < MGM_P2_PUBLAG ? (63 / SPS) : MGM_P2_PUBLAG;
-                    constexpr int PUBEVERY = 4;
+                    constexpr int PUBEVERY = MGM_P2_PUBEVERY;
                     if (i == LL - 1) {
                         wait_vmcnt<0>();
                         if (lane == 0) __hip_atomic_store(prog_out, (unsigned)LL, RLX_AGENT);
@@ -751,7 +764,7 @@ template <int LPL, bool FH, bool WEIGHTED, int MGM>
 static hipError_t launch2_one(const PassParams &p, int ntasks, hipStream_t s)
 {
     if constexpr (LPL == 1 || LPL == 2 || LPL == 4 || LPL == 8) {
-        if (p.C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true>(p, ntasks, s);
+        if (p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true>(p, ntasks, s);
     }
     return launch2_c8<LPL, FH, WEIGHTED, MGM, false>(p, ntasks, s);
 }
