@@ -25,6 +25,10 @@ struct mgm_cv {
     uint8_t *d8 = nullptr;
     unsigned *bad8 = nullptr;  // device word: 1 = not representable
     int c8_state = 0;          // 0 none, 1 written (validity not read back yet), 2 valid, -1 invalid
+    // K2 skips the fp32 write when its costs are known to fit the compact form (single-word census):
+    // nothing on the hot path reads `d` then, and it is decoded from d8 if somebody asks for it.
+    int f32_state = 1;         // 1 current, 0 stale (d8 holds the volume)
+    mgm_ctx *owner = nullptr;
 };
 
 namespace {
@@ -376,6 +380,7 @@ int mgm_cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, mgm_cv **out)
     cv->ny = ny;
     cv->dmin = dmin;
     cv->dmax = dmax;
+    cv->owner = c;
     hipError_t e = hipMalloc((void **)&cv->d, sizeof(float) * (size_t)nx * ny * (size_t)L);
     if (e != hipSuccess) {
         delete cv;
@@ -395,10 +400,22 @@ int mgm_cv_upload(mgm_ctx *c, const float *dense, int nx, int ny, int dmin, int 
     (*out)->c8_state = 0;
     return MGM_OK;
 }
+// make cv->d current (see mgm_cv::f32_state); enqueued on the context's stream
+static int ensure_f32(mgm_ctx *c, const mgm_cv *ccv)
+{
+    mgm_cv *cv = const_cast<mgm_cv *>(ccv);
+    if (cv->f32_state) return MGM_OK;
+    if (!cv->d8 || cv->c8_state < 1) return fail(c, MGM_ERR_INTERNAL, "cost volume has neither an fp32 nor a compact copy");
+    TimeScope t(c, "k_expand");
+    HIPCHK(c, launch_expand(cv->d8, (long long)cv->nx * cv->ny * (cv->dmax - cv->dmin + 1), cv->d, c->stream));
+    cv->f32_state = 1;
+    return MGM_OK;
+}
 int mgm_cv_download(mgm_ctx *c, const mgm_cv *cv, float *dense)
 {
     if (!c || !cv || !dense) return fail(c, MGM_ERR_INVALID, "mgm_cv_download: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int r = ensure_f32(c, cv)) return r;
     const size_t n = (size_t)cv->nx * cv->ny * (size_t)(cv->dmax - cv->dmin + 1);
     HIPCHK(c, hipMemcpyAsync(dense, cv->d, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     return mgm_ctx_synchronize(c);
@@ -415,6 +432,7 @@ int mgm_cv_dims(const mgm_cv *cv, int *nx, int *ny, int *dmin, int *dmax)
 void *mgm_cv_device_ptr(mgm_cv *cv)
 {
     if (!cv) return nullptr;
+    if (cv->owner && ensure_f32(cv->owner, cv)) return nullptr;
     cv->c8_state = 0;  // the caller may write through the pointer: re-derive the compact copy at the next use
     return cv->d;
 }
@@ -467,6 +485,8 @@ static int c8_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *use)
         HIPCHK(c, hipMemcpyAsync(c->h_words + 3, cv->bad8, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         cv->c8_state = c->h_words[3] ? -1 : 2;
+        if (cv->c8_state < 0 && !cv->f32_state)
+            return fail(c, MGM_ERR_INTERNAL, "cost volume predicted to fit the compact form does not");
     }
     *use = cv->c8_state == 2;
     return MGM_OK;
@@ -507,6 +527,7 @@ int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int
         p.bad8 = (*out)->bad8;
         (*out)->c8_state = 1;
     }
+    (*out)->f32_state = 1;
     p.nx = u->nx;
     p.ny = u->ny;
     p.vnx = v->nx;
@@ -541,6 +562,15 @@ int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int
         p.nch = nwords;
     }
     p.trunc = truncDist * (float)p.nch;  // mgm_costvolume.h:401,405
+    // A census cost over one descriptor word is a bit count 0..32, clipped to `trunc`: with trunc = +INF
+    // or an integer up to 254 every cost fits the compact form, and the fp32 volume -- which neither K3
+    // nor k_wta reads then -- is only materialised on demand (ensure_f32).
+    if (p.C8 && costfn == 2 && p.nch == 1 &&
+        (p.trunc == __builtin_huge_valf() || (p.trunc >= 0.0f && p.trunc <= 254.0f && p.trunc == rintf(p.trunc))) &&
+        !(getenv("MGM_HIP_LAZY_F32") && atoi(getenv("MGM_HIP_LAZY_F32")) == 0)) {
+        p.C = nullptr;
+        (*out)->f32_state = 0;
+    }
     {
         TimeScope t(c, "k_cost");
         HIPCHK(c, launch_cost(p, c->stream));
@@ -669,6 +699,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     }
 
     for (int v = 0; v < nb; v++) {
+        if (!use_c8 && (r = ensure_f32(c, Cs[v]))) return r;
         p.vol[v].C = Cs[v]->d;
         p.vol[v].C8 = use_c8 ? Cs[v]->d8 : nullptr;
         p.vol[v].Lr = (float *)c->lr.p + (size_t)v * count * lr_stride;
@@ -781,6 +812,8 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
     WtaParams w{};
     w.C = C->d + pix0 * L;
     w.C8 = (C->c8_state == 2 && c->force_build != 1) ? C->d8 + pix0 * L : nullptr;
+    if (!w.C8)
+        if (int r = ensure_f32(c, C)) return r;
     w.Lr = lr;
     w.S = Sout;
     w.out = out;

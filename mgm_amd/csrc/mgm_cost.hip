@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
     const int lane = threadIdx.x & 63;
     const int x = (int)(pix % P.nx), y = (int)(pix / P.nx);
     const long long vpix = (long long)P.vnx * P.vny;
-    float *Cp = P.C + pix * P.L;
+    float *Cp = P.C ? P.C + pix * P.L : nullptr;  // nullptr: only the compact copy is wanted
     uint8_t *Cp8 = P.C8 ? P.C8 + pix * P.L : nullptr;
     const bool yin = (y < P.vny);  // q.y = p.y >= 0 always
     bool anyfinite = false, bad8 = false;
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
             }
         }
         e = (e < P.trunc) ? e : P.trunc;
-        Cp[o] = e;
+        if (Cp) Cp[o] = e;
         anyfinite |= finite_bits(e);
         if (Cp8) {
             const unsigned b = c8_encode(e);
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
     // no valid hypothesis for this pixel => all labels cost 0 (mgm_costvolume.h:414-421)
     if (__builtin_amdgcn_ballot_w64(anyfinite) == 0ull)
         for (int o = lane; o < P.L; o += 64) {
-            Cp[o] = 0.0f;
+            if (Cp) Cp[o] = 0.0f;
             if (Cp8) Cp8[o] = 0;
         }
     else if (Cp8 && __builtin_amdgcn_ballot_w64(bad8) != 0ull && lane == 0)
@@ -146,15 +146,118 @@ __global__ void __launch_bounds__(256) k_compact(const float *__restrict__ C, lo
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(bad8, 1u);
 }
 
+// the fp32 volume back from its compact copy (exact: every byte decodes to the float it was made from)
+__global__ void __launch_bounds__(256) k_expand(const uint8_t *__restrict__ C8, long long n, float *__restrict__ C)
+{
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < n) {
+            const unsigned w = *reinterpret_cast<const unsigned *>(C8 + i);
+            float4 f;
+            f.x = c8_decode(w & 255u);
+            f.y = c8_decode((w >> 8) & 255u);
+            f.z = c8_decode((w >> 16) & 255u);
+            f.w = c8_decode(w >> 24);
+            *reinterpret_cast<float4 *>(C + i) = f;
+        } else {
+            for (int k = 0; k < 4 && i + k < n; k++) C[i + k] = c8_decode(C8[i + k]);
+        }
+    }
+}
+
+hipError_t launch_expand(const uint8_t *C8, long long n, float *C, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_expand, dim3(256 * 16), dim3(256), 0, s, C8, n, C);
+    return hipGetLastError();
+}
+
 hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s)
 {
     hipLaunchKernelGGL(k_compact, dim3(256 * 16), dim3(256), 0, s, C, n, C8, bad8);
     return hipGetLastError();
 }
 
+// K2 for the case whose costs are known to fit the compact form (single-word census, trunc = +INF or an
+// integer <= 254; see mgm_costvolume_build_dev): integer arithmetic only, the compact volume only.
+// One wavefront per pixel; lane l owns the LPL consecutive labels l*LPL.. -- LPL bytes, one store.
+//   cost = min(popcount(cu ^ cv), trunc), trunc for a hypothesis outside the right image
+//   (mgm_costvolume.h:65-78, 401-412); a pixel without a finite cost is all zeros (414-421).
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <int LPL>
+__global__ void __launch_bounds__(256) k_cost_census8(const uint32_t *__restrict__ cu, const uint32_t *__restrict__ cv,
+                                                      int nx, int ny, int vnx, int vny, int dmin, unsigned tb,
+                                                      uint8_t *__restrict__ C8)
+{
+    constexpr int L = LPL * 64;
+    const long long npix = (long long)nx * ny;
+    const int lane = threadIdx.x & 63;
+    for (long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (long long)gridDim.x * 4) {
+        const int x = (int)(pix % nx), y = (int)(pix / nx);
+        const uint32_t wu = cu[pix];
+        const int q0 = x + dmin + lane * LPL;
+        const bool yin = y < vny;
+        const uint32_t *row = cv + (long long)(yin ? y : 0) * vnx;
+        unsigned b[LPL];
+        if (yin && q0 >= 0 && q0 + LPL <= vnx) {  // the whole group lies inside the right image
+            uint32_t wv[LPL];
+            if constexpr (LPL % 4 == 0) {
+#pragma unroll
+                for (int h = 0; h < LPL / 4; h++) {
+                    const u32x4_a4 t = *reinterpret_cast<const u32x4_a4 *>(row + q0 + 4 * h);
+                    wv[4 * h] = t.x; wv[4 * h + 1] = t.y; wv[4 * h + 2] = t.z; wv[4 * h + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < LPL; k++) wv[k] = row[q0 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < LPL; k++) {
+                const unsigned pc = (unsigned)__builtin_popcount(wu ^ wv[k]);
+                b[k] = pc < tb ? pc : tb;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < LPL; k++) {
+                const int q = q0 + k;
+                const bool in = yin && q >= 0 && q < vnx;
+                const unsigned pc = (unsigned)__builtin_popcount(wu ^ row[in ? q : 0]);
+                b[k] = in ? (pc < tb ? pc : tb) : tb;
+            }
+        }
+        bool fin = false;
+#pragma unroll
+        for (int k = 0; k < LPL; k++) fin |= b[k] != 255u;
+        const bool anyfinite = __builtin_amdgcn_ballot_w64(fin) != 0ull;
+        uint8_t *dst = C8 + pix * L + lane * LPL;
+        if constexpr (LPL == 1) {
+            dst[0] = (uint8_t)(anyfinite ? b[0] : 0u);
+        } else if constexpr (LPL == 2) {
+            *reinterpret_cast<unsigned short *>(dst) = (unsigned short)(anyfinite ? (b[0] | (b[1] << 8)) : 0u);
+        } else {
+#pragma unroll
+            for (int h = 0; h < LPL / 4; h++) {
+                const unsigned w = b[4 * h] | (b[4 * h + 1] << 8) | (b[4 * h + 2] << 16) | (b[4 * h + 3] << 24);
+                reinterpret_cast<unsigned *>(dst)[h] = anyfinite ? w : 0u;
+            }
+        }
+    }
+}
+
 hipError_t launch_cost(const CostParams &p, hipStream_t s)
 {
     const long long npix = (long long)p.nx * p.ny;
+    if (!p.C && p.C8 && p.costfn == 2 && p.nch == 1 && c8_supported(p.L)) {
+        const unsigned tb = p.trunc == __builtin_huge_valf() ? 255u : (unsigned)p.trunc;
+        long long nb = (npix + 3) / 4;
+        if (nb > 256 * 32) nb = 256 * 32;
+        const dim3 grid((unsigned)nb), block(256);
+        switch (p.L / 64) {
+            case 1: hipLaunchKernelGGL(k_cost_census8<1>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+            case 2: hipLaunchKernelGGL(k_cost_census8<2>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+            case 4: hipLaunchKernelGGL(k_cost_census8<4>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+            default: hipLaunchKernelGGL(k_cost_census8<8>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+        }
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_cost, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, p);
     return hipGetLastError();
 }

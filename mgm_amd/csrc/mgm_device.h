@@ -80,6 +80,7 @@ hipError_t launch_pass2_lpl(const PassParams &p, int ntasks, bool fh, int wmode,
 // compact-cost support: labels per lane for which the C8 forms of K3 / k_wta exist
 inline bool c8_supported(int L) { return L == 64 || L == 128 || L == 256 || L == 512; }
 hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s);
+hipError_t launch_expand(const uint8_t *C8, long long n, float *C, hipStream_t s);
 hipError_t launch_wta(const WtaParams &p, hipStream_t s);
 hipError_t launch_refine(const float *S, long long npix, int L, int dmin, int method, float *out, float *outcost,
                          hipStream_t s);

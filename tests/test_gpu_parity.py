@@ -100,7 +100,12 @@ COSTS = [(1, (40, 23), (-7, 8), "none", "ad", 3, np.inf), (3, (40, 23), (-7, 8),
          (3, (40, 23), (-30, 40), "none", "census", 3, np.inf), (3, (40, 23), (-30, 40), "none", "census", 5, np.inf),
          (1, (70, 23), (30, 100), "none", "census", 7, 20.0), (1, (40, 23), (-7, 8), "census", "ad", 3, np.inf),
          (3, (33, 17), (-70, 70), "none", "sd", 3, 50.0), (1, (1, 1), (0, 0), "none", "ad", 3, np.inf),
-         (1, (5, 3), (-300, 211), "none", "census", 3, np.inf)]
+         (1, (5, 3), (-300, 211), "none", "census", 3, np.inf),
+         # single-word census at label counts with a compact form: K2 writes bytes only, the fp32 volume is decoded on
+         # demand (trunc +INF or a small integer); a fractional trunc or a two-word descriptor takes the general kernel
+         (1, (70, 23), (-40, 23), "none", "census", 5, np.inf), (1, (70, 23), (-100, 27), "none", "census", 5, 7.0),
+         (1, (70, 23), (-200, 55), "none", "census", 5, 7.5), (1, (300, 9), (-255, 0), "none", "census", 7, np.inf),
+         (1, (300, 9), (-255, 0), "none", "census", 5, 0.0), (1, (90, 31), (0, 63), "none", "census", 3, np.inf)]
 
 
 @pytest.mark.parametrize("case", COSTS, ids=lambda c: "%dch-%s-%s-w%d" % (c[0], c[3], c[4], c[5]))
@@ -113,6 +118,11 @@ def test_costvolume_vs_oracle(ctx, oracle, case):
     dmaxI = np.full((ny, nx), dmax, np.float32)
     cv = ctx.costvolume(u, v, dminI, dmaxI, pre, dist, td, win)
     assert ndiff(a, cv.download()) == 0
+    if dmax - dmin + 1 >= 64:  # ... and the volume aggregates to the oracle's result whichever copy the kernels read
+        So, oo, co = oracle.mgm(a, dmin, 8.0, 32.0, 8, 3, 0, 1)
+        S, o, c = ctx.aggregate(cv, 8.0, 32.0, 8, 3, 0, 1, None, None, want_S=True)
+        assert ndiff(S.download(), So) == 0 and ndiff(o, oo) == 0 and ndiff(c, co) == 0
+        S.free()
     cv.free()
 
 
