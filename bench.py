@@ -188,11 +188,11 @@ def main():
         prof = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(prof):
             tj = json.load(open(prof))
-            if tj.get("workload") == args.workload:
-                traffic = tj.get("aggregation_hbm_bytes_per_volume")
+            if tj.get("workload") == args.workload and tj.get("pairs_per_step") == B:
+                traffic = tj.get("aggregation_hbm_bytes_per_step")
         roofline = {"bound": "hbm", "kernel": "%s (one launch per batch of %d volumes) + k_wta (one launch per volume): the 8-direction aggregation" % (pass_name, B),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": (traffic * B if traffic is not None else None), "algorithmic_bytes_per_launch": alg_bytes,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                     "avg_launch_ms": {k: avg[k] for k in sorted(avg)},
                     "per_kernel": {
                         pass_name: {"alg_bytes": 8.0 * w["NDIR"] * cells * B,

@@ -15,7 +15,8 @@ def per_kernel(path, counter):
     return {k: (sum(v.values()) / len(v), len(v)) for k, v in per.items()}
 
 
-fetch, write, workload, out_md, out_json = sys.argv[1:6]
+fetch, write, workload, B, out_md, out_json = sys.argv[1:7]
+B = int(B)
 F, W = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
 rows, total = [], 0.0
 for k in sorted(F):
@@ -23,16 +24,20 @@ for k in sorted(F):
         continue
     fb, wb = F[k][0] * 2 * 1024, W.get(k, (0, 0))[0] * 1024
     rows.append((k, F[k][1], F[k][0], fb / 1e9, W.get(k, (0, 0))[0], wb / 1e9))
-    if "k_pass" in k or "k_wta" in k:
-        total += fb + wb
+    if "k_pass" in k:
+        total += fb + wb          # one launch per step covers the whole batch
+    elif "k_wta" in k:
+        total += B * (fb + wb)    # one launch per volume
 with open(out_md, "w") as f:
     f.write("# HBM traffic per launch, workload %s (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)\n\n" % workload)
     f.write("FETCH_SIZE x2 correction per MI355X_MICROARCH.md; averages over the profiled launches.\n\n")
     f.write("| kernel | launches | FETCH_SIZE (KB, raw) | read GB (x2) | WRITE_SIZE (KB) | write GB |\n|---|---|---|---|---|---|\n")
     for r in rows:
         f.write("| `%s` | %d | %.4g | %.3f | %.4g | %.3f |\n" % r)
-    f.write("\nAggregation (pass kernel + k_wta) HBM bytes per volume: %.2f GB\n" % (total / 1e9))
-json.dump({"workload": workload, "aggregation_hbm_bytes_per_volume": total,
+    f.write("\nAggregation of one batch of %d volumes (one pass-kernel launch + %d k_wta launches): %.2f GB of HBM traffic, %.2f GB per volume\n"
+            % (B, B, total / 1e9, total / 1e9 / B))
+json.dump({"workload": workload, "pairs_per_step": B, "aggregation_hbm_bytes_per_step": total,
+           "aggregation_hbm_bytes_per_volume": total / B,
            "per_kernel": {r[0]: {"read_bytes": r[3] * 1e9, "write_bytes": r[5] * 1e9} for r in rows}},
           open(out_json, "w"), indent=1)
 print(open(out_md).read())
