@@ -110,44 +110,59 @@ static void die(mgm_ctx *ctx, int rc, const char *what)
     exit(rc == MGM_ERR_UNSUPPORTED ? 2 : 1);
 }
 
-// One run of the path: mgm.cc:372 + 376-385 (u,v) or 373 + 405-414 (v,u with the negated range).
-static void run_path(mgm_ctx *ctx, const HostImg &u, const HostImg &v, int dmin, int dmax, const Opts &o, HostImg &off,
-                     HostImg &cost)
-{
-    int rc;
+// One run of the path: mgm.cc:372 + 376-385 (u,v) or 373 + 405-414 (v,u with the negated range), in three stages so
+// that the two runs of a pair can share one launch of the pass kernel (mgm_aggregate_batch_dev).
+struct Run {
     mgm_img *du = nullptr, *dv = nullptr, *dw = nullptr, *dout = nullptr, *dcost = nullptr;
     mgm_cv *C = nullptr;
     bool weighted_msg = false;
-    if ((rc = mgm_img_upload(ctx, u.data.data(), u.nx, u.ny, u.nch, &du))) die(ctx, rc, "upload");
-    if ((rc = mgm_img_upload(ctx, v.data.data(), v.nx, v.ny, v.nch, &dv))) die(ctx, rc, "upload");
+    int nx = 0, ny = 0;
+};
+
+static void prepare_run(mgm_ctx *ctx, const HostImg &u, const HostImg &v, int dmin, int dmax, const Opts &o, Run &r)
+{
+    int rc;
+    r.nx = u.nx;
+    r.ny = u.ny;
+    if ((rc = mgm_img_upload(ctx, u.data.data(), u.nx, u.ny, u.nch, &r.du))) die(ctx, rc, "upload");
+    if ((rc = mgm_img_upload(ctx, v.data.data(), v.nx, v.ny, v.nch, &r.dv))) die(ctx, rc, "upload");
     // compute_mgm_weights(u, aP2, aThresh)   [aP1 is parsed and unused in the reference too, mgm.cc:372]
-    if ((rc = mgm_weights_dev(ctx, du, o.aP2, o.aThresh, &dw))) die(ctx, rc, "mgm_weights");
+    if ((rc = mgm_weights_dev(ctx, r.du, o.aP2, o.aThresh, &r.dw))) die(ctx, rc, "mgm_weights");
     if (o.aP2 != 1.0f) {  // mgm() announces the weighted mode on stdout (mgm_core.cc:420-423)
         std::vector<float> w((size_t)u.npix() * 8);
-        if ((rc = mgm_img_download(ctx, dw, w.data()))) die(ctx, rc, "download");
-        weighted_msg = std::any_of(w.begin(), w.end(), [](float x) { return x != 1.0f; });
+        if ((rc = mgm_img_download(ctx, r.dw, w.data()))) die(ctx, rc, "download");
+        r.weighted_msg = std::any_of(w.begin(), w.end(), [](float x) { return x != 1.0f; });
     }
-    if ((rc = mgm_costvolume_build_dev(ctx, du, dv, dmin, dmax, o.prefilter, o.distance, o.truncDist, o.census_win, &C)))
+    if ((rc = mgm_costvolume_build_dev(ctx, r.du, r.dv, dmin, dmax, o.prefilter, o.distance, o.truncDist, o.census_win, &r.C)))
         die(ctx, rc, "mgm_costvolume_build");
-    if ((rc = mgm_img_create(ctx, u.nx, u.ny, 1, &dout)) || (rc = mgm_img_create(ctx, u.nx, u.ny, 1, &dcost)))
+    if ((rc = mgm_img_create(ctx, u.nx, u.ny, 1, &r.dout)) || (rc = mgm_img_create(ctx, u.nx, u.ny, 1, &r.dcost)))
         die(ctx, rc, "mgm_img_create");
+}
+
+static void aggregate_run(mgm_ctx *ctx, const Opts &o, Run &r)
+{
+    const int rc = mgm_aggregate_dev(ctx, r.C, r.dw, o.P1, o.P2, o.NDIR, o.TSGM, o.FH, o.FIX, o.refine, r.dout, r.dcost, nullptr);
+    if (rc) die(ctx, rc, "mgm_aggregate");
+}
+
+static void finish_run(mgm_ctx *ctx, const Opts &o, Run &r, HostImg &off, HostImg &cost)
+{
+    int rc;
+    off.nx = cost.nx = r.nx;
+    off.ny = cost.ny = r.ny;
+    off.nch = cost.nch = 1;
+    off.data.resize((size_t)r.nx * r.ny);
+    cost.data.resize((size_t)r.nx * r.ny);
+    if ((rc = mgm_img_download(ctx, r.dout, off.data.data())) || (rc = mgm_img_download(ctx, r.dcost, cost.data.data())))
+        die(ctx, rc, "download");
     // the reference prints one digit per pass from inside mgm() (mgm_core.cc:491), then
     // print_solution_energy prints "\n" (mgm_print_energy.h:109-111)
-    rc = mgm_aggregate_dev(ctx, C, dw, o.P1, o.P2, o.NDIR, o.TSGM, o.FH, o.FIX, o.refine, dout, dcost, nullptr);
-    if (rc) die(ctx, rc, "mgm_aggregate");
-    off.nx = cost.nx = u.nx;
-    off.ny = cost.ny = u.ny;
-    off.nch = cost.nch = 1;
-    off.data.resize(u.npix());
-    cost.data.resize(u.npix());
-    if ((rc = mgm_img_download(ctx, dout, off.data.data())) || (rc = mgm_img_download(ctx, dcost, cost.data.data())))
-        die(ctx, rc, "download");
-    if (weighted_msg) printf(" USING IMAGE DEPENDENT WEIGHTS\n");
+    if (r.weighted_msg) printf(" USING IMAGE DEPENDENT WEIGHTS\n");
     for (int p = 0; p < o.NDIR; p++) printf("%d", p);
     printf("\n");
     fflush(stdout);
-    mgm_cv_free(ctx, C);
-    for (mgm_img *im : {du, dv, dw, dout, dcost}) mgm_img_free(ctx, im);
+    mgm_cv_free(ctx, r.C);
+    for (mgm_img *im : {r.du, r.dv, r.dw, r.dout, r.dcost}) mgm_img_free(ctx, im);
 }
 
 int main(int argc, char **argv)
@@ -226,11 +241,28 @@ int main(int argc, char **argv)
         if (rc) { fprintf(stderr, "mgm: no usable MI355X device (mgm_ctx_create = %d); there is no CPU path\n", rc); return 1; }
 
         HostImg outoff, outcost, outoffR, outcostR;
-        run_path(ctx, u, v, o.dmin, o.dmax, o, outoff, outcost);
+        Run L, R;
+        prepare_run(ctx, u, v, o.dmin, o.dmax, o, L);
+        bool together = false;
+        if (TESTLRRL != 0 && u.nx == v.nx && u.ny == v.ny && env_param("MGM_BATCH_LR", 1) != 0) {
+            // both runs of the pair (mgm.cc:376-385 and 405-414) through ONE launch of the pass kernel
+            prepare_run(ctx, v, u, -o.dmax, -o.dmin, o, R);  // mgm.cc:366, 405
+            const mgm_cv *Cs[2] = {L.C, R.C};
+            const mgm_img *Ws[2] = {L.dw, R.dw};
+            mgm_img *Os[2] = {L.dout, R.dout}, *Cc[2] = {L.dcost, R.dcost};
+            rc = mgm_aggregate_batch_dev(ctx, 2, Cs, Ws, o.P1, o.P2, o.NDIR, o.TSGM, o.FH, o.FIX, o.refine, Os, Cc, nullptr);
+            if (rc == MGM_OK) together = true;
+            else if (rc != MGM_ERR_UNSUPPORTED) die(ctx, rc, "mgm_aggregate_batch");
+            // (one image weighted, the other not: the two runs take different update functions)
+        }
+        if (!together) aggregate_run(ctx, o, L);
+        finish_run(ctx, o, L, outoff, outcost);
         if (MEDIAN != 0) outoff = median_filter(outoff, (int)MEDIAN);
         if (nolr_file[0]) npy::write(nolr_file, outoff);
         if (TESTLRRL != 0) {
-            run_path(ctx, v, u, -o.dmax, -o.dmin, o, outoffR, outcostR);  // mgm.cc:366, 405
+            if (!R.C) prepare_run(ctx, v, u, -o.dmax, -o.dmin, o, R);  // mgm.cc:366, 405
+            if (!together) aggregate_run(ctx, o, R);
+            finish_run(ctx, o, R, outoffR, outcostR);
             if (MEDIAN != 0) outoffR = median_filter(outoffR, (int)MEDIAN);
             const HostImg tmpL = outoff, tmpR = outoffR;
             leftright_test(outoffR, tmpL, (float)TAU);
