@@ -38,6 +38,9 @@ __device__ __forceinline__ void dma4(const void *src_lane, void *dst_base)
 {
     __builtin_amdgcn_global_load_lds((glb_vptr)src_lane, (lds_vptr)dst_base, 4, 0, AUX);
 }
+#ifndef MGM_P2_LATE_STORE
+#define MGM_P2_LATE_STORE 0   // the Lr slab is stored at the end of the step instead of right after the update
+#endif
 #ifndef MGM_P2_NT_STORE
 #define MGM_P2_NT_STORE 0   // 1: the Lr slabs are written with the non-temporal hint
 #endif
@@ -583,16 +586,19 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     ph[1] += clock64() - c1;  // combine
                 }
                 const unsigned long long c2 = prof ? clock64() : 0;
-                if (!(P.xflags & 1)) {
-                    float *q = Lrb + pix * L + lane * LPL;
+                auto store_lr = [&]() {
+                    if (!(P.xflags & 1)) {
+                        float *q = Lrb + pix * L + lane * LPL;
 #if MGM_P2_NT_STORE
 #pragma unroll
-                    for (int k = 0; k < LPL; k++) __builtin_nontemporal_store(Lv[k], q + k);
+                        for (int k = 0; k < LPL; k++) __builtin_nontemporal_store(Lv[k], q + k);
 #else
 #pragma unroll
-                    for (int k = 0; k < LPL; k++) q[k] = Lv[k];
+                        for (int k = 0; k < LPL; k++) q[k] = Lv[k];
 #endif
-                }
+                    }
+                };
+                if constexpr (!MGM_P2_LATE_STORE) store_lr();
                 const float m = slab_min<LPL>(Lv);
                 nb_i.m = m;
                 if (prof) {
@@ -665,6 +671,10 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                         if (lane == 0) __hip_atomic_store(prog_out, (unsigned)(i - PUBLAG + 1), RLX_AGENT);
                     }
                 }
+                // The 15 lock-stepped waves reach their Lr store together and the stores drain one at a time; a wave
+                // that overwrites the stored registers right away stalls on that queue.  Issued last, the drain
+                // overlaps the barrier and the next step's LDS reads instead.
+                if constexpr (MGM_P2_LATE_STORE) store_lr();
             }
         };
 

@@ -112,8 +112,13 @@ __device__ __forceinline__ void neighbour_min(const float (&Lv)[LPL], float (&N)
 // exact sum: a min-plus scan in f64, which holds these sums exactly.  If the premise does not hold
 // the result is merely another guess; the caller's fixed-point sweeps remain the ground truth.
 template <int LPL, bool FWD>
-__device__ __forceinline__ float fh_repair(float a, float P1, int lane)
+__device__ __forceinline__ float fh_repair(float a, float P1, int lane_in)
 {
+    // (cold path: keep its lane masks and f64 constants from being hoisted into the caller's hot loop, where they
+    // would push live scalar registers into spills)
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    asm volatile("" : "+v"(P1));
     auto from_prev = [&](double v, int d) { return FWD ? __shfl_up(v, d) : __shfl_down(v, d); };
     auto has_prev = [&](int d) { return FWD ? lane >= d : lane + d < 64; };
     const double P1d = (double)P1, Rd = (double)LPL * (double)P1;
