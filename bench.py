@@ -72,10 +72,27 @@ def cpu_baseline(w, seconds_target=15.0):
     orc.refine(S, w["dmin"], "vfit", o, c)
     dt = time.perf_counter() - t0
     vol_per_s = (rows / w["ny"]) / dt  # linear in the number of rows
-    return {"value": vol_per_s, "unit": "disparity-volumes/s", "cores": 1, "kind": "port",
-            "sample": "%dx%dx%d band (%d of %d rows) of the same workload, %.1f s of CPU time, extrapolated "
-                      "linearly in rows; oracle/mgm_oracle.c, 1 thread" % (nx, rows, L, rows, w["ny"], dt),
-            "mcell_updates_per_s": nx * rows * L * w["NDIR"] / dt / 1e6}
+    res = {"value": vol_per_s, "unit": "disparity-volumes/s", "cores": 1, "kind": "port",
+           "sample": "%dx%dx%d band (%d of %d rows) of the same workload, %.1f s of CPU time, extrapolated "
+                     "linearly in rows; oracle/mgm_oracle.c, 1 thread" % (nx, rows, L, rows, w["ny"], dt),
+           "mcell_updates_per_s": nx * rows * L * w["NDIR"] / dt / 1e6}
+    # The reference parallelises each diagonal of a pass with OpenMP (mgm_core.cc:505-579); the port does the same.
+    # That only pays on full-length diagonals, so this leg runs ONE whole volume on up to 32 threads.
+    from oracle.oracle import usable_cpus
+    T = min(32, usable_cpus())
+    if T > 1 and os.environ.get("MGM_BENCH_OMP", "1") != "0":
+        orc.set_threads(T)
+        u, v, _ = synth.stereo_pair(nx, w["ny"], w["dmin"] * 3 // 4, 0)
+        t0 = time.perf_counter()
+        C = orc.costvolume(u, v, w["dmin"], w["dmax"], "none", "census", np.inf, w["win"])
+        S, o, c = orc.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1)
+        orc.refine(S, w["dmin"], "vfit", o, c)
+        dto = time.perf_counter() - t0
+        res["openmp"] = {"value": 1.0 / dto, "cores": T, "sample": "one whole %dx%dx%d volume, %.1f s wall" % (nx, w["ny"], L, dto)}
+        if 1.0 / dto > res["value"]:  # the headline CPU figure is the better of the two legs
+            res.update({"value": 1.0 / dto, "cores": T, "mcell_updates_per_s": nx * w["ny"] * L * w["NDIR"] / dto / 1e6,
+                        "sample": res["openmp"]["sample"] + " on %d OpenMP threads; 1 thread: %.4f volumes/s (%s)" % (T, vol_per_s, res["sample"])})
+    return res
 
 
 def main():
