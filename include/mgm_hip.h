@@ -110,7 +110,8 @@ int mgm_weights_dev(mgm_ctx *ctx, const mgm_img *u, float aP, float aThresh, mgm
  *   NDIR 1..8, MGM (TSGM) 1..4, use_fh: USE_TRUNCATED_LINEAR_POTENTIALS,
  *   fix_overcount: TSGM_FIX_OVERCOUNT.
  * refine: NULL/"none" gives mgm()'s own outputs (integer labels dmin+argmin);
- *   "vfit" additionally applies subpixel_refinement_sgm in the same kernel.
+ *   "vfit" additionally applies subpixel_refinement_sgm in the same kernel; "parabola", "cubic" and
+ *   "parabolaOCV" apply it as a second kernel on the corrected S.
  * out/outcost: nx*ny images.  S: NULL, or receives the corrected aggregated
  *   volume that mgm() returns (costs one extra volume write). */
 int mgm_aggregate_dev(mgm_ctx *ctx, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int NDIR, int MGM,
@@ -156,7 +157,8 @@ int mgm_selftest_div3(mgm_ctx *ctx, unsigned long long *nbad);
 
 /* ---- sub-pixel refinement: subpixel_refinement_sgm ---------------------- */
 /* method in {"none","vfit","parabola","cubic","parabolaOCV"}; unknown => none
- * (mgm_refine.h:28-35).  Built: none, vfit.  out/outcost are read and updated. */
+ * (mgm_refine.h:28-35).  out/outcost are read and updated.  (vfit is also fused into mgm_aggregate*'s
+ * WTA kernel; the other methods run as a second kernel on the corrected S, in mgm_aggregate* too.) */
 int mgm_refine_dev(mgm_ctx *ctx, const mgm_cv *S, const char *method, mgm_img *out, mgm_img *outcost);
 int mgm_refine(mgm_ctx *ctx, const mgm_cv *S, const char *method, float *out, float *outcost);
 

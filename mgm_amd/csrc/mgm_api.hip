@@ -50,7 +50,7 @@ struct mgm_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // workspace
-    Buf lr, hand, handm, words, tasks, census_u, census_v, dbg;
+    Buf lr, hand, handm, words, tasks, census_u, census_v, dbg, stmp;
     int debug_stats = 0;  // MGM_HIP_DEBUG_STATS=1: per-workgroup timing summary of K3 on stderr
     unsigned *h_words = nullptr;  // pinned mirror of the control words
     // cached task table key
@@ -255,7 +255,7 @@ int mgm_ctx_destroy(mgm_ctx *c)
     if (!c) return MGM_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (Buf *b : {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v, &c->dbg})
+    for (Buf *b : {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v, &c->dbg, &c->stmp})
         if (b->p) hipFree(b->p);
     for (auto &t : c->tim) {
         hipEventDestroy(t.a);
@@ -830,6 +830,24 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
     return MGM_OK;
 }
 
+// K4-K6 with any refinement of the reference's table: none/vfit are fused into k_wta; parabola, cubic and
+// parabolaOCV (refine.h:6-145) run as a second kernel on the corrected S (the caller's, or a scratch volume).
+static int run_wta_refine(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const float *lr, long long lr_stride,
+                          int NDIR, int fix_overcount, int ridx, float *out, float *outcost, float *Sout)
+{
+    if (ridx <= 1) return run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, ridx, out, outcost, Sout);
+    const int L = C->dmax - C->dmin + 1;
+    int r;
+    if (!Sout) {
+        if ((r = reserve(c, c->stmp, sizeof(float) * (size_t)npix * L))) return r;
+        Sout = (float *)c->stmp.p;
+    }
+    if ((r = run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, 0, out, outcost, Sout))) return r;
+    TimeScope t(c, "k_refine");
+    HIPCHK(c, launch_refine(Sout, npix, L, C->dmin, ridx, out, outcost, c->stream));
+    return MGM_OK;
+}
+
 int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm_img *const *w8, float P1, float P2, int NDIR,
                             int MGM, int use_fh, int fix_overcount, const char *refine, mgm_img *const *out,
                             mgm_img *const *outcost, mgm_cv **S)
@@ -853,7 +871,6 @@ int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm
             return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: weights for all volumes or for none");
     }
     const int ridx = refinement_index(refine);
-    if (ridx > 1) return fail(c, MGM_ERR_UNSUPPORTED, "fused refinement supports none|vfit only");
     HIPCHK(c, hipSetDevice(c->device));
     int r;
     if ((r = run_passes(c, C, (w8 && w8[0]) ? w8 : nullptr, n, P1, P2, MGM, use_fh, 0, NDIR))) return r;
@@ -865,7 +882,7 @@ int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm
             Sout = S[v]->d;
         }
         const float *lr = (const float *)c->lr.p + (size_t)v * NDIR * c->last_stride;
-        if ((r = run_wta(c, C[v], 0, npix, lr, c->last_stride, NDIR, fix_overcount, ridx, out[v]->d, outcost[v]->d, Sout)))
+        if ((r = run_wta_refine(c, C[v], 0, npix, lr, c->last_stride, NDIR, fix_overcount, ridx, out[v]->d, outcost[v]->d, Sout)))
             return r;
     }
     return MGM_OK;
@@ -905,10 +922,9 @@ int mgm_wta_rows_dev(mgm_ctx *c, const mgm_cv *C, int row0, int nrows, const voi
     if (row0 < 0 || nrows < 1 || row0 + nrows > C->ny || NDIR < 1 || NDIR > kMaxDirs)
         return fail(c, MGM_ERR_INVALID, "mgm_wta_rows: bad row range or NDIR");
     const int ridx = refinement_index(refine);
-    if (ridx > 1) return fail(c, MGM_ERR_UNSUPPORTED, "fused refinement supports none|vfit only");
     HIPCHK(c, hipSetDevice(c->device));
     const long long L = C->dmax - C->dmin + 1, slab = (long long)nrows * C->nx * L;
-    return run_wta(c, C, (long long)row0 * C->nx, (long long)nrows * C->nx, (const float *)lr_slabs, slab, NDIR,
+    return run_wta_refine(c, C, (long long)row0 * C->nx, (long long)nrows * C->nx, (const float *)lr_slabs, slab, NDIR,
                    fix_overcount, ridx, (float *)out_rows, (float *)outcost_rows, nullptr);
 }
 
@@ -963,7 +979,6 @@ int mgm_refine_dev(mgm_ctx *c, const mgm_cv *S, const char *method, mgm_img *out
         return fail(c, MGM_ERR_INVALID, "mgm_refine: image size mismatch");
     const int m = refinement_index(method);
     if (m == 0) return MGM_OK;  // "none" and unknown names (mgm_refine.h:28-35)
-    if (m != 1) return fail(c, MGM_ERR_UNSUPPORTED, "refinement parabola/cubic/parabolaOCV is not built yet");
     HIPCHK(c, hipSetDevice(c->device));
     TimeScope t(c, "k_refine");
     HIPCHK(c, launch_refine(S->d, (long long)S->nx * S->ny, S->dmax - S->dmin + 1, S->dmin, m, out->d, outcost->d,

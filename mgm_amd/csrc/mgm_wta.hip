@@ -174,8 +174,92 @@ hipError_t launch_wta(const WtaParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
-// Stand-alone refinement on a materialised (corrected) S: one thread per pixel.
-__global__ void __launch_bounds__(256) k_refine(const float *__restrict__ S, long long npix, int L, int dmin,
+// refine.h:40-68
+__device__ __forceinline__ void parabolafit(const float (&v)[4], float &v_min, float &x_min)
+{
+    if (v[1] > v[0] && v[1] > v[2]) {
+        x_min = 0;
+        v_min = v[1];
+        return;
+    }
+    const float c = v[1];
+    const float b = (v[2] - v[0]) / 2;
+    const float a = (v[2] - 2 * v[1] + v[0]) / 2;
+    float x = -b / (2 * a);
+    if (x > 1) x = 1;
+    if (x < -1) x = -1;
+    v_min = (a * x + b) * x + c;
+    x_min = x;
+}
+
+// refine.h:6-38 (the doubling of a and b and the clamp of a are the reference's)
+__device__ __forceinline__ void parabolafit_ocv(const float (&v)[4], float &v_min, float &x_min)
+{
+    if (v[1] > v[0] && v[1] > v[2]) {
+        x_min = 0;
+        v_min = v[1];
+        return;
+    }
+    const float c = v[1];
+    float b = (v[2] - v[0]) / 2;
+    float a = (v[2] - 2 * v[1] + v[0]) / 2;
+    a *= 2;
+    b *= 2;
+    a = a > 1.0 ? a : 1.0;
+    float x = (-b + a) / (2 * a);
+    if (x > 1) x = 1;
+    if (x < -1) x = -1;
+    v_min = (a * x + b) * x + c;
+    x_min = x;
+}
+
+// refine.h:94-99: evaluated in double (the literals are doubles), narrowed on return
+__device__ __forceinline__ float cubic_interp(const float (&p)[4], const float x)
+{
+    return p[1] + 0.5 * x *
+                      (p[2] - p[0] + x * (2.0 * p[0] - 5.0 * p[1] + 4.0 * p[2] - p[3] + x * (3.0 * (p[1] - p[2]) + p[3] - p[0])));
+}
+
+// refine.h:102-145: p = {S[o-1], S[o], S[o+1], S[o+2]}; the cubic treats p[1]..p[2] as the unit interval
+__device__ __forceinline__ void cubicfit(const float (&p)[4], float &out_pmin, float &out_xmin)
+{
+    float pmin, xmin;
+    if (p[1] < p[2]) {
+        pmin = p[1];
+        xmin = 0.0;
+    } else {
+        pmin = p[2];
+        xmin = 1.0;
+    }
+    const double a = 0.5 * 3.0 * (3.0 * (p[1] - p[2]) + p[3] - p[0]);
+    const double b = 2.0 * p[0] - 5.0 * p[1] + 4.0 * p[2] - p[3];
+    const double c = 0.5 * (p[2] - p[0]);
+    const double discr = b * b - 4.0 * a * c;
+    if (discr >= 0) {
+        const double z1 = (-b + __builtin_sqrt(discr)) / (2.0 * a);
+        const double z2 = (-b - __builtin_sqrt(discr)) / (2.0 * a);
+        if (z1 > 0.0 && z1 < 1.0) {
+            const float tmp = cubic_interp(p, z1);
+            if (tmp < pmin) {
+                pmin = tmp;
+                xmin = z1;
+            }
+        }
+        if (z2 > 0.0 && z2 < 1.0) {
+            const float tmp = cubic_interp(p, z2);
+            if (tmp < pmin) {
+                pmin = tmp;
+                xmin = z2;
+            }
+        }
+    }
+    out_pmin = pmin;
+    out_xmin = xmin;
+}
+
+// Stand-alone refinement on a materialised (corrected) S: one thread per pixel (subpixel_refinement_sgm,
+// mgm_refine.h:40-70; method = index into its table: 1 vfit, 2 parabola, 3 cubic, 4 parabolaOCV).
+__global__ void __launch_bounds__(256) k_refine(const float *__restrict__ S, long long npix, int L, int dmin, int method,
                                                 float *__restrict__ out, float *__restrict__ outcost)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,8 +269,12 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ S, lon
     const int o = (int)minP;
     if (o - 1 >= dmin && o + 2 <= dmin + L - 1) {
         const float *Si = S + i * L + (o - dmin);
-        float vmin, dx;
-        vfit(Si[-1], Si[0], Si[1], vmin, dx);
+        const float v[4] = {Si[-1], Si[0], Si[1], Si[2]};
+        float vmin = outcost[i], dx = 0;
+        if (method == 1) vfit(v[0], v[1], v[2], vmin, dx);
+        else if (method == 2) parabolafit(v, vmin, dx);
+        else if (method == 3) cubicfit(v, vmin, dx);
+        else parabolafit_ocv(v, vmin, dx);
         out[i] = (float)o + dx;
         outcost[i] = vmin;
     }
@@ -195,8 +283,8 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ S, lon
 hipError_t launch_refine(const float *S, long long npix, int L, int dmin, int method, float *out, float *outcost,
                          hipStream_t s)
 {
-    if (method != 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_refine, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, S, npix, L, dmin, out, outcost);
+    if (method < 1 || method > 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_refine, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, S, npix, L, dmin, method, out, outcost);
     return hipGetLastError();
 }
 

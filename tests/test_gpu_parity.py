@@ -58,7 +58,28 @@ def test_golden_aggregation(ctx, name):
     fin = np.isfinite(g["outcost"])
     assert ndiff(fo[fin], g["out_vfit"][fin]) == 0 and ndiff(fc, g["outcost_vfit"]) == 0
     assert np.nanmax(np.abs(fo[fin] - g["out_vfit"][fin]), initial=0) <= VFIT_TOL
+    # the other refinements of the reference's table (refine.h; the cubic evaluates in double): as a second kernel
+    # on S, both stand-alone and behind mgm_aggregate
+    for meth in ("parabola", "cubic", "parabolaOCV"):
+        ro, rc = ctx.refine(S, meth, g["out"], g["outcost"])
+        assert ndiff(ro[fin], g["out_" + meth][fin]) == 0 and ndiff(rc, g["outcost_" + meth]) == 0, meth
+        _, fo, fc = ctx.aggregate(cv, *args, meth, want_S=False)
+        assert ndiff(fo[fin], g["out_" + meth][fin]) == 0 and ndiff(fc, g["outcost_" + meth]) == 0, meth
     S.free(), cv.free()
+
+
+@pytest.mark.parametrize("meth", ["parabola", "cubic", "parabolaOCV"])
+def test_refinements_vs_oracle_on_a_real_volume(ctx, oracle, meth):
+    nx, ny, dmin, dmax = 120, 50, -63, 64
+    u, v, _ = synth.stereo_pair(nx, ny, -30, 30)
+    C = oracle.costvolume(u, v, dmin, dmax, "none", "census", np.inf, 5)
+    So, oo, co = oracle.mgm(C, dmin, 8.0, 32.0, 8, 3, 0, 1)
+    ro, rc = oracle.refine(So, dmin, meth, oo, co)
+    cv = ctx.upload_volume(C, dmin)
+    _, fo, fc = ctx.aggregate(cv, 8.0, 32.0, 8, 3, 0, 1, None, meth, want_S=False)
+    fin = np.isfinite(co)
+    assert ndiff(fo[fin], ro[fin]) == 0 and ndiff(fc, rc) == 0
+    cv.free()
 
 
 # ---- seeded sweeps against the oracle ----------------------------------------------
