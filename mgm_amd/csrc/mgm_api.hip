@@ -506,7 +506,6 @@ int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int
         pre = 1;
     }
     if (costfn > 2) return fail(c, MGM_ERR_UNSUPPORTED, "distance ncc/btad/btsd is not built yet");
-    if (pre > 1) return fail(c, MGM_ERR_UNSUPPORTED, "prefilter sobelx/gblur is not built yet");
 
     int r = MGM_OK;
     if (*out) {  // caller-provided volume to refill (must have the right geometry)
@@ -560,6 +559,40 @@ int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int
         p.u = (const float *)c->census_u.p;  // -p census with an ad/sd cost: words read as floats
         p.v = (const float *)c->census_v.p;
         p.nch = nwords;
+    }
+    if (pre == 2 || pre == 3) {  // sobelx / gblur of both images (mgm_costvolume.h:366-373), then AD or SD on them
+        const size_t nu = (size_t)u->nx * u->ny * u->nch, nv = (size_t)v->nx * v->ny * v->nch;
+        if ((r = reserve(c, c->census_u, sizeof(float) * nu))) return r;
+        if ((r = reserve(c, c->census_v, sizeof(float) * nv))) return r;
+        TimeScope t(c, "k_filter2d");
+        if (pre == 2) {
+            static const float sob[9] = {-1, 0, 1, -2, 0, 2, -1, 0, 1};  // img_tools.h:129-137
+            HIPCHK(c, launch_filter2d(u->d, u->nx, u->ny, u->nch, sob, 3, 3, (float *)c->census_u.p, c->stream));
+            HIPCHK(c, launch_filter2d(v->d, v->nx, v->ny, v->nch, sob, 3, 3, (float *)c->census_v.p, c->stream));
+        } else {
+            // gblur_gray with sigma = 1 (img_tools.h:140-180): the taps are computed on the host exactly as there
+            const float sigma = 1.0f;
+            const float radius = 3 * fabsf(sigma);
+            int rr = (int)ceil((double)(1 + 2 * radius));
+            rr = rr < 1 ? 1 : (rr > 39 ? 39 : rr);
+            float k[39];
+            const int cw = (rr - 1) / 2;
+            float m = 0;
+            for (int i = 0; i < rr; i++) {
+                const float x = (float)hypot((double)(i - cw), 0.0);
+                const float g = (float)exp((double)(-x * x / (2 * sigma * sigma)));  // (double-precision exp, as compiled there)
+                k[i] = g;
+                m += g;
+            }
+            for (int i = 0; i < rr; i++) k[i] /= m;
+            if ((r = reserve(c, c->stmp, sizeof(float) * std::max(nu, nv)))) return r;
+            HIPCHK(c, launch_filter2d(u->d, u->nx, u->ny, u->nch, k, rr, 1, (float *)c->stmp.p, c->stream));
+            HIPCHK(c, launch_filter2d((const float *)c->stmp.p, u->nx, u->ny, u->nch, k, 1, rr, (float *)c->census_u.p, c->stream));
+            HIPCHK(c, launch_filter2d(v->d, v->nx, v->ny, v->nch, k, rr, 1, (float *)c->stmp.p, c->stream));
+            HIPCHK(c, launch_filter2d((const float *)c->stmp.p, v->nx, v->ny, v->nch, k, 1, rr, (float *)c->census_v.p, c->stream));
+        }
+        p.u = (const float *)c->census_u.p;
+        p.v = (const float *)c->census_v.p;
     }
     p.trunc = truncDist * (float)p.nch;  // mgm_costvolume.h:401,405
     // A census cost over one descriptor word is a bit count 0..32, clipped to `trunc`: with trunc = +INF

@@ -69,6 +69,48 @@ hipError_t launch_census(const float *u, int nx, int ny, int nch, int winradius,
     return hipGetLastError();
 }
 
+// ---- prefilters of the non-census costs ------------------------------------------
+// apply_filter (img_tools.h:105-127) with a small 2-D kernel: Neumann boundary (the nearest pixel), products
+// accumulated in row-major kernel order in fp32, exactly as the reference's loops do.  One thread per output
+// sample.  Serves sobelx (3x3) and, called twice, the separable gblur (1 x r, then r x 1; img_tools.h:140-180).
+struct FilterTaps {
+    float f[39];
+};
+__global__ void __launch_bounds__(256) k_filter2d(const float *__restrict__ u, int nx, int ny, int nch, const FilterTaps K,
+                                                  int fnx, int fny, float *__restrict__ out)
+{
+    const long long npix = (long long)nx * ny;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * nch) return;
+    const int c = (int)(idx / npix);
+    const long long p = idx % npix;
+    const int i = (int)(p % nx), j = (int)(p / nx);
+    const int hfnx = fnx / 2, hfny = fny / 2;
+    const float *pl = u + (long long)c * npix;
+    float v = 0;
+    for (int jj = 0; jj < fny; jj++)
+        for (int ii = 0; ii < fnx; ii++) {
+            int x = i + ii - hfnx, y = j + jj - hfny;
+            x = x >= 0 ? x : 0;
+            x = x < nx ? x : nx - 1;
+            y = y >= 0 ? y : 0;
+            y = y < ny ? y : ny - 1;
+            v += pl[x + (long long)y * nx] * K.f[ii + jj * fnx];
+        }
+    out[idx] = v;
+}
+
+hipError_t launch_filter2d(const float *u, int nx, int ny, int nch, const float *taps, int fnx, int fny, float *out,
+                           hipStream_t s)
+{
+    if (fnx * fny > 39) return hipErrorInvalidValue;
+    FilterTaps K;
+    for (int i = 0; i < fnx * fny; i++) K.f[i] = taps[i];
+    const long long n = (long long)nx * ny * nch;
+    hipLaunchKernelGGL(k_filter2d, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, nx, ny, nch, K, fnx, fny, out);
+    return hipGetLastError();
+}
+
 // ---- K2 -----------------------------------------------------------------------
 // One wavefront per pixel; lane l fills labels o = l, l+64, ... so that every
 // store instruction writes 64 consecutive floats of the pixel's slab.

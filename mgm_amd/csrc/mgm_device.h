@@ -97,6 +97,8 @@ struct CostParams {
     float trunc;                 // truncDist * nch
 };
 hipError_t launch_cost(const CostParams &p, hipStream_t s);
+hipError_t launch_filter2d(const float *u, int nx, int ny, int nch, const float *taps, int fnx, int fny, float *out,
+                           hipStream_t s);
 hipError_t launch_weights(const float *u, int nx, int ny, int nch, float aP, float aThresh, float *w8,
                           hipStream_t s);
 hipError_t launch_selftest_div3(unsigned long long *nbad, hipStream_t s);

@@ -53,6 +53,10 @@ def worker(win):
         ("synth_census_allinvalid", s_u, s_v, 70, 80, "none", "census", np.inf),   # every q outside => zeros
         ("synth_sd", s_u, s_v, -10, 6, "none", "sd", 400.0),
         ("synth_pcensus_ad", s_u, s_v, -10, 6, "census", "ad", np.inf),            # -p census keeps the AD cost
+        ("synth_sobelx_ad", s_u, s_v, -10, 6, "sobelx", "ad", np.inf),             # prefilters of the non-census costs
+        ("fountain_rgb_sobelx_sd", uL, uR, -20, 12, "sobelx", "sd", 9000.0),
+        ("synth_gblur_ad", s_u, s_v, -10, 6, "gblur", "ad", 40.0),
+        ("fountain_rgb_gblur_sd", uL, uR, -20, 12, "gblur", "sd", np.inf),
     ]
     if win != 3:
         cv_cases = [c for c in cv_cases if "census" in c[0]]
@@ -97,9 +101,14 @@ def worker(win):
                 d["out_" + meth] = ro
                 d["outcost_" + meth] = rc
             cases["agg_" + name] = d
+    only = os.environ.get("MGM_GOLDEN_ONLY")  # add fixtures without rewriting the (byte-wise timestamped) old ones
+    n = 0
     for name, d in cases.items():
+        if only and only not in name:
+            continue
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
-    print("window %d: wrote %d cases" % (win, len(cases)))
+        n += 1
+    print("window %d: wrote %d cases" % (win, n))
 
 
 if __name__ == "__main__":
@@ -107,7 +116,7 @@ if __name__ == "__main__":
         worker(int(sys.argv[1]))
     else:
         for f in os.listdir(HERE):
-            if f.endswith(".npz"):
+            if f.endswith(".npz") and not os.environ.get("MGM_GOLDEN_ONLY"):
                 os.remove(os.path.join(HERE, f))
         for win in (3, 5, 7):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), str(win)],

@@ -22,8 +22,8 @@ def test_device_selftest_exact_division_by_three(ctx):
 @pytest.mark.parametrize("name", golden_cases("cv"))
 def test_golden_costvolume(ctx, name):
     g = load_golden(name)
-    if str(g["prefilter"]) not in ("none", "census") or str(g["distance"]) not in ("ad", "sd", "census"):
-        pytest.skip("mode not built on the device yet")
+    if str(g["distance"]) not in ("ad", "sd", "census"):
+        pytest.skip("ncc / btad / btsd costs are not built on the device (nor restated in the oracle)")
     u, v = ctx.upload_image(g["u"]), ctx.upload_image(g["v"])
     cv = ctx.costvolume_dev(u, v, int(g["dmin"]), int(g["dmax"]), str(g["prefilter"]), str(g["distance"]),
                             float(g["truncDist"]), int(g["census_win"]))
@@ -126,7 +126,11 @@ COSTS = [(1, (40, 23), (-7, 8), "none", "ad", 3, np.inf), (3, (40, 23), (-7, 8),
          # demand (trunc +INF or a small integer); a fractional trunc or a two-word descriptor takes the general kernel
          (1, (70, 23), (-40, 23), "none", "census", 5, np.inf), (1, (70, 23), (-100, 27), "none", "census", 5, 7.0),
          (1, (70, 23), (-200, 55), "none", "census", 5, 7.5), (1, (300, 9), (-255, 0), "none", "census", 7, np.inf),
-         (1, (300, 9), (-255, 0), "none", "census", 5, 0.0), (1, (90, 31), (0, 63), "none", "census", 3, np.inf)]
+         (1, (300, 9), (-255, 0), "none", "census", 5, 0.0), (1, (90, 31), (0, 63), "none", "census", 3, np.inf),
+         # sobelx / gblur prefilters (Neumann boundary, the reference's accumulation order) under AD and SD
+         (1, (40, 23), (-7, 8), "sobelx", "ad", 3, np.inf), (3, (33, 17), (-20, 12), "sobelx", "sd", 3, 900.0),
+         (1, (40, 23), (-7, 8), "gblur", "ad", 3, np.inf), (3, (33, 17), (-20, 12), "gblur", "sd", 3, 50.0),
+         (1, (3, 2), (-2, 2), "gblur", "ad", 3, np.inf), (1, (70, 23), (-40, 23), "gblur", "ad", 3, 30.0)]
 
 
 @pytest.mark.parametrize("case", COSTS, ids=lambda c: "%dch-%s-%s-w%d" % (c[0], c[3], c[4], c[5]))
@@ -151,7 +155,7 @@ def test_unsupported_and_invalid_inputs_fail_loudly(ctx):
     import mgm_amd
     u, v, _ = synth.stereo_pair(16, 8, -3, 3)
     du, dv = ctx.upload_image(u), ctx.upload_image(v)
-    for kw in (dict(prefilter="sobelx"), dict(distance="ncc")):
+    for kw in (dict(distance="ncc"), dict(distance="btad")):
         with pytest.raises(mgm_amd.MgmError) as e:
             ctx.costvolume_dev(du, dv, -3, 3, **kw)
         assert e.value.code == mgm_amd.MGM_ERR_UNSUPPORTED
