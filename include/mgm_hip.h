@@ -162,6 +162,18 @@ int mgm_selftest_div3(mgm_ctx *ctx, unsigned long long *nbad);
 int mgm_refine_dev(mgm_ctx *ctx, const mgm_cv *S, const char *method, mgm_img *out, mgm_img *outcost);
 int mgm_refine(mgm_ctx *ctx, const mgm_cv *S, const char *method, float *out, float *outcost);
 
+/* ---- what main() does to the disparity maps right after the path (device images in, device images out) ---- */
+/* median_filter (img_tools.h:203-238, called at mgm.cc:396, 419 when MEDIAN != 0): per channel, the window
+ * (2*radius+1)^2 clipped at the border, NaN samples ignored, the upper median v[n/2]; an all-NaN window
+ * leaves the pixel unchanged.  radius 1..7.  out must have in's size (and must not be in). */
+int mgm_median_dev(mgm_ctx *ctx, const mgm_img *in, int radius, mgm_img *out);
+/* leftright_test (mgm.cc:68-91, called at 420-423): out[x,y] = d[x,y] if Lx = round(x + d) lies inside `other`
+ * and |Lx + other[Lx,y] - x| <= tau, NaN otherwise.  d and out have one size, `other` may have another width. */
+int mgm_leftright_dev(mgm_ctx *ctx, const mgm_img *d, const mgm_img *other, float tau, mgm_img *out);
+/* the back-projected image main() writes as its optional third output (mgm.cc:433-443): v sampled at x + disp
+ * (integer truncation of the reference's float index), u where that falls outside v. */
+int mgm_backproject_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, const mgm_img *disp, mgm_img *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mgm_costvolume_build_dev", "mgm_costvolume_build", "mgm_weights_dev",
     "mgm_aggregate_dev", "mgm_aggregate", "mgm_debug_download_lr", "mgm_refine_dev", "mgm_refine",
     "mgm_selftest_div3", "mgm_aggregate_passes_dev", "mgm_lr_device_ptr", "mgm_wta_rows_dev",
-    "mgm_aggregate_batch_dev",
+    "mgm_aggregate_batch_dev", "mgm_median_dev", "mgm_leftright_dev", "mgm_backproject_dev",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -82,6 +82,9 @@ def load_library():
     L.mgm_weights_dev.argtypes = [vp, vp, f, f, pp]
     L.mgm_aggregate_dev.argtypes = [vp, vp, vp, f, f, i, i, i, i, cp, vp, vp, pp]
     L.mgm_aggregate.argtypes = [vp, vp, fp, f, f, i, i, i, i, cp, fp, fp, pp]
+    L.mgm_median_dev.argtypes = [vp, vp, i, vp]
+    L.mgm_leftright_dev.argtypes = [vp, vp, vp, f, vp]
+    L.mgm_backproject_dev.argtypes = [vp, vp, vp, vp, vp]
     L.mgm_aggregate_batch_dev.argtypes = [vp, i, pp, pp, f, f, i, i, i, i, cp, pp, pp, pp]
     L.mgm_debug_download_lr.argtypes = [vp, i, fp]
     L.mgm_refine_dev.argtypes = [vp, vp, cp, vp, vp]
@@ -238,6 +241,24 @@ class Context:
                                              use_fh, fix_overcount, refine.encode() if refine else None, out.h,
                                              outcost.h, C.byref(S) if want_S else None))
         return (CostVolume(self, S) if want_S else None), out, outcost
+
+    def median_dev(self, img, radius, out=None):
+        nch, ny, nx = img.shape
+        out = out or self.new_image(nx, ny, nch)
+        self._chk(self.lib.mgm_median_dev(self.h, img.h, radius, out.h))
+        return out
+
+    def leftright_dev(self, d, other, tau, out=None):
+        _, ny, nx = d.shape
+        out = out or self.new_image(nx, ny)
+        self._chk(self.lib.mgm_leftright_dev(self.h, d.h, other.h, tau, out.h))
+        return out
+
+    def backproject_dev(self, u, v, disp, out=None):
+        nch, ny, nx = u.shape
+        out = out or self.new_image(nx, ny, nch)
+        self._chk(self.lib.mgm_backproject_dev(self.h, u.h, v.h, disp.h, out.h))
+        return out
 
     def aggregate_batch_dev(self, Cvs, P1, P2, NDIR, MGM, use_fh=0, fix_overcount=1, w8s=None, refine=None, outs=None,
                             outcosts=None, want_S=False):

@@ -1019,6 +1019,40 @@ int mgm_refine_dev(mgm_ctx *c, const mgm_cv *S, const char *method, mgm_img *out
     return MGM_OK;
 }
 
+int mgm_median_dev(mgm_ctx *c, const mgm_img *in, int radius, mgm_img *out)
+{
+    if (!c || !in || !out || in == out) return fail(c, MGM_ERR_INVALID, "mgm_median: bad arguments");
+    if (out->nx != in->nx || out->ny != in->ny || out->nch != in->nch) return fail(c, MGM_ERR_INVALID, "mgm_median: image size mismatch");
+    if (radius < 1 || radius > 7) return fail(c, MGM_ERR_UNSUPPORTED, "mgm_median: radius must be 1..7");
+    HIPCHK(c, hipSetDevice(c->device));
+    TimeScope t(c, "k_median");
+    HIPCHK(c, launch_median(in->d, in->nx, in->ny, in->nch, radius, out->d, c->stream));
+    return MGM_OK;
+}
+
+int mgm_leftright_dev(mgm_ctx *c, const mgm_img *d, const mgm_img *other, float tau, mgm_img *out)
+{
+    if (!c || !d || !other || !out || out == other) return fail(c, MGM_ERR_INVALID, "mgm_leftright: bad arguments");
+    if (d->nch != 1 || other->nch != 1 || out->nch != 1 || out->nx != d->nx || out->ny != d->ny || other->ny < d->ny)
+        return fail(c, MGM_ERR_INVALID, "mgm_leftright: image size mismatch");
+    HIPCHK(c, hipSetDevice(c->device));
+    TimeScope t(c, "k_leftright");
+    HIPCHK(c, launch_leftright(d->d, d->nx, d->ny, other->d, other->nx, tau, out->d, c->stream));
+    return MGM_OK;
+}
+
+int mgm_backproject_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, const mgm_img *disp, mgm_img *out)
+{
+    if (!c || !u || !v || !disp || !out) return fail(c, MGM_ERR_INVALID, "mgm_backproject: null argument");
+    if (u->nch != v->nch || disp->nx != u->nx || disp->ny != u->ny || disp->nch != 1 || out->nx != u->nx || out->ny != u->ny ||
+        out->nch != u->nch)
+        return fail(c, MGM_ERR_INVALID, "mgm_backproject: image size mismatch");
+    HIPCHK(c, hipSetDevice(c->device));
+    TimeScope t(c, "k_backproject");
+    HIPCHK(c, launch_backproject(u->d, u->nx, u->ny, u->nch, v->d, v->nx, v->ny, disp->d, out->d, c->stream));
+    return MGM_OK;
+}
+
 int mgm_refine(mgm_ctx *c, const mgm_cv *S, const char *method, float *out, float *outcost)
 {
     if (!c || !S || !out || !outcost) return fail(c, MGM_ERR_INVALID, "mgm_refine: null argument");

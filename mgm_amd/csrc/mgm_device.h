@@ -82,6 +82,11 @@ inline bool c8_supported(int L) { return L == 64 || L == 128 || L == 256 || L ==
 hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s);
 hipError_t launch_expand(const uint8_t *C8, long long n, float *C, hipStream_t s);
 hipError_t launch_wta(const WtaParams &p, hipStream_t s);
+hipError_t launch_median(const float *u, int nx, int ny, int nch, int radius, float *out, hipStream_t s);
+hipError_t launch_leftright(const float *dx, int nc, int nr, const float *Rdx, int Rnc, float threshold, float *out,
+                            hipStream_t s);
+hipError_t launch_backproject(const float *u, int nx, int ny, int nch, const float *v, int vnx, int vny, const float *disp,
+                              float *out, hipStream_t s);
 hipError_t launch_refine(const float *S, long long npix, int L, int dmin, int method, float *out, float *outcost,
                          hipStream_t s);
 hipError_t launch_census(const float *u, int nx, int ny, int nch, int winradius, uint32_t *out, hipStream_t s);

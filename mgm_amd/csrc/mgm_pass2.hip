@@ -284,6 +284,8 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
         unsigned known = 0;
         bool dead = false;
         unsigned long long n_slow = 0, t_slow = 0, n_spin = 0, t_ret = 0, t_bar = 0, t_iss = 0;
+        (void)n_slow;
+        (void)n_spin;
 
         // Per C piece: the (clamped) source pointer of the NEXT target step and its pixel index.
         // Target step t wants pixel i = t-1-SL*r of line r; out-of-range steps re-read an end pixel

@@ -76,27 +76,6 @@ static HostImg median_filter(const HostImg &u, int radius)
     return M;
 }
 
-// leftright_test (mgm.cc:68-91)
-static void leftright_test(HostImg &dx, const HostImg &Rdx, float threshold)
-{
-    const int nc = dx.nx, nr = dx.ny, Rnc = Rdx.nx;
-    for (int y = 0; y < nr; y++)
-        for (int x = 0; x < nc; x++) {
-            const int i = x + y * nc;
-            const float d = dx.data[i];
-            // round(x + d) converted to int; a NaN disparity lands outside every image
-            const double rr = round((double)(x + d));
-            const int Lx = (rr >= -2147483648.0 && rr <= 2147483647.0) ? (int)rr : -2147483647 - 1;
-            if (Lx < Rnc && Lx >= 0) {
-                const int Lidx = Lx + y * Rnc;
-                const float Rx = Lx + Rdx.data[Lidx];
-                if (fabs(Rx - x) > threshold) dx.data[i] = NAN;
-            } else {
-                dx.data[i] = NAN;
-            }
-        }
-}
-
 struct Opts {
     int dmin, dmax, NDIR;
     float P1, P2, aP2, aThresh, truncDist;
@@ -145,24 +124,50 @@ static void aggregate_run(mgm_ctx *ctx, const Opts &o, Run &r)
     if (rc) die(ctx, rc, "mgm_aggregate");
 }
 
-static void finish_run(mgm_ctx *ctx, const Opts &o, Run &r, HostImg &off, HostImg &cost)
+// what mgm() and print_solution_energy put on stdout for one run (mgm_core.cc:420-423, 491; mgm_print_energy.h:109-111)
+static void report_run(const Opts &o, const Run &r)
 {
-    int rc;
-    off.nx = cost.nx = r.nx;
-    off.ny = cost.ny = r.ny;
-    off.nch = cost.nch = 1;
-    off.data.resize((size_t)r.nx * r.ny);
-    cost.data.resize((size_t)r.nx * r.ny);
-    if ((rc = mgm_img_download(ctx, r.dout, off.data.data())) || (rc = mgm_img_download(ctx, r.dcost, cost.data.data())))
-        die(ctx, rc, "download");
-    // the reference prints one digit per pass from inside mgm() (mgm_core.cc:491), then
-    // print_solution_energy prints "\n" (mgm_print_energy.h:109-111)
     if (r.weighted_msg) printf(" USING IMAGE DEPENDENT WEIGHTS\n");
     for (int p = 0; p < o.NDIR; p++) printf("%d", p);
     printf("\n");
     fflush(stdout);
+}
+
+static HostImg download(mgm_ctx *ctx, const mgm_img *im, int nx, int ny, int nch)
+{
+    HostImg h;
+    h.nx = nx;
+    h.ny = ny;
+    h.nch = nch;
+    h.data.resize((size_t)nx * ny * nch);
+    const int rc = mgm_img_download(ctx, im, h.data.data());
+    if (rc) die(ctx, rc, "download");
+    return h;
+}
+
+static void free_run(mgm_ctx *ctx, Run &r)
+{
     mgm_cv_free(ctx, r.C);
     for (mgm_img *im : {r.du, r.dv, r.dw, r.dout, r.dcost}) mgm_img_free(ctx, im);
+    r = Run();
+}
+
+// outoff = median_filter(outoff, MEDIAN) on the device (mgm.cc:396, 419); radii beyond the kernel's range on the host
+static void median_run(mgm_ctx *ctx, Run &r, int radius)
+{
+    mgm_img *tmp = nullptr;
+    int rc = mgm_img_create(ctx, r.nx, r.ny, 1, &tmp);
+    if (rc) die(ctx, rc, "mgm_img_create");
+    rc = mgm_median_dev(ctx, r.dout, radius, tmp);
+    if (rc == MGM_ERR_UNSUPPORTED) {
+        const HostImg m = median_filter(download(ctx, r.dout, r.nx, r.ny, 1), radius);
+        mgm_img_free(ctx, tmp);
+        if ((rc = mgm_img_upload(ctx, m.data.data(), r.nx, r.ny, 1, &tmp))) die(ctx, rc, "upload");
+    } else if (rc) {
+        die(ctx, rc, "mgm_median");
+    }
+    mgm_img_free(ctx, r.dout);
+    r.dout = tmp;
 }
 
 int main(int argc, char **argv)
@@ -240,7 +245,7 @@ int main(int argc, char **argv)
         int rc = mgm_ctx_create((int)env_param("MGM_DEVICE", 0), &ctx);
         if (rc) { fprintf(stderr, "mgm: no usable MI355X device (mgm_ctx_create = %d); there is no CPU path\n", rc); return 1; }
 
-        HostImg outoff, outcost, outoffR, outcostR;
+        HostImg outoff, outcost;
         Run L, R;
         prepare_run(ctx, u, v, o.dmin, o.dmax, o, L);
         bool together = false;
@@ -256,37 +261,40 @@ int main(int argc, char **argv)
             // (one image weighted, the other not: the two runs take different update functions)
         }
         if (!together) aggregate_run(ctx, o, L);
-        finish_run(ctx, o, L, outoff, outcost);
-        if (MEDIAN != 0) outoff = median_filter(outoff, (int)MEDIAN);
-        if (nolr_file[0]) npy::write(nolr_file, outoff);
+        report_run(o, L);
+        if (MEDIAN != 0) median_run(ctx, L, (int)MEDIAN);
+        if (nolr_file[0]) npy::write(nolr_file, download(ctx, L.dout, L.nx, L.ny, 1));
         if (TESTLRRL != 0) {
             if (!R.C) prepare_run(ctx, v, u, -o.dmax, -o.dmin, o, R);  // mgm.cc:366, 405
             if (!together) aggregate_run(ctx, o, R);
-            finish_run(ctx, o, R, outoffR, outcostR);
-            if (MEDIAN != 0) outoffR = median_filter(outoffR, (int)MEDIAN);
-            const HostImg tmpL = outoff, tmpR = outoffR;
-            leftright_test(outoffR, tmpL, (float)TAU);
-            leftright_test(outoff, tmpR, (float)TAU);
+            report_run(o, R);
+            if (MEDIAN != 0) median_run(ctx, R, (int)MEDIAN);
+            // leftright_test both ways on copies of the unchecked maps (mgm.cc:420-423)
+            mgm_img *Lchk = nullptr, *Rchk = nullptr;
+            if ((rc = mgm_img_create(ctx, L.nx, L.ny, 1, &Lchk)) || (rc = mgm_img_create(ctx, R.nx, R.ny, 1, &Rchk)))
+                die(ctx, rc, "mgm_img_create");
+            if ((rc = mgm_leftright_dev(ctx, R.dout, L.dout, (float)TAU, Rchk)) ||
+                (rc = mgm_leftright_dev(ctx, L.dout, R.dout, (float)TAU, Lchk)))
+                die(ctx, rc, "mgm_leftright");
+            mgm_img_free(ctx, L.dout);
+            mgm_img_free(ctx, R.dout);
+            L.dout = Lchk;
+            R.dout = Rchk;
         }
-        mgm_ctx_destroy(ctx);
-
-        // back-projected image (mgm.cc:433-443), with the reference's float index arithmetic
+        outoff = download(ctx, L.dout, L.nx, L.ny, 1);
+        outcost = download(ctx, L.dcost, L.nx, L.ny, 1);
+        // back-projected image (mgm.cc:433-443)
         HostImg syn;
-        syn.nx = u.nx;
-        syn.ny = u.ny;
-        syn.nch = u.nch;
-        syn.data.assign((size_t)u.npix() * u.nch, 0.0f);
-        if (f_back)
-            for (int x = 0; x < u.nx; x++)
-                for (int y = 0; y < u.ny; y++) {
-                    const float qx = outoff.data[x + u.nx * y];
-                    const float px = x + qx, py = (float)y;
-                    const bool inside = px >= 0 && py >= 0 && px < v.nx && py < v.ny;
-                    for (int c = 0; c < u.nch; c++)
-                        syn.data[x + y * u.nx + c * u.npix()] =
-                            inside ? v.data[(size_t)(x + qx + (y + 0.0f) * v.nx + c * v.npix())]
-                                   : u.data[x + y * u.nx + c * u.npix()];
-                }
+        if (f_back) {
+            mgm_img *dsyn = nullptr;
+            if ((rc = mgm_img_create(ctx, u.nx, u.ny, u.nch, &dsyn))) die(ctx, rc, "mgm_img_create");
+            if ((rc = mgm_backproject_dev(ctx, L.du, L.dv, L.dout, dsyn))) die(ctx, rc, "mgm_backproject");
+            syn = download(ctx, dsyn, u.nx, u.ny, u.nch);
+            mgm_img_free(ctx, dsyn);
+        }
+        free_run(ctx, L);
+        free_run(ctx, R);
+        mgm_ctx_destroy(ctx);
         npy::write(f_out, outoff);
         if (f_cost) npy::write(f_cost, outcost);
         if (f_back) npy::write(f_back, syn);

@@ -29,6 +29,11 @@ CASES = [
     ("sd trunc, no overcount fix, tau", 1, "-r -9 -R 14 -t sd -truncDist 300 -O 2",
      dict(TSGM="1", TSGM_FIX_OVERCOUNT="0", TESTLRRL_TAU="2.5")),
     ("unknown names fall back silently", 1, "-r -8 -R 8 -t nope -p sobel_x -s bogus -O 4", dict(TSGM="2")),
+    ("sobelx prefilter, cubic refinement", 1, "-r -10 -R 10 -p sobelx -t ad -s cubic -O 4", dict(TSGM="2")),
+    ("gblur prefilter, parabola, median radius 2", 3, "-r -12 -R 9 -p gblur -t sd -s parabola -O 8",
+     dict(TSGM="3", MEDIAN="2")),
+    ("parabolaOCV, census, median radius 3, tight tau", 1, "-r -16 -R 8 -t census -s parabolaOCV -O 8",
+     dict(TSGM="3", MEDIAN="3", TESTLRRL_TAU="0.5", CENSUS_NCC_WIN="5")),
 ]
 
 
