@@ -505,7 +505,6 @@ int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int
         dist = 2;
         pre = 1;
     }
-    if (costfn > 2) return fail(c, MGM_ERR_UNSUPPORTED, "distance ncc/btad/btsd is not built yet");
 
     int r = MGM_OK;
     if (*out) {  // caller-provided volume to refill (must have the right geometry)
@@ -534,6 +533,7 @@ int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int
     p.dmin = dmin;
     p.L = dmax - dmin + 1;
     p.costfn = costfn;
+    p.hwin = census_win / 2;  // computeC_clippedNCC: CENSUS_NCC_WIN()/2
     p.nch = u->nch;
     p.u = u->d;
     p.v = v->d;

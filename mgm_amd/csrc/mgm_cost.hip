@@ -111,6 +111,71 @@ hipError_t launch_filter2d(const float *u, int nx, int ny, int nch, const float 
     return hipGetLastError();
 }
 
+// ---- the costs that look at more than one sample per image ------------------------
+// Birchfield-Tomasi dissimilarity of one channel (mgm_costvolume.h:82-110): half-sample interpolation along x --
+// the "/2.0" is a double division narrowed back to float -- then the symmetric interval distance.
+#define MGM_MIN3(a, b, c) (((a) < (b)) ? (((a) < (c)) ? (a) : (c)) : (((c) < (b)) ? (c) : (b)))
+#define MGM_MAX3(a, b, c) (((a) > (b)) ? (((a) > (c)) ? (a) : (c)) : (((c) > (b)) ? (c) : (b)))
+__device__ __forceinline__ float btad1(const float *__restrict__ pu, int nx, int px, const float *__restrict__ pv, int vnx, int qx)
+{
+    const float IL = pu[px];
+    float ILp = IL, ILm = IL;
+    if (px < nx - 1) ILp = (float)((IL + pu[px + 1]) / 2.0);
+    if (px >= 1) ILm = (float)((IL + pu[px - 1]) / 2.0);
+    const float IR = pv[qx];
+    float IRp = IR, IRm = IR;
+    if (qx < vnx - 1) IRp = (float)((IR + pv[qx + 1]) / 2.0);
+    if (qx >= 1) IRm = (float)((IR + pv[qx - 1]) / 2.0);
+    const float IminR = MGM_MIN3(IRm, IRp, IR);
+    const float ImaxR = MGM_MAX3(IRm, IRp, IR);
+    const float IminL = MGM_MIN3(ILm, ILp, IL);
+    const float ImaxL = MGM_MAX3(ILm, ILp, IL);
+    const float dLR = MGM_MAX3(0, IL - ImaxR, IminR - IL);
+    const float dRL = MGM_MAX3(0, IR - ImaxL, IminL - IR);
+    const float BT = (dLR < dRL) ? dLR : dRL;
+    return (float)__builtin_fabs((double)BT);
+}
+
+// computeC_clippedNCC (mgm_costvolume.h:137-165): window sums in float, the normalisation in double (0.0000001 and
+// sqrt are doubles), a window sample outside either image or NaN => INFINITY.
+__device__ __forceinline__ float cost_ncc(const CostParams &P, int px, int py, int qx, int qy)
+{
+    const long long npix = (long long)P.nx * P.ny, vpix = (long long)P.vnx * P.vny;
+    const int nch = P.nch, hw = P.hwin;
+    float NCC = 0;
+    for (int t = 0; t < nch; t++) {
+        float mu1 = 0, mu2 = 0, s1 = 0, s2 = 0, prod = 0;
+        int n = 0;
+        for (int i = -hw; i <= hw; i++)
+            for (int j = -hw; j <= hw; j++) {
+                const int ax = px + i, ay = py + j, bx = qx + i, by = qy + j;
+                if (ax < 0 || ay < 0 || ax >= P.nx || ay >= P.ny || bx < 0 || by < 0 || bx >= P.vnx || by >= P.vny)
+                    return __builtin_huge_valf();
+                const float v1 = P.u[ax + (long long)ay * P.nx + t * npix];
+                const float v2 = P.v[bx + (long long)by * P.vnx + t * vpix];
+                if (!(v1 == v1) || !(v2 == v2)) return __builtin_huge_valf();
+                mu1 += v1;
+                mu2 += v2;
+                s1 += v1 * v1;
+                s2 += v2 * v2;
+                prod += v1 * v2;
+                n++;
+            }
+        mu1 /= n;
+        mu2 /= n;
+        s1 /= n;
+        s2 /= n;
+        prod /= n;
+        const float var = (s1 - mu1 * mu1) * (s2 - mu2 * mu2);
+        const double den = (0.0000001 > var) ? 0.0000001 : (double)var;
+        NCC = (float)(NCC + (prod - mu1 * mu2) / __builtin_sqrt(den));
+    }
+    const float m = (NCC < nch) ? NCC : (float)nch;
+    const float c = (0 > m) ? 0 : m;
+    const float clipped = nch - c;
+    return clipped * 64;
+}
+
 // ---- K2 -----------------------------------------------------------------------
 // One wavefront per pixel; lane l fills labels o = l, l+64, ... so that every
 // store instruction writes 64 consecutive floats of the pixel's slab.
@@ -138,6 +203,16 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
                     r += (float)__builtin_popcount(xr);
                 }
                 e = (float)((double)r * 1.0 / (double)P.nch);
+            } else if (P.costfn == 3) {
+                e = cost_ncc(P, x, y, qx, y);
+            } else if (P.costfn >= 4) {  // computeC_BTAD / computeC_BTSD (mgm_costvolume.h:114-135)
+                float val = 0;
+                for (int t = 0; t < P.nch; t++) {
+                    const float b = btad1(P.u + (long long)t * npix + (long long)y * P.nx, P.nx, x,
+                                          P.v + (long long)t * vpix + (long long)y * P.vnx, P.vnx, qx);
+                    val += (P.costfn == 5) ? b * b : b;
+                }
+                e = val;
             } else {
                 float tmp = 0;
                 for (int t = 0; t < P.nch; t++) {

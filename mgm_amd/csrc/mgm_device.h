@@ -98,7 +98,8 @@ struct CostParams {
     unsigned *bad8;              // set to 1 if some cost is not representable in the compact form
     int nx, ny, vnx, vny, nch;   // nch = channels of the (prefiltered) images
     int dmin, L;
-    int costfn;                  // 0 ad, 1 sd, 2 census
+    int costfn;                  // 0 ad, 1 sd, 2 census, 3 ncc, 4 btad, 5 btsd
+    int hwin;                    // ncc: half window (CENSUS_NCC_WIN / 2)
     float trunc;                 // truncDist * nch
 };
 hipError_t launch_cost(const CostParams &p, hipStream_t s);

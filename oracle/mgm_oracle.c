@@ -260,6 +260,82 @@ static float cost_census(const uint32_t *cu, const uint32_t *cv, int nx, int ny,
     return (float)(r * 1.0 / nwords);
 }
 
+/* Birchfield-Tomasi dissimilarity of one channel, mgm_costvolume.h:82-110: half-sample interpolation along x
+ * (the "/2.0" is a double division narrowed back to float), then the symmetric interval distance. */
+#define MIN3_(a, b, c) (((a) < (b)) ? (((a) < (c)) ? (a) : (c)) : (((c) < (b)) ? (c) : (b)))
+#define MAX3_(a, b, c) (((a) > (b)) ? (((a) > (c)) ? (a) : (c)) : (((c) > (b)) ? (c) : (b)))
+static float btad1(const float *u, const float *v, int nx, int ny, int vnx, int vny, int t, int px, int py, int qx, int qy)
+{
+    const float *pu = u + (size_t)t * nx * ny + (size_t)py * nx;
+    const float *pv = v + (size_t)t * vnx * vny + (size_t)qy * vnx;
+    float IL = pu[px];
+    float ILp = IL, ILm = IL;
+    if (px < nx - 1) ILp = (float)((IL + pu[px + 1]) / 2.0);
+    if (px >= 1) ILm = (float)((IL + pu[px - 1]) / 2.0);
+    float IR = pv[qx];
+    float IRp = IR, IRm = IR;
+    if (qx < vnx - 1) IRp = (float)((IR + pv[qx + 1]) / 2.0);
+    if (qx >= 1) IRm = (float)((IR + pv[qx - 1]) / 2.0);
+    float IminR = MIN3_(IRm, IRp, IR);
+    float ImaxR = MAX3_(IRm, IRp, IR);
+    float IminL = MIN3_(ILm, ILp, IL);
+    float ImaxL = MAX3_(ILm, ILp, IL);
+    float dLR = MAX3_(0, IL - ImaxR, IminR - IL);
+    float dRL = MAX3_(0, IR - ImaxL, IminL - IR);
+    float BT = MIN_(dLR, dRL);
+    return (float)fabs(BT);
+}
+
+/* computeC_BTAD / computeC_BTSD, mgm_costvolume.h:114-135 */
+static float cost_bt(const float *u, const float *v, int nx, int ny, int vnx, int vny, int nch, int px, int py, int qx,
+                     int qy, int squared)
+{
+    float val = 0;
+    for (int t = 0; t < nch; t++) {
+        float x = btad1(u, v, nx, ny, vnx, vny, t, px, py, qx, qy);
+        val += squared ? x * x : x;
+    }
+    return val;
+}
+
+/* computeC_clippedNCC, mgm_costvolume.h:137-165: sums in float, the normalisation in double (the 0.0000001 and
+ * sqrt are double), a sample outside either image (valnan) or NaN in the window => INFINITY. */
+static float cost_ncc(const float *u, const float *v, int nx, int ny, int vnx, int vny, int nch, int px, int py, int qx,
+                      int qy, int hwindow)
+{
+    float NCC = 0;
+    for (int t = 0; t < nch; t++) {
+        float mu1 = 0, mu2 = 0, s1 = 0, s2 = 0, prod = 0;
+        int n = 0;
+        for (int i = -hwindow; i <= hwindow; i++)
+            for (int j = -hwindow; j <= hwindow; j++) {
+                int ax = px + i, ay = py + j, bx = qx + i, by = qy + j;
+                if (ax < 0 || ay < 0 || ax >= nx || ay >= ny || bx < 0 || by < 0 || bx >= vnx || by >= vny) return INFINITY;
+                float v1 = u[ax + (size_t)ay * nx + (size_t)t * nx * ny];
+                float v2 = v[bx + (size_t)by * vnx + (size_t)t * vnx * vny];
+                if (isnan(v1) || isnan(v2)) return INFINITY;
+                mu1 += v1;
+                mu2 += v2;
+                s1 += v1 * v1;
+                s2 += v2 * v2;
+                prod += v1 * v2;
+                n++;
+            }
+        mu1 /= n;
+        mu2 /= n;
+        s1 /= n;
+        s2 /= n;
+        prod /= n;
+        float var = (s1 - mu1 * mu1) * (s2 - mu2 * mu2);
+        double den = (0.0000001 > var) ? 0.0000001 : (double)var;
+        NCC = (float)(NCC + (prod - mu1 * mu2) / sqrt(den));
+    }
+    float m = (NCC < nch) ? NCC : (float)nch;
+    float c = (0 > m) ? 0 : m;
+    float clipped = nch - c;
+    return clipped * 64;
+}
+
 /*
  * allocate_and_fill_sgm_costvolume, mgm_costvolume.h:337-424, uniform range.
  * u: nx*ny*nch, v: vnx*vny*nch.  C: [ny][nx][L], L = dmax-dmin+1.
@@ -267,7 +343,6 @@ static float cost_census(const uint32_t *cu, const uint32_t *cv, int nx, int ny,
  * picks the cost FUNCTION before the "census forces both" fix (355 vs 358-362):
  * -p census with -t ad transforms the images but keeps AD on the float-typed
  * census words.
- * Returns 0, or <0 for modes not restated (ncc, btad, btsd).
  */
 int orc_costvolume(const float *in_u, const float *in_v, int nx, int ny, int nch, int vnx, int vny, int dmin,
                    int dmax, int prefilter, int distance, float truncDist, int census_win, float *C)
@@ -278,7 +353,6 @@ int orc_costvolume(const float *in_u, const float *in_v, int nx, int ny, int nch
         distance = DIST_CENSUS;
         prefilter = PRE_CENSUS;
     }
-    if (costfn == DIST_NCC || costfn == DIST_BTAD || costfn == DIST_BTSD) return -10;
 
     const float *u = in_u, *v = in_v;
     float *fu = 0, *fv = 0;
@@ -330,8 +404,12 @@ int orc_costvolume(const float *in_u, const float *in_v, int nx, int ny, int nch
                         e = cost_census(cu, cv, nx, ny, vnx, vny, cnch, ii, jj, qx, qy);
                     else if (costfn == DIST_AD)
                         e = cost_ad(u, v, nx, ny, vnx, vny, cnch, ii, jj, qx, qy);
-                    else
+                    else if (costfn == DIST_SD)
                         e = cost_sd(u, v, nx, ny, vnx, vny, cnch, ii, jj, qx, qy);
+                    else if (costfn == DIST_NCC)
+                        e = cost_ncc(u, v, nx, ny, vnx, vny, cnch, ii, jj, qx, qy, census_win / 2);
+                    else
+                        e = cost_bt(u, v, nx, ny, vnx, vny, cnch, ii, jj, qx, qy, costfn == DIST_BTSD);
                 }
                 e = MIN_(e, tr);
                 Cp[o - dmin] = e;

@@ -57,9 +57,13 @@ def worker(win):
         ("fountain_rgb_sobelx_sd", uL, uR, -20, 12, "sobelx", "sd", 9000.0),
         ("synth_gblur_ad", s_u, s_v, -10, 6, "gblur", "ad", 40.0),
         ("fountain_rgb_gblur_sd", uL, uR, -20, 12, "gblur", "sd", np.inf),
+        ("fountain_rgb_ncc", uL, uR, -20, 12, "none", "ncc", np.inf),               # CENSUS_NCC_WIN is the NCC window too
+        ("synth_ncc_trunc", s_u, s_v, -10, 6, "none", "ncc", 0.5),
+        ("synth_btad", s_u, s_v, -10, 6, "none", "btad", np.inf),
+        ("fountain_rgb_btsd", uL, uR, -20, 12, "none", "btsd", 2000.0),
     ]
     if win != 3:
-        cv_cases = [c for c in cv_cases if "census" in c[0]]
+        cv_cases = [c for c in cv_cases if "census" in c[0] or "_ncc" in c[0]]
     for name, u, v, dmin, dmax, pre, dist, td in cv_cases:
         if (pre == "census" or dist == "census") and (u.shape[0] * (win * win - 1)) % 8:
             continue

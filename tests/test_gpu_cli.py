@@ -32,6 +32,8 @@ CASES = [
     ("sobelx prefilter, cubic refinement", 1, "-r -10 -R 10 -p sobelx -t ad -s cubic -O 4", dict(TSGM="2")),
     ("gblur prefilter, parabola, median radius 2", 3, "-r -12 -R 9 -p gblur -t sd -s parabola -O 8",
      dict(TSGM="3", MEDIAN="2")),
+    ("ncc cost, window 5", 1, "-r -10 -R 10 -t ncc -O 4", dict(TSGM="2", CENSUS_NCC_WIN="5")),
+    ("btsd cost, 3 channels", 3, "-r -12 -R 9 -t btsd -truncDist 500 -O 8", dict(TSGM="3")),
     ("parabolaOCV, census, median radius 3, tight tau", 1, "-r -16 -R 8 -t census -s parabolaOCV -O 8",
      dict(TSGM="3", MEDIAN="3", TESTLRRL_TAU="0.5", CENSUS_NCC_WIN="5")),
 ]
@@ -68,6 +70,6 @@ def test_cli_refuses_what_is_not_built(tmp_path):
     np.save(tmp_path / "u.npy", u[0])
     np.save(tmp_path / "v.npy", v[0])
     base = [OURS, str(tmp_path / "u.npy"), str(tmp_path / "v.npy"), str(tmp_path / "d.npy")]
-    for extra, env in (([], dict(TSGM_ITER="2")), ([], dict(WITH_MGM2="1")), (["-t", "ncc"], {})):
+    for extra, env in (([], dict(TSGM_ITER="2")), ([], dict(WITH_MGM2="1"))):
         r = subprocess.run(base[:1] + extra + base[1:], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 2 and "not" in r.stderr

@@ -44,7 +44,8 @@ def test_costvolume_sweep(oracle, reference):
         for (dmin, dmax) in [(-5, 4), (2, 9), (-40, -33), (35, 41)]:
             for vv in (v, v2):
                 for pre, dist in [("none", "ad"), ("none", "sd"), ("none", "census"), ("census", "ad"), ("sobelx", "ad"),
-                                  ("gblur", "sd"), ("sobel_x", "ad"), ("none", "foo")]:
+                                  ("gblur", "sd"), ("sobel_x", "ad"), ("none", "foo"), ("none", "ncc"), ("gblur", "ncc"),
+                                  ("none", "btad"), ("sobelx", "btsd")]:
                     if "census" in (pre, dist) and (nch * (win * win - 1)) % 8:
                         continue
                     for td in (np.inf, 20.0):
