@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=4, choices=[1, 2, 3, 4],
+    ap.add_argument("--batch", type=int, default=8, choices=[1, 2, 3, 4, 5, 6, 7, 8],
                     help="pairs per step and GPU: their volumes share ONE launch of the pass kernel (pairs mode)")
     ap.add_argument("--mode", default="pairs", choices=["pairs", "directions"],
                     help="N>1: 'pairs' = independent pairs, one per GPU (weak scaling, default); 'directions' = ONE "

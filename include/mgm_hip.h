@@ -120,12 +120,13 @@ int mgm_aggregate_dev(mgm_ctx *ctx, const mgm_cv *C, const mgm_img *w8, float P1
 int mgm_aggregate(mgm_ctx *ctx, const mgm_cv *C, const float *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
                   int fix_overcount, const char *refine, float *out, float *outcost, mgm_cv **S);
 
-/* n (1..4) volumes of identical size and label count aggregated by ONE launch of the pass kernel:
+/* n (1..8) volumes of identical size and label count aggregated by ONE launch of the pass kernel:
  * the two runs of mgm() that main() makes for a stereo pair, left->right (mgm.cc:376-385) and
  * right->left (mgm.cc:405-414), or the volumes of consecutive pairs.  Every volume gets exactly the
  * result mgm_aggregate_dev would give it; the point is throughput -- the scan-line passes of one
  * volume form dependency chains (band after band) that leave compute units waiting, and the other
- * volumes' bands fill those gaps.  C, out, outcost: arrays of n handles.  w8: NULL, or an array of n
+ * volumes' bands fill those gaps (from three volumes on, two bands share a compute unit).  The workspace holds
+ * NDIR fp32 volumes per batched volume.  C, out, outcost: arrays of n handles.  w8: NULL, or an array of n
  * weight images (for all volumes or none; all weighted or all unweighted).  S: NULL, or an array of
  * n handles to receive the corrected aggregated volumes. */
 int mgm_aggregate_batch_dev(mgm_ctx *ctx, int n, const mgm_cv *const *C, const mgm_img *const *w8, float P1, float P2,

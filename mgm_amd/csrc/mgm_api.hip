@@ -756,6 +756,8 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.P2 = P2;
     p.dbg = nullptr;
     p.xflags = 0;
+    p.wg_per_cu = nb >= 3 ? 2 : 1;  // measured: two bands per CU pay from three volumes per launch on
+    if (const char *e = getenv("MGM_HIP_WG_PER_CU")) p.wg_per_cu = atoi(e);
     if (const char *e = getenv("MGM_HIP_XFLAGS")) p.xflags = atoi(e);
     if (c->debug_stats && R2) {
         if ((r = reserve(c, c->dbg, sizeof(unsigned long long) * 16 * (size_t)c->ntasks))) return r;
@@ -886,7 +888,7 @@ int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm
                             mgm_img *const *outcost, mgm_cv **S)
 {
     if (!c || !C || !out || !outcost || n < 1) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: null argument");
-    if (n > kMaxBatch) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: at most 4 volumes per call");
+    if (n > kMaxBatch) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: at most 8 volumes per call");
     if (NDIR < 1 || NDIR > kMaxDirs)  // the reference reads past its 8-entry table for -O 16 (mgm_core.cc:489)
         return fail(c, MGM_ERR_INVALID, "NDIR must be 1..8");
     if (MGM < 1 || MGM > 4) return fail(c, MGM_ERR_INVALID, "MGM (TSGM) must be 1..4");

@@ -30,10 +30,10 @@ struct PassGeom {
 };
 
 // One launch of the pass kernel may aggregate several cost volumes of identical geometry (the
-// left->right and right->left volumes of a stereo pair, say): work items are then (volume, pass,
+// left->right and right->left volumes of a stereo pair, consecutive pairs): work items are then (volume, pass,
 // band), and the long dependency chains of one volume's column passes are hidden behind the other
 // volumes' work.
-constexpr int kMaxBatch = 4;
+constexpr int kMaxBatch = 8;
 struct PassVolume {
     const float *C;     // [npix][L]
     const uint8_t *C8;  // [npix][L] compact costs (integers 0..254, 255 = +INF) or nullptr (all volumes alike)
@@ -48,6 +48,7 @@ struct PassParams {
     unsigned *ticket;   // work-item ticket counter
     unsigned *err;      // watchdog word
     const int2 *tasks;  // ticket -> (volume*8 + pass, band)
+    int wg_per_cu;            // 1 or 2 workgroups per compute unit (second build; see launch2_c8)
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
     long long npix, nvol;

@@ -107,13 +107,13 @@ template <int LPL>
 constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 1; }
 
 #ifndef MGM_P2_WAVES_PER_EU
-#define MGM_P2_WAVES_PER_EU 4
+#define MGM_P2_WAVES_PER_EU 8   // (compact unweighted kernels only; every other kernel is built for 4)
 #endif
 #ifndef MGM_P2_NC
 #define MGM_P2_NC 14
 #endif
 #ifndef MGM_P2_LDS_KB
-#define MGM_P2_LDS_KB 160
+#define MGM_P2_LDS_KB 78
 #endif
 #ifndef MGM_P2_DECOUPLED
 #define MGM_P2_DECOUPLED 0   // 1: waves synchronise point-to-point through LDS step counters; 0: one s_barrier per step
@@ -170,7 +170,7 @@ struct Plan {
     }
     static constexpr bool fits(int rt, int rdepth, int d)
     {
-        return d >= 2 && d <= rdepth - 1 && lds_floats3(rt, rdepth) * 4 <= (LPL <= 4 ? MGM_P2_LDS_KB : 160) * 1024 &&
+        return d >= 2 && d <= rdepth - 1 && lds_floats3(rt, rdepth) * 4 <= ((C8 && LPL <= 4 && NS == 1) ? MGM_P2_LDS_KB : 160) * 1024 &&
                nA * (d - 1) <= 63 && nB * (d - 1) <= 63;
     }
     static constexpr int pick(int what)  // 0: RT, 1: RDEPTH, 2: D
@@ -224,7 +224,7 @@ __device__ __forceinline__ void combine_unit_E(const float (&C)[LPL], const floa
 
 template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8>
 __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, true, C8>::NL) * 64,
-                                  (LPL <= 4 ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
+                                  ((C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
 {
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
     constexpr bool pubE = !WEIGHTED && !(FH && MGM == 2);  // slabs carry E = T - m; minima not needed
@@ -763,7 +763,12 @@ static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 {
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
     using PL = Plan<LPL, NS, WEIGHTED || (FH && MGM == 2), C8>;
-    const size_t shmem = sizeof(float) * (size_t)PL::lds_floats(PL::D);
+    size_t shmem = sizeof(float) * (size_t)PL::lds_floats(PL::D);
+    // Occupancy is chosen per launch through the LDS request: the compact unweighted kernels are built for two
+    // workgroups per CU (<= 64 VGPRs, < 80 KB of LDS).  Two bands per CU hide each other's barrier and LDS stalls --
+    // right when the launch is throughput-bound (a batch of volumes); a single volume is bound by the chain of
+    // bands, where the doubled step latency costs more than it gives, so it asks for > half the LDS and runs alone.
+    if (p.wg_per_cu < 2 && shmem < 81 * 1024) shmem = 81 * 1024;
     auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
