@@ -163,6 +163,21 @@ int mgm_selftest_div3(mgm_ctx *ctx, unsigned long long *nbad);
 int mgm_refine_dev(mgm_ctx *ctx, const mgm_cv *S, const char *method, mgm_img *out, mgm_img *outcost);
 int mgm_refine(mgm_ctx *ctx, const mgm_cv *S, const char *method, float *out, float *outcost);
 
+/* ---- TSGM_ITER > 1: main()'s loop mgm.cc:377-388 ------------------------------------------------------------
+ * The reference builds the cost volume once and calls mgm() TSGM_ITER times with range images that
+ * update_dmin_dmax narrows around the previous solution.  The volume is the same every time, hence so are the
+ * scan-line passes: only the winner search and the refinement see the new ranges.  mgm_wta_windowed_dev does
+ * exactly that part again on the Lr volumes the context still holds from its last mgm_aggregate_dev(C, NDIR)
+ * call: the winner of pixel p is the first strict minimum of S over the disparities [(int)dminI(p), (int)dmaxI(p)]
+ * (mgm_core.cc:592-609 with S allocated from those images, 426), the refinement gate (mgm_refine.h:58) uses the
+ * same window, and a disparity of the window outside C's range holds what it holds there: 0 - (NDIR-1)*INF, or 0
+ * without the over-count fix.  Any refinement name. */
+int mgm_wta_windowed_dev(mgm_ctx *ctx, const mgm_cv *C, int NDIR, int fix_overcount, const char *refine,
+                         const mgm_img *dminI, const mgm_img *dmaxI, mgm_img *out, mgm_img *outcost);
+/* update_dmin_dmax (mgm.cc:120-158; main() uses slack 3, radius 2) followed by the two
+ * remove_nonfinite_values_Img calls (mgm.cc:387-388): dminI/dmaxI are updated in place from the disparity map. */
+int mgm_update_ranges_dev(mgm_ctx *ctx, const mgm_img *outoff, mgm_img *dminI, mgm_img *dmaxI, int slack, int radius);
+
 /* ---- what main() does to the disparity maps right after the path (device images in, device images out) ---- */
 /* median_filter (img_tools.h:203-238, called at mgm.cc:396, 419 when MEDIAN != 0): per channel, the window
  * (2*radius+1)^2 clipped at the border, NaN samples ignored, the upper median v[n/2]; an all-NaN window

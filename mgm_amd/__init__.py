@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "mgm_aggregate_dev", "mgm_aggregate", "mgm_debug_download_lr", "mgm_refine_dev", "mgm_refine",
     "mgm_selftest_div3", "mgm_aggregate_passes_dev", "mgm_lr_device_ptr", "mgm_wta_rows_dev",
     "mgm_aggregate_batch_dev", "mgm_median_dev", "mgm_leftright_dev", "mgm_backproject_dev",
+    "mgm_wta_windowed_dev", "mgm_update_ranges_dev",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -83,6 +84,8 @@ def load_library():
     L.mgm_aggregate_dev.argtypes = [vp, vp, vp, f, f, i, i, i, i, cp, vp, vp, pp]
     L.mgm_aggregate.argtypes = [vp, vp, fp, f, f, i, i, i, i, cp, fp, fp, pp]
     L.mgm_median_dev.argtypes = [vp, vp, i, vp]
+    L.mgm_wta_windowed_dev.argtypes = [vp, vp, i, i, cp, vp, vp, vp, vp]
+    L.mgm_update_ranges_dev.argtypes = [vp, vp, vp, vp, i, i]
     L.mgm_leftright_dev.argtypes = [vp, vp, vp, f, vp]
     L.mgm_backproject_dev.argtypes = [vp, vp, vp, vp, vp]
     L.mgm_aggregate_batch_dev.argtypes = [vp, i, pp, pp, f, f, i, i, i, i, cp, pp, pp, pp]
@@ -241,6 +244,17 @@ class Context:
                                              use_fh, fix_overcount, refine.encode() if refine else None, out.h,
                                              outcost.h, C.byref(S) if want_S else None))
         return (CostVolume(self, S) if want_S else None), out, outcost
+
+    def wta_windowed_dev(self, Cv, NDIR, fix_overcount, refine, dminI, dmaxI, out=None, outcost=None):
+        nx, ny, _, _ = Cv.dims
+        out = out or self.new_image(nx, ny)
+        outcost = outcost or self.new_image(nx, ny)
+        self._chk(self.lib.mgm_wta_windowed_dev(self.h, Cv.h, NDIR, fix_overcount, refine.encode() if refine else None,
+                                                dminI.h, dmaxI.h, out.h, outcost.h))
+        return out, outcost
+
+    def update_ranges_dev(self, outoff, dminI, dmaxI, slack=3, radius=2):
+        self._chk(self.lib.mgm_update_ranges_dev(self.h, outoff.h, dminI.h, dmaxI.h, slack, radius))
 
     def median_dev(self, img, radius, out=None):
         nch, ny, nx = img.shape

@@ -61,6 +61,8 @@ struct mgm_ctx {
     long long last_nvol = 0;    // floats per volume
     long long last_stride = 0;  // floats between the Lr volumes of consecutive passes (>= last_nvol)
     int last_ndir = 0;
+    int last_batch = 0;
+    const mgm_cv *last_cvs[kMaxBatch] = {};  // the volumes of the last aggregation (identity only, never dereferenced)
     bool pending_check = false;
     // timing
     bool timing = false;
@@ -835,13 +837,16 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     c->last_nvol = nvol;
     c->last_stride = lr_stride;
     c->last_ndir = count;
+    c->last_batch = nb;
+    for (int v = 0; v < kMaxBatch; v++) c->last_cvs[v] = v < nb ? Cs[v] : nullptr;
 
     return MGM_OK;
 }
 
 // K4-K6 over `npix` pixels starting at pixel `pix0` of C, reading pass p's Lr from lr + p*lr_stride.
 static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const float *lr, long long lr_stride, int NDIR,
-                   int fix_overcount, int ridx, float *out, float *outcost, float *Sout)
+                   int fix_overcount, int ridx, float *out, float *outcost, float *Sout, const float *wlo = nullptr,
+                   const float *whi = nullptr)
 {
     const int L = C->dmax - C->dmin + 1;
     WtaParams w{};
@@ -860,6 +865,8 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
     w.FIX = fix_overcount;
     w.dmin = C->dmin;
     w.refine = ridx;
+    w.wlo = wlo;
+    w.whi = whi;
     TimeScope t(c, "k_wta");
     HIPCHK(c, launch_wta(w, c->stream));
     return MGM_OK;
@@ -868,18 +875,23 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
 // K4-K6 with any refinement of the reference's table: none/vfit are fused into k_wta; parabola, cubic and
 // parabolaOCV (refine.h:6-145) run as a second kernel on the corrected S (the caller's, or a scratch volume).
 static int run_wta_refine(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const float *lr, long long lr_stride,
-                          int NDIR, int fix_overcount, int ridx, float *out, float *outcost, float *Sout)
+                          int NDIR, int fix_overcount, int ridx, float *out, float *outcost, float *Sout,
+                          const float *wlo = nullptr, const float *whi = nullptr)
 {
-    if (ridx <= 1) return run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, ridx, out, outcost, Sout);
+    if (ridx <= 1 && !wlo) return run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, ridx, out, outcost, Sout);
+    if (ridx == 0) return run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, 0, out, outcost, Sout, wlo, whi);
     const int L = C->dmax - C->dmin + 1;
     int r;
     if (!Sout) {
         if ((r = reserve(c, c->stmp, sizeof(float) * (size_t)npix * L))) return r;
         Sout = (float *)c->stmp.p;
     }
-    if ((r = run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, 0, out, outcost, Sout))) return r;
+    if ((r = run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, 0, out, outcost, Sout, wlo, whi))) return r;
+    // what a disparity of a pixel's window outside the volume holds: S stays 0, minus (NDIR-1)*C with C = +INF
+    float vout = 0.0f;
+    if (fix_overcount == 1) vout = vout - (float)(NDIR - 1) * __builtin_huge_valf();
     TimeScope t(c, "k_refine");
-    HIPCHK(c, launch_refine(Sout, npix, L, C->dmin, ridx, out, outcost, c->stream));
+    HIPCHK(c, launch_refine(Sout, npix, L, C->dmin, ridx, wlo, whi, vout, out, outcost, c->stream));
     return MGM_OK;
 }
 
@@ -1016,8 +1028,42 @@ int mgm_refine_dev(mgm_ctx *c, const mgm_cv *S, const char *method, mgm_img *out
     if (m == 0) return MGM_OK;  // "none" and unknown names (mgm_refine.h:28-35)
     HIPCHK(c, hipSetDevice(c->device));
     TimeScope t(c, "k_refine");
-    HIPCHK(c, launch_refine(S->d, (long long)S->nx * S->ny, S->dmax - S->dmin + 1, S->dmin, m, out->d, outcost->d,
-                            c->stream));
+    HIPCHK(c, launch_refine(S->d, (long long)S->nx * S->ny, S->dmax - S->dmin + 1, S->dmin, m, nullptr, nullptr, 0.0f, out->d,
+                            outcost->d, c->stream));
+    return MGM_OK;
+}
+
+int mgm_wta_windowed_dev(mgm_ctx *c, const mgm_cv *C, int NDIR, int fix_overcount, const char *refine, const mgm_img *dminI,
+                         const mgm_img *dmaxI, mgm_img *out, mgm_img *outcost)
+{
+    if (!c || !C || !dminI || !dmaxI || !out || !outcost) return fail(c, MGM_ERR_INVALID, "mgm_wta_windowed: null argument");
+    const int nx = C->nx, ny = C->ny, L = C->dmax - C->dmin + 1;
+    for (const mgm_img *im : {dminI, dmaxI, (const mgm_img *)out, (const mgm_img *)outcost})
+        if (im->nx != nx || im->ny != ny || im->nch != 1) return fail(c, MGM_ERR_INVALID, "mgm_wta_windowed: image size mismatch");
+    int slot = -1;
+    for (int v = 0; v < c->last_batch; v++)
+        if (c->last_cvs[v] == C) slot = v;
+    if (!c->lr.p || slot < 0 || c->last_ndir != NDIR || c->last_nvol != (long long)nx * ny * L)
+        return fail(c, MGM_ERR_INVALID, "mgm_wta_windowed: this volume was not part of the context's last aggregation with NDIR passes");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_wta_refine(c, C, 0, (long long)nx * ny, (const float *)c->lr.p + (size_t)slot * NDIR * c->last_stride, c->last_stride, NDIR, fix_overcount,
+                          refinement_index(refine), out->d, outcost->d, nullptr, dminI->d, dmaxI->d);
+}
+
+int mgm_update_ranges_dev(mgm_ctx *c, const mgm_img *outoff, mgm_img *dminI, mgm_img *dmaxI, int slack, int radius)
+{
+    if (!c || !outoff || !dminI || !dmaxI) return fail(c, MGM_ERR_INVALID, "mgm_update_ranges: null argument");
+    for (const mgm_img *im : {(const mgm_img *)dminI, (const mgm_img *)dmaxI})
+        if (im->nx != outoff->nx || im->ny != outoff->ny || im->nch != 1 || outoff->nch != 1)
+            return fail(c, MGM_ERR_INVALID, "mgm_update_ranges: image size mismatch");
+    if (radius < 0 || radius > 16) return fail(c, MGM_ERR_INVALID, "mgm_update_ranges: radius must be 0..16");
+    HIPCHK(c, hipSetDevice(c->device));
+    int r;
+    if ((r = reserve(c, c->words, sizeof(unsigned) * kCtrlWords))) return r;
+    TimeScope t(c, "k_update_ranges");
+    // (the two words of the global minimum / maximum live at the end of the control block, which K3 does not use)
+    HIPCHK(c, launch_update_ranges(outoff->d, outoff->nx, outoff->ny, slack, radius, dminI->d, dmaxI->d,
+                                   (float *)c->words.p + kCtrlWords - 2, c->stream));
     return MGM_OK;
 }
 

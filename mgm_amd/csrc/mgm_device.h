@@ -67,6 +67,10 @@ struct WtaParams {
     float *out, *outcost;
     long long npix, nvol;
     int L, NDIR, FIX, dmin, refine;  // refine: 0 none, 1 vfit
+    // mgm() called with range images narrower or wider than the volume's own range (mgm.cc:377-388, every TSGM_ITER
+    // iteration after the first): the winner is sought among the disparities [(int)wlo, (int)whi] of each pixel; a
+    // disparity of that window outside the volume holds S = 0 - (NDIR-1)*INF (0 without the over-count fix).
+    const float *wlo, *whi;          // nullptr: the whole range
 };
 
 // launchers (one per translation unit)
@@ -88,8 +92,10 @@ hipError_t launch_leftright(const float *dx, int nc, int nr, const float *Rdx, i
                             hipStream_t s);
 hipError_t launch_backproject(const float *u, int nx, int ny, int nch, const float *v, int vnx, int vny, const float *disp,
                               float *out, hipStream_t s);
-hipError_t launch_refine(const float *S, long long npix, int L, int dmin, int method, float *out, float *outcost,
-                         hipStream_t s);
+hipError_t launch_refine(const float *S, long long npix, int L, int dmin, int method, const float *wlo, const float *whi,
+                         float vout, float *out, float *outcost, hipStream_t s);
+hipError_t launch_update_ranges(const float *outoff, int nx, int ny, int slack, int radius, float *dminI, float *dmaxI,
+                                float *scratch2, hipStream_t s);
 hipError_t launch_census(const float *u, int nx, int ny, int nch, int winradius, uint32_t *out, hipStream_t s);
 struct CostParams {
     const float *u, *v;          // planar images (float, or census words reinterpreted)

@@ -103,10 +103,16 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
             // first strict minimum among finite entries, ascending o
             float best = f_inf();
             int bi = 0x7fffffff;
+            const bool windowed = P.wlo != nullptr;
+            int wl = 0, wh = 0;  // window in label indices
+            if (windowed) {
+                wl = (int)P.wlo[pix] - P.dmin;  // Dvec(int min, int max) of allocate_costvolume: float -> int
+                wh = (int)P.whi[pix] - P.dmin;
+            }
 #pragma unroll
             for (int k = 0; k < LPL; k++) {
                 const float v = S[k];
-                if ((exact || o0 + k < L) && finite_bits(v) && best > v) {
+                if ((exact || o0 + k < L) && (!windowed || (o0 + k >= wl && o0 + k <= wh)) && finite_bits(v) && best > v) {
                     best = v;
                     bi = o0 + k;
                 }
@@ -120,12 +126,28 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
                     bi = oi;
                 }
             }
+            if (windowed) {
+                // window labels outside the volume, in scan order: below it, (the volume), above it
+                float vout = 0.0f;
+                if (P.FIX == 1) vout = vout - (float)(P.NDIR - 1) * f_inf();
+                if (finite_bits(vout)) {
+                    if (wl < 0 && wl <= wh && !(best < vout)) {
+                        best = vout;
+                        bi = wl;
+                    }
+                    const int hi0 = wl > L ? wl : L;
+                    if (wh >= L && hi0 <= wh && vout < best) {
+                        best = vout;
+                        bi = hi0;
+                    }
+                }
+            }
             float outv, outc = best;
             if (bi == 0x7fffffff) {
                 outv = __builtin_nanf("");  // the reference leaves minP uninitialised here
             } else {
                 outv = (float)(bi + P.dmin);
-                if (P.refine == 1 && bi - 1 >= 0 && bi + 2 <= L - 1) {  // mgm_refine.h:58
+                if (P.refine == 1 && !windowed && bi - 1 >= 0 && bi + 2 <= L - 1) {  // mgm_refine.h:58
 #pragma unroll
                     for (int k = 0; k < LPL; k++) sS[wv][o0 + k] = S[k];
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -258,8 +280,10 @@ __device__ __forceinline__ void cubicfit(const float (&p)[4], float &out_pmin, f
 }
 
 // Stand-alone refinement on a materialised (corrected) S: one thread per pixel (subpixel_refinement_sgm,
-// mgm_refine.h:40-70; method = index into its table: 1 vfit, 2 parabola, 3 cubic, 4 parabolaOCV).
+// mgm_refine.h:40-70; method = index into its table: 1 vfit, 2 parabola, 3 cubic, 4 parabolaOCV).  With range
+// images (wlo/whi, see WtaParams) the gate uses the pixel's window and disparities outside the volume read `vout`.
 __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ S, long long npix, int L, int dmin, int method,
+                                                const float *__restrict__ wlo, const float *__restrict__ whi, float vout,
                                                 float *__restrict__ out, float *__restrict__ outcost)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -267,9 +291,15 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ S, lon
     const float minP = out[i];
     if (!(minP == minP)) return;  // NaN label (no finite S): undefined in the reference
     const int o = (int)minP;
-    if (o - 1 >= dmin && o + 2 <= dmin + L - 1) {
-        const float *Si = S + i * L + (o - dmin);
-        const float v[4] = {Si[-1], Si[0], Si[1], Si[2]};
+    const int lo = wlo ? (int)wlo[i] : dmin, hi = whi ? (int)whi[i] : dmin + L - 1;
+    if (o - 1 >= lo && o + 2 <= hi) {
+        const float *Si = S + i * L;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int d = o - 1 + k - dmin;
+            v[k] = (d >= 0 && d < L) ? Si[d] : vout;
+        }
         float vmin = outcost[i], dx = 0;
         if (method == 1) vfit(v[0], v[1], v[2], vmin, dx);
         else if (method == 2) parabolafit(v, vmin, dx);
@@ -280,11 +310,89 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ S, lon
     }
 }
 
-hipError_t launch_refine(const float *S, long long npix, int L, int dmin, int method, float *out, float *outcost,
-                         hipStream_t s)
+hipError_t launch_refine(const float *S, long long npix, int L, int dmin, int method, const float *wlo, const float *whi,
+                         float vout, float *out, float *outcost, hipStream_t s)
 {
     if (method < 1 || method > 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_refine, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, S, npix, L, dmin, method, out, outcost);
+    hipLaunchKernelGGL(k_refine, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, S, npix, L, dmin, method, wlo, whi, vout,
+                       out, outcost);
+    return hipGetLastError();
+}
+
+// ---- update_dmin_dmax (mgm.cc:120-158) + the two remove_nonfinite_values_Img calls that follow it (387-388) ------
+// global finite minimum / maximum of the disparity map (image_minmax, img_tools.h:183-199): floats ordered
+// through their bit patterns so that integer atomics can reduce them
+__device__ __forceinline__ unsigned f2ord(float f)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o)
+{
+    return __builtin_bit_cast(float, (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__global__ void __launch_bounds__(256) k_minmax_init(unsigned *mm)
+{
+    mm[0] = f2ord(__builtin_huge_valf());   // gmin = +INF
+    mm[1] = f2ord(-__builtin_huge_valf());  // gmax = -INF
+}
+__global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ u, long long n, unsigned *mm)
+{
+    float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = u[i];
+        if (finite_bits(v)) {
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+    }
+    atomicMin(mm + 0, f2ord(lo));
+    atomicMax(mm + 1, f2ord(hi));
+}
+__global__ void __launch_bounds__(256) k_update_ranges(const float *__restrict__ outoff, int nx, int ny, int slack, int r,
+                                                       const unsigned *__restrict__ mm, float *__restrict__ dminI,
+                                                       float *__restrict__ dmaxI)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nx * ny) return;
+    const int i = (int)(idx % nx), j = (int)(idx / nx);
+    const float gmin = ord2f(mm[0]), gmax = ord2f(mm[1]);
+    float dmin = __builtin_huge_valf(), dmax = -__builtin_huge_valf();
+    for (int dj = -r; dj <= r; dj++)
+        for (int di = -r; di <= r; di++) {
+            int x = i + di, y = j + dj;  // valneumann
+            x = x >= 0 ? x : 0;
+            x = x < nx ? x : nx - 1;
+            y = y >= 0 ? y : 0;
+            y = y < ny ? y : ny - 1;
+            const float v = outoff[x + (long long)y * nx];
+            const float a = finite_bits(v) ? v - slack : gmin - slack;
+            const float b = finite_bits(v) ? v + slack : gmax + slack;
+            dmin = __builtin_fminf(dmin, a);
+            dmax = __builtin_fmaxf(dmax, b);
+        }
+    float lo = dminI[idx], hi = dmaxI[idx];
+    if (finite_bits(dmin)) {
+        lo = dmin;
+        hi = dmax;
+    }
+    // remove_nonfinite_values_Img(dminI, gmin), (dmaxI, gmax)
+    dminI[idx] = finite_bits(lo) ? lo : gmin;
+    dmaxI[idx] = finite_bits(hi) ? hi : gmax;
+}
+
+hipError_t launch_update_ranges(const float *outoff, int nx, int ny, int slack, int radius, float *dminI, float *dmaxI,
+                                float *scratch2, hipStream_t s)
+{
+    unsigned *mm = reinterpret_cast<unsigned *>(scratch2);
+    const long long n = (long long)nx * ny;
+    if (slack < 0) slack = -slack;
+    hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, s, mm);
+    long long nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_minmax, dim3((unsigned)nb), dim3(256), 0, s, outoff, n, mm);
+    hipLaunchKernelGGL(k_update_ranges, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, outoff, nx, ny, slack, radius, mm, dminI,
+                       dmaxI);
     return hipGetLastError();
 }
 

@@ -8,9 +8,8 @@
 // computed on the CPU.  Image files: .npy (h,w[,c]) only in this build (the reference's iio
 // reads the same files; PNG/TIFF need libraries this image lacks).
 //
-// Not supported (exit code 2, message on stderr): ragged ranges (-m/-M files that are not
-// constant, TSGM_ITER > 1), WITH_MGM2=1, costs/prefilters/refinements the library reports as
-// MGM_ERR_UNSUPPORTED.
+// Not supported (exit code 2, message on stderr): -m/-M range files that are not constant (a ragged
+// cost volume), WITH_MGM2=1.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -170,6 +169,26 @@ static void median_run(mgm_ctx *ctx, Run &r, int radius)
     r.dout = tmp;
 }
 
+// iterations 2..TSGM_ITER of main()'s loop (mgm.cc:377-388): the ranges narrow around the previous solution
+// (update_dmin_dmax), the volume -- and with it every scan-line pass -- stays the same, so only the winner search and
+// the refinement are redone, on the Lr volumes the context still holds
+static void iterate_run(mgm_ctx *ctx, const Opts &o, Run &r, int iterations, int dmin, int dmax)
+{
+    if (iterations < 2) return;
+    std::vector<float> lo((size_t)r.nx * r.ny, (float)dmin), hi((size_t)r.nx * r.ny, (float)dmax);
+    mgm_img *dlo = nullptr, *dhi = nullptr;
+    int rc;
+    if ((rc = mgm_img_upload(ctx, lo.data(), r.nx, r.ny, 1, &dlo)) || (rc = mgm_img_upload(ctx, hi.data(), r.nx, r.ny, 1, &dhi)))
+        die(ctx, rc, "upload");
+    for (int it = 1; it < iterations; it++) {
+        if ((rc = mgm_update_ranges_dev(ctx, r.dout, dlo, dhi, 3, 2))) die(ctx, rc, "mgm_update_ranges");
+        if ((rc = mgm_wta_windowed_dev(ctx, r.C, o.NDIR, o.FIX, o.refine, dlo, dhi, r.dout, r.dcost))) die(ctx, rc, "mgm_wta_windowed");
+        report_run(o, r);
+    }
+    mgm_img_free(ctx, dlo);
+    mgm_img_free(ctx, dhi);
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2 || !strcmp(argv[1], "-h")) return 0 * puts("usage:\n\tmgm [-options] u v out [cost [backflow]]");
@@ -218,7 +237,7 @@ int main(int argc, char **argv)
     const double TSGM_ITER = env_param("TSGM_ITER", 1), TESTLRRL = env_param("TESTLRRL", 1);
     const double TAU = env_param("TESTLRRL_TAU", 1.0), MEDIAN = env_param("MEDIAN", 0);
     if (env_param("WITH_MGM2", 0) != 0) { fprintf(stderr, "mgm: WITH_MGM2=1 is not supported (its result is thread-order dependent)\n"); return 2; }
-    if (TSGM_ITER != 1) { fprintf(stderr, "mgm: TSGM_ITER != 1 needs per-pixel ranges (not built yet)\n"); return 2; }
+    if ((int)TSGM_ITER < 1) { fprintf(stderr, "mgm: TSGM_ITER < 1 is not supported\n"); return 2; }
 
     try {
         HostImg u = npy::read(f_u), v = npy::read(f_v);
@@ -262,12 +281,14 @@ int main(int argc, char **argv)
         }
         if (!together) aggregate_run(ctx, o, L);
         report_run(o, L);
+        iterate_run(ctx, o, L, (int)TSGM_ITER, o.dmin, o.dmax);
         if (MEDIAN != 0) median_run(ctx, L, (int)MEDIAN);
         if (nolr_file[0]) npy::write(nolr_file, download(ctx, L.dout, L.nx, L.ny, 1));
         if (TESTLRRL != 0) {
             if (!R.C) prepare_run(ctx, v, u, -o.dmax, -o.dmin, o, R);  // mgm.cc:366, 405
             if (!together) aggregate_run(ctx, o, R);
             report_run(o, R);
+            iterate_run(ctx, o, R, (int)TSGM_ITER, -o.dmax, -o.dmin);
             if (MEDIAN != 0) median_run(ctx, R, (int)MEDIAN);
             // leftright_test both ways on copies of the unchecked maps (mgm.cc:420-423)
             mgm_img *Lchk = nullptr, *Rchk = nullptr;

@@ -34,6 +34,12 @@ CASES = [
      dict(TSGM="3", MEDIAN="2")),
     ("ncc cost, window 5", 1, "-r -10 -R 10 -t ncc -O 4", dict(TSGM="2", CENSUS_NCC_WIN="5")),
     ("btsd cost, 3 channels", 3, "-r -12 -R 9 -t btsd -truncDist 500 -O 8", dict(TSGM="3")),
+    ("TSGM_ITER=2: ranges narrowed around the first solution", 1, "-r -16 -R 8 -t census -s vfit -O 8",
+     dict(TSGM="3", TSGM_ITER="2", CENSUS_NCC_WIN="5")),
+    ("TSGM_ITER=3, no over-count fix (window labels outside the volume compete), cubic", 1, "-r -10 -R 10 -t ad -s cubic -O 4",
+     dict(TSGM="2", TSGM_ITER="3", TSGM_FIX_OVERCOUNT="0")),
+    ("TSGM_ITER=2, 3 channels, weights, median, no LR", 3, "-r -20 -R 12 -t ad -O 8 -aP2 4 -aThresh 12 -s parabola",
+     dict(TSGM="4", TSGM_ITER="2", MEDIAN="1", TESTLRRL="0")),
     ("parabolaOCV, census, median radius 3, tight tau", 1, "-r -16 -R 8 -t census -s parabolaOCV -O 8",
      dict(TSGM="3", MEDIAN="3", TESTLRRL_TAU="0.5", CENSUS_NCC_WIN="5")),
 ]
@@ -70,6 +76,6 @@ def test_cli_refuses_what_is_not_built(tmp_path):
     np.save(tmp_path / "u.npy", u[0])
     np.save(tmp_path / "v.npy", v[0])
     base = [OURS, str(tmp_path / "u.npy"), str(tmp_path / "v.npy"), str(tmp_path / "d.npy")]
-    for extra, env in (([], dict(TSGM_ITER="2")), ([], dict(WITH_MGM2="1"))):
+    for extra, env in (([], dict(TSGM_ITER="0")), ([], dict(WITH_MGM2="1"))):
         r = subprocess.run(base[:1] + extra + base[1:], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 2 and "not" in r.stderr
