@@ -92,12 +92,21 @@ int mgm_cv_free(mgm_ctx *ctx, mgm_cv *cv);
 int mgm_costvolume_build_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, int dmin, int dmax,
                              const char *prefilter, const char *distance, float truncDist, int census_win,
                              mgm_cv **C);
-/* Host-buffer form taking the reference's per-pixel range images (dminI/dmaxI,
- * mgm.cc:338-353).  Ranges must be uniform (every pixel the same integer
- * [dmin,dmax]); ragged ranges return MGM_ERR_UNSUPPORTED. */
+/* Host-buffer form taking the reference's per-pixel range images (dminI/dmaxI, mgm.cc:338-353), converted to
+ * int as Dvec's constructor does (mgm_costvolume.h:323).  Uniform ranges take the fast path.  RAGGED ranges
+ * (-m/-M files) give a volume over the hull of all ranges in which a pixel only owns the disparities of its own
+ * range -- the others read +INF, as Dvec::operator[] does (dvec.cc:129), and are exempt from the "no finite cost"
+ * rule; mgm_aggregate* then searches the winner and gates the refinement inside each pixel's range.  Hirschmueller
+ * potentials only: use_fh with a ragged volume returns MGM_ERR_UNSUPPORTED.  The hull may span at most 512 labels. */
 int mgm_costvolume_build(mgm_ctx *ctx, const float *u, const float *v, int nx, int ny, int nch, int vnx, int vny,
                          const float *dminI, const float *dmaxI, const char *prefilter, const char *distance,
                          float truncDist, int census_win, mgm_cv **C);
+
+/* Device form of the ragged build: dminI/dmaxI are nx*ny device images, [hull_min, hull_max] must contain every
+ * pixel's (int) range. */
+int mgm_costvolume_build_ranged_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, const mgm_img *dminI,
+                                    const mgm_img *dmaxI, int hull_min, int hull_max, const char *prefilter,
+                                    const char *distance, float truncDist, int census_win, mgm_cv **C);
 
 /* ---- edge weights: compute_mgm_weights --------------------------------- */
 int mgm_weights_dev(mgm_ctx *ctx, const mgm_img *u, float aP, float aThresh, mgm_img **w8);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "mgm_aggregate_dev", "mgm_aggregate", "mgm_debug_download_lr", "mgm_refine_dev", "mgm_refine",
     "mgm_selftest_div3", "mgm_aggregate_passes_dev", "mgm_lr_device_ptr", "mgm_wta_rows_dev",
     "mgm_aggregate_batch_dev", "mgm_median_dev", "mgm_leftright_dev", "mgm_backproject_dev",
-    "mgm_wta_windowed_dev", "mgm_update_ranges_dev",
+    "mgm_wta_windowed_dev", "mgm_update_ranges_dev", "mgm_costvolume_build_ranged_dev",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -84,6 +84,7 @@ def load_library():
     L.mgm_aggregate_dev.argtypes = [vp, vp, vp, f, f, i, i, i, i, cp, vp, vp, pp]
     L.mgm_aggregate.argtypes = [vp, vp, fp, f, f, i, i, i, i, cp, fp, fp, pp]
     L.mgm_median_dev.argtypes = [vp, vp, i, vp]
+    L.mgm_costvolume_build_ranged_dev.argtypes = [vp, vp, vp, vp, vp, i, i, cp, cp, f, i, pp]
     L.mgm_wta_windowed_dev.argtypes = [vp, vp, i, i, cp, vp, vp, vp, vp]
     L.mgm_update_ranges_dev.argtypes = [vp, vp, vp, vp, i, i]
     L.mgm_leftright_dev.argtypes = [vp, vp, vp, f, vp]

@@ -29,6 +29,9 @@ struct mgm_cv {
     // nothing on the hot path reads `d` then, and it is decoded from d8 if somebody asks for it.
     int f32_state = 1;         // 1 current, 0 stale (d8 holds the volume)
     mgm_ctx *owner = nullptr;
+    // ragged volume: the per-pixel range images it was built from (device, nx*ny floats each), else nullptr.
+    // dmin/dmax are then the hull of all ranges; labels outside a pixel's own range hold +INF.
+    float *rlo = nullptr, *rhi = nullptr;
 };
 
 namespace {
@@ -448,6 +451,8 @@ int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
     hipFree(cv->d);
     if (cv->d8) hipFree(cv->d8);
     if (cv->bad8) hipFree(cv->bad8);
+    if (cv->rlo) hipFree(cv->rlo);
+    if (cv->rhi) hipFree(cv->rhi);
     delete cv;
     return MGM_OK;
 }
@@ -495,8 +500,30 @@ static int c8_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *use)
 }
 
 // ---- cost volume ------------------------------------------------------------
+static int costvolume_build(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int dmin, int dmax, const mgm_img *rloI,
+                            const mgm_img *rhiI, const char *prefilter, const char *distance, float truncDist, int census_win,
+                            mgm_cv **out);
+
 int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int dmin, int dmax, const char *prefilter,
                              const char *distance, float truncDist, int census_win, mgm_cv **out)
+{
+    return costvolume_build(c, u, v, dmin, dmax, nullptr, nullptr, prefilter, distance, truncDist, census_win, out);
+}
+
+int mgm_costvolume_build_ranged_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, const mgm_img *dminI, const mgm_img *dmaxI,
+                                    int hull_min, int hull_max, const char *prefilter, const char *distance, float truncDist,
+                                    int census_win, mgm_cv **out)
+{
+    if (!c || !u || !dminI || !dmaxI) return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build_ranged: null argument");
+    for (const mgm_img *im : {dminI, dmaxI})
+        if (im->nx != u->nx || im->ny != u->ny || im->nch != 1)
+            return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build_ranged: the range images must have the left image's size");
+    return costvolume_build(c, u, v, hull_min, hull_max, dminI, dmaxI, prefilter, distance, truncDist, census_win, out);
+}
+
+static int costvolume_build(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int dmin, int dmax, const mgm_img *rloI,
+                            const mgm_img *rhiI, const char *prefilter, const char *distance, float truncDist, int census_win,
+                            mgm_cv **out)
 {
     if (!c || !u || !v || !out) return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: null argument");
     if (u->nch != v->nch) return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: channel counts differ");
@@ -520,6 +547,22 @@ int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int
     p.C8 = nullptr;
     p.bad8 = nullptr;
     (*out)->c8_state = 0;
+    if (rloI) {  // the volume keeps its own copy of the range images: K4-K6 need them again
+        const size_t nb = sizeof(float) * (size_t)u->nx * u->ny;
+        for (float **q : {&(*out)->rlo, &(*out)->rhi})
+            if (!*q && hipMalloc((void **)q, nb) != hipSuccess) {
+                *q = nullptr;
+                return fail(c, MGM_ERR_NOMEM, "mgm_costvolume_build: range images");
+            }
+        HIPCHK(c, hipMemcpyAsync((*out)->rlo, rloI->d, nb, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync((*out)->rhi, rhiI->d, nb, hipMemcpyDeviceToDevice, c->stream));
+    } else if ((*out)->rlo) {  // a refilled volume that used to be ragged
+        hipFree((*out)->rlo);
+        hipFree((*out)->rhi);
+        (*out)->rlo = (*out)->rhi = nullptr;
+    }
+    p.rlo = (*out)->rlo;
+    p.rhi = (*out)->rhi;
     if (c8_supported(dmax - dmin + 1) && !(getenv("MGM_HIP_C8") && atoi(getenv("MGM_HIP_C8")) == 0)) {
         if ((r = c8_alloc(c, *out))) return r;
         HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
@@ -600,7 +643,7 @@ int mgm_costvolume_build_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int
     // A census cost over one descriptor word is a bit count 0..32, clipped to `trunc`: with trunc = +INF
     // or an integer up to 254 every cost fits the compact form, and the fp32 volume -- which neither K3
     // nor k_wta reads then -- is only materialised on demand (ensure_f32).
-    if (p.C8 && costfn == 2 && p.nch == 1 &&
+    if (p.C8 && !p.rlo && costfn == 2 && p.nch == 1 &&
         (p.trunc == __builtin_huge_valf() || (p.trunc >= 0.0f && p.trunc <= 254.0f && p.trunc == rintf(p.trunc))) &&
         !(getenv("MGM_HIP_LAZY_F32") && atoi(getenv("MGM_HIP_LAZY_F32")) == 0)) {
         p.C = nullptr;
@@ -619,18 +662,29 @@ int mgm_costvolume_build(mgm_ctx *c, const float *u, const float *v, int nx, int
 {
     if (!c || !u || !v || !dminI || !dmaxI || !out) return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: null argument");
     // Dvec::init receives the float range values converted to int (dvec.cc:55-60)
-    const int dmin = (int)dminI[0], dmax = (int)dmaxI[0];
-    for (long long i = 0; i < (long long)nx * ny; i++)
-        if ((int)dminI[i] != dmin || (int)dmaxI[i] != dmax)
-            return fail(c, MGM_ERR_UNSUPPORTED, "per-pixel (ragged) disparity ranges are not built yet");
-    mgm_img *du = nullptr, *dv = nullptr;
+    int dmin = (int)dminI[0], dmax = (int)dmaxI[0];
+    bool ragged = false;
+    for (long long i = 0; i < (long long)nx * ny; i++) {
+        const int lo = (int)dminI[i], hi = (int)dmaxI[i];
+        if (hi < lo) return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: a pixel's range is empty (dmax < dmin)");
+        ragged |= lo != dmin || hi != dmax;
+    }
+    if (ragged)  // the dense layout spans the hull of all ranges
+        for (long long i = 0; i < (long long)nx * ny; i++) {
+            dmin = std::min(dmin, (int)dminI[i]);
+            dmax = std::max(dmax, (int)dmaxI[i]);
+        }
+    mgm_img *du = nullptr, *dv = nullptr, *dlo = nullptr, *dhi = nullptr;
     *out = nullptr;
     int r = mgm_img_upload(c, u, nx, ny, nch, &du);
     if (!r) r = mgm_img_upload(c, v, vnx, vny, nch, &dv);
-    if (!r) r = mgm_costvolume_build_dev(c, du, dv, dmin, dmax, prefilter, distance, truncDist, census_win, out);
+    if (!r && ragged) r = mgm_img_upload(c, dminI, nx, ny, 1, &dlo);
+    if (!r && ragged) r = mgm_img_upload(c, dmaxI, nx, ny, 1, &dhi);
+    if (!r)
+        r = ragged ? mgm_costvolume_build_ranged_dev(c, du, dv, dlo, dhi, dmin, dmax, prefilter, distance, truncDist, census_win, out)
+                   : mgm_costvolume_build_dev(c, du, dv, dmin, dmax, prefilter, distance, truncDist, census_win, out);
     if (!r) r = mgm_ctx_synchronize(c);
-    mgm_img_free(c, du);
-    mgm_img_free(c, dv);
+    for (mgm_img *im : {du, dv, dlo, dhi}) mgm_img_free(c, im);
     return r;
 }
 
@@ -681,6 +735,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         weighted = wv;
     }
     const bool fh = use_fh > 0;
+    for (int v = 0; v < nb; v++)
+        if (fh && Cs[v]->rlo)
+            return fail(c, MGM_ERR_UNSUPPORTED, "FH potentials on a ragged cost volume are not built yet (the min-convolution "
+                                                "runs over the receiving pixel's own range, mgm_core.cc:166-186, 229-281)");
     const int NS = pass_ns(fh, weighted);
 
     // compact costs (one byte per label) when the volume allows it
@@ -865,8 +923,11 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
     w.FIX = fix_overcount;
     w.dmin = C->dmin;
     w.refine = ridx;
-    w.wlo = wlo;
-    w.whi = whi;
+    // range images are whole-image arrays; this call may cover a slab of rows starting at pix0
+    w.wlo = wlo ? wlo + pix0 : nullptr;
+    w.whi = whi ? whi + pix0 : nullptr;
+    w.clo = C->rlo ? C->rlo + pix0 : nullptr;
+    w.chi = C->rhi ? C->rhi + pix0 : nullptr;
     TimeScope t(c, "k_wta");
     HIPCHK(c, launch_wta(w, c->stream));
     return MGM_OK;
@@ -878,6 +939,10 @@ static int run_wta_refine(mgm_ctx *c, const mgm_cv *C, long long pix0, long long
                           int NDIR, int fix_overcount, int ridx, float *out, float *outcost, float *Sout,
                           const float *wlo = nullptr, const float *whi = nullptr)
 {
+    if (!wlo && C->rlo) {  // a ragged volume: S is allocated from the same range images (mgm_core.cc:426)
+        wlo = C->rlo;
+        whi = C->rhi;
+    }
     if (ridx <= 1 && !wlo) return run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, ridx, out, outcost, Sout);
     if (ridx == 0) return run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, 0, out, outcost, Sout, wlo, whi);
     const int L = C->dmax - C->dmin + 1;
@@ -891,7 +956,8 @@ static int run_wta_refine(mgm_ctx *c, const mgm_cv *C, long long pix0, long long
     float vout = 0.0f;
     if (fix_overcount == 1) vout = vout - (float)(NDIR - 1) * __builtin_huge_valf();
     TimeScope t(c, "k_refine");
-    HIPCHK(c, launch_refine(Sout, npix, L, C->dmin, ridx, wlo, whi, vout, out, outcost, c->stream));
+    HIPCHK(c, launch_refine(Sout, npix, L, C->dmin, ridx, wlo ? wlo + pix0 : nullptr, whi ? whi + pix0 : nullptr, vout, out,
+                            outcost, c->stream));
     return MGM_OK;
 }
 

@@ -191,9 +191,19 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
     uint8_t *Cp8 = P.C8 ? P.C8 + pix * P.L : nullptr;
     const bool yin = (y < P.vny);  // q.y = p.y >= 0 always
     bool anyfinite = false, bad8 = false;
+    int rl = 0, rh = P.L - 1;  // the pixel's own label range (ragged volumes)
+    if (P.rlo) {
+        rl = (int)P.rlo[pix] - P.dmin;
+        rh = (int)P.rhi[pix] - P.dmin;
+    }
     for (int o = lane; o < P.L; o += 64) {
         const int qx = x + o + P.dmin;
         float e = P.trunc;
+        if (o < rl || o > rh) {  // not a label of this pixel
+            if (Cp) Cp[o] = __builtin_huge_valf();
+            if (Cp8) Cp8[o] = 255;
+            continue;
+        }
         if (yin && qx >= 0 && qx < P.vnx) {
             const long long q = (long long)y * P.vnx + qx;
             if (P.costfn == 2) {
@@ -236,6 +246,7 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
     // no valid hypothesis for this pixel => all labels cost 0 (mgm_costvolume.h:414-421)
     if (__builtin_amdgcn_ballot_w64(anyfinite) == 0ull)
         for (int o = lane; o < P.L; o += 64) {
+            if (o < rl || o > rh) continue;
             if (Cp) Cp[o] = 0.0f;
             if (Cp8) Cp8[o] = 0;
         }

@@ -71,6 +71,8 @@ struct WtaParams {
     // iteration after the first): the winner is sought among the disparities [(int)wlo, (int)whi] of each pixel; a
     // disparity of that window outside the volume holds S = 0 - (NDIR-1)*INF (0 without the over-count fix).
     const float *wlo, *whi;          // nullptr: the whole range
+    // ragged C (CostParams::rlo/rhi): a disparity outside the pixel's own range does not exist in C either
+    const float *clo, *chi;
 };
 
 // launchers (one per translation unit)
@@ -108,6 +110,10 @@ struct CostParams {
     int costfn;                  // 0 ad, 1 sd, 2 census, 3 ncc, 4 btad, 5 btsd
     int hwin;                    // ncc: half window (CENSUS_NCC_WIN / 2)
     float trunc;                 // truncDist * nch
+    // ragged volume (per-pixel ranges from range images, mgm_costvolume.h:276-299, 323): pixel p only has the
+    // disparities [(int)rlo(p), (int)rhi(p)]; the others are +INF in the dense layout and exempt from the
+    // "no finite cost => zeros" rule.  nullptr: every pixel has the whole range.
+    const float *rlo, *rhi;
 };
 hipError_t launch_cost(const CostParams &p, hipStream_t s);
 hipError_t launch_filter2d(const float *u, int nx, int ny, int nch, const float *taps, int fnx, int fny, float *out,

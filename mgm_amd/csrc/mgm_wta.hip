@@ -94,6 +94,16 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
 #pragma unroll
                 for (int k = 0; k < LPL; k++) S[k] = S[k] - f * c[u][k];
             }
+            // what a disparity outside the volume -- or, in a ragged volume, outside the pixel's own range -- holds in the
+            // reference's S: never incremented (0), then the over-count term with C = +INF (mgm_core.cc:582-599)
+            float vout = 0.0f;
+            if (P.FIX == 1) vout = vout - (float)(P.NDIR - 1) * f_inf();
+            if (P.clo) {
+                const int cl = (int)P.clo[pix] - P.dmin, ch = (int)P.chi[pix] - P.dmin;
+#pragma unroll
+                for (int k = 0; k < LPL; k++)
+                    if (o0 + k < cl || o0 + k > ch) S[k] = vout;
+            }
             if (P.S) {
                 float *q = P.S + pix * L + o0;
 #pragma unroll
@@ -128,8 +138,6 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
             }
             if (windowed) {
                 // window labels outside the volume, in scan order: below it, (the volume), above it
-                float vout = 0.0f;
-                if (P.FIX == 1) vout = vout - (float)(P.NDIR - 1) * f_inf();
                 if (finite_bits(vout)) {
                     if (wl < 0 && wl <= wh && !(best < vout)) {
                         best = vout;

@@ -8,8 +8,8 @@
 // computed on the CPU.  Image files: .npy (h,w[,c]) only in this build (the reference's iio
 // reads the same files; PNG/TIFF need libraries this image lacks).
 //
-// Not supported (exit code 2, message on stderr): -m/-M range files that are not constant (a ragged
-// cost volume), WITH_MGM2=1.
+// Not supported (exit code 2, message on stderr): FH potentials together with -m/-M range files that are not
+// constant (a ragged cost volume), WITH_MGM2=1.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -97,7 +97,8 @@ struct Run {
     int nx = 0, ny = 0;
 };
 
-static void prepare_run(mgm_ctx *ctx, const HostImg &u, const HostImg &v, int dmin, int dmax, const Opts &o, Run &r)
+static void prepare_run(mgm_ctx *ctx, const HostImg &u, const HostImg &v, int dmin, int dmax, const Opts &o, Run &r,
+                        const HostImg *lo = nullptr, const HostImg *hi = nullptr)
 {
     int rc;
     r.nx = u.nx;
@@ -111,8 +112,28 @@ static void prepare_run(mgm_ctx *ctx, const HostImg &u, const HostImg &v, int dm
         if ((rc = mgm_img_download(ctx, r.dw, w.data()))) die(ctx, rc, "download");
         r.weighted_msg = std::any_of(w.begin(), w.end(), [](float x) { return x != 1.0f; });
     }
-    if ((rc = mgm_costvolume_build_dev(ctx, r.du, r.dv, dmin, dmax, o.prefilter, o.distance, o.truncDist, o.census_win, &r.C)))
+    bool ragged = false;
+    if (lo) {  // range images (-m/-M, mgm.cc:342-353): Dvec takes them as ints (mgm_costvolume.h:323)
+        dmin = (int)lo->data[0];
+        dmax = (int)hi->data[0];
+        for (size_t i = 0; i < lo->data.size(); i++) ragged |= (int)lo->data[i] != dmin || (int)hi->data[i] != dmax;
+    }
+    if (ragged) {
+        for (size_t i = 0; i < lo->data.size(); i++) {
+            dmin = std::min(dmin, (int)lo->data[i]);
+            dmax = std::max(dmax, (int)hi->data[i]);
+        }
+        mgm_img *dlo = nullptr, *dhi = nullptr;
+        if ((rc = mgm_img_upload(ctx, lo->data.data(), u.nx, u.ny, 1, &dlo)) || (rc = mgm_img_upload(ctx, hi->data.data(), u.nx, u.ny, 1, &dhi)))
+            die(ctx, rc, "upload");
+        rc = mgm_costvolume_build_ranged_dev(ctx, r.du, r.dv, dlo, dhi, dmin, dmax, o.prefilter, o.distance, o.truncDist,
+                                             o.census_win, &r.C);
+        mgm_img_free(ctx, dlo);
+        mgm_img_free(ctx, dhi);
+        if (rc) die(ctx, rc, "mgm_costvolume_build_ranged");
+    } else if ((rc = mgm_costvolume_build_dev(ctx, r.du, r.dv, dmin, dmax, o.prefilter, o.distance, o.truncDist, o.census_win, &r.C))) {
         die(ctx, rc, "mgm_costvolume_build");
+    }
     if ((rc = mgm_img_create(ctx, u.nx, u.ny, 1, &r.dout)) || (rc = mgm_img_create(ctx, u.nx, u.ny, 1, &r.dcost)))
         die(ctx, rc, "mgm_img_create");
 }
@@ -172,10 +193,15 @@ static void median_run(mgm_ctx *ctx, Run &r, int radius)
 // iterations 2..TSGM_ITER of main()'s loop (mgm.cc:377-388): the ranges narrow around the previous solution
 // (update_dmin_dmax), the volume -- and with it every scan-line pass -- stays the same, so only the winner search and
 // the refinement are redone, on the Lr volumes the context still holds
-static void iterate_run(mgm_ctx *ctx, const Opts &o, Run &r, int iterations, int dmin, int dmax)
+static void iterate_run(mgm_ctx *ctx, const Opts &o, Run &r, int iterations, int dmin, int dmax, const HostImg *lo0 = nullptr,
+                        const HostImg *hi0 = nullptr)
 {
     if (iterations < 2) return;
     std::vector<float> lo((size_t)r.nx * r.ny, (float)dmin), hi((size_t)r.nx * r.ny, (float)dmax);
+    if (lo0) {
+        lo = lo0->data;
+        hi = hi0->data;
+    }
     mgm_img *dlo = nullptr, *dhi = nullptr;
     int rc;
     if ((rc = mgm_img_upload(ctx, lo.data(), r.nx, r.ny, 1, &dlo)) || (rc = mgm_img_upload(ctx, hi.data(), r.nx, r.ny, 1, &dhi)))
@@ -243,20 +269,20 @@ int main(int argc, char **argv)
         HostImg u = npy::read(f_u), v = npy::read(f_v);
         remove_nonfinite(u, 0);
         remove_nonfinite(v, 0);
-        if (min_file[0]) {  // mgm.cc:342-353: only constant range images are supported
-            HostImg a = npy::read(min_file), b = npy::read(max_file);
-            remove_nonfinite(a, (float)o.dmin);
-            remove_nonfinite(b, (float)o.dmax);
-            for (size_t i = 0; i < a.data.size(); i++)
-                if (b.data[i] < a.data[i] + 1) b.data[i] = ceilf(a.data[i] + 1);
-            for (size_t i = 0; i < a.data.size(); i++)
-                if ((int)a.data[i] != (int)a.data[0] || (int)b.data[i] != (int)b.data[0]) {
-                    fprintf(stderr, "mgm: per-pixel disparity ranges (-m/-M) are not built yet\n");
-                    return 2;
-                }
-            o.dmin = (int)a.data[0];
-            o.dmax = (int)b.data[0];
+        HostImg rlo, rhi;  // -m / -M range images of the left->right run (mgm.cc:342-353); the right->left run keeps -r/-R
+        if (min_file[0]) {
+            rlo = npy::read(min_file);
+            rhi = npy::read(max_file);
+            if (rlo.nx != u.nx || rlo.ny != u.ny || rhi.nx != u.nx || rhi.ny != u.ny || rlo.nch != 1 || rhi.nch != 1) {
+                fprintf(stderr, "mgm: the -m/-M images must have the size of the left image\n");
+                return 1;
+            }
+            remove_nonfinite(rlo, (float)o.dmin);
+            remove_nonfinite(rhi, (float)o.dmax);
+            for (size_t i = 0; i < rlo.data.size(); i++)
+                if (rhi.data[i] < rlo.data[i] + 1) rhi.data[i] = ceilf(rlo.data[i] + 1);
         }
+        const HostImg *plo = min_file[0] ? &rlo : nullptr, *phi = min_file[0] ? &rhi : nullptr;
         o.P1 *= u.nch;  // mgm.cc:356-357
         o.P2 *= u.nch;
 
@@ -266,9 +292,9 @@ int main(int argc, char **argv)
 
         HostImg outoff, outcost;
         Run L, R;
-        prepare_run(ctx, u, v, o.dmin, o.dmax, o, L);
+        prepare_run(ctx, u, v, o.dmin, o.dmax, o, L, plo, phi);
         bool together = false;
-        if (TESTLRRL != 0 && u.nx == v.nx && u.ny == v.ny && env_param("MGM_BATCH_LR", 1) != 0) {
+        if (TESTLRRL != 0 && !plo && u.nx == v.nx && u.ny == v.ny && env_param("MGM_BATCH_LR", 1) != 0) {
             // both runs of the pair (mgm.cc:376-385 and 405-414) through ONE launch of the pass kernel
             prepare_run(ctx, v, u, -o.dmax, -o.dmin, o, R);  // mgm.cc:366, 405
             const mgm_cv *Cs[2] = {L.C, R.C};
@@ -281,7 +307,7 @@ int main(int argc, char **argv)
         }
         if (!together) aggregate_run(ctx, o, L);
         report_run(o, L);
-        iterate_run(ctx, o, L, (int)TSGM_ITER, o.dmin, o.dmax);
+        iterate_run(ctx, o, L, (int)TSGM_ITER, o.dmin, o.dmax, plo, phi);
         if (MEDIAN != 0) median_run(ctx, L, (int)MEDIAN);
         if (nolr_file[0]) npy::write(nolr_file, download(ctx, L.dout, L.nx, L.ny, 1));
         if (TESTLRRL != 0) {

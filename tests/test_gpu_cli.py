@@ -40,6 +40,13 @@ CASES = [
      dict(TSGM="2", TSGM_ITER="3", TSGM_FIX_OVERCOUNT="0")),
     ("TSGM_ITER=2, 3 channels, weights, median, no LR", 3, "-r -20 -R 12 -t ad -O 8 -aP2 4 -aThresh 12 -s parabola",
      dict(TSGM="4", TSGM_ITER="2", MEDIAN="1", TESTLRRL="0")),
+    ("ragged ranges from -m/-M files (NaNs, empty ranges repaired), census vfit", 1,
+     "-r -16 -R 8 -t census -s vfit -O 8 -m {ranges}/lo.npy -M {ranges}/hi.npy", dict(TSGM="3", CENSUS_NCC_WIN="5")),
+    ("ragged ranges, TSGM_ITER=2, no over-count fix, weights, 3 channels", 3,
+     "-r -16 -R 8 -t ad -O 8 -aP2 4 -aThresh 12 -s parabola -m {ranges}/lo.npy -M {ranges}/hi.npy",
+     dict(TSGM="4", TSGM_ITER="2", TSGM_FIX_OVERCOUNT="0")),
+    ("ragged ranges, TSGM=2, cubic, median, no LR", 1, "-r -16 -R 8 -t sd -s cubic -O 4 -m {ranges}/lo.npy -M {ranges}/hi.npy",
+     dict(TSGM="2", MEDIAN="1", TESTLRRL="0")),
     ("parabolaOCV, census, median radius 3, tight tau", 1, "-r -16 -R 8 -t census -s parabolaOCV -O 8",
      dict(TSGM="3", MEDIAN="3", TESTLRRL_TAU="0.5", CENSUS_NCC_WIN="5")),
 ]
@@ -49,14 +56,23 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
 def test_cli_matches_reference(case, tmp_path):
     name, nch, args, env = case
-    u, v, _ = synth.stereo_pair(112, 72, -16, 8, seed=42, nch=nch)
+    u, v, gt = synth.stereo_pair(112, 72, -16, 8, seed=42, nch=nch)
     np.save(tmp_path / "u.npy", np.ascontiguousarray(u.transpose(1, 2, 0)) if nch > 1 else u[0])
     np.save(tmp_path / "v.npy", np.ascontiguousarray(v.transpose(1, 2, 0)) if nch > 1 else v[0])
+    if "{ranges}" in args:  # per-pixel range images around the true disparity, as a coarse-to-fine caller would pass
+        rng = np.random.default_rng(8)
+        gt2 = np.asarray(gt, np.float32).reshape(72, 112)
+        lo = np.floor(gt2 - rng.integers(1, 7, size=gt2.shape)).astype(np.float32) + rng.random(gt2.shape).astype(np.float32)
+        hi = lo + rng.integers(0, 14, size=gt2.shape).astype(np.float32)      # some ranges empty: main() repairs them
+        lo[rng.random(gt2.shape) < 0.02] = np.nan                             # ... and replaces non-finite bounds
+        hi[rng.random(gt2.shape) < 0.02] = np.inf
+        np.save(tmp_path / "lo.npy", lo)
+        np.save(tmp_path / "hi.npy", hi)
     outs = {}
     for tag, exe in (("ref", REF), ("ours", OURS)):
         d = tmp_path / tag
         d.mkdir()
-        a = args.format(tmp=d).split()
+        a = args.format(tmp=d, ranges=tmp_path).split()
         cmd = [exe] + a + [str(tmp_path / "u.npy"), str(tmp_path / "v.npy"), str(d / "disp.npy"), str(d / "cost.npy"),
                            str(d / "back.npy")]
         e = dict(os.environ, OMP_NUM_THREADS="4", **env)
@@ -76,6 +92,12 @@ def test_cli_refuses_what_is_not_built(tmp_path):
     np.save(tmp_path / "u.npy", u[0])
     np.save(tmp_path / "v.npy", v[0])
     base = [OURS, str(tmp_path / "u.npy"), str(tmp_path / "v.npy"), str(tmp_path / "d.npy")]
-    for extra, env in (([], dict(TSGM_ITER="0")), ([], dict(WITH_MGM2="1"))):
+    lo = np.zeros((16, 32), np.float32) - 4
+    lo[3, 3] = -2
+    np.save(tmp_path / "lo.npy", lo)
+    np.save(tmp_path / "hi.npy", lo + 6)
+    ragged_fh = ["-m", str(tmp_path / "lo.npy"), "-M", str(tmp_path / "hi.npy")]
+    for extra, env in (([], dict(TSGM_ITER="0")), ([], dict(WITH_MGM2="1")),
+                       (ragged_fh, dict(USE_TRUNCATED_LINEAR_POTENTIALS="1"))):
         r = subprocess.run(base[:1] + extra + base[1:], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 2 and "not" in r.stderr

@@ -154,15 +154,43 @@ def test_costvolume_vs_oracle(ctx, oracle, case):
     cv.free()
 
 
+def test_ragged_costvolume(ctx, oracle):
+    """-m/-M range images: the volume spans the hull of all ranges; a pixel owns only its own range (the rest reads +INF,
+    dvec.cc:129) and the "no finite cost => zeros" rule looks at that range alone (mgm_costvolume.h:414-421)."""
+    nx, ny = 60, 25
+    u, v, gt = synth.stereo_pair(nx, ny, -14, 6)
+    rng = np.random.default_rng(4)
+    lo = (gt - rng.integers(1, 5, size=gt.shape)).astype(np.float32) + np.float32(0.3)
+    hi = lo + rng.integers(1, 9, size=gt.shape).astype(np.float32)
+    lo[0, :4], hi[0, :4] = 70, 75                     # every hypothesis of these pixels lies outside the right image
+    cv = ctx.costvolume(u, v, lo, hi, "none", "census", np.inf, 5)
+    _, _, dmin, dmax = cv.dims
+    ilo, ihi = lo.astype(np.int32), hi.astype(np.int32)  # C's (int) conversion: towards zero
+    assert dmin == ilo.min() and dmax == ihi.max()
+    full = oracle.costvolume(u, v, dmin, dmax, "none", "census", np.inf, 5)
+    # the oracle's own zero rule looks at the whole hull: recompute "finite" from the geometry
+    o = np.arange(dmin, dmax + 1)[None, None, :]
+    x = np.arange(nx)[None, :, None]
+    inside = (x + o >= 0) & (x + o < nx)
+    own = (o >= ilo[..., None]) & (o <= ihi[..., None])
+    want = np.where(own & inside, full, np.float32(np.inf)).astype(np.float32)
+    none_finite = ~(own & inside).any(axis=2)
+    want[none_finite[..., None] & own] = 0
+    assert ndiff(cv.download(), want) == 0
+    cv.free()
+
+
 def test_unsupported_and_invalid_inputs_fail_loudly(ctx):
     import mgm_amd
     u, v, _ = synth.stereo_pair(16, 8, -3, 3)
     du, dv = ctx.upload_image(u), ctx.upload_image(v)
     ragged = np.full((8, 16), -3, np.float32)
     ragged[2, 2] = -2
-    with pytest.raises(mgm_amd.MgmError) as e:
-        ctx.costvolume(u, v, ragged, np.full((8, 16), 3, np.float32))
+    rcv = ctx.costvolume(u, v, ragged, np.full((8, 16), 3, np.float32))   # a ragged volume builds ...
+    with pytest.raises(mgm_amd.MgmError) as e:                            # ... but FH potentials on it are not built
+        ctx.aggregate(rcv, 2.0, 9.0, 4, 2, 1)
     assert e.value.code == mgm_amd.MGM_ERR_UNSUPPORTED
+    rcv.free()
     cv = ctx.costvolume_dev(du, dv, -3, 3)
     for bad in (dict(NDIR=9, MGM=2), dict(NDIR=4, MGM=5), dict(NDIR=0, MGM=1)):
         with pytest.raises(mgm_amd.MgmError) as e:
