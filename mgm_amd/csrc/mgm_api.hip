@@ -53,7 +53,7 @@ struct mgm_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // workspace
-    Buf lr, hand, handm, words, tasks, census_u, census_v, dbg, stmp;
+    Buf lr, hand, handm, words, tasks, census_u, census_v, dbg, stmp, ones8;
     int debug_stats = 0;  // MGM_HIP_DEBUG_STATS=1: per-workgroup timing summary of K3 on stderr
     unsigned *h_words = nullptr;  // pinned mirror of the control words
     // cached task table key
@@ -260,7 +260,7 @@ int mgm_ctx_destroy(mgm_ctx *c)
     if (!c) return MGM_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (Buf *b : {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v, &c->dbg, &c->stmp})
+    for (Buf *b : {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8})
         if (b->p) hipFree(b->p);
     for (auto &t : c->tim) {
         hipEventDestroy(t.a);
@@ -735,10 +735,33 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         weighted = wv;
     }
     const bool fh = use_fh > 0;
-    for (int v = 0; v < nb; v++)
-        if (fh && Cs[v]->rlo)
-            return fail(c, MGM_ERR_UNSUPPORTED, "FH potentials on a ragged cost volume are not built yet (the min-convolution "
-                                                "runs over the receiving pixel's own range, mgm_core.cc:166-186, 229-281)");
+    // FH potentials on a ragged volume: the min-convolution runs over the RECEIVING pixel's range (mgm_core.cc:242-271), so
+    // it cannot be done once by the producer.  The weighted FH kernels convolve on the consumer side anyway: use them,
+    // with all-ones weights if the caller has none (update_costW_trunclinear with DeltaI = 1 is what the reference calls
+    // then, mgm_core.cc:563-570) -- except for TSGM = 2 without weights, which is update_cost2_trunclinear with its
+    // boundary fix-up (166-186, 197-219) and is not built.
+    bool ragged = false;
+    for (int v = 0; v < nb; v++) ragged |= Cs[v]->rlo != nullptr;
+    // The dense layout of a ragged volume relies on foreign labels staying +INF through every update (C = +INF there).
+    // That holds as long as every slab keeps a finite minimum, which a finite P2 guarantees (every term is capped at
+    // m + P2); with P2 = +INF a pixel whose neighbours' ranges miss its own gets an all-INF slab, the next one INF - INF.
+    if (ragged && !(P2 < __builtin_huge_valf()))
+        return fail(c, MGM_ERR_UNSUPPORTED, "a ragged cost volume with P2 = +INF is not built (foreign labels would not stay +INF)");
+    const float *ones8 = nullptr;
+    if (fh && ragged)
+        for (int v = 1; v < nb; v++)
+            if (Cs[v]->dmin != Cs[0]->dmin) return fail(c, MGM_ERR_UNSUPPORTED, "batched ragged volumes must share their hull under FH potentials");
+    if (fh && ragged && !weighted) {
+        if (MGM == 2)
+            return fail(c, MGM_ERR_UNSUPPORTED, "FH potentials with TSGM=2 and no weights on a ragged cost volume are not built yet "
+                                                "(update_cost2_trunclinear's boundary fix-up, mgm_core.cc:166-186)");
+        if ((r = reserve(c, c->ones8, sizeof(float) * (size_t)npix * 8))) return r;
+        std::vector<float> one((size_t)npix * 8, 1.0f);
+        HIPCHK(c, hipMemcpyAsync(c->ones8.p, one.data(), sizeof(float) * one.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ones8 = (const float *)c->ones8.p;
+        weighted = true;
+    }
     const int NS = pass_ns(fh, weighted);
 
     // compact costs (one byte per label) when the volume allows it
@@ -796,7 +819,9 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         p.vol[v].C = Cs[v]->d;
         p.vol[v].C8 = use_c8 ? Cs[v]->d8 : nullptr;
         p.vol[v].Lr = (float *)c->lr.p + (size_t)v * count * lr_stride;
-        p.vol[v].w8 = weighted ? w8s[v]->d : nullptr;
+        p.vol[v].w8 = ones8 ? ones8 : (weighted ? w8s[v]->d : nullptr);
+        p.vol[v].rlo = (fh && ragged) ? Cs[v]->rlo : nullptr;
+        p.vol[v].rhi = (fh && ragged) ? Cs[v]->rhi : nullptr;
     }
     p.hand = (float *)c->hand.p;
     p.handm = (float *)c->handm.p;
@@ -808,6 +833,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.nvol = lr_stride;
     p.L = L;
     p.MGM = MGM;
+    p.dmin = C->dmin;
     p.NDIR = PEND;
     p.pass0 = first;
     p.LLmax = maxLL;

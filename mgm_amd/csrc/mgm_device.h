@@ -39,6 +39,7 @@ struct PassVolume {
     const uint8_t *C8;  // [npix][L] compact costs (integers 0..254, 255 = +INF) or nullptr (all volumes alike)
     float *Lr;          // NDIR volumes, pass p at Lr + (p - pass0)*nvol
     const float *w8;    // 8 planes [npix] or nullptr (all volumes alike)
+    const float *rlo, *rhi;  // ragged volume: per-pixel range images (only the weighted FH kernels read them), or nullptr
 };
 struct PassParams {
     PassVolume vol[kMaxBatch];
@@ -52,7 +53,7 @@ struct PassParams {
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
     long long npix, nvol;
-    int L, MGM, NDIR;
+    int L, MGM, NDIR, dmin;
     int pass0;          // pass p writes its Lr volume to slot p - pass0
     int LLmax, maxbands;
     float P1, P2;

@@ -165,12 +165,17 @@ __global__ void __launch_bounds__(R * 64) k_pass(const PassParams P)
                         float D[4];
 #pragma unroll
                         for (int k = 0; k < 4; k++) D[k] = V.w8[(long long)g.wplane[k] * P.npix + pix];
+                        int rl = 0, rh = 0x7fffffff;  // the pixel's own label range (ragged volumes, FH only)
+                        if (FH && V.rlo) {
+                            rl = (int)V.rlo[pix] - P.dmin;
+                            rh = (int)V.rhi[pix] - P.dmin;
+                        }
                         if constexpr (!FH) {
                             if (form == 0) combine_whirsch<LPL>(Cpf[u], nb_i, nb_s, nb_b, nb_f, D, P1, P2, MGM, Lv);
                             else combine_whirsch<LPL>(Cpf[u], nb_f, nb_b, nb_s, nb_i, D, P1, P2, MGM, Lv);
                         } else {
-                            if (form == 0) combine_wfh<LPL>(Cpf[u], nb_i, nb_s, nb_b, nb_f, D, P1, P2, MGM, lane, L, Lv);
-                            else combine_wfh<LPL>(Cpf[u], nb_f, nb_b, nb_s, nb_i, D, P1, P2, MGM, lane, L, Lv);
+                            if (form == 0) combine_wfh<LPL>(Cpf[u], nb_i, nb_s, nb_b, nb_f, D, P1, P2, MGM, lane, L, Lv, rl, rh);
+                            else combine_wfh<LPL>(Cpf[u], nb_f, nb_b, nb_s, nb_i, D, P1, P2, MGM, lane, L, Lv, rl, rh);
                         }
                     }
                 } else {

@@ -567,6 +567,11 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                         float Dw[4];
 #pragma unroll
                         for (int k = 0; k < 4; k++) Dw[k] = V.w8[(long long)g.wplane[k] * P.npix + pix];
+                        int rl = 0, rh = 0x7fffffff;  // the pixel's own label range (ragged volumes, FH only)
+                        if (FH && V.rlo) {
+                            rl = (int)V.rlo[pix] - P.dmin;
+                            rh = (int)V.rhi[pix] - P.dmin;
+                        }
                         if constexpr (!FH) {
                             if constexpr (FORM == 0)
                                 combine_whirsch<LPL>(Cv, nb_i, nb_same, nb_back, nb_fwd, Dw, P1, P2, MGM, Lv);
@@ -574,9 +579,9 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                                 combine_whirsch<LPL>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, Lv);
                         } else {
                             if constexpr (FORM == 0)
-                                combine_wfh<LPL, true>(Cv, nb_i, nb_same, nb_back, nb_fwd, Dw, P1, P2, MGM, lane, L, Lv);
+                                combine_wfh<LPL, true>(Cv, nb_i, nb_same, nb_back, nb_fwd, Dw, P1, P2, MGM, lane, L, Lv, rl, rh);
                             else
-                                combine_wfh<LPL, true>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, lane, L, Lv);
+                                combine_wfh<LPL, true>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, lane, L, Lv, rl, rh);
                         }
                     }
                 } else {

@@ -343,31 +343,38 @@ __device__ __forceinline__ void combine_whirsch(const float (&C)[LPL], const Nb<
 template <int LPL, bool FULL = false>
 __device__ __forceinline__ void combine_wfh(const float (&C)[LPL], const Nb<LPL, 1> &n1, const Nb<LPL, 1> &n2,
                                             const Nb<LPL, 1> &n3, const Nb<LPL, 1> &n4, const float (&D)[4], float P1,
-                                            float P2, int MGM, int lane, int L, float (&out)[LPL])
+                                            float P2, int MGM, int lane, int L, float (&out)[LPL], int rl = 0,
+                                            int rh = 0x7fffffff)
 {
-    float e[LPL], M[LPL];
+    // [rl, rh]: the receiving pixel's own label range in a ragged volume.  The reference copies the neighbour's
+    // values over THAT range (foreign labels read +INF) and convolves there (mgm_core.cc:242-271): masking the slab
+    // to the range before the convolution is the same thing, since +INF + P1 never wins a minimum.
+    auto take = [&](const Nb<LPL, 1> &n, float (&M)[LPL]) {
 #pragma unroll
-    for (int k = 0; k < LPL; k++) M[k] = n1.w[0][k];
+        for (int k = 0; k < LPL; k++) {
+            const int o = lane * LPL + k;
+            M[k] = (o >= rl && o <= rh) ? n.w[0][k] : f_inf();
+        }
+    };
+    float e[LPL], M[LPL];
+    take(n1, M);
     fh_minconv<LPL, FULL>(M, n1.m, P1 * D[0], P2 * D[0], lane, L);
 #pragma unroll
     for (int k = 0; k < LPL; k++) e[k] = M[k] - n1.m;
     if (MGM >= 2) {
-#pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = n2.w[0][k];
+        take(n2, M);
         fh_minconv<LPL, FULL>(M, n2.m, P1 * D[1], P2 * D[1], lane, L);
 #pragma unroll
         for (int k = 0; k < LPL; k++) e[k] += M[k] - n2.m;
     }
     if (MGM >= 3) {
-#pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = n3.w[0][k];
+        take(n3, M);
         fh_minconv<LPL, FULL>(M, n3.m, P1 * D[2], P2 * D[2], lane, L);
 #pragma unroll
         for (int k = 0; k < LPL; k++) e[k] += M[k] - n3.m;
     }
     if (MGM >= 4) {
-#pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = n4.w[0][k];
+        take(n4, M);
         fh_minconv<LPL, FULL>(M, n4.m, P1 * D[3], P2 * D[3], lane, L);
 #pragma unroll
         for (int k = 0; k < LPL; k++) e[k] += M[k] - n4.m;
