@@ -38,16 +38,7 @@ __device__ __forceinline__ void dma4(const void *src_lane, void *dst_base)
 {
     __builtin_amdgcn_global_load_lds((glb_vptr)src_lane, (lds_vptr)dst_base, 4, 0, AUX);
 }
-#ifndef MGM_P2_LATE_STORE
-#define MGM_P2_LATE_STORE 0   // the Lr slab is stored at the end of the step instead of right after the update
-#endif
-#ifndef MGM_P2_NT_STORE
-#define MGM_P2_NT_STORE 0   // 1: the Lr slabs are written with the non-temporal hint
-#endif
-#ifndef MGM_P2_EXP
-#define MGM_P2_EXP 0   // timing experiments (wrong results): 1 plain loads for the hand-off, 2 no progress/minimum DMA, 4 no hand-off slab DMA
-#endif
-constexpr int AUX_SC1 = (MGM_P2_EXP & 1) ? 0 : 16;  // agent-scope (L1-bypassing) cache policy bit
+constexpr int AUX_SC1 = 16;  // agent-scope (L1-bypassing) cache policy bit
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
@@ -154,7 +145,7 @@ struct Plan {
     static constexpr int NDMA = C8 ? (NC + LPD - 1) / LPD : NCA * IPS;                // C pieces per step (loader A)
     // DMA instructions per step: loader A = its C pieces + hand-off slabs [+ minimum] + progress word
     // compact costs with two loaders: A = hand-off only, B = all C pieces
-    static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + ((MGM_P2_EXP & 4) ? 0 : NS * IPS) + ((MGM_P2_EXP & 2) ? 0 : 1 + (HASM ? 1 : 0));
+    static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + NS * IPS + 1 + (HASM ? 1 : 0);
     static constexpr int nB = (C8 && NL == 2) ? NDMA : (NC - NCA) * IPS;
     static constexpr bool DEC = MGM_P2_DECOUPLED != 0;
     // Ring geometry: RT = T-ring slots per line (2 with barriers), RDEPTH = steps of C / hand-off data the rings
@@ -363,19 +354,15 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     }
                     if (dbg) t_slow += wall_clock64() - t0;
                 }
-                if constexpr (!(MGM_P2_EXP & 4)) {
 #pragma unroll
                 for (int q = 0; q < NS; q++)
 #pragma unroll
                     for (int c = 0; c < IPS; c++)
                         if (c * 64 + lane < LPL * 16)
                             dma16<AUX_SC1>(hptr + q * LP + c * 256, Hring + (slot * NS + q) * LP + c * 256);
-                }
-                if constexpr (!(MGM_P2_EXP & 2)) {
                 if constexpr (!pubE)
                     if (lane == 0) dma4<AUX_SC1>(hmptr, Hm + slot);
                 if (lane == 0) dma4<AUX_SC1>(prog_in, Hprog + slot);
-                }
                 const bool adv = ht >= 0 && ht < LL - 1;
                 hptr += adv ? NSLP : 0;
                 hmptr += adv ? 1 : 0;
@@ -593,19 +580,11 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     ph[1] += clock64() - c1;  // combine
                 }
                 const unsigned long long c2 = prof ? clock64() : 0;
-                auto store_lr = [&]() {
-                    if (!(P.xflags & 1)) {
-                        float *q = Lrb + pix * L + lane * LPL;
-#if MGM_P2_NT_STORE
+                if (!(P.xflags & 1)) {
+                    float *q = Lrb + pix * L + lane * LPL;
 #pragma unroll
-                        for (int k = 0; k < LPL; k++) __builtin_nontemporal_store(Lv[k], q + k);
-#else
-#pragma unroll
-                        for (int k = 0; k < LPL; k++) q[k] = Lv[k];
-#endif
-                    }
-                };
-                if constexpr (!MGM_P2_LATE_STORE) store_lr();
+                    for (int k = 0; k < LPL; k++) q[k] = Lv[k];
+                }
                 const float m = slab_min<LPL>(Lv);
                 nb_i.m = m;
                 if (prof) {
@@ -678,10 +657,6 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                         if (lane == 0) __hip_atomic_store(prog_out, (unsigned)(i - PUBLAG + 1), RLX_AGENT);
                     }
                 }
-                // The 15 lock-stepped waves reach their Lr store together and the stores drain one at a time; a wave
-                // that overwrites the stored registers right away stalls on that queue.  Issued last, the drain
-                // overlaps the barrier and the next step's LDS reads instead.
-                if constexpr (MGM_P2_LATE_STORE) store_lr();
             }
         };
 
