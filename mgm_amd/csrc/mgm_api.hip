@@ -842,7 +842,19 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.P2 = P2;
     p.dbg = nullptr;
     p.xflags = 0;
-    p.wg_per_cu = nb >= 3 ? 2 : 1;  // measured: two bands per CU pay from three volumes per launch on
+    {
+        // Two bands per CU pay when the launch is bound by throughput, not by the longest chain of bands: compare the
+        // band-steps one CU has to run with the critical path of the slowest pass (steps of slope*lines + line length
+        // + ~10 per band hand-off).  Measured break-even at a ratio of ~1.8: cfg3 needs 3 volumes per launch, one
+        // 4096x4096 volume is enough.
+        double work = 0, chain = 0;
+        for (int q = first; q < PEND; q++) {
+            const PassGeom &g = p.g[q];
+            work += (double)nb * g.nbands * (g.LL + g.slope * R);
+            chain = std::max(chain, (double)g.slope * g.NL + g.LL + 10.0 * g.nbands);
+        }
+        p.wg_per_cu = (work / 256.0 > 1.8 * chain) ? 2 : 1;
+    }
     if (const char *e = getenv("MGM_HIP_WG_PER_CU")) p.wg_per_cu = atoi(e);
     if (const char *e = getenv("MGM_HIP_XFLAGS")) p.xflags = atoi(e);
     if (c->debug_stats && R2) {

@@ -360,12 +360,15 @@ __global__ void __launch_bounds__(256) k_cost_census8(const uint32_t *__restrict
             dst[0] = (uint8_t)(anyfinite ? b[0] : 0u);
         } else if constexpr (LPL == 2) {
             *reinterpret_cast<unsigned short *>(dst) = (unsigned short)(anyfinite ? (b[0] | (b[1] << 8)) : 0u);
-        } else {
+        } else if constexpr (LPL % 4 == 0) {
 #pragma unroll
             for (int h = 0; h < LPL / 4; h++) {
                 const unsigned w = b[4 * h] | (b[4 * h + 1] << 8) | (b[4 * h + 2] << 16) | (b[4 * h + 3] << 24);
                 reinterpret_cast<unsigned *>(dst)[h] = anyfinite ? w : 0u;
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < LPL; k++) dst[k] = (uint8_t)(anyfinite ? b[k] : 0u);
         }
     }
 }
@@ -381,7 +384,9 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
         switch (p.L / 64) {
             case 1: hipLaunchKernelGGL(k_cost_census8<1>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
             case 2: hipLaunchKernelGGL(k_cost_census8<2>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+            case 3: hipLaunchKernelGGL(k_cost_census8<3>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
             case 4: hipLaunchKernelGGL(k_cost_census8<4>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+            case 6: hipLaunchKernelGGL(k_cost_census8<6>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
             default: hipLaunchKernelGGL(k_cost_census8<8>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
         }
         return hipGetLastError();

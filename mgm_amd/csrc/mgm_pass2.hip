@@ -178,7 +178,7 @@ struct Plan {
     static constexpr int rd(int) { return RDEPTH; }
     static constexpr int lds_floats(int) { return lds_floats3(RT, RDEPTH); }
     static_assert(D >= 2, "no feasible pipeline depth");
-    static_assert(!C8 || (64 % LPS == 0), "compact slabs must tile a DMA piece");
+    static_assert(!C8 || LPD >= 1, "a compact slab must fit a DMA piece");  // (64 % LPS lanes of a piece may idle: L = 192, 384)
     static_assert((RT & (RT - 1)) == 0, "RT must be a power of two");
 };
 
@@ -515,13 +515,16 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                         const unsigned w = *reinterpret_cast<const unsigned short *>(src);
                         Cv[0] = c8_decode(w & 255u);
                         Cv[1] = c8_decode(w >> 8);
-                    } else {
+                    } else if constexpr (LPL % 4 == 0) {
 #pragma unroll
                         for (int h = 0; h < LPL / 4; h++) {
                             const unsigned w = reinterpret_cast<const unsigned *>(src)[h];
 #pragma unroll
                             for (int k = 0; k < 4; k++) Cv[h * 4 + k] = c8_decode((w >> (8 * k)) & 255u);
                         }
+                    } else {  // 3 or 6 labels per lane: the lane's bytes are not word-aligned
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) Cv[k] = c8_decode(src[k]);
                     }
                 } else {
                     const float *src = c_src0 + cslot * LP;
@@ -760,9 +763,7 @@ static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 template <int LPL, bool FH, bool WEIGHTED, int MGM>
 static hipError_t launch2_one(const PassParams &p, int ntasks, hipStream_t s)
 {
-    if constexpr (LPL == 1 || LPL == 2 || LPL == 4 || LPL == 8) {
-        if (p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true>(p, ntasks, s);
-    }
+    if (p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true>(p, ntasks, s);
     return launch2_c8<LPL, FH, WEIGHTED, MGM, false>(p, ntasks, s);
 }
 

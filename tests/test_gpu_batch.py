@@ -15,6 +15,7 @@ MODES = [
     (60, 33, 128, 8, 3, 0, 8.0, 32.0, True),       # weighted Hirschmueller
     (60, 33, 64, 4, 2, 1, 2.0, 50.0, True),        # weighted FH, 4 directions
     (70, 41, 100, 8, 3, 0, 8.0, 32.0, False),      # label count the second build does not take: first build
+    (66, 30, 192, 8, 3, 1, 2.0, 20000.0, False),   # 3 labels per lane: compact slabs leave 4 lanes of a DMA piece idle
 ]
 
 

@@ -125,6 +125,7 @@ COSTS = [(1, (40, 23), (-7, 8), "none", "ad", 3, np.inf), (3, (40, 23), (-7, 8),
          (1, (70, 23), (-40, 23), "none", "census", 5, np.inf), (1, (70, 23), (-100, 27), "none", "census", 5, 7.0),
          (1, (70, 23), (-200, 55), "none", "census", 5, 7.5), (1, (300, 9), (-255, 0), "none", "census", 7, np.inf),
          (1, (300, 9), (-255, 0), "none", "census", 5, 0.0), (1, (90, 31), (0, 63), "none", "census", 3, np.inf),
+         (1, (70, 23), (-100, 91), "none", "census", 5, np.inf), (1, (40, 9), (-200, 183), "none", "census", 3, 6.0),  # 192, 384 labels
          # sobelx / gblur prefilters (Neumann boundary, the reference's accumulation order) under AD and SD
          (1, (40, 23), (-7, 8), "sobelx", "ad", 3, np.inf), (3, (33, 17), (-20, 12), "sobelx", "sd", 3, 900.0),
          (1, (40, 23), (-7, 8), "gblur", "ad", 3, np.inf), (3, (33, 17), (-20, 12), "gblur", "sd", 3, 50.0),
