@@ -1,0 +1,72 @@
+"""Seeded random small cases against the oracle: odd image sizes (down to 1x1), label counts on both sides of every
+kernel-selection threshold, every mode -- the corners the structured sweeps do not visit."""
+import numpy as np
+import pytest
+
+from helpers import ndiff
+from mgm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+LABELS = [1, 2, 3, 5, 31, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 511, 512]
+
+
+@pytest.mark.parametrize("seed", range(160))
+def test_random_case_vs_oracle(ctx, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    nx, ny = int(rng.integers(1, 40)), int(rng.integers(1, 30))
+    if seed % 5 == 0:
+        nx, ny = [(1, 1), (1, 7), (7, 1), (2, 2), (3, 3), (2, 9), (9, 2), (4, 3)][(seed // 5) % 8]
+    L = LABELS[int(rng.integers(0, len(LABELS)))]
+    if nx * ny * L > 60000:
+        L = LABELS[int(rng.integers(0, 8))]
+    NDIR = int(rng.integers(1, 9))
+    MGM = int(rng.integers(1, 5))
+    FH = int(rng.integers(0, 2))
+    P1, P2 = [(8.0, 32.0), (2.0, 9.0), (1.5, 20000.0), (2.0, np.inf), (0.5, 3.25)][int(rng.integers(0, 5))]
+    fix = int(rng.integers(0, 2))
+    dmin = int(rng.integers(-300, 300))
+    integer = rng.random() < 0.6
+    C = synth.raw_volume(nx, ny, L, seed=seed, inf_frac=float(rng.choice([0.0, 0.05, 0.5])))
+    if not integer:
+        C = (C * np.float32(1.0 / 3.0)).astype(np.float32)
+    w8 = None
+    if rng.random() < 0.3:
+        w8 = np.where(rng.random((8, ny, nx)) < 0.5, np.float32(rng.choice([4.0, 0.3, 1.0 / 3.0])), np.float32(1)).astype(np.float32)
+    refine = [None, "vfit", "parabola", "cubic", "parabolaOCV"][int(rng.integers(0, 5))]
+    So, oo, co = oracle.mgm(C, dmin, P1, P2, NDIR, MGM, FH, fix, w8)
+    if refine:
+        oo2 = np.where(np.isfinite(co), oo, dmin).astype(np.float32)
+        ro, rc = oracle.refine(So, dmin, refine, oo2, co)
+    else:
+        ro, rc = oo, co
+    cv = ctx.upload_volume(C, dmin)
+    S, o, c = ctx.aggregate(cv, P1, P2, NDIR, MGM, FH, fix, w8, refine, want_S=True)
+    tag = (nx, ny, L, NDIR, MGM, FH, P1, P2, fix, integer, w8 is not None, refine)
+    assert ndiff(S.download(), So) == 0, tag
+    assert ndiff(c, rc) == 0, tag
+    fin = np.isfinite(co)
+    assert ndiff(o[fin], ro[fin]) == 0, tag
+    S.free(), cv.free()
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_costvolume_vs_oracle(ctx, oracle, seed):
+    rng = np.random.default_rng(5000 + seed)
+    nch = int(rng.choice([1, 3]))
+    nx, ny = int(rng.integers(1, 50)), int(rng.integers(1, 25))
+    vnx, vny = (nx, ny) if rng.random() < 0.7 else (max(1, nx - int(rng.integers(0, 5))), max(1, ny - int(rng.integers(0, 4))))
+    L = int(rng.choice([1, 7, 33, 64, 100, 128, 192, 256]))
+    dmin = int(rng.integers(-L, 10))
+    pre = str(rng.choice(["none", "census", "sobelx", "gblur"]))
+    dist = str(rng.choice(["ad", "sd", "census", "ncc", "btad", "btsd"]))
+    win = int(rng.choice([3, 5, 7]))
+    if "census" in (pre, dist) and (nch * (win * win - 1)) % 8:
+        win = 3
+    td = float(rng.choice([np.inf, 30.0, 7.0, 2.5]))
+    u = rng.integers(0, 256, size=(nch, ny, nx)).astype(np.float32)
+    v = rng.integers(0, 256, size=(nch, vny, vnx)).astype(np.float32)
+    a = oracle.costvolume(u, v, dmin, dmin + L - 1, pre, dist, td, win)
+    cv = ctx.costvolume_dev(ctx.upload_image(u), ctx.upload_image(v), dmin, dmin + L - 1, pre, dist, td, win)
+    assert ndiff(cv.download(), a) == 0, (nch, nx, ny, vnx, vny, L, dmin, pre, dist, win, td)
+    cv.free()
