@@ -65,6 +65,9 @@ struct mgm_ctx {
     long long last_stride = 0;  // floats between the Lr volumes of consecutive passes (>= last_nvol)
     int last_ndir = 0;
     int last_batch = 0;
+    int last_L = 0, last_Lk = 0;          // labels of the last aggregation, and the label stride its kernels ran with (>= last_L)
+    Buf padf[kMaxBatch], pad8[kMaxBatch];  // padded copies of the cost volumes of a launch whose label count was padded
+    bool last_pad_c8 = false;
     const mgm_cv *last_cvs[kMaxBatch] = {};  // the volumes of the last aggregation (identity only, never dereferenced)
     bool pending_check = false;
     // timing
@@ -260,7 +263,9 @@ int mgm_ctx_destroy(mgm_ctx *c)
     if (!c) return MGM_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (Buf *b : {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8})
+    for (Buf *b : {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8, &c->padf[0], &c->padf[1], &c->padf[2], &c->padf[3], &c->padf[4], &c->padf[5],
+                   &c->padf[6], &c->padf[7], &c->pad8[0], &c->pad8[1], &c->pad8[2], &c->pad8[3], &c->pad8[4], &c->pad8[5], &c->pad8[6],
+                   &c->pad8[7]})
         if (b->p) hipFree(b->p);
     for (auto &t : c->tim) {
         hipEventDestroy(t.a);
@@ -704,14 +709,36 @@ int mgm_weights_dev(mgm_ctx *c, const mgm_img *u, float aP, float aThresh, mgm_i
 // workspace slot p - first.  Shared by mgm_aggregate_dev and the direction-sharded multi-GPU path.
 // K3 over `nb` cost volumes of identical geometry in one launch (see PassVolume).  Volume v's Lr volumes
 // end up at lr + v*count*lr_stride.
+// smallest label count the second K3 build takes that holds L labels (0: none)
+static int padded_labels(int L)
+{
+    for (int lp : {64, 128, 192, 256, 384, 512})
+        if (lp >= L) return lp;
+    return 0;
+}
+
 static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int nb, float P1, float P2, int MGM,
-                      int use_fh, int first, int count)
+                      int use_fh, int first, int count, bool allow_pad = false)
 {
     const mgm_cv *C = Cs[0];
-    const int nx = C->nx, ny = C->ny, L = C->dmax - C->dmin + 1;
+    const int nx = C->nx, ny = C->ny, Lreal = C->dmax - C->dmin + 1;
     const int PEND = first + count;
     HIPCHK(c, hipSetDevice(c->device));
 
+    // A label count the second build does not take (not 64, 128, 192, 256, 384 or 512) runs PADDED: the kernels see
+    // the next such count, the extra label slots hold +INF costs -- "no such label", exactly what a read past a Dvec
+    // returns (dvec.cc:129) -- and stay +INF through every update as long as P2 is finite (every term is capped at
+    // m + P2).  With P2 = +INF, or when asked not to, such a volume takes the first build.
+    int L = Lreal;
+    bool padded = false;
+    if (allow_pad && c->force_build != 1 && pass2_lines(Lreal, false) == 0 && P2 < __builtin_huge_valf() &&
+        !(getenv("MGM_HIP_PAD") && atoi(getenv("MGM_HIP_PAD")) == 0)) {
+        const int lp = padded_labels(Lreal);
+        if (lp) {
+            L = lp;
+            padded = true;
+        }
+    }
     const long long npix = (long long)nx * ny, nvol = npix * L;
     const int lpl = pass_lpl(L), LP = lpl * 64;
     int r;
@@ -766,10 +793,30 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
 
     // compact costs (one byte per label) when the volume allows it
     bool use_c8 = true;
-    for (int v = 0; v < nb; v++) {
-        bool u = false;
-        if ((r = c8_resolve(c, Cs[v], &u))) return r;
-        use_c8 = use_c8 && u;
+    if (padded) {
+        // padded copies of the costs: the compact form if every volume allows it, else fp32
+        HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
+        for (int v = 0; v < nb; v++) {
+            if ((r = ensure_f32(c, Cs[v]))) return r;
+            if ((r = reserve(c, c->pad8[v], (size_t)npix * L))) return r;
+            TimeScope t(c, "k_pad");
+            HIPCHK(c, launch_pad(Cs[v]->d, npix, Lreal, L, nullptr, (uint8_t *)c->pad8[v].p, words + 3, c->stream));
+        }
+        HIPCHK(c, hipMemcpyAsync(c->h_words + 3, words + 3, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        use_c8 = c->h_words[3] == 0 && !(getenv("MGM_HIP_C8") && atoi(getenv("MGM_HIP_C8")) == 0);
+        if (!use_c8)
+            for (int v = 0; v < nb; v++) {
+                if ((r = reserve(c, c->padf[v], sizeof(float) * (size_t)npix * L))) return r;
+                TimeScope t(c, "k_pad");
+                HIPCHK(c, launch_pad(Cs[v]->d, npix, Lreal, L, (float *)c->padf[v].p, nullptr, nullptr, c->stream));
+            }
+    } else {
+        for (int v = 0; v < nb; v++) {
+            bool u = false;
+            if ((r = c8_resolve(c, Cs[v], &u))) return r;
+            use_c8 = use_c8 && u;
+        }
     }
     if (c->force_build == 1) use_c8 = false;
     // second build (LDS-DMA loaders) whenever the slabs are whole DMA pieces
@@ -816,8 +863,8 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
 
     for (int v = 0; v < nb; v++) {
         if (!use_c8 && (r = ensure_f32(c, Cs[v]))) return r;
-        p.vol[v].C = Cs[v]->d;
-        p.vol[v].C8 = use_c8 ? Cs[v]->d8 : nullptr;
+        p.vol[v].C = padded ? (const float *)c->padf[v].p : Cs[v]->d;
+        p.vol[v].C8 = use_c8 ? (padded ? (const uint8_t *)c->pad8[v].p : Cs[v]->d8) : nullptr;
         p.vol[v].Lr = (float *)c->lr.p + (size_t)v * count * lr_stride;
         p.vol[v].w8 = ones8 ? ones8 : (weighted ? w8s[v]->d : nullptr);
         p.vol[v].rlo = (fh && ragged) ? Cs[v]->rlo : nullptr;
@@ -832,6 +879,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.npix = npix;
     p.nvol = lr_stride;
     p.L = L;
+    p.Lreal = Lreal;
     p.MGM = MGM;
     p.dmin = C->dmin;
     p.NDIR = PEND;
@@ -934,22 +982,34 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     c->last_stride = lr_stride;
     c->last_ndir = count;
     c->last_batch = nb;
+    c->last_L = Lreal;
+    c->last_Lk = L;
+    c->last_pad_c8 = padded && use_c8;
     for (int v = 0; v < kMaxBatch; v++) c->last_cvs[v] = v < nb ? Cs[v] : nullptr;
 
     return MGM_OK;
 }
 
 // K4-K6 over `npix` pixels starting at pixel `pix0` of C, reading pass p's Lr from lr + p*lr_stride.
+// `slot` >= 0: the volume was slot `slot` of the context's last aggregation; if that launch ran with a padded label
+// count, its padded cost copies and label stride are used (see run_passes).  slot < 0: plain [pix][L] layout.
 static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const float *lr, long long lr_stride, int NDIR,
                    int fix_overcount, int ridx, float *out, float *outcost, float *Sout, const float *wlo = nullptr,
-                   const float *whi = nullptr)
+                   const float *whi = nullptr, int slot = -1)
 {
-    const int L = C->dmax - C->dmin + 1;
+    const int Lreal = C->dmax - C->dmin + 1;
+    const bool padded = slot >= 0 && c->last_Lk > c->last_L && c->last_L == Lreal;
+    const int L = padded ? c->last_Lk : Lreal;
     WtaParams w{};
-    w.C = C->d + pix0 * L;
-    w.C8 = (C->c8_state == 2 && c->force_build != 1) ? C->d8 + pix0 * L : nullptr;
-    if (!w.C8)
-        if (int r = ensure_f32(c, C)) return r;
+    if (padded) {
+        w.C = c->last_pad_c8 ? nullptr : (const float *)c->padf[slot].p + pix0 * L;
+        w.C8 = c->last_pad_c8 ? (const uint8_t *)c->pad8[slot].p + pix0 * L : nullptr;
+    } else {
+        w.C = C->d + pix0 * L;
+        w.C8 = (C->c8_state == 2 && c->force_build != 1) ? C->d8 + pix0 * L : nullptr;
+        if (!w.C8)
+            if (int r = ensure_f32(c, C)) return r;
+    }
     w.Lr = lr;
     w.S = Sout;
     w.out = out;
@@ -957,6 +1017,7 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
     w.npix = npix;
     w.nvol = lr_stride;
     w.L = L;
+    w.Lreal = Lreal;
     w.NDIR = NDIR;
     w.FIX = fix_overcount;
     w.dmin = C->dmin;
@@ -975,21 +1036,21 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
 // parabolaOCV (refine.h:6-145) run as a second kernel on the corrected S (the caller's, or a scratch volume).
 static int run_wta_refine(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const float *lr, long long lr_stride,
                           int NDIR, int fix_overcount, int ridx, float *out, float *outcost, float *Sout,
-                          const float *wlo = nullptr, const float *whi = nullptr)
+                          const float *wlo = nullptr, const float *whi = nullptr, int slot = -1)
 {
     if (!wlo && C->rlo) {  // a ragged volume: S is allocated from the same range images (mgm_core.cc:426)
         wlo = C->rlo;
         whi = C->rhi;
     }
-    if (ridx <= 1 && !wlo) return run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, ridx, out, outcost, Sout);
-    if (ridx == 0) return run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, 0, out, outcost, Sout, wlo, whi);
+    if (ridx <= 1 && !wlo) return run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, ridx, out, outcost, Sout, nullptr, nullptr, slot);
+    if (ridx == 0) return run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, 0, out, outcost, Sout, wlo, whi, slot);
     const int L = C->dmax - C->dmin + 1;
     int r;
     if (!Sout) {
         if ((r = reserve(c, c->stmp, sizeof(float) * (size_t)npix * L))) return r;
         Sout = (float *)c->stmp.p;
     }
-    if ((r = run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, 0, out, outcost, Sout, wlo, whi))) return r;
+    if ((r = run_wta(c, C, pix0, npix, lr, lr_stride, NDIR, fix_overcount, 0, out, outcost, Sout, wlo, whi, slot))) return r;
     // what a disparity of a pixel's window outside the volume holds: S stays 0, minus (NDIR-1)*C with C = +INF
     float vout = 0.0f;
     if (fix_overcount == 1) vout = vout - (float)(NDIR - 1) * __builtin_huge_valf();
@@ -1024,7 +1085,7 @@ int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm
     const int ridx = refinement_index(refine);
     HIPCHK(c, hipSetDevice(c->device));
     int r;
-    if ((r = run_passes(c, C, (w8 && w8[0]) ? w8 : nullptr, n, P1, P2, MGM, use_fh, 0, NDIR))) return r;
+    if ((r = run_passes(c, C, (w8 && w8[0]) ? w8 : nullptr, n, P1, P2, MGM, use_fh, 0, NDIR, /*allow_pad=*/true))) return r;
     const long long npix = (long long)nx * ny;
     for (int v = 0; v < n; v++) {
         float *Sout = nullptr;
@@ -1033,7 +1094,8 @@ int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm
             Sout = S[v]->d;
         }
         const float *lr = (const float *)c->lr.p + (size_t)v * NDIR * c->last_stride;
-        if ((r = run_wta_refine(c, C[v], 0, npix, lr, c->last_stride, NDIR, fix_overcount, ridx, out[v]->d, outcost[v]->d, Sout)))
+        if ((r = run_wta_refine(c, C[v], 0, npix, lr, c->last_stride, NDIR, fix_overcount, ridx, out[v]->d, outcost[v]->d, Sout, nullptr,
+                                nullptr, v)))
             return r;
     }
     return MGM_OK;
@@ -1062,7 +1124,7 @@ int mgm_aggregate_passes_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, flo
 
 void *mgm_lr_device_ptr(mgm_ctx *c, int slot)
 {
-    if (!c || !c->lr.p || slot < 0 || slot >= c->last_ndir) return nullptr;
+    if (!c || !c->lr.p || slot < 0 || slot >= c->last_ndir || c->last_Lk != c->last_L) return nullptr;
     return (float *)c->lr.p + (size_t)slot * c->last_stride;
 }
 
@@ -1102,8 +1164,10 @@ int mgm_debug_download_lr(mgm_ctx *c, int pass, float *dense)
     if (!c || !dense || pass < 0 || pass >= c->last_ndir || !c->lr.p)
         return fail(c, MGM_ERR_INVALID, "mgm_debug_download_lr: nothing to download");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(dense, (const float *)c->lr.p + (size_t)pass * c->last_stride, sizeof(float) * c->last_nvol,
-                             hipMemcpyDeviceToHost, c->stream));
+    // (a launch with a padded label count keeps last_Lk floats per pixel, of which the first last_L exist)
+    HIPCHK(c, hipMemcpy2DAsync(dense, sizeof(float) * c->last_L, (const float *)c->lr.p + (size_t)pass * c->last_stride,
+                               sizeof(float) * c->last_Lk, sizeof(float) * c->last_L, (size_t)(c->last_nvol / c->last_Lk),
+                               hipMemcpyDeviceToHost, c->stream));
     return mgm_ctx_synchronize(c);
 }
 
@@ -1147,11 +1211,11 @@ int mgm_wta_windowed_dev(mgm_ctx *c, const mgm_cv *C, int NDIR, int fix_overcoun
     int slot = -1;
     for (int v = 0; v < c->last_batch; v++)
         if (c->last_cvs[v] == C) slot = v;
-    if (!c->lr.p || slot < 0 || c->last_ndir != NDIR || c->last_nvol != (long long)nx * ny * L)
+    if (!c->lr.p || slot < 0 || c->last_ndir != NDIR || c->last_L != L)
         return fail(c, MGM_ERR_INVALID, "mgm_wta_windowed: this volume was not part of the context's last aggregation with NDIR passes");
     HIPCHK(c, hipSetDevice(c->device));
     return run_wta_refine(c, C, 0, (long long)nx * ny, (const float *)c->lr.p + (size_t)slot * NDIR * c->last_stride, c->last_stride, NDIR, fix_overcount,
-                          refinement_index(refine), out->d, outcost->d, nullptr, dminI->d, dmaxI->d);
+                          refinement_index(refine), out->d, outcost->d, nullptr, dminI->d, dmaxI->d, slot);
 }
 
 int mgm_update_ranges_dev(mgm_ctx *c, const mgm_img *outoff, mgm_img *dminI, mgm_img *dmaxI, int slack, int radius)

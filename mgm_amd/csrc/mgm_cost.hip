@@ -298,6 +298,34 @@ hipError_t launch_expand(const uint8_t *C8, long long n, float *C, hipStream_t s
     return hipGetLastError();
 }
 
+// [pix][L] -> [pix][LP] (LP > L, a multiple of 64): the label slots L..LP-1 get +INF, i.e. "no such label" (dvec.cc:129).
+// Writes the fp32 copy and/or the compact copy (with its "not representable" flag).  One wave per pixel.
+__global__ void __launch_bounds__(256) k_pad(const float *__restrict__ C, long long npix, int L, int LP, float *__restrict__ Cp,
+                                             uint8_t *__restrict__ C8p, unsigned *bad8)
+{
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    for (long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (long long)gridDim.x * 4)
+        for (int o = lane; o < LP; o += 64) {
+            const float x = o < L ? C[pix * L + o] : __builtin_huge_valf();
+            if (Cp) Cp[pix * LP + o] = x;
+            if (C8p) {
+                const unsigned b = c8_encode(x);
+                bad |= b > 255u;
+                C8p[pix * LP + o] = (uint8_t)b;
+            }
+        }
+    if (C8p && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicOr(bad8, 1u);
+}
+
+hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, unsigned *bad8, hipStream_t s)
+{
+    long long nb = (npix + 3) / 4;
+    if (nb > 256 * 32) nb = 256 * 32;
+    hipLaunchKernelGGL(k_pad, dim3((unsigned)nb), dim3(256), 0, s, C, npix, L, LP, Cp, C8p, bad8);
+    return hipGetLastError();
+}
+
 hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s)
 {
     hipLaunchKernelGGL(k_compact, dim3(256 * 16), dim3(256), 0, s, C, n, C8, bad8);

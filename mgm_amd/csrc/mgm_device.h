@@ -54,6 +54,7 @@ struct PassParams {
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
     long long npix, nvol;
     int L, MGM, NDIR, dmin;
+    int Lreal;          // labels that exist (<= L): a label count the second build does not take runs padded to L with +INF costs
     int pass0;          // pass p writes its Lr volume to slot p - pass0
     int LLmax, maxbands;
     float P1, P2;
@@ -68,6 +69,7 @@ struct WtaParams {
     float *out, *outcost;
     long long npix, nvol;
     int L, NDIR, FIX, dmin, refine;  // refine: 0 none, 1 vfit
+    int Lreal;                       // labels that exist (<= L, the stride of C / C8 / Lr); S is written with stride Lreal
     // mgm() called with range images narrower or wider than the volume's own range (mgm.cc:377-388, every TSGM_ITER
     // iteration after the first): the winner is sought among the disparities [(int)wlo, (int)whi] of each pixel; a
     // disparity of that window outside the volume holds S = 0 - (NDIR-1)*INF (0 without the over-count fix).
@@ -88,6 +90,7 @@ hipError_t launch_pass2_lpl(const PassParams &p, int ntasks, bool fh, int wmode,
 // compact-cost support: labels per lane for which the C8 forms of K3 / k_wta exist
 inline bool c8_supported(int L) { return L == 64 || L == 128 || L == 192 || L == 256 || L == 384 || L == 512; }
 hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s);
+hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, unsigned *bad8, hipStream_t s);
 hipError_t launch_expand(const uint8_t *C8, long long n, float *C, hipStream_t s);
 hipError_t launch_wta(const WtaParams &p, hipStream_t s);
 hipError_t launch_median(const float *u, int nx, int ny, int nch, int radius, float *out, hipStream_t s);

@@ -569,9 +569,9 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                                 combine_whirsch<LPL>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, Lv);
                         } else {
                             if constexpr (FORM == 0)
-                                combine_wfh<LPL, true>(Cv, nb_i, nb_same, nb_back, nb_fwd, Dw, P1, P2, MGM, lane, L, Lv, rl, rh);
+                                combine_wfh<LPL>(Cv, nb_i, nb_same, nb_back, nb_fwd, Dw, P1, P2, MGM, lane, P.Lreal, Lv, rl, rh);
                             else
-                                combine_wfh<LPL, true>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, lane, L, Lv, rl, rh);
+                                combine_wfh<LPL>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, lane, P.Lreal, Lv, rl, rh);
                         }
                     }
                 } else {
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 #pragma unroll
                         for (int k = 0; k < LPL; k++) nb_i.w[0][k] = Lv[k];
                         unsigned sw = 0;
-                        fh_minconv<LPL, true>(nb_i.w[0], m, P1, P2, lane, L, sw);
+                        fh_minconv<LPL>(nb_i.w[0], m, P1, P2, lane, P.Lreal, sw);
                         if (prof) { fh_sweeps += sw; fh_max = sw > fh_max ? sw : fh_max; fh_n++; fh_rep += sw > 2; }
                     }
                     if constexpr (pubE) {

@@ -220,8 +220,7 @@ template <int LPL, bool FULL = false>
 __device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, float P2, int lane, int L, unsigned &sweeps)
 {
     fh_scan<LPL, true>(M, P1, lane, sweeps);
-    if constexpr (!FULL) {
-        // label slots >= L hold +INF on entry; the forward scan has filled them with ramp values
+    if (L < 64 * LPL) {  // (wave-uniform) label slots >= L hold +INF on entry; the forward scan has filled them with ramp values
 #pragma unroll
         for (int k = 0; k < LPL; k++) M[k] = (lane * LPL + k < L) ? M[k] : f_inf();
     }

@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
     constexpr int LP = LPL * 64;
     __shared__ float sS[4][LP];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int L = P.L;
+    const int L = P.L;          // stride of the slabs (a multiple of 64 when EXACT)
+    const int Lr_ = P.Lreal;    // labels that exist
     constexpr bool exact = EXACT;  // L == 64*LPL: no label slot is padding, loads need no guard
     const int o0 = lane * LPL;
     const bool c8 = P.C8 && exact;  // compact costs: one byte per label (wave-uniform)
@@ -105,10 +106,10 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
                     if (o0 + k < cl || o0 + k > ch) S[k] = vout;
             }
             if (P.S) {
-                float *q = P.S + pix * L + o0;
+                float *q = P.S + pix * Lr_ + o0;
 #pragma unroll
                 for (int k = 0; k < LPL; k++)
-                    if (exact || o0 + k < L) q[k] = S[k];
+                    if (o0 + k < Lr_) q[k] = S[k];
             }
             // first strict minimum among finite entries, ascending o
             float best = f_inf();
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
 #pragma unroll
             for (int k = 0; k < LPL; k++) {
                 const float v = S[k];
-                if ((exact || o0 + k < L) && (!windowed || (o0 + k >= wl && o0 + k <= wh)) && finite_bits(v) && best > v) {
+                if (o0 + k < Lr_ && (!windowed || (o0 + k >= wl && o0 + k <= wh)) && finite_bits(v) && best > v) {
                     best = v;
                     bi = o0 + k;
                 }
@@ -143,8 +144,8 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
                         best = vout;
                         bi = wl;
                     }
-                    const int hi0 = wl > L ? wl : L;
-                    if (wh >= L && hi0 <= wh && vout < best) {
+                    const int hi0 = wl > Lr_ ? wl : Lr_;
+                    if (wh >= Lr_ && hi0 <= wh && vout < best) {
                         best = vout;
                         bi = hi0;
                     }
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
                 outv = __builtin_nanf("");  // the reference leaves minP uninitialised here
             } else {
                 outv = (float)(bi + P.dmin);
-                if (P.refine == 1 && !windowed && bi - 1 >= 0 && bi + 2 <= L - 1) {  // mgm_refine.h:58
+                if (P.refine == 1 && !windowed && bi - 1 >= 0 && bi + 2 <= Lr_ - 1) {  // mgm_refine.h:58
 #pragma unroll
                     for (int k = 0; k < LPL; k++) sS[wv][o0 + k] = S[k];
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
