@@ -95,3 +95,21 @@ def test_quarter_size_end_to_end_vs_oracle(ctx, oracle):
     oracle.set_threads(1)
     for h in (cv, du, dv):
         h.free()
+
+
+def test_full_size_batch_equals_single(ctx, vol256):
+    """Four full-size volumes in one pass launch (two bands per CU, the occupancy bench.py runs at) give each volume
+    exactly the result of its own launch (one band per CU, chain-bound)."""
+    P1, P2, NDIR, MGM, FH = 2.0, 20000.0, 8, 3, 1
+    rng = np.random.default_rng(17)
+    vols = [vol256] + [np.roll(vol256, int(rng.integers(1, 200)), axis=k % 3) for k in range(3)]
+    cvs = [ctx.upload_volume(v, -255) for v in vols]
+    ref = []
+    for cv in cvs:
+        _, o, c = ctx.aggregate_dev(cv, P1, P2, NDIR, MGM, FH, 1, None, "vfit")
+        ref.append((o.download(), c.download()))
+    _, outs, outcs = ctx.aggregate_batch_dev(cvs, P1, P2, NDIR, MGM, FH, 1, None, "vfit")
+    for b in range(len(cvs)):
+        assert ndiff(outs[b].download(), ref[b][0]) == 0 and ndiff(outcs[b].download(), ref[b][1]) == 0, b
+    for cv in cvs:
+        cv.free()
