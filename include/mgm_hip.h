@@ -96,9 +96,8 @@ int mgm_costvolume_build_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, i
  * int as Dvec's constructor does (mgm_costvolume.h:323).  Uniform ranges take the fast path.  RAGGED ranges
  * (-m/-M files) give a volume over the hull of all ranges in which a pixel only owns the disparities of its own
  * range -- the others read +INF, as Dvec::operator[] does (dvec.cc:129), and are exempt from the "no finite cost"
- * rule; mgm_aggregate* then searches the winner and gates the refinement inside each pixel's range.  Two
- * combinations return MGM_ERR_UNSUPPORTED on a ragged volume: FH potentials with TSGM = 2 and no weights (the
- * reference's boundary fix-up, mgm_core.cc:166-186), and P2 = +INF.  The hull may span at most 512 labels; batched volumes that are ragged
+ * rule; mgm_aggregate* then searches the winner and gates the refinement inside each pixel's range.  One
+ * combination returns MGM_ERR_UNSUPPORTED on a ragged volume: P2 = +INF.  The hull may span at most 512 labels; batched volumes that are ragged
  * must share hull_min. */
 int mgm_costvolume_build(mgm_ctx *ctx, const float *u, const float *v, int nx, int ny, int nch, int vnx, int vny,
                          const float *dminI, const float *dmaxI, const char *prefilter, const char *distance,

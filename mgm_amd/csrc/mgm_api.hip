@@ -778,10 +778,13 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     if (fh && ragged)
         for (int v = 1; v < nb; v++)
             if (Cs[v]->dmin != Cs[0]->dmin) return fail(c, MGM_ERR_UNSUPPORTED, "batched ragged volumes must share their hull under FH potentials");
+    bool fh2_ragged = false;
     if (fh && ragged && !weighted) {
-        if (MGM == 2)
-            return fail(c, MGM_ERR_UNSUPPORTED, "FH potentials with TSGM=2 and no weights on a ragged cost volume are not built yet "
-                                                "(update_cost2_trunclinear's boundary fix-up, mgm_core.cc:166-186)");
+        // TSGM = 2 without weights is update_cost2_trunclinear with its boundary fix-up (166-186, 197-219): the second
+        // build has it (combine_fh2_ragged); the first build does not
+        fh2_ragged = MGM == 2;
+        if (fh2_ragged && (c->force_build == 1 || (pass2_lines(L, false) == 0)))
+            return fail(c, MGM_ERR_UNSUPPORTED, "FH potentials with TSGM=2 and no weights on a ragged cost volume need the second build");
         if ((r = reserve(c, c->ones8, sizeof(float) * (size_t)npix * 8))) return r;
         std::vector<float> one((size_t)npix * 8, 1.0f);
         HIPCHK(c, hipMemcpyAsync(c->ones8.p, one.data(), sizeof(float) * one.size(), hipMemcpyHostToDevice, c->stream));
@@ -880,6 +883,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.nvol = lr_stride;
     p.L = L;
     p.Lreal = Lreal;
+    p.fh2_ragged = fh2_ragged ? 1 : 0;
     p.MGM = MGM;
     p.dmin = C->dmin;
     p.NDIR = PEND;

@@ -54,6 +54,7 @@ struct PassParams {
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
     long long npix, nvol;
     int L, MGM, NDIR, dmin;
+    int fh2_ragged;     // 1: FH, TSGM = 2, no weights, ragged volume: update_cost2_trunclinear with its boundary fix-up
     int Lreal;          // labels that exist (<= L): a label count the second build does not take runs padded to L with +INF costs
     int pass0;          // pass p writes its Lr volume to slot p - pass0
     int LLmax, maxbands;

@@ -568,7 +568,10 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                             else
                                 combine_whirsch<LPL>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, Lv);
                         } else {
-                            if constexpr (FORM == 0)
+                            if (MGM == 2 && P.fh2_ragged) {  // (all-ones weights: the unweighted TSGM = 2 function of the reference)
+                                if constexpr (FORM == 0) combine_fh2_ragged<LPL>(Cv, nb_i, nb_same, P1, P2, lane, P.Lreal, rl, rh, Lv);
+                                else combine_fh2_ragged<LPL>(Cv, nb_fwd, nb_back, P1, P2, lane, P.Lreal, rl, rh, Lv);
+                            } else if constexpr (FORM == 0)
                                 combine_wfh<LPL>(Cv, nb_i, nb_same, nb_back, nb_fwd, Dw, P1, P2, MGM, lane, P.Lreal, Lv, rl, rh);
                             else
                                 combine_wfh<LPL>(Cv, nb_fwd, nb_back, nb_same, nb_i, Dw, P1, P2, MGM, lane, P.Lreal, Lv, rl, rh);

@@ -383,4 +383,45 @@ __device__ __forceinline__ void combine_wfh(const float (&C)[LPL], const Nb<LPL,
 }
 
 
+// update_cost2_trunclinear on a RAGGED volume (mgm_core.cc:197-219): the two neighbour slabs are copied over the
+// receiving pixel's label range [rl, rh], FixBounrady_for_minConvTruncatedLinear (166-186) then folds what lies
+// outside that range into its two end labels -- the forward recurrence over the neighbour's labels up to rl, the
+// backward one down to rh, both on the neighbour's RAW values -- and the min-convolution runs over the range.
+// In the dense layout a neighbour's missing labels hold +INF, so those two recurrences are plain scans of its
+// whole slab read at labels rl and rh.
+template <int LPL>
+__device__ __forceinline__ void combine_fh2_ragged(const float (&C)[LPL], const Nb<LPL, 1> &n1, const Nb<LPL, 1> &n2,
+                                                   float P1, float P2, int lane, int L, int rl, int rh, float (&out)[LPL])
+{
+    auto at = [&](const float (&v)[LPL], int o) {  // v's value at label o (wave-uniform o)
+        float x = v[0];
+#pragma unroll
+        for (int k = 1; k < LPL; k++) x = (o % LPL == k) ? v[k] : x;
+        return __shfl(x, o / LPL);
+    };
+    auto prepare = [&](const Nb<LPL, 1> &n, float (&M)[LPL]) {
+        float F[LPL], B[LPL];
+        unsigned sweeps = 0;
+#pragma unroll
+        for (int k = 0; k < LPL; k++) F[k] = B[k] = n.w[0][k];
+        fh_scan<LPL, true>(F, P1, lane, sweeps);
+        fh_scan<LPL, false>(B, P1, lane, sweeps);
+        const float TL = at(F, rl), TR = at(B, rh);
+#pragma unroll
+        for (int k = 0; k < LPL; k++) {
+            const int o = lane * LPL + k;
+            float x = (o >= rl && o <= rh) ? n.w[0][k] : f_inf();
+            if (o == rl) x = fminf(x, TL);
+            if (o == rh) x = fminf(x, TR);
+            M[k] = x;
+        }
+        fh_minconv<LPL>(M, n.m, P1, P2, lane, L);
+    };
+    float M1[LPL], M2[LPL];
+    prepare(n1, M1);
+    prepare(n2, M2);
+#pragma unroll
+    for (int k = 0; k < LPL; k++) out[k] = C[k] + (((M1[k] - n1.m) + M2[k]) - n2.m) * 0.5f;
+}
+
 }  // namespace mgm

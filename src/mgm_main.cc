@@ -8,8 +8,8 @@
 // computed on the CPU.  Image files: .npy (h,w[,c]) only in this build (the reference's iio
 // reads the same files; PNG/TIFF need libraries this image lacks).
 //
-// Not supported (exit code 2, message on stderr): FH potentials together with -m/-M range files that are not
-// constant (a ragged cost volume), WITH_MGM2=1.
+// Not supported (exit code 2, message on stderr): P2 = inf together with -m/-M range files that are not constant
+// (a ragged cost volume), WITH_MGM2=1.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

@@ -55,6 +55,12 @@ CASES = [
      dict(TSGM="2", TSGM_ITER="2", USE_TRUNCATED_LINEAR_POTENTIALS="1")),
     ("ragged ranges, FH, TSGM=4, non-integer costs", 1, "-P1 1.5 -P2 700 -r -16 -R 8 -t sd -O 8 -m {ranges}/lo.npy -M {ranges}/hi.npy",
      dict(TSGM="4", USE_TRUNCATED_LINEAR_POTENTIALS="1", TESTLRRL="0")),
+    ("ragged ranges, FH, TSGM=2 WITHOUT weights (update_cost2_trunclinear and its boundary fix-up)", 1,
+     "-P1 2 -P2 9 -r -16 -R 8 -t census -O 8 -s vfit -m {ranges}/lo.npy -M {ranges}/hi.npy",
+     dict(TSGM="2", USE_TRUNCATED_LINEAR_POTENTIALS="1", CENSUS_NCC_WIN="5")),
+    ("ragged ranges, FH, TSGM=2 without weights, 3 channels, TSGM_ITER=2", 3,
+     "-P1 1.5 -P2 40 -r -16 -R 8 -t ad -O 4 -m {ranges}/lo.npy -M {ranges}/hi.npy",
+     dict(TSGM="2", TSGM_ITER="2", USE_TRUNCATED_LINEAR_POTENTIALS="1")),
     ("parabolaOCV, census, median radius 3, tight tau", 1, "-r -16 -R 8 -t census -s parabolaOCV -O 8",
      dict(TSGM="3", MEDIAN="3", TESTLRRL_TAU="0.5", CENSUS_NCC_WIN="5")),
 ]
@@ -106,6 +112,6 @@ def test_cli_refuses_what_is_not_built(tmp_path):
     np.save(tmp_path / "hi.npy", lo + 6)
     ragged_fh = ["-m", str(tmp_path / "lo.npy"), "-M", str(tmp_path / "hi.npy")]
     for extra, env in (([], dict(TSGM_ITER="0")), ([], dict(WITH_MGM2="1")),
-                       (ragged_fh, dict(USE_TRUNCATED_LINEAR_POTENTIALS="1", TSGM="2")), (ragged_fh + ["-P2", "inf"], {})):
+                       (ragged_fh + ["-P2", "inf"], {})):
         r = subprocess.run(base[:1] + extra + base[1:], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 2 and "not" in r.stderr

@@ -188,8 +188,8 @@ def test_unsupported_and_invalid_inputs_fail_loudly(ctx):
     ragged = np.full((8, 16), -3, np.float32)
     ragged[2, 2] = -2
     rcv = ctx.costvolume(u, v, ragged, np.full((8, 16), 3, np.float32))   # a ragged volume builds ...
-    with pytest.raises(mgm_amd.MgmError) as e:                            # ... FH, TSGM=2, no weights on it is not built
-        ctx.aggregate(rcv, 2.0, 9.0, 4, 2, 1)
+    with pytest.raises(mgm_amd.MgmError) as e:                            # ... but does not aggregate with P2 = +INF
+        ctx.aggregate(rcv, 2.0, float("inf"), 4, 2, 1)
     assert e.value.code == mgm_amd.MGM_ERR_UNSUPPORTED
     rcv.free()
     cv = ctx.costvolume_dev(du, dv, -3, 3)
