@@ -727,11 +727,11 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
 
     // A label count the second build does not take (not 64, 128, 192, 256, 384 or 512) runs PADDED: the kernels see
     // the next such count, the extra label slots hold +INF costs -- "no such label", exactly what a read past a Dvec
-    // returns (dvec.cc:129) -- and stay +INF through every update as long as P2 is finite (every term is capped at
-    // m + P2).  With P2 = +INF, or when asked not to, such a volume takes the first build.
+    // returns (dvec.cc:129) -- and stay +INF through every update: C = +INF there and every pixel of a volume with a
+    // uniform range has a finite minimum, so the added term is finite.
     int L = Lreal;
     bool padded = false;
-    if (allow_pad && c->force_build != 1 && pass2_lines(Lreal, false) == 0 && P2 < __builtin_huge_valf() &&
+    if (allow_pad && c->force_build != 1 && pass2_lines(Lreal, false) == 0 &&
         !(getenv("MGM_HIP_PAD") && atoi(getenv("MGM_HIP_PAD")) == 0)) {
         const int lp = padded_labels(Lreal);
         if (lp) {
@@ -769,11 +769,12 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // boundary fix-up (166-186, 197-219) and is not built.
     bool ragged = false;
     for (int v = 0; v < nb; v++) ragged |= Cs[v]->rlo != nullptr;
-    // The dense layout of a ragged volume relies on foreign labels staying +INF through every update (C = +INF there).
-    // That holds as long as every slab keeps a finite minimum, which a finite P2 guarantees (every term is capped at
-    // m + P2); with P2 = +INF a pixel whose neighbours' ranges miss its own gets an all-INF slab, the next one INF - INF.
+    // The dense layout of a ragged volume relies on every slab keeping a finite minimum, which a finite P2 guarantees
+    // (every term is capped at m + P2).  With P2 = +INF a pixel whose neighbours' ranges miss its own gets an all-INF
+    // slab and the next one INF - INF = NaN; from there on the result depends on which operand of the reference's
+    // `a < b ? a : b` minima holds the NaN, which v_min_f32 does not reproduce.
     if (ragged && !(P2 < __builtin_huge_valf()))
-        return fail(c, MGM_ERR_UNSUPPORTED, "a ragged cost volume with P2 = +INF is not built (foreign labels would not stay +INF)");
+        return fail(c, MGM_ERR_UNSUPPORTED, "a ragged cost volume with P2 = +INF is not built (NaN propagation of the reference's minima)");
     const float *ones8 = nullptr;
     if (fh && ragged)
         for (int v = 1; v < nb; v++)

@@ -110,8 +110,7 @@ def test_cli_refuses_what_is_not_built(tmp_path):
     lo[3, 3] = -2
     np.save(tmp_path / "lo.npy", lo)
     np.save(tmp_path / "hi.npy", lo + 6)
-    ragged_fh = ["-m", str(tmp_path / "lo.npy"), "-M", str(tmp_path / "hi.npy")]
-    for extra, env in (([], dict(TSGM_ITER="0")), ([], dict(WITH_MGM2="1")),
-                       (ragged_fh + ["-P2", "inf"], {})):
+    ragged = ["-m", str(tmp_path / "lo.npy"), "-M", str(tmp_path / "hi.npy")]
+    for extra, env in (([], dict(TSGM_ITER="0")), ([], dict(WITH_MGM2="1")), (ragged + ["-P2", "inf"], {})):
         r = subprocess.run(base[:1] + extra + base[1:], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 2 and "not" in r.stderr
