@@ -34,57 +34,68 @@ __device__ __forceinline__ void vfit(float v0, float v1, float v2, float &v_min,
     v_min = v2 + (x_min - 1.0f) * slope;
 }
 
-// PPW pixels per wave and iteration: all their slabs are requested before the first is consumed.
+// PPW slabs per wave and iteration: all of them are requested before the first is consumed.
 // One KiB per stream per wave leaves HBM at ~4.7 TB/s, two at ~6 TB/s (tools/microbench/bw.hip).
-template <int LPL, int PPW, bool EXACT>
+// MAXD: upper bound of NDIR the instance is built for (4 or 8): with at most 4 directions twice the slabs fit the
+// registers of a wave.
+// SUB: pixels per slab.  A slab is the 64*LPL consecutive floats a wave loads per stream; with L = 64*LPL/SUB labels
+// that is SUB consecutive pixels, each reduced by its own 64/SUB lanes -- 128 labels run as LPL = 4, SUB = 2 (16-byte
+// loads, two arg-mins per butterfly) instead of LPL = 2, SUB = 1.  SUB > 1 needs EXACT and npix % SUB == 0.
+template <int LPL, int PPW, bool EXACT, int MAXD = kMaxDirs, int SUB = 1>
 __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
 {
+    static_assert(SUB == 1 || EXACT, "several pixels per slab only without padding lanes");
     constexpr int LP = LPL * 64;
+    constexpr int LANES = 64 / SUB;  // lanes per pixel
     __shared__ float sS[4][LP];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int L = P.L;          // stride of the slabs (a multiple of 64 when EXACT)
+    const int L = P.L;          // label stride of a pixel (a multiple of 64/SUB... when EXACT: L * SUB == LP)
     const int Lr_ = P.Lreal;    // labels that exist
-    constexpr bool exact = EXACT;  // L == 64*LPL: no label slot is padding, loads need no guard
-    const int o0 = lane * LPL;
+    constexpr bool exact = EXACT;  // no label slot is padding, loads need no guard
+    const int Ls = SUB > 1 ? LP : L;          // floats per slab
+    const int m0 = lane * LPL;                // this lane's offset in the slab
+    const int sub = lane / LANES;             // its pixel of the slab
+    const int o0 = (lane % LANES) * LPL;      // its first label
     const bool c8 = P.C8 && exact;  // compact costs: one byte per label (wave-uniform)
-    // grid-stride over groups of PPW consecutive pixels
-    for (long long pix0 = ((long long)blockIdx.x * 4 + wv) * PPW; pix0 < P.npix; pix0 += (long long)gridDim.x * 4 * PPW) {
-        float c[PPW][LPL], l[kMaxDirs][PPW][LPL];
+    const long long nslab = P.npix / SUB;
+    // grid-stride over groups of PPW consecutive slabs
+    for (long long g0 = ((long long)blockIdx.x * 4 + wv) * PPW; g0 < nslab; g0 += (long long)gridDim.x * 4 * PPW) {
+        float c[PPW][LPL], l[MAXD][PPW][LPL];
 #pragma unroll
         for (int u = 0; u < PPW; u++) {
-            const long long pix = pix0 + u < P.npix ? pix0 + u : P.npix - 1;
+            const long long g = g0 + u < nslab ? g0 + u : nslab - 1;
             if (c8) {
-                const uint8_t *q = P.C8 + pix * L + o0;
+                const uint8_t *q = P.C8 + g * Ls + m0;
 #pragma unroll
                 for (int k = 0; k < LPL; k++) c[u][k] = c8_decode(q[k]);
             } else {
-                const float *q = P.C + pix * L + o0;
+                const float *q = P.C + g * Ls + m0;
 #pragma unroll
-                for (int k = 0; k < LPL; k++) c[u][k] = (exact || o0 + k < L) ? q[k] : f_inf();
+                for (int k = 0; k < LPL; k++) c[u][k] = (exact || m0 + k < L) ? q[k] : f_inf();
             }
         }
 #pragma unroll
-        for (int p = 0; p < kMaxDirs; p++) {
+        for (int p = 0; p < MAXD; p++) {
             if (p < P.NDIR) {
 #pragma unroll
                 for (int u = 0; u < PPW; u++) {
-                    const long long pix = pix0 + u < P.npix ? pix0 + u : P.npix - 1;
-                    const float *q = P.Lr + (long long)p * P.nvol + pix * L + o0;
+                    const long long g = g0 + u < nslab ? g0 + u : nslab - 1;
+                    const float *q = P.Lr + (long long)p * P.nvol + g * Ls + m0;
 #pragma unroll
-                    for (int k = 0; k < LPL; k++) l[p][u][k] = (exact || o0 + k < L) ? q[k] : f_inf();
+                    for (int k = 0; k < LPL; k++) l[p][u][k] = (exact || m0 + k < L) ? q[k] : f_inf();
                 }
             }
         }
 #pragma unroll
         for (int u = 0; u < PPW; u++) {
-            const long long pix = pix0 + u;
-            if (pix >= P.npix) break;
+            if (g0 + u >= nslab) break;
+            const long long pix = (g0 + u) * SUB + sub;  // (per lane group)
             // S = ((0 + L0) + L1) + ... in pass order (mgm_core.cc:582-587)
             float S[LPL];
 #pragma unroll
             for (int k = 0; k < LPL; k++) S[k] = 0.0f;
 #pragma unroll
-            for (int p = 0; p < kMaxDirs; p++) {
+            for (int p = 0; p < MAXD; p++) {
                 if (p < P.NDIR) {
 #pragma unroll
                     for (int k = 0; k < LPL; k++) S[k] = S[k] + l[p][u][k];
@@ -129,7 +140,7 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
                 }
             }
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
+            for (int d = LANES / 2; d >= 1; d >>= 1) {  // (xor partners stay inside the pixel's lane group)
                 const float ov = __shfl_xor(best, d);
                 const int oi = __shfl_xor(bi, d);
                 if (ov < best || (ov == best && oi < bi)) {
@@ -152,23 +163,23 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
                 }
             }
             float outv, outc = best;
-            if (bi == 0x7fffffff) {
-                outv = __builtin_nanf("");  // the reference leaves minP uninitialised here
-            } else {
-                outv = (float)(bi + P.dmin);
-                if (P.refine == 1 && !windowed && bi - 1 >= 0 && bi + 2 <= Lr_ - 1) {  // mgm_refine.h:58
+            if (bi == 0x7fffffff) outv = __builtin_nanf("");  // the reference leaves minP uninitialised here
+            else outv = (float)(bi + P.dmin);
+            if (P.refine == 1 && !windowed) {  // (wave-uniform) every lane stages its part of S, each pixel reads its own
 #pragma unroll
-                    for (int k = 0; k < LPL; k++) sS[wv][o0 + k] = S[k];
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const float v0 = sS[wv][bi - 1], v1 = sS[wv][bi], v2 = sS[wv][bi + 1];
+                for (int k = 0; k < LPL; k++) sS[wv][m0 + k] = S[k];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (bi != 0x7fffffff && bi - 1 >= 0 && bi + 2 <= Lr_ - 1) {  // mgm_refine.h:58
+                    const float *sp = sS[wv] + sub * L;
+                    const float v0 = sp[bi - 1], v1 = sp[bi], v2 = sp[bi + 1];
                     float vmin, dx;
                     vfit(v0, v1, v2, vmin, dx);
                     outv = (float)(bi + P.dmin) + dx;
                     outc = vmin;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next pixel overwrites sS
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next slab overwrites sS
             }
-            if (lane == 0) {
+            if (lane % LANES == 0) {
                 P.out[pix] = outv;
                 P.outcost[pix] = outc;
             }
@@ -187,10 +198,32 @@ hipError_t launch_wta(const WtaParams &p, hipStream_t s)
     }
     if (nb > 256ll * per_cu) nb = 256ll * per_cu;  // a bounded grid (workgroups of 4 waves), grid-stride beyond
     const dim3 grid((unsigned)nb), block(256);
+    static int wide4 = -1;  // MGM_HIP_WTA_WIDE4=0: the 8-direction instance also for NDIR <= 4 (A/B timing)
+    if (wide4 < 0) {
+        const char *e = getenv("MGM_HIP_WTA_WIDE4");
+        wide4 = e ? atoi(e) != 0 : 1;
+    }
+    // 128 and 64 labels: two / four pixels per 256-float slab (16-byte loads, one butterfly for all of them)
+    static int packed = -1;
+    if (packed < 0) {
+        const char *e = getenv("MGM_HIP_WTA_PACKED");
+        packed = e ? atoi(e) != 0 : 1;
+    }
+    if (packed && p.Lreal == p.L && (p.L == 128 || p.L == 64) && p.npix % (256 / p.L) == 0) {
+        if (p.L == 128) {
+            if (p.NDIR <= 4) hipLaunchKernelGGL((k_wta<4, 4, true, 4, 2>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((k_wta<4, 2, true, kMaxDirs, 2>), grid, block, 0, s, p);
+        } else {
+            if (p.NDIR <= 4) hipLaunchKernelGGL((k_wta<4, 4, true, 4, 4>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((k_wta<4, 2, true, kMaxDirs, 4>), grid, block, 0, s, p);
+        }
+        return hipGetLastError();
+    }
     switch (pass_lpl(p.L)) {
 #define WTA_CASE(LPL, PPW)                                                                  \
     case LPL:                                                                               \
-        if (p.L == 64 * LPL) hipLaunchKernelGGL((k_wta<LPL, PPW, true>), grid, block, 0, s, p);  \
+        if (p.L == 64 * LPL && p.NDIR <= 4 && wide4) hipLaunchKernelGGL((k_wta<LPL, 2 * PPW, true, 4>), grid, block, 0, s, p); \
+        else if (p.L == 64 * LPL) hipLaunchKernelGGL((k_wta<LPL, PPW, true>), grid, block, 0, s, p);  \
         else hipLaunchKernelGGL((k_wta<LPL, 1, false>), grid, block, 0, s, p);               \
         break;
         WTA_CASE(1, 4)
