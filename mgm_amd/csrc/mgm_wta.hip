@@ -229,7 +229,7 @@ hipError_t launch_wta(const WtaParams &p, hipStream_t s)
         WTA_CASE(1, 4)
         WTA_CASE(2, 4)
         WTA_CASE(3, 2)
-        WTA_CASE(4, 2)
+        WTA_CASE(4, 3)
         WTA_CASE(6, 1)
         WTA_CASE(8, 1)
 #undef WTA_CASE
