@@ -101,16 +101,18 @@ def aggregate_direction_sharded(ctx, cv, P1, P2, NDIR, MGM, use_fh, fix_overcoun
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     nx, ny, dmin, dmax = cv.dims
     L = dmax - dmin + 1
+    if world == 1:  # nothing to shard: the plain call (which may also pad odd label counts and pick its occupancy)
+        _, o, c = ctx.aggregate_dev(cv, P1, P2, NDIR, MGM, use_fh, fix_overcount, w8, refine)
+        ctx.synchronize()
+        views = [device_view(ctx.lib.mgm_img_device_ptr(im.h), (ny, nx)).clone() for im in (o, c)]
+        o.free(), c.free()
+        return views[0], views[1]
     first, count = passes_of_rank(NDIR, world, rank)
     ctx.aggregate_passes_dev(cv, P1, P2, MGM, use_fh, first, count, w8)
     ctx.synchronize()  # Lr volumes complete before RCCL reads them (different streams)
-    if world == 1 and ctx.lr_device_ptr(1) in (None, ctx.lr_device_ptr(0) + 4 * ny * nx * L):
-        # nothing to exchange and the workspace is contiguous [NDIR][ny][nx][L] in pass order
-        recv = device_view(ctx.lr_device_ptr(0), (NDIR, ny, nx, L))
-    else:
-        lr_local = [device_view(ctx.lr_device_ptr(k), (ny, nx, L)) for k in range(count)]
-        recv = exchange_lr(lr_local, NDIR, ny, dist, group)
-        torch.cuda.synchronize()
+    lr_local = [device_view(ctx.lr_device_ptr(k), (ny, nx, L)) for k in range(count)]
+    recv = exchange_lr(lr_local, NDIR, ny, dist, group)
+    torch.cuda.synchronize()
     slabs = row_slabs(ny, world)
     r0, nr = slabs[rank]
     out = torch.empty((max(nr, 1), nx), dtype=torch.float32, device="cuda")
