@@ -130,7 +130,7 @@ int mgm_aggregate_dev(mgm_ctx *ctx, const mgm_cv *C, const mgm_img *w8, float P1
 int mgm_aggregate(mgm_ctx *ctx, const mgm_cv *C, const float *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
                   int fix_overcount, const char *refine, float *out, float *outcost, mgm_cv **S);
 
-/* n (1..8) volumes of identical size and label count aggregated by ONE launch of the pass kernel:
+/* n (1..16) volumes of identical size and label count aggregated by ONE launch of the pass kernel:
  * the two runs of mgm() that main() makes for a stereo pair, left->right (mgm.cc:376-385) and
  * right->left (mgm.cc:405-414), or the volumes of consecutive pairs.  Every volume gets exactly the
  * result mgm_aggregate_dev would give it; the point is throughput -- the scan-line passes of one

@@ -263,9 +263,12 @@ int mgm_ctx_destroy(mgm_ctx *c)
     if (!c) return MGM_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (Buf *b : {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8, &c->padf[0], &c->padf[1], &c->padf[2], &c->padf[3], &c->padf[4], &c->padf[5],
-                   &c->padf[6], &c->padf[7], &c->pad8[0], &c->pad8[1], &c->pad8[2], &c->pad8[3], &c->pad8[4], &c->pad8[5], &c->pad8[6],
-                   &c->pad8[7]})
+    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
+    for (int v = 0; v < kMaxBatch; v++) {
+        bufs.push_back(&c->padf[v]);
+        bufs.push_back(&c->pad8[v]);
+    }
+    for (Buf *b : bufs)
         if (b->p) hipFree(b->p);
     for (auto &t : c->tim) {
         hipEventDestroy(t.a);
@@ -824,7 +827,16 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     }
     if (c->force_build == 1) use_c8 = false;
     // second build (LDS-DMA loaders) whenever the slabs are whole DMA pieces
-    const int R2 = c->force_build == 1 ? 0 : pass2_lines(L, use_c8);
+    // 128 / 64 labels: 2 / 4 volumes of the launch share every wave of the 256-label kernels (k_pass2<..., SUBV>) -- a
+    // step is mostly fixed cost, so it may as well serve several volumes.  Compact costs, Hirschmueller, no weights,
+    // and a volume count that divides.
+    int subv = 1;
+    if (c->force_build != 1 && use_c8 && !weighted && !fh && (L == 128 || L == 64) && nb % (256 / L) == 0 &&
+        !(getenv("MGM_HIP_SUBV") && atoi(getenv("MGM_HIP_SUBV")) == 0))
+        subv = 256 / L;
+    const int ngroups = nb / subv;  // work items address groups of `subv` volumes
+    const int Lk = L * subv;        // label slots of a wave
+    const int R2 = c->force_build == 1 ? 0 : pass2_lines(Lk, use_c8);
     const int R = R2 ? R2 : kR;
     PassParams p{};
     int maxLL = 0, maxbands = 0;
@@ -839,16 +851,17 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // NDIR slabs of one pixel (read together by k_wta) do not fall on the same HBM channel.
     const long long lr_stride = nvol + lr_pad_floats();
     if ((r = reserve(c, c->lr, sizeof(float) * (size_t)lr_stride * count * nb))) return r;
-    if ((r = reserve(c, c->hand, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * LP))) return r;
+    const int LPk = subv > 1 ? Lk : LP;  // floats per hand-off slab
+    if ((r = reserve(c, c->hand, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * LPk))) return r;
     if ((r = reserve(c, c->handm, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL))) return r;
 
     // task table: ticket -> (pass, band); item (p, b) always follows (p, b-1)
-    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != (PEND * 16 + first) * kMaxBatch + nb - 1 || c->tk_r != R) {
+    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != ((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv || c->tk_r != R) {
         // Passes with more bands (the column passes of a wide image) have the longer dependency
         // chain, so tickets are dealt by RELATIVE progress b / nbands(pass): every pass advances at
         // the rate that lets all of them finish together.  Within a pass the order is still by band.
         std::vector<int2> tasks;
-        for (int v = 0; v < nb; v++)
+        for (int v = 0; v < ngroups; v++)
             for (int q = first; q < PEND; q++)
                 for (int b = 0; b < p.g[q].nbands; b++) tasks.push_back(make_int2(v * kMaxDirs + q, b));
         std::stable_sort(tasks.begin(), tasks.end(), [&](const int2 &a, const int2 &b) {
@@ -861,7 +874,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         c->ntasks = (int)tasks.size();
         c->tk_nx = nx;
         c->tk_ny = ny;
-        c->tk_ndir = (PEND * 16 + first) * kMaxBatch + nb - 1;
+        c->tk_ndir = ((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv;
         c->tk_r = R;
     }
 
@@ -884,6 +897,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.nvol = lr_stride;
     p.L = L;
     p.Lreal = Lreal;
+    p.subv = subv;
     p.fh2_ragged = fh2_ragged ? 1 : 0;
     p.MGM = MGM;
     p.dmin = C->dmin;
@@ -903,7 +917,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         double work = 0, chain = 0;
         for (int q = first; q < PEND; q++) {
             const PassGeom &g = p.g[q];
-            work += (double)nb * g.nbands * (g.LL + g.slope * R);
+            work += (double)ngroups * g.nbands * (g.LL + g.slope * R);
             chain = std::max(chain, (double)g.slope * g.NL + g.LL + 10.0 * g.nbands);
         }
         p.wg_per_cu = (work / 256.0 > 1.8 * chain) ? 2 : 1;
@@ -1070,7 +1084,7 @@ int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm
                             mgm_img *const *outcost, mgm_cv **S)
 {
     if (!c || !C || !out || !outcost || n < 1) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: null argument");
-    if (n > kMaxBatch) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: at most 8 volumes per call");
+    if (n > kMaxBatch) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: at most 16 volumes per call");
     if (NDIR < 1 || NDIR > kMaxDirs)  // the reference reads past its 8-entry table for -O 16 (mgm_core.cc:489)
         return fail(c, MGM_ERR_INVALID, "NDIR must be 1..8");
     if (MGM < 1 || MGM > 4) return fail(c, MGM_ERR_INVALID, "MGM (TSGM) must be 1..4");

@@ -33,7 +33,7 @@ struct PassGeom {
 // left->right and right->left volumes of a stereo pair, consecutive pairs): work items are then (volume, pass,
 // band), and the long dependency chains of one volume's column passes are hidden behind the other
 // volumes' work.
-constexpr int kMaxBatch = 8;
+constexpr int kMaxBatch = 16;
 struct PassVolume {
     const float *C;     // [npix][L]
     const uint8_t *C8;  // [npix][L] compact costs (integers 0..254, 255 = +INF) or nullptr (all volumes alike)
@@ -49,6 +49,7 @@ struct PassParams {
     unsigned *ticket;   // work-item ticket counter
     unsigned *err;      // watchdog word
     const int2 *tasks;  // ticket -> (volume*8 + pass, band)
+    int subv;                 // volumes per wave (1; 2 at 128 labels, 4 at 64: k_pass2<..., SUBV>); work items then address groups of volumes
     int wg_per_cu;            // 1 or 2 workgroups per compute unit (second build; see launch2_c8)
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)

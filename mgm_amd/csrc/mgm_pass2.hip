@@ -213,10 +213,18 @@ __device__ __forceinline__ void combine_unit_E(const float (&C)[LPL], const floa
     }
 }
 
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8>
+// SUBV > 1: the wave's 256 label slots hold the slabs of SUBV different VOLUMES of the launch (128 labels: 2, 64: 4),
+// same pass, same line, same pixel -- every lane group walks its own volume, nothing crosses between them, and a step
+// that is mostly fixed cost (barrier, LDS round trips, DMA issue) serves SUBV volumes.  The LDS rings, the hand-off
+// slabs and the compact-cost pieces simply carry [volume 0 | volume 1 | ...]; what differs per lane group is the base
+// pointers, the slab minimum and the two edge lanes of the label neighbourhood.  LPL = 4, compact costs,
+// Hirschmueller potentials, no weights.
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1>
 __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, true, C8>::NL) * 64,
                                   ((C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
 {
+    static_assert(SUBV == 1 || (LPL == 4 && C8 && !FH && !WEIGHTED), "volumes share a wave only in the compact Hirschmueller kernels");
+    constexpr int LANES = 64 / SUBV;  // lanes per volume
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
     constexpr bool pubE = !WEIGHTED && !(FH && MGM == 2);  // slabs carry E = T - m; minima not needed
     using PL = Plan<LPL, NS, !pubE, C8>;
@@ -249,7 +257,8 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     const int2 tk = P.tasks[ticket];
     const int vp = tk.x, band = tk.y;  // vp = volume*8 + pass
     const int pass = vp & (kMaxDirs - 1);
-    const PassVolume &V = P.vol[vp / kMaxDirs];
+    const int vgrp = (vp / kMaxDirs) * SUBV;  // first volume of this work item
+    const PassVolume &V = P.vol[vgrp];
     unsigned long long *dbg = P.dbg ? P.dbg + (long long)ticket * 16 : nullptr;
     if (dbg && tid == 0) dbg[0] = wall_clock64();
     const PassGeom &g = P.g[pass];
@@ -293,7 +302,12 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             r = r < NC ? r : NC - 1;
             int j = band * NC + r;
             j = j < NLn ? j : NLn - 1;
-            if constexpr (C8)
+            if constexpr (C8 && SUBV > 1) {
+                constexpr int CPV = LPS / SUBV;  // 16-byte chunks of a line's slab that belong to one volume
+                const int chunk = lane % LPS;
+                const uint8_t *c8 = P.vol[vgrp + chunk / CPV].C8;
+                cptr[q] = reinterpret_cast<const float *>(c8 + (g.base + (long long)j * g.jstep) * L + (chunk % CPV) * 16);
+            } else if constexpr (C8)
                 cptr[q] = reinterpret_cast<const float *>(V.C8 + (g.base + (long long)j * g.jstep) * L + (lane % LPS) * 16);
             else
                 cptr[q] = V.C + (g.base + (long long)j * g.jstep) * L + lane * 4;
@@ -470,7 +484,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     const bool has_prev = line_ok && (j >= 1);
     const bool to_lds = (r < NC - 1) && (j + 1 < NLn);
     const bool to_global = (r == NC - 1) && (band + 1 < g.nbands);
-    float *__restrict__ Lrb = V.Lr + (long long)(pass - P.pass0) * P.nvol;
+    float *__restrict__ Lrb = P.vol[vgrp + (SUBV > 1 ? lane / LANES : 0)].Lr + (long long)(pass - P.pass0) * P.nvol;
     const long long pix0 = g.base + (long long)j * g.jstep;
     const float *fwd_src0 = r > 0 ? Tring + (r - 1) * RT * NSLP + lane * LPL : Hring + lane * LPL;
     const float *fwd_m0 = r > 0 ? Tm + (r - 1) * RT : Hm;
@@ -587,11 +601,24 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                 }
                 const unsigned long long c2 = prof ? clock64() : 0;
                 if (!(P.xflags & 1)) {
-                    float *q = Lrb + pix * L + lane * LPL;
+                    float *q = Lrb + pix * L + (lane % LANES) * LPL;
 #pragma unroll
                     for (int k = 0; k < LPL; k++) q[k] = Lv[k];
                 }
-                const float m = slab_min<LPL>(Lv);
+                float m;
+                if constexpr (SUBV == 1) {
+                    m = slab_min<LPL>(Lv);
+                } else {  // one minimum per lane group
+                    m = Lv[0];
+#pragma unroll
+                    for (int k = 1; k < LPL; k++) m = fminf(m, Lv[k]);
+                    m = dpp_min_row_shr1(m, m);
+                    m = dpp_min_row_shr2(m, m);
+                    m = dpp_min_row_shr4(m, m);
+                    m = dpp_min_row_shr8(m, m);                      // lane 15 of every row: the row's minimum
+                    if constexpr (SUBV == 2) m = dpp_min_bcast15(m, m);  // rows 1 and 3 take in rows 0 and 2
+                    m = __shfl(m, lane | (LANES - 1));              // the group's last lane has it
+                }
                 nb_i.m = m;
                 if (prof) {
                     float mm = m;
@@ -602,7 +629,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                 if constexpr (!WEIGHTED) {
                     if constexpr (!FH) {
                         float N[LPL];
-                        neighbour_min<LPL>(Lv, N);
+                        neighbour_min<LPL>(Lv, N, SUBV > 1 && lane % LANES == 0, SUBV > 1 && lane % LANES == LANES - 1);
                         const float cap = m + P2;
 #pragma unroll
                         for (int k = 0; k < LPL; k++) nb_i.w[0][k] = fminf(fminf(Lv[k], N[k] + P1), cap);
@@ -744,7 +771,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 }
 
 // ---- launcher (one translation unit per LPL: -DMGM_P2_LPL=n) -----------------------
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1>
 static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 {
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
@@ -755,7 +782,7 @@ static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
     // right when the launch is throughput-bound (a batch of volumes); a single volume is bound by the chain of
     // bands, where the doubled step latency costs more than it gives, so it asks for > half the LDS and runs alone.
     if (p.wg_per_cu < 2 && shmem < 81 * 1024) shmem = 81 * 1024;
-    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8>;
+    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8, SUBV>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
@@ -766,6 +793,11 @@ static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 template <int LPL, bool FH, bool WEIGHTED, int MGM>
 static hipError_t launch2_one(const PassParams &p, int ntasks, hipStream_t s)
 {
+    if constexpr (LPL == 4 && !FH && !WEIGHTED) {  // several volumes per wave (128 / 64 labels)
+        if (p.subv == 2 && p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 2>(p, ntasks, s);
+        if (p.subv == 4 && p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 4>(p, ntasks, s);
+    }
+    if (p.subv > 1) return hipErrorInvalidValue;
     if (p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true>(p, ntasks, s);
     return launch2_c8<LPL, FH, WEIGHTED, MGM, false>(p, ntasks, s);
 }

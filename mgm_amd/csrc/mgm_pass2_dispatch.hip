@@ -21,7 +21,7 @@ int pass2_lines(int L, bool c8)
 
 hipError_t launch_pass2(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s)
 {
-    switch (p.L % 64 ? 0 : p.L / 64) {
+    switch (p.subv > 1 ? 4 : (p.L % 64 ? 0 : p.L / 64)) {
         case 1: return launch_pass2_lpl<1>(p, ntasks, fh, wmode, s);
         case 2: return launch_pass2_lpl<2>(p, ntasks, fh, wmode, s);
         case 3: return launch_pass2_lpl<3>(p, ntasks, fh, wmode, s);

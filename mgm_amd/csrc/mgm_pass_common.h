@@ -78,10 +78,14 @@ __device__ __forceinline__ float slab_min(const float (&v)[LPL])
 
 // N[o] = min(L[o-1], L[o+1]) with +INF outside the label range (dvec.cc:129)
 template <int LPL>
-__device__ __forceinline__ void neighbour_min(const float (&Lv)[LPL], float (&N)[LPL])
+__device__ __forceinline__ void neighbour_min(const float (&Lv)[LPL], float (&N)[LPL], bool first_lane = false,
+                                              bool last_lane = false)
 {
-    const float left = dpp_shr1(Lv[LPL - 1], f_inf());
-    const float right = dpp_shl1(Lv[0], f_inf());
+    // first_lane / last_lane: this lane starts / ends a label range inside the wave (several volumes per wave)
+    float left = dpp_shr1(Lv[LPL - 1], f_inf());
+    float right = dpp_shl1(Lv[0], f_inf());
+    left = first_lane ? f_inf() : left;
+    right = last_lane ? f_inf() : right;
 #pragma unroll
     for (int k = 0; k < LPL; k++) {
         const float lo = k ? Lv[k - 1] : left;

@@ -16,6 +16,9 @@ MODES = [
     (60, 33, 64, 4, 2, 1, 2.0, 50.0, True),        # weighted FH, 4 directions
     (70, 41, 100, 8, 3, 0, 8.0, 32.0, False),      # label count the second build does not take: first build
     (66, 30, 192, 8, 3, 1, 2.0, 20000.0, False),   # 3 labels per lane: compact slabs leave 4 lanes of a DMA piece idle
+    (83, 47, 64, 8, 3, 0, 8.0, 32.0, False),       # 64 labels: four volumes share a wave when the batch divides by 4
+    (83, 47, 128, 4, 2, 0, 8.0, 32.0, False),      # 128 labels: two volumes per wave (the cfg2 mode)
+    (50, 31, 100, 8, 4, 0, 8.0, 32.0, False),      # 100 labels padded to 128, then two volumes per wave
 ]
 
 
