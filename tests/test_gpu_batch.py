@@ -22,7 +22,7 @@ MODES = [
 ]
 
 
-@pytest.mark.parametrize("nb", [2, 3, 5, 8])
+@pytest.mark.parametrize("nb", [2, 3, 5, 8, 16])
 @pytest.mark.parametrize("mode", MODES)
 def test_batch_equals_single(ctx, mode, nb):
     nx, ny, L, NDIR, MGM, FH, P1, P2, weighted = mode
