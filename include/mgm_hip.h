@@ -97,8 +97,8 @@ int mgm_costvolume_build_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, i
  * (-m/-M files) give a volume over the hull of all ranges in which a pixel only owns the disparities of its own
  * range -- the others read +INF, as Dvec::operator[] does (dvec.cc:129), and are exempt from the "no finite cost"
  * rule; mgm_aggregate* then searches the winner and gates the refinement inside each pixel's range.  One
- * combination returns MGM_ERR_UNSUPPORTED on a ragged volume: P2 = +INF.  The hull may span at most 512 labels; batched volumes that are ragged
- * must share hull_min. */
+ * combination returns MGM_ERR_UNSUPPORTED on a ragged volume: P2 = +INF.  The hull may span at most 512
+ * labels; batched ragged volumes must share hull_min under FH potentials. */
 int mgm_costvolume_build(mgm_ctx *ctx, const float *u, const float *v, int nx, int ny, int nch, int vnx, int vny,
                          const float *dminI, const float *dmaxI, const char *prefilter, const char *distance,
                          float truncDist, int census_win, mgm_cv **C);
@@ -135,8 +135,8 @@ int mgm_aggregate(mgm_ctx *ctx, const mgm_cv *C, const float *w8, float P1, floa
  * right->left (mgm.cc:405-414), or the volumes of consecutive pairs.  Every volume gets exactly the
  * result mgm_aggregate_dev would give it; the point is throughput -- the scan-line passes of one
  * volume form dependency chains (band after band) that leave compute units waiting, and the other
- * volumes' bands fill those gaps (from three volumes on, two bands share a compute unit).  The workspace holds
- * NDIR fp32 volumes per batched volume.  C, out, outcost: arrays of n handles.  w8: NULL, or an array of n
+ * volumes' bands fill those gaps (a throughput-bound launch puts two bands on a compute unit; at 128 / 64
+ * labels two / four volumes share every wavefront).  The workspace holds NDIR fp32 volumes per batched volume.  C, out, outcost: arrays of n handles.  w8: NULL, or an array of n
  * weight images (for all volumes or none; all weighted or all unweighted).  S: NULL, or an array of
  * n handles to receive the corrected aggregated volumes. */
 int mgm_aggregate_batch_dev(mgm_ctx *ctx, int n, const mgm_cv *const *C, const mgm_img *const *w8, float P1, float P2,
