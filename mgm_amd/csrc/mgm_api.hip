@@ -828,10 +828,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     if (c->force_build == 1) use_c8 = false;
     // second build (LDS-DMA loaders) whenever the slabs are whole DMA pieces
     // 128 / 64 labels: 2 / 4 volumes of the launch share every wave of the 256-label kernels (k_pass2<..., SUBV>) -- a
-    // step is mostly fixed cost, so it may as well serve several volumes.  Compact costs, Hirschmueller, no weights,
-    // and a volume count that divides.
+    // step is mostly fixed cost, so it may as well serve several volumes.  Compact costs, no weights, not FH with
+    // TSGM = 2 (whose slabs travel with their minimum), and a volume count that divides.
     int subv = 1;
-    if (c->force_build != 1 && use_c8 && !weighted && !fh && (L == 128 || L == 64) && nb % (256 / L) == 0 &&
+    if (c->force_build != 1 && use_c8 && !weighted && !(fh && MGM == 2) && (L == 128 || L == 64) && nb % (256 / L) == 0 &&
         !(getenv("MGM_HIP_SUBV") && atoi(getenv("MGM_HIP_SUBV")) == 0))
         subv = 256 / L;
     const int ngroups = nb / subv;  // work items address groups of `subv` volumes

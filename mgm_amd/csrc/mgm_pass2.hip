@@ -217,13 +217,13 @@ __device__ __forceinline__ void combine_unit_E(const float (&C)[LPL], const floa
 // same pass, same line, same pixel -- every lane group walks its own volume, nothing crosses between them, and a step
 // that is mostly fixed cost (barrier, LDS round trips, DMA issue) serves SUBV volumes.  The LDS rings, the hand-off
 // slabs and the compact-cost pieces simply carry [volume 0 | volume 1 | ...]; what differs per lane group is the base
-// pointers, the slab minimum and the two edge lanes of the label neighbourhood.  LPL = 4, compact costs,
-// Hirschmueller potentials, no weights.
+// pointers, the slab minimum and the edge lanes of the label neighbourhood / of the FH scans.  LPL = 4, compact
+// costs, no weights, the kernels that publish E (everything but FH with TSGM = 2).
 template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1>
 __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, true, C8>::NL) * 64,
                                   ((C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
 {
-    static_assert(SUBV == 1 || (LPL == 4 && C8 && !FH && !WEIGHTED), "volumes share a wave only in the compact Hirschmueller kernels");
+    static_assert(SUBV == 1 || (LPL == 4 && C8 && !WEIGHTED && !(FH && MGM == 2)), "volumes share a wave only in the compact unweighted kernels that publish E");
     constexpr int LANES = 64 / SUBV;  // lanes per volume
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
     constexpr bool pubE = !WEIGHTED && !(FH && MGM == 2);  // slabs carry E = T - m; minima not needed
@@ -637,7 +637,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 #pragma unroll
                         for (int k = 0; k < LPL; k++) nb_i.w[0][k] = Lv[k];
                         unsigned sw = 0;
-                        fh_minconv<LPL>(nb_i.w[0], m, P1, P2, lane, P.Lreal, sw);
+                        fh_minconv<LPL, false, SUBV>(nb_i.w[0], m, P1, P2, lane, P.Lreal, sw);
                         if (prof) { fh_sweeps += sw; fh_max = sw > fh_max ? sw : fh_max; fh_n++; fh_rep += sw > 2; }
                     }
                     if constexpr (pubE) {
@@ -793,7 +793,7 @@ static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 template <int LPL, bool FH, bool WEIGHTED, int MGM>
 static hipError_t launch2_one(const PassParams &p, int ntasks, hipStream_t s)
 {
-    if constexpr (LPL == 4 && !FH && !WEIGHTED) {  // several volumes per wave (128 / 64 labels)
+    if constexpr (LPL == 4 && !WEIGHTED && !(FH && MGM == 2)) {  // several volumes per wave (128 / 64 labels)
         if (p.subv == 2 && p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 2>(p, ntasks, s);
         if (p.subv == 4 && p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 4>(p, ntasks, s);
     }

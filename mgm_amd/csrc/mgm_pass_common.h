@@ -115,23 +115,25 @@ __device__ __forceinline__ void neighbour_min(const float (&Lv)[LPL], float (&N)
 // origin).  Successive rounding is monotone, so the winning origin is the one with the smallest
 // exact sum: a min-plus scan in f64, which holds these sums exactly.  If the premise does not hold
 // the result is merely another guess; the caller's fixed-point sweeps remain the ground truth.
-template <int LPL, bool FWD>
+// GROUPS: label ranges per wave (several volumes per wave): lane groups of 64/GROUPS lanes scan independently.
+template <int LPL, bool FWD, int GROUPS = 1>
 __device__ __forceinline__ float fh_repair(float a, float P1, int lane_in)
 {
+    constexpr int GL = 64 / GROUPS;
     // (cold path: keep its lane masks and f64 constants from being hoisted into the caller's hot loop, where they
     // would push live scalar registers into spills)
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     asm volatile("" : "+v"(P1));
     auto from_prev = [&](double v, int d) { return FWD ? __shfl_up(v, d) : __shfl_down(v, d); };
-    auto has_prev = [&](int d) { return FWD ? lane >= d : lane + d < 64; };
+    auto has_prev = [&](int d) { return FWD ? (lane % GL) >= d : (lane % GL) + d < GL; };
     const double P1d = (double)P1, Rd = (double)LPL * (double)P1;
     const double inf = (double)f_inf();
     const double b = (double)(a + P1);  // first step of every chain that starts at this lane's carry-out
     const double pb = from_prev(b, 1);           // (a shuffle must not sit under a divergent condition)
     double s = has_prev(1) ? pb + Rd : inf;      // = origin' + LPL*P1; the surplus P1 comes off below
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
+    for (int d = 1; d < GL; d <<= 1) {
         const double t = from_prev(s, d) + (double)d * Rd;
         if (has_prev(d)) s = t < s ? t : s;
     }
@@ -153,9 +155,11 @@ __device__ __forceinline__ float fh_repair(float a, float P1, int lane_in)
 // One direction of minConvTruncatedLinear.  FWD: M[o] = min(M[o-1] + P1, M[o]) for rising o.
 // Written for the VALU issue budget (four waves share a SIMD: every slot costs 16 cycles): the
 // guess is a min-plus scan of fused DPP instructions, 2 slots per log-step.
-template <int LPL, bool FWD>
+template <int LPL, bool FWD, int GROUPS = 1>
 __device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, unsigned &sweeps)
 {
+    static_assert(GROUPS == 1 || GROUPS == 2 || GROUPS == 4, "lane groups of 64, 32 or 16");
+    constexpr int GL = 64 / GROUPS;            // lanes per label range
     constexpr int K0 = FWD ? 0 : LPL - 1;      // first label of the lane in scan order
     constexpr int K1 = FWD ? LPL - 1 : 0;      // last
     constexpr int DK = FWD ? 1 : -1;
@@ -177,24 +181,38 @@ __device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, uns
         c = dpp_min_row_shr2(c, c + r2);
         c = dpp_min_row_shr4(c, c + r4);
         c = dpp_min_row_shr8(c, c + r8);
-        // lane 15 of the row before (rows 1..3), then lane 31 (rows 2..3), at their distance in lanes
-        const float offA = row >= 1 ? (float)(li + 1) * rampP : f_inf();
-        const float offB = row >= 2 ? (float)(li + 1 + (row == 3 ? 16 : 0)) * rampP : f_inf();
-        c = fminf(c, dpp_add_bcast15(c, offA));
-        c = fminf(c, dpp_add_bcast31(c, offB));
+        // lane 15 of the row before (rows 1..3), then lane 31 (rows 2..3), at their distance in lanes -- as far as those
+        // rows belong to the same label range
+        if constexpr (GROUPS <= 2) {
+            const float offA = (GROUPS == 1 ? row >= 1 : (row & 1)) ? (float)(li + 1) * rampP : f_inf();
+            c = fminf(c, dpp_add_bcast15(c, offA));
+        }
+        if constexpr (GROUPS == 1) {
+            const float offB = row >= 2 ? (float)(li + 1 + (row == 3 ? 16 : 0)) * rampP : f_inf();
+            c = fminf(c, dpp_add_bcast31(c, offB));
+        }
     } else {
         c = dpp_min_row_shl1(c, c + r1);
         c = dpp_min_row_shl2(c, c + r2);
         c = dpp_min_row_shl4(c, c + r4);
         c = dpp_min_row_shl8(c, c + r8);
-        const float t3 = readlane_f(c, 48);                   // total of row 3 (at its first lane)
-        const float t2 = fminf(readlane_f(c, 32), t3 + r16);  // rows 2..3
-        const float t1 = fminf(readlane_f(c, 16), t2 + r16);  // rows 1..3
-        const float tp = row == 0 ? t1 : (row == 1 ? t2 : t3);
-        const float offD = row <= 2 ? (float)(16 - li) * rampP : f_inf();
-        c = fminf(c, tp + offD);
+        if constexpr (GROUPS == 1) {
+            const float t3 = readlane_f(c, 48);                   // total of row 3 (at its first lane)
+            const float t2 = fminf(readlane_f(c, 32), t3 + r16);  // rows 2..3
+            const float t1 = fminf(readlane_f(c, 16), t2 + r16);  // rows 1..3
+            const float tp = row == 0 ? t1 : (row == 1 ? t2 : t3);
+            const float offD = row <= 2 ? (float)(16 - li) * rampP : f_inf();
+            c = fminf(c, tp + offD);
+        } else if constexpr (GROUPS == 2) {  // rows 0 and 2 take in the row after them (same label range)
+            const float t1 = readlane_f(c, 16), t3 = readlane_f(c, 48);
+            const float tp = row == 0 ? t1 : t3;
+            const float offD = (row & 1) ? f_inf() : (float)(16 - li) * rampP;
+            c = fminf(c, tp + offD);
+        }
+        (void)r16;
     }
-    const float p1edge = (FWD ? lane == 0 : lane == 63) ? f_inf() : P1;  // no carry into the first lane
+    // no carry into the first lane of a label range
+    const float p1edge = (FWD ? lane % GL == 0 : lane % GL == GL - 1) ? f_inf() : P1;
     float f[LPL];
     bool boosted = false;
     for (int it = 0; it < 70; it++) {
@@ -212,23 +230,25 @@ __device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, uns
             // (e.g. over a stretch of +INF costs).  Plain sweeps would repair one lane per sweep.
             // Re-derive every carry as the exact image of its winning origin instead.
             boosted = true;
-            c = fh_repair<LPL, FWD>(a, P1, lane);
+            c = fh_repair<LPL, FWD, GROUPS>(a, P1, lane);
         }
     }
 #pragma unroll
     for (int k = 0; k < LPL; k++) M[k] = f[k];
 }
 
-// FULL: L == 64*LPL, no label slot of the wave is padding
-template <int LPL, bool FULL = false>
+// L: labels of a range (<= 64*LPL/GROUPS); the label slots beyond it are padding.  (FULL is a leftover tag: the padding
+// check is made at run time.)  GROUPS: independent label ranges in the wave, each with its own minimum m (per lane).
+template <int LPL, bool FULL = false, int GROUPS = 1>
 __device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, float P2, int lane, int L, unsigned &sweeps)
 {
-    fh_scan<LPL, true>(M, P1, lane, sweeps);
-    if (L < 64 * LPL) {  // (wave-uniform) label slots >= L hold +INF on entry; the forward scan has filled them with ramp values
+    constexpr int GL = 64 / GROUPS;
+    fh_scan<LPL, true, GROUPS>(M, P1, lane, sweeps);
+    if (L < GL * LPL) {  // (wave-uniform) label slots >= L hold +INF on entry; the forward scan has filled them with ramp values
 #pragma unroll
-        for (int k = 0; k < LPL; k++) M[k] = (lane * LPL + k < L) ? M[k] : f_inf();
+        for (int k = 0; k < LPL; k++) M[k] = ((lane % GL) * LPL + k < L) ? M[k] : f_inf();
     }
-    fh_scan<LPL, false>(M, P1, lane, sweeps);
+    fh_scan<LPL, false, GROUPS>(M, P1, lane, sweeps);
     if (P2 < f_inf()) {
         const float cap = m + P2;
 #pragma unroll

@@ -19,6 +19,10 @@ MODES = [
     (83, 47, 64, 8, 3, 0, 8.0, 32.0, False),       # 64 labels: four volumes share a wave when the batch divides by 4
     (83, 47, 128, 4, 2, 0, 8.0, 32.0, False),      # 128 labels: two volumes per wave (the cfg2 mode)
     (50, 31, 100, 8, 4, 0, 8.0, 32.0, False),      # 100 labels padded to 128, then two volumes per wave
+    (83, 47, 128, 8, 3, 1, 2.0, 20000.0, False),   # FH, two volumes per wave: lane-group min-convolution scans
+    (61, 29, 64, 8, 4, 1, 1.5, 9.0, False),        # FH, four volumes per wave
+    (50, 31, 100, 8, 1, 1, 2.0, 9.0, False),       # FH on 100 labels padded to 128 (padding mask per lane group)
+    (40, 23, 128, 4, 2, 1, 2.0, 9.0, False),       # FH with TSGM = 2 keeps one volume per wave
 ]
 
 
