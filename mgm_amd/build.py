@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libmgm_hip.so")
 
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+          "-Wall", "-Wno-unused-function"]
 # per-translation-unit extras (see the header comment of each file)
 # (source, object suffix, extra flags)
 UNITS = [("mgm_pass.hip", "", ["-fno-honor-nans"])]

@@ -136,12 +136,12 @@ struct TimeScope {  // brackets one kernel launch with events when timing is on
             on = false;
             return;
         }
-        hipEventRecord(t.a, c->stream);
+        (void)hipEventRecord(t.a, c->stream);
     }
     ~TimeScope()
     {
         if (!on) return;
-        hipEventRecord(t.b, c->stream);
+        (void)hipEventRecord(t.b, c->stream);
         c->tim.push_back(t);
     }
 };
@@ -247,7 +247,7 @@ int mgm_ctx_create(int device, mgm_ctx **out)
         return MGM_ERR_HIP;
     }
     if (hipHostMalloc((void **)&c->h_words, 16 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
-        hipStreamDestroy(c->stream);
+        (void)hipStreamDestroy(c->stream);
         delete c;
         return MGM_ERR_HIP;
     }
@@ -261,21 +261,21 @@ int mgm_ctx_create(int device, mgm_ctx **out)
 int mgm_ctx_destroy(mgm_ctx *c)
 {
     if (!c) return MGM_OK;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
     std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);
         bufs.push_back(&c->pad8[v]);
     }
     for (Buf *b : bufs)
-        if (b->p) hipFree(b->p);
+        if (b->p) (void)hipFree(b->p);
     for (auto &t : c->tim) {
-        hipEventDestroy(t.a);
-        hipEventDestroy(t.b);
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
     }
-    if (c->h_words) hipHostFree(c->h_words);
-    hipStreamDestroy(c->stream);
+    if (c->h_words) (void)hipHostFree(c->h_words);
+    (void)hipStreamDestroy(c->stream);
     delete c;
     return MGM_OK;
 }
@@ -308,10 +308,10 @@ int mgm_timing_enable(mgm_ctx *c, int enable)
 int mgm_timing_reset(mgm_ctx *c)
 {
     if (!c) return MGM_ERR_INVALID;
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     for (auto &t : c->tim) {
-        hipEventDestroy(t.a);
-        hipEventDestroy(t.b);
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
     }
     c->tim.clear();
     return MGM_OK;
@@ -372,10 +372,10 @@ int mgm_img_free(mgm_ctx *c, mgm_img *im)
 {
     if (!im) return MGM_OK;
     if (c) {
-        hipSetDevice(c->device);
-        hipStreamSynchronize(c->stream);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
     }
-    hipFree(im->d);
+    (void)hipFree(im->d);
     delete im;
     return MGM_OK;
 }
@@ -453,14 +453,14 @@ int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
 {
     if (!cv) return MGM_OK;
     if (c) {
-        hipSetDevice(c->device);
-        hipStreamSynchronize(c->stream);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
     }
-    hipFree(cv->d);
-    if (cv->d8) hipFree(cv->d8);
-    if (cv->bad8) hipFree(cv->bad8);
-    if (cv->rlo) hipFree(cv->rlo);
-    if (cv->rhi) hipFree(cv->rhi);
+    (void)hipFree(cv->d);
+    if (cv->d8) (void)hipFree(cv->d8);
+    if (cv->bad8) (void)hipFree(cv->bad8);
+    if (cv->rlo) (void)hipFree(cv->rlo);
+    if (cv->rhi) (void)hipFree(cv->rhi);
     delete cv;
     return MGM_OK;
 }
@@ -565,8 +565,8 @@ static int costvolume_build(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int 
         HIPCHK(c, hipMemcpyAsync((*out)->rlo, rloI->d, nb, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync((*out)->rhi, rhiI->d, nb, hipMemcpyDeviceToDevice, c->stream));
     } else if ((*out)->rlo) {  // a refilled volume that used to be ragged
-        hipFree((*out)->rlo);
-        hipFree((*out)->rhi);
+        (void)hipFree((*out)->rlo);
+        (void)hipFree((*out)->rhi);
         (*out)->rlo = (*out)->rhi = nullptr;
     }
     p.rlo = (*out)->rlo;

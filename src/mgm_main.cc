@@ -240,7 +240,7 @@ int main(int argc, char **argv)
     o.NDIR = atoi(pick_option(&argc, argv, "O", "4"));
     o.P1 = (float)atof(pick_option(&argc, argv, "P1", "8"));
     o.P2 = (float)atof(pick_option(&argc, argv, "P2", "32"));
-    (void)atof(pick_option(&argc, argv, "aP1", "1"));
+    pick_option(&argc, argv, "aP1", "1");  // accepted and unused, as in the reference
     o.aP2 = (float)atof(pick_option(&argc, argv, "aP2", "1"));
     o.aThresh = (float)atof(pick_option(&argc, argv, "aThresh", "5"));
     o.distance = pick_option(&argc, argv, "t", "ad");
