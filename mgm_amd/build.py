@@ -77,13 +77,22 @@ def build(force=False, verbose=False):
 def build_cli(force=False):
     """The host program: src/mgm_main.cc (plain g++) linked against libmgm_hip.so -> mgm_amd/bin/mgm."""
     src = os.path.join(HERE, "..", "src", "mgm_main.cc")
-    hdrs = [os.path.join(HERE, "..", "src", "npyio.h"), os.path.join(HERE, "..", "include", "mgm_hip.h")]
+    hdrs = [os.path.join(HERE, "..", "src", "npyio.h"), os.path.join(HERE, "..", "src", "imgio.h"),
+            os.path.join(HERE, "..", "include", "mgm_hip.h")]
     exe = os.path.join(HERE, "bin", "mgm")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     if force or _stale(exe, [src, LIB] + hdrs):
         rocm = os.path.dirname(os.path.dirname(hipcc()))
         cmd = ["g++", "-O2", "-std=c++17", "-Wall", src, "-L" + LIBDIR, "-lmgm_hip", "-L" + os.path.join(rocm, "lib"),
-               "-lamdhip64", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", exe]
+               "-lamdhip64", "-lz", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", exe]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode:
+            raise RuntimeError("g++ failed:\n%s\n%s" % (" ".join(cmd), r.stdout))
+    # the image decoders alone, no GPU library: format conversion and the CPU tests of src/imgio.h
+    conv_src = os.path.join(HERE, "..", "src", "imgconv.cc")
+    conv = os.path.join(HERE, "bin", "imgconv")
+    if force or _stale(conv, [conv_src] + hdrs[:2]):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", conv_src, "-lz", "-o", conv]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode:
             raise RuntimeError("g++ failed:\n%s\n%s" % (" ".join(cmd), r.stdout))

@@ -5,8 +5,8 @@
 // orchestration and post-processing -- with the hot path (cost volume, aggregation, WTA,
 // refinement; mgm.cc:372-385 and 405-414) running on the MI355X through the C ABI of
 // include/mgm_hip.h.  Everything here is host glue; no stereo arithmetic of the path is
-// computed on the CPU.  Image files: .npy (h,w[,c]) only in this build (the reference's iio
-// reads the same files; PNG/TIFF need libraries this image lacks).
+// computed on the CPU.  Image files (src/imgio.h): PNG, TIFF, PGM/PPM, PFM and .npy in -- what the
+// reference's iio decodes them to -- and float TIFF, PFM or .npy out.
 //
 // Not supported (exit code 2, message on stderr): P2 = inf together with -m/-M range files that are not constant
 // (a ragged cost volume), WITH_MGM2=1.
@@ -20,7 +20,7 @@
 #include <vector>
 
 #include "../include/mgm_hip.h"
-#include "npyio.h"
+#include "imgio.h"
 
 // ---- environment "smart parameters" (smartparameter.h:26-50): double, read once --------------
 static double env_param(const char *name, double dflt)
@@ -221,7 +221,7 @@ int main(int argc, char **argv)
     if (!strcmp(argv[1], "-?")) return 0 * puts("Compute stereo disparities by the MGM algorithm.");
     if (!strcmp(argv[1], "--version")) return 0 * puts("mgm 2.0 (mgm-hip, MI355X)");
     if (!strcmp(argv[1], "--help"))
-        return 0 * puts("mgm [options] in_u in_v out_disp [out_cost [out_backflow]]   (.npy images)\n"
+        return 0 * puts("mgm [options] in_u in_v out_disp [out_cost [out_backflow]]   (in: png tif pgm ppm pfm npy; out: tif pfm npy)\n"
                         "options: -r dmin(-30) -R dmax(30) -O NDIR(4) -P1 (8) -P2 (32) -p prefilter(none) -t distance(ad)\n"
                         "         -truncDist (inf) -s subpix(none) -aP1 (1) -aP2 (1) -aThresh (5) -m FILE -M FILE -l FILE\n"
                         "environment: CENSUS_NCC_WIN=3 TESTLRRL=1 TESTLRRL_TAU=1.0 MEDIAN=0 TSGM=4 TSGM_ITER=1\n"
@@ -266,13 +266,13 @@ int main(int argc, char **argv)
     if ((int)TSGM_ITER < 1) { fprintf(stderr, "mgm: TSGM_ITER < 1 is not supported\n"); return 2; }
 
     try {
-        HostImg u = npy::read(f_u), v = npy::read(f_v);
+        HostImg u = imgio::read(f_u), v = imgio::read(f_v);
         remove_nonfinite(u, 0);
         remove_nonfinite(v, 0);
         HostImg rlo, rhi;  // -m / -M range images of the left->right run (mgm.cc:342-353); the right->left run keeps -r/-R
         if (min_file[0]) {
-            rlo = npy::read(min_file);
-            rhi = npy::read(max_file);
+            rlo = imgio::read(min_file);
+            rhi = imgio::read(max_file);
             if (rlo.nx != u.nx || rlo.ny != u.ny || rhi.nx != u.nx || rhi.ny != u.ny || rlo.nch != 1 || rhi.nch != 1) {
                 fprintf(stderr, "mgm: the -m/-M images must have the size of the left image\n");
                 return 1;
@@ -309,7 +309,7 @@ int main(int argc, char **argv)
         report_run(o, L);
         iterate_run(ctx, o, L, (int)TSGM_ITER, o.dmin, o.dmax, plo, phi);
         if (MEDIAN != 0) median_run(ctx, L, (int)MEDIAN);
-        if (nolr_file[0]) npy::write(nolr_file, download(ctx, L.dout, L.nx, L.ny, 1));
+        if (nolr_file[0]) imgio::write(nolr_file, download(ctx, L.dout, L.nx, L.ny, 1));
         if (TESTLRRL != 0) {
             if (!R.C) prepare_run(ctx, v, u, -o.dmax, -o.dmin, o, R);  // mgm.cc:366, 405
             if (!together) aggregate_run(ctx, o, R);
@@ -342,9 +342,9 @@ int main(int argc, char **argv)
         free_run(ctx, L);
         free_run(ctx, R);
         mgm_ctx_destroy(ctx);
-        npy::write(f_out, outoff);
-        if (f_cost) npy::write(f_cost, outcost);
-        if (f_back) npy::write(f_back, syn);
+        imgio::write(f_out, outoff);
+        if (f_cost) imgio::write(f_cost, outcost);
+        if (f_back) imgio::write(f_back, syn);
     } catch (const std::exception &e) {
         fprintf(stderr, "mgm: %s\n", e.what());
         return 1;

@@ -114,3 +114,40 @@ def test_cli_refuses_what_is_not_built(tmp_path):
     for extra, env in (([], dict(TSGM_ITER="0")), ([], dict(WITH_MGM2="1")), (ragged + ["-P2", "inf"], {})):
         r = subprocess.run(base[:1] + extra + base[1:], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 2 and "not" in r.stderr
+
+
+REF_IMG = os.path.join(ROOT, "oracle", "_ref", "mgm_img")  # the reference CLI with iio's PNG/TIFF support
+CONV = os.path.join(ROOT, "mgm_amd", "bin", "imgconv")
+
+MAKEFILE_TESTS = [  # the two command lines of the reference's `make test` (Makefile:16-18), on PNG files, TIFF outputs
+    ("-P2 20000 -P1 2 -r -20 -R 12 -t census -s vfit -O 8", dict(MEDIAN="1", CENSUS_NCC_WIN="3", USE_TRUNCATED_LINEAR_POTENTIALS="1", TSGM="3")),
+    ("-P2 20000 -P1 4 -r -20 -R 12 -p sobel_x -truncDist 63 -s vfit -O 8", dict(MEDIAN="1", USE_TRUNCATED_LINEAR_POTENTIALS="1", TSGM="3")),
+]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_IMG), reason="oracle/_ref/mgm_img was not built (needs libpng/libtiff headers)")
+@pytest.mark.parametrize("case", MAKEFILE_TESTS, ids=["census", "sobel_x"])
+def test_cli_png_in_tiff_out_matches_reference(case, tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    args, env = case
+    u, v, _ = synth.stereo_pair(112, 72, -16, 8, seed=43, nch=3)
+    for n, a in (("u", u), ("v", v)):
+        PIL.fromarray(np.clip(np.round(a.transpose(1, 2, 0)), 0, 255).astype(np.uint8)).save(tmp_path / (n + ".png"))
+    outs = {}
+    for tag, exe in (("ref", REF_IMG), ("ours", OURS)):
+        d = tmp_path / tag
+        d.mkdir()
+        cmd = [exe] + args.split() + [str(tmp_path / "u.png"), str(tmp_path / "v.png"), str(d / "disp.tif"), str(d / "cost.tif"), str(d / "back.tif")]
+        r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="4", **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr)
+        files = {}
+        for f in ("disp", "cost", "back"):
+            c = subprocess.run([CONV, str(d / (f + ".tif")), str(d / (f + ".npy"))], capture_output=True, text=True)
+            assert c.returncode == 0, (tag, f, c.stderr)
+            files[f] = np.load(d / (f + ".npy"))
+        outs[tag] = (r.stdout, files)
+    assert outs["ref"][0] == outs["ours"][0], "stdout differs"
+    for f in outs["ref"][1]:
+        a, b = outs["ref"][1][f], outs["ours"][1][f]
+        assert a.shape == b.shape and np.isfinite(a).any(), f
+        assert ndiff(a, b) == 0, f
