@@ -59,6 +59,9 @@ inline void inflate_into(const uint8_t *src, size_t n, uint8_t *dst, size_t expe
     if (out_left) throw std::runtime_error(what + ": compressed data ends early or is corrupt");
 }
 
+// A corrupt header must not turn into a huge allocation: no supported coding expands by more than ~1:4096.
+inline bool plausible(double decoded_bytes, size_t coded_bytes) { return decoded_bytes <= (double)coded_bytes * 4096.0 + 65536.0; }
+
 // planar float image from interleaved samples
 template <class GET>
 inline HostImg planar(int nx, int ny, int nch, GET get)
@@ -125,6 +128,7 @@ inline HostImg decode(const bytes &f, const std::string &path)
         throw bad("bad bit depth");
     if (interlace) throw bad("interlaced (Adam7) PNG files are not supported by this build");
     const size_t rowbytes = ((size_t)w * ch * depth + 7) / 8;
+    if (!plausible((rowbytes + 1) * (double)h, idat.size())) throw bad("image size does not fit the file");
     bytes raw((rowbytes + 1) * h);
     inflate_into(idat.data(), idat.size(), raw.data(), raw.size(), path);
 
@@ -210,7 +214,7 @@ struct Reader {
     std::runtime_error bad(const std::string &m) const { return std::runtime_error(path + ": " + m); }
     uint64_t rd(size_t off, int n) const
     {
-        if (off + n > f.size()) throw bad("truncated TIFF");
+        if (off > f.size() || (size_t)n > f.size() - off) throw bad("truncated TIFF");
         uint64_t v = 0;
         for (int i = 0; i < n; i++) v |= (uint64_t)f[off + (be ? n - 1 - i : i)] << (8 * i);
         return v;
@@ -317,6 +321,7 @@ inline HostImg decode(const bytes &f, const std::string &path)
             const uint64_t cnt = R.big ? R.rd(p + 4, 8) : R.rd(p + 4, 4);
             if (type == 0 || type > 18 || !tsize[type]) throw R.bad("bad tag type");
             const int sz = tsize[type];
+            if (cnt > f.size()) throw R.bad("bad tag count");
             const size_t inl = R.big ? 8 : 4, vp = p + (R.big ? 12 : 8);
             const size_t off = cnt * sz <= inl ? vp : (size_t)R.rd(vp, (int)inl);
             out.resize(cnt);
@@ -360,6 +365,9 @@ inline HostImg decode(const bytes &f, const std::string &path)
     const int planes = planarcfg == 2 ? spp : 1, cs = planarcfg == 2 ? 1 : spp;  // samples per pixel within a chunk
     if (offs.size() < across * down * planes || cnts.size() < offs.size()) throw R.bad("short strip/tile tables");
 
+    if (W > 0x7fffffff || H > 0x7fffffff || spp < 1 || spp > 1024 ||
+        !plausible((double)W * (double)H * spp * bytesps, f.size()) || !plausible((double)cw * (double)chh * spp * bytesps, f.size()))
+        throw R.bad("image size does not fit the file");
     const size_t np = (size_t)W * H;
     HostImg im;
     im.nx = (int)W;
@@ -382,7 +390,7 @@ inline HostImg decode(const bytes &f, const std::string &path)
                 const size_t ci = (size_t)((pl * down + cy) * across + cx);
                 const uint64_t rows = tiled ? chh : std::min<uint64_t>(chh, H - cy * chh);
                 const size_t rowb = (size_t)cw * cs * bytesps, expect = rowb * rows;
-                if (offs[ci] + cnts[ci] > f.size()) throw R.bad("strip/tile outside the file");
+                if (offs[ci] > f.size() || cnts[ci] > f.size() - offs[ci]) throw R.bad("strip/tile outside the file");
                 const uint8_t *src = &f[offs[ci]];
                 buf.resize(expect);
                 switch (comp) {
@@ -549,6 +557,7 @@ inline HostImg decode(const bytes &f, const std::string &path)
     }
     if (kind == '2' || kind == '3') {
         token();
+        if (n > f.size()) throw bad("truncated data");
         std::vector<float> s(n);
         for (size_t i = 0; i < n; i++) s[i] = (float)atoi(token().c_str());
         return planar(w, h, ch, [&](size_t i) { return s[i]; });
