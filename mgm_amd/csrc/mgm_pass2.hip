@@ -106,15 +106,6 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 
 #ifndef MGM_P2_LDS_KB
 #define MGM_P2_LDS_KB 78
 #endif
-#ifndef MGM_P2_DECOUPLED
-#define MGM_P2_DECOUPLED 0   // 1: waves synchronise point-to-point through LDS step counters; 0: one s_barrier per step
-#endif
-#ifndef MGM_P2_RT
-#define MGM_P2_RT 4          // decoupled: slots per line of the LDS ring between consecutive lines (power of two)
-#endif
-#ifndef MGM_P2_RC
-#define MGM_P2_RC 6          // decoupled: steps of C / hand-off data the LDS rings hold
-#endif
 #ifndef MGM_P2_C8_NL
 #define MGM_P2_C8_NL 1
 #endif
@@ -147,7 +138,6 @@ struct Plan {
     // compact costs with two loaders: A = hand-off only, B = all C pieces
     static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + NS * IPS + 1 + (HASM ? 1 : 0);
     static constexpr int nB = (C8 && NL == 2) ? NDMA : (NC - NCA) * IPS;
-    static constexpr bool DEC = MGM_P2_DECOUPLED != 0;
     // Ring geometry: RT = T-ring slots per line (2 with barriers), RDEPTH = steps of C / hand-off data the rings
     // hold, D = steps of DMA kept in flight (D <= RDEPTH-1).  The largest of a few candidates that fits in LDS.
     static constexpr int cring_floats(int rdepth) { return C8 ? rdepth * NDMA * 256 : NC * rdepth * LP; }
@@ -156,7 +146,7 @@ struct Plan {
         return NC * rt * NS * LP       // T ring
                + NC * rt               // T minima
                + rdepth * NS * LP      // hand-off ring
-               + 2 * rdepth + 8 + 32   // hand-off minima, progress words, task word, step counters
+               + 2 * rdepth + 8 + 32   // hand-off minima, progress words, task word (+ spare)
                + cring_floats(rdepth); // C ring
     }
     static constexpr bool fits(int rt, int rdepth, int d)
@@ -166,8 +156,8 @@ struct Plan {
     }
     static constexpr int pick(int what)  // 0: RT, 1: RDEPTH, 2: D
     {
-        const int rts[2] = {DEC ? MGM_P2_RT : 2, 2};
-        const int rds[3] = {DEC ? MGM_P2_RC : MGM_P2_MAXD + 1, 4, 3};
+        const int rts[2] = {2, 2};
+        const int rds[3] = {MGM_P2_MAXD + 1, 4, 3};
         for (int a = 0; a < 2; a++)
             for (int b = 0; b < 3; b++)
                 for (int d = MGM_P2_MAXD; d >= 2; d--)
@@ -233,7 +223,6 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     constexpr int LPW = NCA;   // C lines per loader wave (NC - NCA == NCA when there are two loaders)
     constexpr int RD = PL::rd(D);  // C / hand-off ring depth (steps)
     constexpr int RT = PL::RT;     // T-ring slots per line
-    constexpr bool DEC = PL::DEC;
     using NbT = Nb<LPL, NS>;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -244,14 +233,10 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     float *Hm = Tm + NC * RT;                     // [RD]
     unsigned *Hprog = reinterpret_cast<unsigned *>(Hm + RD);  // [RD]
     int *s_task = reinterpret_cast<int *>(Hprog + RD);
-    // decoupled mode: stepdone[r] = steps compute wave r has completed; landed[w] = steps whose DMA of loader w has landed
-    unsigned *stepdone = reinterpret_cast<unsigned *>(s_task + 4);
-    unsigned *landed = stepdone + NC;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) *s_task = (int)atomicAdd(P.ticket, 1u);
-    if (tid < NC + 2) stepdone[tid] = 0;
     __syncthreads();
     const int ticket = *s_task;
     const int2 tk = P.tasks[ticket];
@@ -388,50 +373,6 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             else wait_vmcnt<PL::nB *(D - 1)>();
         };
 
-        if constexpr (DEC) {
-            // ---- decoupled: no barriers.  Target step t goes to ring slot t % RD once every compute wave
-            // is done with step t-RD; after the counted wait the steps that have landed are published.
-            int slot = 0, lslot = (RD - (D % RD)) % RD;  // lslot = slot of target step t-D
-            for (int t = 0; t < nsteps; t++) {
-                if (t >= RD) {
-                    unsigned spins = 0;
-                    const unsigned long long tbp = dbg ? wall_clock64() : 0;
-                    for (;;) {
-                        unsigned v = lane < NC ? __hip_atomic_load(stepdone + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                                               : 0x7fffffffu;
-                        const float vm = wave_min((float)v);  // (< 2^24: exact)
-                        if ((int)vm >= t - RD + 1 || dead) break;
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (SPIN_LIMIT << 2)) {
-                            if (lane == 0) __hip_atomic_store(P.err, 2u, RLX_AGENT);
-                            dead = true;
-                        }
-                    }
-                    asm volatile("" ::: "memory");
-                    if (dbg) t_bar += wall_clock64() - tbp;
-                }
-                if (wl == 0 && from_global && t >= D) {
-                    // freshest progress word that has landed: the one issued with target step t-D
-                    const unsigned k = __builtin_amdgcn_readfirstlane(lds_read_u32_opaque(Hprog + lslot));
-                    known = k > known ? k : known;
-                }
-                const unsigned long long ta = dbg ? wall_clock64() : 0;
-                issue(slot);
-                slot = slot + 1 == RD ? 0 : slot + 1;
-                lslot = lslot + 1 == RD ? 0 : lslot + 1;
-                const unsigned long long tb = dbg ? wall_clock64() : 0;
-                retire();  // targets <= t-D+1 have landed
-                if (t - D + 2 > 0 && lane == 0)
-                    __hip_atomic_store(landed + wl, (unsigned)(t - D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (dbg) {
-                    const unsigned long long tc = wall_clock64();
-                    t_iss += tb - ta;
-                    t_ret += tc - tb;
-                }
-            }
-            wait_vmcnt<0>();
-            if (lane == 0) __hip_atomic_store(landed + wl, (unsigned)nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
         int slot = 0;
         for (int t = 0; t < D; t++) {  // prologue: steps 0..D-1
             issue(slot);
@@ -464,7 +405,6 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                 t_ret += tc - tb;
                 t_bar += td - tc;
             }
-        }
         }
         if (dbg && wl == 0 && lane == 0) {
             dbg[2] = wall_clock64();
@@ -696,55 +636,6 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 
         int cslot = 0;
         unsigned long long t_cbar = 0;
-        if constexpr (DEC) {
-            // ---- decoupled: before step s this wave needs (a) the previous line's wave to have finished step
-            // s-1 (its slab for this step is in the ring), (b) the DMA of step s to have landed, (c) room in
-            // its own ring slot: the next line's wave must have fetched the slab written RT steps ago.
-            const unsigned *f_prev = r > 0 ? stepdone + (r - 1) : nullptr;
-            const unsigned *f_next = to_lds ? stepdone + (r + 1) : nullptr;
-            const unsigned *f_land = landed + ((C8 || r < NCA) ? 0 : 1);
-            bool wdead = false;
-            unsigned long long fa = 0, fb = 0, fc = 0;  // polls that failed on (a), (b), (c)
-            auto wait_ready = [&](int s) {
-                const unsigned np = (unsigned)s, nl = (unsigned)s + 1u;
-                const int nn = s - RT + 2;
-                unsigned spins = 0;
-                for (;;) {
-                    const unsigned a = f_prev ? __hip_atomic_load(f_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : np;
-                    const unsigned b = f_next ? __hip_atomic_load(f_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffffu;
-                    const unsigned c = __hip_atomic_load(f_land, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if ((a >= np && (int)b >= nn && c >= nl) || wdead) break;
-                    if (prof) { fa += a < np; fb += (int)b < nn; fc += c < nl; }
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (SPIN_LIMIT << 2)) {
-                        if (lane == 0) __hip_atomic_store(P.err, 3u, RLX_AGENT);
-                        wdead = true;
-                    }
-                }
-                asm volatile("" ::: "memory");  // LDS is in order per wave: the data reads below follow the flag reads
-            };
-            auto done = [&](int s) {
-                asm volatile("" ::: "memory");  // ... and the counter store follows this step's slab stores
-                if (lane == 0) __hip_atomic_store(stepdone + r, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            };
-            for (int s = 0; s < nsteps; s += 3) {
-                const unsigned long long t0 = prof ? wall_clock64() : 0;
-                wait_ready(s);
-                if (prof) t_cbar += wall_clock64() - t0;
-                step(s, cslot, wA, wB, wC);
-                done(s);
-                cslot = cslot + 1 == RD ? 0 : cslot + 1;
-                wait_ready(s + 1);
-                step(s + 1, cslot, wB, wC, wA);
-                done(s + 1);
-                cslot = cslot + 1 == RD ? 0 : cslot + 1;
-                wait_ready(s + 2);
-                step(s + 2, cslot, wC, wA, wB);
-                done(s + 2);
-                cslot = cslot + 1 == RD ? 0 : cslot + 1;
-            }
-            if (prof && lane == 0) dbg[1] = (1ull << 63) | (fa << 42) | (fb << 21) | fc;
-        } else {
         step_barrier((P.xflags & 8) != 0);  // B0: the loaders' prologue has landed
         for (int s = 0; s < nsteps; s += 3) {
             step(s, cslot, wA, wB, wC);
@@ -758,7 +649,6 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             step(s + 2, cslot, wC, wA, wB);
             cslot = cslot + 1 == RD ? 0 : cslot + 1;
             step_barrier((P.xflags & 8) != 0);
-        }
         }
         if (dbg && r == NC / 2 && lane == 0) {
             dbg[14] = t_cbar * 3;
