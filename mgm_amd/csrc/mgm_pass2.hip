@@ -541,8 +541,11 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                 }
                 const unsigned long long c2 = prof ? clock64() : 0;
                 if (!(P.xflags & 1)) {
-                    // xflags & 16 (timing experiment, wrong results): every Lr store lands in a small cache-resident window
+#ifdef MGM_P2_XFLAG16  // xflags & 16 (timing experiment, wrong results): every Lr store lands in a small cache-resident window
                     float *q = Lrb + ((P.xflags & 16) ? (pix & 255) : pix) * L + (lane % LANES) * LPL;
+#else
+                    float *q = Lrb + pix * L + (lane % LANES) * LPL;
+#endif
 #pragma unroll
                     for (int k = 0; k < LPL; k++) q[k] = Lv[k];
                 }
