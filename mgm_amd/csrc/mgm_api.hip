@@ -924,6 +924,9 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     }
     if (const char *e = getenv("MGM_HIP_WG_PER_CU")) p.wg_per_cu = atoi(e);
     if (const char *e = getenv("MGM_HIP_XFLAGS")) p.xflags = atoi(e);
+    if ((p.xflags || c->debug_stats) && R2 && !pass2_devtools())
+        return fail(c, MGM_ERR_UNSUPPORTED, "MGM_HIP_XFLAGS / MGM_HIP_DEBUG_STATS need a development build of the pass kernels "
+                                            "(MGM_P2_DEFINES=-DMGM_P2_DEV=1 python -m mgm_amd.build --force)");
     if (c->debug_stats && R2) {
         if ((r = reserve(c, c->dbg, sizeof(unsigned long long) * 16 * (size_t)c->ntasks))) return r;
         HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, sizeof(unsigned long long) * 16 * (size_t)c->ntasks, c->stream));

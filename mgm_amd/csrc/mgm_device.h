@@ -52,7 +52,7 @@ struct PassParams {
     int subv;                 // volumes per wave (1; 2 at 128 labels, 4 at 64: k_pass2<..., SUBV>); work items then address groups of volumes
     int wg_per_cu;            // 1 or 2 workgroups per compute unit (second build; see launch2_c8)
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA, 4 ignore
-                              // inter-band waits, 8 skip step barriers, 16 Lr stores into a cache-resident window (-DMGM_P2_XFLAG16 builds only)
+                              // inter-band waits, 8 skip step barriers, 16 Lr stores into a cache-resident window (-DMGM_P2_XFLAG16 builds only); all of them need a -DMGM_P2_DEV=1 build
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
     long long npix, nvol;
     int L, MGM, NDIR, dmin;
@@ -87,6 +87,7 @@ int pass_ns(bool fh, bool weighted);  // slabs per hand-off slot
 int pass_lpl(int L);                  // disparities per lane the pass kernel is instantiated for
 // second build (LDS-DMA loader waves); pass2_lines(L) = lines per band, 0 if L is not supported by it
 int pass2_lines(int L, bool c8);
+bool pass2_devtools();  // built with -DMGM_P2_DEV=1 (MGM_HIP_DEBUG_STATS / MGM_HIP_XFLAGS are honoured)
 hipError_t launch_pass2(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s);
 template <int LPL>
 hipError_t launch_pass2_lpl(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s);

@@ -106,6 +106,10 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 
 #ifndef MGM_P2_LDS_KB
 #define MGM_P2_LDS_KB 78
 #endif
+#ifndef MGM_P2_DEV
+#define MGM_P2_DEV 0   // 1: in-kernel timers and experiment switches (development builds: MGM_P2_DEFINES=-DMGM_P2_DEV=1);
+#endif                 // the run-time tests alone cost the issue-bound FH kernel 6 %, so product builds compile them out
+
 #ifndef MGM_P2_C8_NL
 #define MGM_P2_C8_NL 1
 #endif
@@ -244,7 +248,13 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     const int pass = vp & (kMaxDirs - 1);
     const int vgrp = (vp / kMaxDirs) * SUBV;  // first volume of this work item
     const PassVolume &V = P.vol[vgrp];
+#if MGM_P2_DEV  // in-kernel timers (MGM_HIP_DEBUG_STATS) and experiment switches (MGM_HIP_XFLAGS)
     unsigned long long *dbg = P.dbg ? P.dbg + (long long)ticket * 16 : nullptr;
+    const int xflags = P.xflags;
+#else
+    constexpr unsigned long long *dbg = nullptr;
+    constexpr int xflags = 0;
+#endif
     if (dbg && tid == 0) dbg[0] = wall_clock64();
     const PassGeom &g = P.g[pass];
     const int NLn = g.NL, LL = g.LL, L = P.L, form = g.form;
@@ -315,7 +325,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     float *dst = Cring + ((r0 + q) * RD + slot) * LP;
 #pragma unroll
                     for (int c = 0; c < IPS; c++)
-                        if (c * 64 + lane < ((P.xflags & 2) ? 1 : LPL * 16)) dma16<0>(cptr[q] + c * 256, dst + c * 256);
+                        if (c * 64 + lane < ((xflags & 2) ? 1 : LPL * 16)) dma16<0>(cptr[q] + c * 256, dst + c * 256);
                 }
                 const bool adv = (ci[q] >= 0) && (ci[q] < LL - 1);
                 cptr[q] += adv ? cstride : 0;
@@ -323,7 +333,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             }
             if (wl == 0) {
                 const int h = ht < 0 ? 0 : (ht < LL ? ht : LL - 1);
-                if (from_global && !dead && !(P.xflags & 4) && known < (unsigned)h + 1u) {
+                if (from_global && !dead && !(xflags & 4) && known < (unsigned)h + 1u) {
                     // slow path: the producer band is not far enough ahead.  Poll the word through
                     // LDS-DMA as well (no VGPR load, so nothing makes the compiler drain us elsewhere).
                     // Wait for a LEAD beyond the bare need: the producer publishes one pixel per step, so
@@ -383,7 +393,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             dbg[1] = wall_clock64();
             dbg[5] = t_slow;
         }
-        step_barrier((P.xflags & 8) != 0);  // B0
+        step_barrier((xflags & 8) != 0);  // B0
         int uslot = 0;   // slot of the step that is about to run
         for (int s = 0; s < nsteps; s++) {
             if (wl == 0 && from_global) {
@@ -398,7 +408,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             const unsigned long long tb = dbg ? wall_clock64() : 0;
             retire();
             const unsigned long long tc = dbg ? wall_clock64() : 0;
-            step_barrier((P.xflags & 8) != 0);
+            step_barrier((xflags & 8) != 0);
             if (dbg) {
                 const unsigned long long td = wall_clock64();
                 t_iss += tb - ta;
@@ -540,9 +550,9 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     ph[1] += clock64() - c1;  // combine
                 }
                 const unsigned long long c2 = prof ? clock64() : 0;
-                if (!(P.xflags & 1)) {
+                if (!(xflags & 1)) {
 #ifdef MGM_P2_XFLAG16  // xflags & 16 (timing experiment, wrong results): every Lr store lands in a small cache-resident window
-                    float *q = Lrb + ((P.xflags & 16) ? (pix & 255) : pix) * L + (lane % LANES) * LPL;
+                    float *q = Lrb + ((xflags & 16) ? (pix & 255) : pix) * L + (lane % LANES) * LPL;
 #else
                     float *q = Lrb + pix * L + (lane % LANES) * LPL;
 #endif
@@ -639,19 +649,19 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 
         int cslot = 0;
         unsigned long long t_cbar = 0;
-        step_barrier((P.xflags & 8) != 0);  // B0: the loaders' prologue has landed
+        step_barrier((xflags & 8) != 0);  // B0: the loaders' prologue has landed
         for (int s = 0; s < nsteps; s += 3) {
             step(s, cslot, wA, wB, wC);
             cslot = cslot + 1 == RD ? 0 : cslot + 1;
             const unsigned long long t0 = (dbg && r == NC / 2) ? wall_clock64() : 0;
-            step_barrier((P.xflags & 8) != 0);
+            step_barrier((xflags & 8) != 0);
             if (dbg && r == NC / 2) t_cbar += wall_clock64() - t0;
             step(s + 1, cslot, wB, wC, wA);
             cslot = cslot + 1 == RD ? 0 : cslot + 1;
-            step_barrier((P.xflags & 8) != 0);
+            step_barrier((xflags & 8) != 0);
             step(s + 2, cslot, wC, wA, wB);
             cslot = cslot + 1 == RD ? 0 : cslot + 1;
-            step_barrier((P.xflags & 8) != 0);
+            step_barrier((xflags & 8) != 0);
         }
         if (dbg && r == NC / 2 && lane == 0) {
             dbg[14] = t_cbar * 3;

@@ -1,7 +1,12 @@
 """Development aid: run one full-size aggregation with MGM_HIP_DEBUG_STATS=1."""
 import os, sys
 os.environ.setdefault("MGM_HIP_DEBUG_STATS", "1")
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+# the timers / switches live in the development build of the pass kernels: tools/sweep_build.sh dev -DMGM_P2_DEV=1
+DEV = os.path.join(ROOT, "mgm_amd", "lib", "variants", "dev", "libmgm_hip.so")
+if os.path.exists(DEV):
+    os.environ.setdefault("MGM_HIP_LIB", DEV)
 import numpy as np
 import mgm_amd
 from mgm_amd import synth
