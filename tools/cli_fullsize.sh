@@ -1,0 +1,35 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: wall time of the whole command line on a full-size pair (PNG in, TIFF out), ours against the
+# reference CLI (oracle/_ref/mgm_img, OpenMP on the box's cores), and a comparison of the outputs.
+set -u
+T=$(mktemp -d)
+python - "$T" <<'PY'
+import sys, numpy as np
+from PIL import Image
+sys.path.insert(0, ".")
+from mgm_amd import synth
+u, v, _ = synth.stereo_pair(1920, 1080, -255, 0, seed=20150907)
+for n, a in (("u", u), ("v", v)):
+    Image.fromarray(np.clip(np.round(a[0]), 0, 255).astype(np.uint8)).save("%s/%s.png" % (sys.argv[1], n))
+PY
+ARGS="-r -255 -R 0 -t census -s vfit -O 8 -P1 2 -P2 20000"
+export CENSUS_NCC_WIN=5 TSGM=3 USE_TRUNCATED_LINEAR_POTENTIALS=1 MEDIAN=1
+for rep in 1 2; do
+  s=$(date +%s%N); ./mgm_amd/bin/mgm $ARGS $T/u.png $T/v.png $T/o_disp.tif $T/o_cost.tif > $T/o.log; e=$(date +%s%N)
+  echo "ours: $(( (e - s) / 1000000 )) ms wall"
+done
+if [ -x oracle/_ref/mgm_img ]; then
+  s=$(date +%s%N); OMP_NUM_THREADS=${OMP_NUM_THREADS:-16} timeout 1200 oracle/_ref/mgm_img $ARGS $T/u.png $T/v.png $T/r_disp.tif $T/r_cost.tif > $T/r.log; e=$(date +%s%N)
+  echo "reference (OpenMP, ${OMP_NUM_THREADS:-16} threads): $(( (e - s) / 1000000 )) ms wall"
+  for f in disp cost; do ./mgm_amd/bin/imgconv $T/o_$f.tif $T/o_$f.npy > /dev/null; ./mgm_amd/bin/imgconv $T/r_$f.tif $T/r_$f.npy > /dev/null; done
+  python - "$T" <<'PY'
+import sys, numpy as np
+t = sys.argv[1]
+for f in ("disp", "cost"):
+    a, b = np.load("%s/o_%s.npy" % (t, f)), np.load("%s/r_%s.npy" % (t, f))
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    print(f, a.shape, "differing pixels:", int((~same).sum()), "max |diff|:", float(np.nanmax(np.abs(a - b))) if (~same).any() else 0.0)
+print("stdout identical:", open(t + "/o.log").read() == open(t + "/r.log").read())
+PY
+fi
+rm -rf "$T"
