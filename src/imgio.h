@@ -1,7 +1,7 @@
 // imgio.h -- image files for the `mgm` host program: PNG, TIFF, PGM/PPM, PFM and .npy in; float TIFF, PFM and
 // .npy out.  The reference goes through its vendored iio library on top of libpng/libtiff (img_tools.h:18-34,
 // iio/iio.c); this build has neither library's headers, so the decoders are written here against the format
-// specifications (PNG 1.2, TIFF 6.0 + BigTIFF, Netpbm) with zlib as the only dependency.  What a file decodes TO
+// specifications (PNG 1.2 incl. Adam7, TIFF 6.0 + BigTIFF, Netpbm) with zlib as the only dependency.  What a file decodes TO
 // follows iio: samples become floats unchanged (8/16-bit unsigned, float), PNG sub-byte grey is scaled to 0..255,
 // palettes become RGB, tRNS becomes an alpha channel (iio.c:1501-1504: PACKING | EXPAND), TIFF photometric
 // interpretation is ignored (iio reads raw scanlines, iio.c:1657-1880), and images come back in the planar `Img`
@@ -126,48 +126,73 @@ inline HostImg decode(const bytes &f, const std::string &path)
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))) ||
         (ctype == 3 && depth == 16))
         throw bad("bad bit depth");
-    if (interlace) throw bad("interlaced (Adam7) PNG files are not supported by this build");
-    const size_t rowbytes = ((size_t)w * ch * depth + 7) / 8;
-    if (!plausible((rowbytes + 1) * (double)h, idat.size())) throw bad("image size does not fit the file");
-    bytes raw((rowbytes + 1) * h);
+    if (interlace > 1) throw bad("unknown interlace method");
+    // One pass for a plain file, seven reduced images for Adam7 (PNG 1.2 section 8.2): each pass is a complete
+    // filtered image of the pixels x0 + k dx, y0 + l dy.
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole[1] = {{0, 0, 1, 1}};
+    const Pass *passes = interlace ? adam7 : whole;
+    const int npass = interlace ? 7 : 1;
+    auto pass_w = [&](const Pass &q) { return q.x0 < w ? (w - q.x0 + q.dx - 1) / q.dx : 0u; };
+    auto pass_h = [&](const Pass &q) { return q.y0 < h ? (h - q.y0 + q.dy - 1) / q.dy : 0u; };
+    auto row_bytes = [&](uint32_t pw) { return ((size_t)pw * ch * depth + 7) / 8; };
+    double total = 0;
+    for (int k = 0; k < npass; k++)
+        if (pass_w(passes[k]) && pass_h(passes[k])) total += (double)(row_bytes(pass_w(passes[k])) + 1) * pass_h(passes[k]);
+    if (!plausible(total, idat.size()) || !plausible((double)w * h * ch * 4, idat.size())) throw bad("image size does not fit the file");
+    bytes raw((size_t)total);
     inflate_into(idat.data(), idat.size(), raw.data(), raw.size(), path);
 
-    // undo the scanline filters in place (PNG 1.2 section 6)
     const size_t bpp = std::max<size_t>(1, (size_t)ch * depth / 8);
-    bytes zero(rowbytes, 0);
-    for (uint32_t y = 0; y < h; y++) {
-        uint8_t *cur = &raw[(rowbytes + 1) * y + 1];
-        const uint8_t *up = y ? &raw[(rowbytes + 1) * (y - 1) + 1] : zero.data();
-        switch (cur[-1]) {
-        case 0: break;
-        case 1:
-            for (size_t i = bpp; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
-            break;
-        case 2:
-            for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + up[i]);
-            break;
-        case 3:
-            for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + (((i >= bpp ? cur[i - bpp] : 0) + up[i]) >> 1));
-            break;
-        case 4:
-            for (size_t i = 0; i < rowbytes; i++) {
-                const int a = i >= bpp ? cur[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
-                const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-                cur[i] = (uint8_t)(cur[i] + (pa <= pb && pa <= pc ? a : pb <= pc ? b : c));
+    std::vector<unsigned> smp((size_t)w * h * ch);  // samples as written (before any expansion)
+    size_t off = 0;
+    for (int k = 0; k < npass; k++) {
+        const Pass &q = passes[k];
+        const uint32_t pw = pass_w(q), ph = pass_h(q);
+        if (!pw || !ph) continue;
+        const size_t rowbytes = row_bytes(pw);
+        bytes zero(rowbytes, 0);
+        for (uint32_t y = 0; y < ph; y++) {
+            // undo the scanline filter in place (PNG 1.2 section 6)
+            uint8_t *cur = &raw[off + (rowbytes + 1) * y + 1];
+            const uint8_t *up = y ? cur - (rowbytes + 1) : zero.data();
+            switch (cur[-1]) {
+            case 0: break;
+            case 1:
+                for (size_t i = bpp; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
+                break;
+            case 2:
+                for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + up[i]);
+                break;
+            case 3:
+                for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + (((i >= bpp ? cur[i - bpp] : 0) + up[i]) >> 1));
+                break;
+            case 4:
+                for (size_t i = 0; i < rowbytes; i++) {
+                    const int a = i >= bpp ? cur[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
+                    const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                    cur[i] = (uint8_t)(cur[i] + (pa <= pb && pa <= pc ? a : pb <= pc ? b : c));
+                }
+                break;
+            default: throw bad("bad filter type");
             }
-            break;
-        default: throw bad("bad filter type");
+            for (uint32_t x = 0; x < pw; x++)
+                for (int c = 0; c < ch; c++) {
+                    const size_t i = (size_t)x * ch + c;
+                    unsigned v;
+                    if (depth == 8) v = cur[i];
+                    else if (depth == 16) v = (unsigned)cur[2 * i] << 8 | cur[2 * i + 1];
+                    else {
+                        const size_t bit = i * depth;
+                        v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1);
+                    }
+                    smp[((size_t)(q.y0 + y * q.dy) * w + (q.x0 + x * q.dx)) * ch + c] = v;
+                }
         }
+        off += (rowbytes + 1) * ph;
     }
-
-    // samples as written (before any expansion), row by row
-    auto sample = [&](uint32_t y, size_t i) -> unsigned {  // i-th sample of row y
-        const uint8_t *row = &raw[(rowbytes + 1) * y + 1];
-        if (depth == 8) return row[i];
-        if (depth == 16) return (unsigned)row[2 * i] << 8 | row[2 * i + 1];
-        const size_t bit = i * depth;
-        return (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1);
-    };
+    auto sample = [&](uint32_t y, size_t i) -> unsigned { return smp[(size_t)y * w * ch + i]; };  // i-th sample of row y
     const unsigned maxv = depth == 16 ? 65535u : 255u;
     const bool alpha = !trns.empty() && (ctype == 0 || ctype == 2 || ctype == 3);
     const int och = (ctype == 3 ? 3 : ch) + (alpha ? 1 : 0);

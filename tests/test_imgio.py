@@ -164,10 +164,57 @@ def test_png_every_filter_type(tmp_path):
     same(decode(p, tmp_path), a)
 
 
-def test_png_interlaced_and_garbage_are_refused(tmp_path):
+def adam7_png(a, depth):
+    """An interlaced PNG assembled by hand: the seven reduced images of PNG 1.2 section 8.2, filter type 0 or 2."""
+    h, w = a.shape[:2]
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[ch]
+    a3 = a.reshape(h, w, ch)
+    raw = b""
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = a3[y0::dy, x0::dx]
+        if sub.size == 0:
+            continue
+        prev = None
+        for y in range(sub.shape[0]):
+            vals = sub[y].reshape(-1)
+            if depth == 16:
+                row = vals.astype(">u2").tobytes()
+            elif depth == 8:
+                row = vals.astype(np.uint8).tobytes()
+            else:
+                bits = "".join(format(int(v), "0%db" % depth) for v in vals)
+                bits += "0" * (-len(bits) % 8)
+                row = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+            if prev is not None and y % 2:  # filter type 2 (Up) on odd rows of the pass
+                raw += b"\x02" + bytes((c - p) % 256 for c, p in zip(row, prev))
+            else:
+                raw += b"\x00" + row
+            prev = row
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1)) +
+            chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("shape,depth", [((13, 21), 8), ((9, 10, 3), 8), ((17, 5), 16), ((3, 2), 8), ((1, 1), 8), ((11, 19), 2),
+                                         ((8, 8, 4), 8), ((5, 33, 2), 16)])
+def test_png_adam7(tmp_path, shape, depth):
+    rng = np.random.default_rng(sum(shape) + depth)
+    a = rng.integers(0, 1 << depth, shape)
+    p = tmp_path / "a7.png"
+    p.write_bytes(adam7_png(a, depth))
+    if depth == 8 or (depth == 16 and a.ndim == 2):  # the hand-made file is a valid interlaced PNG for PIL as well
+        b = np.array(PIL.open(p))  # (PIL reduces 16-bit multi-channel files to 8 bits: not compared)
+        assert np.array_equal(b.astype(np.int64), a)
+    same(decode(p, tmp_path), a * (255 // ((1 << depth) - 1)) if depth < 8 else a)
+
+
+def test_png_unknown_interlace_and_garbage_are_refused(tmp_path):
     good = png_bytes(2, 2, 8, 0, [b"\x01\x02", b"\x03\x04"])
     bad = bytearray(good)
-    bad[8 + 8 + 12] = 1  # IHDR interlace byte (CRC not checked by this reader)
+    bad[8 + 8 + 12] = 2  # IHDR interlace byte: only 0 and 1 exist (CRC not checked by this reader)
     p = tmp_path / "i.png"
     p.write_bytes(bytes(bad))
     decode(p, tmp_path, expect_fail=True)

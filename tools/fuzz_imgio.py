@@ -35,6 +35,7 @@ def main():
         seeds.append(open(p + ".tif", "rb").read())
     seeds.append(T.tiff_bytes(a.astype("f4"), predictor=3, tile=(16, 16)))
     seeds.append(T.tiff_bytes(a.astype("u2"), predictor=2, planar=True, bigtiff=True, big_endian=True))
+    seeds.append(T.adam7_png(a, 8))
     seeds.append(b"P5\n5 7\n255\n" + bytes(35))
     seeds.append(b"P2\n2 2\n9\n1 2 3 4\n")
     seeds.append(b"Pf\n3 2\n-1\n" + bytes(24))
