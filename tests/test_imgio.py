@@ -514,6 +514,10 @@ def test_inputs_decode_as_iio_decodes_them(tmp_path):
         im.putpalette(bytes([10, 200, 30, 90, 0, 250, 255, 255, 0, 77, 77, 78]))
         im.save(tmp_path / ("pal_%s.png" % n))
     files += [("g2_u.png", "g2_v.png"), ("gt_u.png", "gt_v.png"), ("pal_u.png", "pal_v.png")]
+    u, v = _pair(rng, c=3)
+    for n, a in (("u", u), ("v", v)):
+        (tmp_path / ("a7_%s.png" % n)).write_bytes(adam7_png(a.astype(np.int64), 8))
+    files.append(("a7_u.png", "a7_v.png"))
     for fu, fv in files:
         a = decode(tmp_path / fu, tmp_path)
         np.save(tmp_path / "du.npy", a)
