@@ -401,6 +401,72 @@ __global__ void __launch_bounds__(256) k_cost_census8(const uint32_t *__restrict
     }
 }
 
+// The same costs for label counts that divide 1024, sixteen labels per lane: a wave writes 1 KiB = 1024 / L whole
+// pixels per iteration with 16-byte stores (the 4-byte version above spends its time in per-pixel index arithmetic
+// and load latency: one pixel per wave and iteration).
+template <int L>
+__global__ void __launch_bounds__(256) k_cost_census8w(const uint32_t *__restrict__ cu, const uint32_t *__restrict__ cv,
+                                                       int nx, int ny, int vnx, int vny, int dmin, unsigned tb,
+                                                       uint8_t *__restrict__ C8)
+{
+    static_assert(L == 64 || L == 128 || L == 256 || L == 512, "whole pixels per KiB");
+    constexpr int LP = L / 16;    // lanes per pixel
+    constexpr int PPC = 64 / LP;  // pixels per wave and iteration
+    const long long npix = (long long)nx * ny;
+    const long long nchunk = (npix + PPC - 1) / PPC;
+    const int lane = threadIdx.x & 63, sub = lane / LP, part = lane % LP;
+    const unsigned long long group = (LP == 64 ? ~0ull : ((1ull << (LP % 64)) - 1ull)) << (sub * LP);
+    for (long long chunk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < nchunk; chunk += (long long)gridDim.x * 4) {
+        const long long pix = chunk * PPC + sub;
+        const bool live = pix < npix;
+        const unsigned p32 = live ? (unsigned)pix : 0u;  // (npix < 2^31: checked by the caller)
+        const int y = (int)(p32 / (unsigned)nx), x = (int)(p32 - (unsigned)y * (unsigned)nx);
+        const uint32_t wu = cu[p32];
+        const int q0 = x + dmin + part * 16;
+        const bool yin = y < vny;
+        const uint32_t *row = cv + (long long)(yin ? y : 0) * vnx;
+        unsigned w[4];
+        bool fin = false;
+        if (yin && q0 >= 0 && q0 + 16 <= vnx) {  // the lane's sixteen labels lie inside the right image
+            u32x4_a4 t[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) t[h] = *reinterpret_cast<const u32x4_a4 *>(row + q0 + 4 * h);
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                const unsigned v[4] = {t[h].x, t[h].y, t[h].z, t[h].w};
+                unsigned b[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned pc = (unsigned)__builtin_popcount(wu ^ v[k]);
+                    b[k] = pc < tb ? pc : tb;
+                    fin |= b[k] != 255u;
+                }
+                w[h] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                unsigned b[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int q = q0 + 4 * h + k;
+                    const bool in = yin && q >= 0 && q < vnx;
+                    const unsigned pc = (unsigned)__builtin_popcount(wu ^ row[in ? q : 0]);
+                    b[k] = in ? (pc < tb ? pc : tb) : tb;
+                    fin |= b[k] != 255u;
+                }
+                w[h] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+            }
+        }
+        const bool anyfinite = (__builtin_amdgcn_ballot_w64(fin) & group) != 0ull;  // of this pixel's labels
+        if (live) {
+            uint4 o;
+            o.x = anyfinite ? w[0] : 0u; o.y = anyfinite ? w[1] : 0u; o.z = anyfinite ? w[2] : 0u; o.w = anyfinite ? w[3] : 0u;
+            *reinterpret_cast<uint4 *>(C8 + pix * L + part * 16) = o;
+        }
+    }
+}
+
 hipError_t launch_cost(const CostParams &p, hipStream_t s)
 {
     const long long npix = (long long)p.nx * p.ny;
@@ -408,7 +474,20 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
         const unsigned tb = p.trunc == __builtin_huge_valf() ? 255u : (unsigned)p.trunc;
         long long nb = (npix + 3) / 4;
         if (nb > 256 * 32) nb = 256 * 32;
-        const dim3 grid((unsigned)nb), block(256);
+        const dim3 block(256);
+        if ((p.L == 64 || p.L == 128 || p.L == 256 || p.L == 512) && npix < 0x7fffffffll) {
+            long long nw = (npix * p.L / 1024 + 3) / 4 + 1;
+            if (nw > 256 * 32) nw = 256 * 32;
+            const dim3 gridw((unsigned)nw);
+            switch (p.L) {
+                case 64: hipLaunchKernelGGL(k_cost_census8w<64>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                case 128: hipLaunchKernelGGL(k_cost_census8w<128>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                case 256: hipLaunchKernelGGL(k_cost_census8w<256>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                default: hipLaunchKernelGGL(k_cost_census8w<512>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+            }
+            return hipGetLastError();
+        }
+        const dim3 grid((unsigned)nb);
         switch (p.L / 64) {
             case 1: hipLaunchKernelGGL(k_cost_census8<1>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
             case 2: hipLaunchKernelGGL(k_cost_census8<2>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
