@@ -1,5 +1,7 @@
 """Seeded random small cases against the oracle: odd image sizes (down to 1x1), label counts on both sides of every
 kernel-selection threshold, every mode -- the corners the structured sweeps do not visit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,10 +10,14 @@ from mgm_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+# a longer campaign on demand: MGM_FUZZ_N=4000 MGM_FUZZ_BASE=100000 python -m pytest tests/test_gpu_fuzz.py -m gpu
+FUZZ_N = int(os.environ.get("MGM_FUZZ_N", "0"))
+FUZZ_BASE = int(os.environ.get("MGM_FUZZ_BASE", "0"))
+
 LABELS = [1, 2, 3, 5, 31, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 511, 512]
 
 
-@pytest.mark.parametrize("seed", range(160))
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_N or 160)))
 def test_random_case_vs_oracle(ctx, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     nx, ny = int(rng.integers(1, 40)), int(rng.integers(1, 30))
@@ -50,7 +56,7 @@ def test_random_case_vs_oracle(ctx, oracle, seed):
     S.free(), cv.free()
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_N // 2 or 60)))
 def test_random_costvolume_vs_oracle(ctx, oracle, seed):
     rng = np.random.default_rng(5000 + seed)
     nch = int(rng.choice([1, 3]))
