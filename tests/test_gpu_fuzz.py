@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 # a longer campaign on demand: MGM_FUZZ_N=4000 MGM_FUZZ_BASE=100000 python -m pytest tests/test_gpu_fuzz.py -m gpu
 FUZZ_N = int(os.environ.get("MGM_FUZZ_N", "0"))
 FUZZ_BASE = int(os.environ.get("MGM_FUZZ_BASE", "0"))
+FUZZ_SCALE = int(os.environ.get("MGM_FUZZ_SCALE", "1"))  # image sides up to 40 x 30 times this (several bands per pass from 2 on)
 
 LABELS = [1, 2, 3, 5, 31, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 511, 512]
 
@@ -20,11 +21,11 @@ LABELS = [1, 2, 3, 5, 31, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 25
 @pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_N or 160)))
 def test_random_case_vs_oracle(ctx, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
-    nx, ny = int(rng.integers(1, 40)), int(rng.integers(1, 30))
-    if seed % 5 == 0:
+    nx, ny = int(rng.integers(1, 40 * FUZZ_SCALE)), int(rng.integers(1, 30 * FUZZ_SCALE))
+    if seed % 5 == 0 and FUZZ_SCALE == 1:
         nx, ny = [(1, 1), (1, 7), (7, 1), (2, 2), (3, 3), (2, 9), (9, 2), (4, 3)][(seed // 5) % 8]
     L = LABELS[int(rng.integers(0, len(LABELS)))]
-    if nx * ny * L > 60000:
+    if nx * ny * L > 60000 * FUZZ_SCALE ** 2:
         L = LABELS[int(rng.integers(0, 8))]
     NDIR = int(rng.integers(1, 9))
     MGM = int(rng.integers(1, 5))
