@@ -77,3 +77,50 @@ def test_random_costvolume_vs_oracle(ctx, oracle, seed):
     cv = ctx.costvolume_dev(ctx.upload_image(u), ctx.upload_image(v), dmin, dmin + L - 1, pre, dist, td, win)
     assert ndiff(cv.download(), a) == 0, (nch, nx, ny, vnx, vny, L, dmin, pre, dist, win, td)
     cv.free()
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_N // 4 or 60)))
+def test_random_batch_vs_oracle(ctx, oracle, seed):
+    """Several volumes per launch (volumes per wave at <= 128 labels, padding, compact and fp32 costs mixed by chance)."""
+    rng = np.random.default_rng(9000 + seed)
+    nb = int(rng.integers(1, 17))
+    nx, ny = int(rng.integers(1, 40 * FUZZ_SCALE)), int(rng.integers(1, 30 * FUZZ_SCALE))
+    L = int(rng.choice([5, 31, 64, 65, 100, 127, 128, 129, 192, 200, 256, 300, 384, 512]))
+    if nb * nx * ny * L > 400000 * FUZZ_SCALE ** 2:
+        L = int(rng.choice([31, 64, 100, 128]))
+        nb = min(nb, 4)
+    NDIR = int(rng.integers(1, 9))
+    MGM = int(rng.integers(1, 5))
+    FH = int(rng.integers(0, 2))
+    P1, P2 = [(8.0, 32.0), (2.0, 9.0), (1.5, 20000.0), (2.0, np.inf), (0.5, 3.25)][int(rng.integers(0, 5))]
+    fix = int(rng.integers(0, 2))
+    dmin = int(rng.integers(-300, 300))
+    allint = rng.random() < 0.7
+    weighted = rng.random() < 0.25
+    refine = [None, "vfit", "cubic"][int(rng.integers(0, 3))]
+    Cs, cvs, w8s, w8h = [], [], [], []
+    for b in range(nb):
+        C = synth.raw_volume(nx, ny, L, seed=seed * 17 + b, inf_frac=float(rng.choice([0.0, 0.05, 0.4])))
+        if not allint and rng.random() < 0.5:  # this volume keeps fp32 costs: the launch falls back to one kind for all
+            C = (C * np.float32(1.0 / 3.0)).astype(np.float32)
+        Cs.append(C)
+        cvs.append(ctx.upload_volume(C, dmin))
+        if weighted:
+            w = np.where(rng.random((8, ny, nx)) < 0.5, np.float32(rng.choice([4.0, 0.3])), np.float32(1)).astype(np.float32)
+            w8h.append(w)
+            w8s.append(ctx.upload_image(w))
+    S, outs, outcs = ctx.aggregate_batch_dev(cvs, P1, P2, NDIR, MGM, FH, fix, w8s if weighted else None, refine, want_S=True)
+    tag = (nb, nx, ny, L, NDIR, MGM, FH, P1, P2, fix, allint, weighted, refine)
+    for b in range(nb):
+        So, oo, co = oracle.mgm(Cs[b], dmin, P1, P2, NDIR, MGM, FH, fix, w8h[b] if weighted else None)
+        if refine:
+            oo2 = np.where(np.isfinite(co), oo, dmin).astype(np.float32)
+            ro, rc = oracle.refine(So, dmin, refine, oo2, co)
+        else:
+            ro, rc = oo, co
+        assert ndiff(S[b].download(), So) == 0, (b, tag)
+        assert ndiff(outcs[b].download().reshape(ny, nx), rc) == 0, (b, tag)
+        fin = np.isfinite(co)
+        assert ndiff(outs[b].download().reshape(ny, nx)[fin], ro[fin]) == 0, (b, tag)
+    for x in cvs + S + w8s:
+        x.free()
