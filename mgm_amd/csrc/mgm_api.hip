@@ -597,6 +597,13 @@ static int costvolume_build(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int 
             return fail(c, MGM_ERR_INVALID, "census: nch*(win*win-1) must be a positive multiple of 8");
         const int nwords = (nbits / 8 + 3) / 4;
         if (nwords > kCensusMaxWords) return fail(c, MGM_ERR_UNSUPPORTED, "census descriptor longer than 256 bits");
+        // `-p census` with a non-census distance makes the reference difference the descriptor words AS FLOATS
+        // (mgm_costvolume.h:355-362: the cost function is picked before both names are switched to census).  Up to 24
+        // bits those are denormals and the arithmetic is reproduced; from 25 bits on the words include NaN patterns and
+        // the outcome depends on operand order in the reference's comparisons -- refused rather than approximated.
+        if (costfn != 2 && nbits > 24)
+            return fail(c, MGM_ERR_UNSUPPORTED, "census prefilter with a non-census distance and a descriptor of more than 24 bits "
+                                                "(NaN-valued words): use -t census");
         if ((r = reserve(c, c->census_u, sizeof(uint32_t) * (size_t)u->nx * u->ny * nwords))) return r;
         if ((r = reserve(c, c->census_v, sizeof(uint32_t) * (size_t)v->nx * v->ny * nwords))) return r;
         {

@@ -9,7 +9,7 @@
 // reference's iio decodes them to -- and float TIFF, PFM or .npy out.
 //
 // Not supported (exit code 2, message on stderr): P2 = inf together with -m/-M range files that are not constant
-// (a ragged cost volume), WITH_MGM2=1.
+// (a ragged cost volume), WITH_MGM2=1, `-p census` with a non-census distance and a descriptor of more than 24 bits.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

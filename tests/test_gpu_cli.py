@@ -111,7 +111,8 @@ def test_cli_refuses_what_is_not_built(tmp_path):
     np.save(tmp_path / "lo.npy", lo)
     np.save(tmp_path / "hi.npy", lo + 6)
     ragged = ["-m", str(tmp_path / "lo.npy"), "-M", str(tmp_path / "hi.npy")]
-    for extra, env in (([], dict(TSGM_ITER="0")), ([], dict(WITH_MGM2="1")), (ragged + ["-P2", "inf"], {})):
+    for extra, env in (([], dict(TSGM_ITER="0")), ([], dict(WITH_MGM2="1")), (ragged + ["-P2", "inf"], {}),
+                       (["-p", "census", "-t", "ad"], dict(CENSUS_NCC_WIN="7"))):
         r = subprocess.run(base[:1] + extra + base[1:], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 2 and "not" in r.stderr
 
@@ -151,3 +152,67 @@ def test_cli_png_in_tiff_out_matches_reference(case, tmp_path):
         a, b = outs["ref"][1][f], outs["ours"][1][f]
         assert a.shape == b.shape and np.isfinite(a).any(), f
         assert ndiff(a, b) == 0, f
+
+
+FUZZ_N = int(os.environ.get("MGM_FUZZ_N", "0"))
+FUZZ_BASE = int(os.environ.get("MGM_FUZZ_BASE", "0"))
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference CLI (oracle/_ref/mgm) was not built")
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_N or 24)))
+def test_cli_random_options_match_reference(seed, tmp_path):
+    """Random command lines (every option and environment parameter of the reference's main(), small images):
+    the paths only the whole program exercises -- TSGM_ITER windows, ragged ranges, post-processing."""
+    rng = np.random.default_rng(77000 + seed)
+    nch = int(rng.choice([1, 3]))
+    nx, ny = int(rng.integers(8, 90)), int(rng.integers(6, 60))
+    dmin = int(rng.integers(-20, 1))
+    dmax = dmin + int(rng.integers(2, 40))
+    u, v, gt = synth.stereo_pair(nx, ny, max(dmin, -16), min(dmax, 8) if min(dmax, 8) > max(dmin, -16) else max(dmin, -16) + 1,
+                                 seed=int(rng.integers(0, 1000)), nch=nch)
+    np.save(tmp_path / "u.npy", np.ascontiguousarray(u.transpose(1, 2, 0)) if nch > 1 else u[0])
+    np.save(tmp_path / "v.npy", np.ascontiguousarray(v.transpose(1, 2, 0)) if nch > 1 else v[0])
+    fh = int(rng.integers(0, 2))
+    P1, P2 = [(8, 32), (2, 9), (1.5, 700), (4, 20000), (0.5, 3.25)][int(rng.integers(0, 5))]
+    args = ["-r", str(dmin), "-R", str(dmax), "-O", str(int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 4, 8]))),
+            "-P1", str(P1), "-P2", str(P2),
+            "-t", str(rng.choice(["ad", "sd", "census", "ncc", "btad", "btsd"])),
+            "-p", str(rng.choice(["none", "none", "census", "sobelx", "gblur"])),
+            "-s", str(rng.choice(["none", "vfit", "parabola", "cubic", "parabolaOCV"]))]
+    if rng.random() < 0.3:
+        args += ["-aP2", str(rng.choice([4, 0.3])), "-aThresh", str(rng.choice([5, 12]))]
+    if rng.random() < 0.3:
+        args += ["-truncDist", str(rng.choice([63, 300, 20]))]
+    env = dict(TSGM=str(int(rng.integers(1, 5))), TSGM_ITER=str(int(rng.choice([1, 1, 2, 3]))),
+               TSGM_FIX_OVERCOUNT=str(int(rng.integers(0, 2))), USE_TRUNCATED_LINEAR_POTENTIALS=str(fh),
+               MEDIAN=str(int(rng.choice([0, 0, 1, 2]))), TESTLRRL=str(int(rng.integers(0, 2))),
+               TESTLRRL_TAU=str(rng.choice([1.0, 0.5, 2.5])), CENSUS_NCC_WIN=str(int(rng.choice([3, 5, 7]))))
+    if rng.random() < 0.3:  # per-pixel range images, some empty or non-finite: main() repairs them
+        lo = np.floor(rng.integers(dmin - 3, dmax, size=(ny, nx))).astype(np.float32) + rng.random((ny, nx)).astype(np.float32)
+        hi = lo + rng.integers(0, 14, size=(ny, nx)).astype(np.float32)
+        lo[rng.random((ny, nx)) < 0.02] = np.nan
+        hi[rng.random((ny, nx)) < 0.02] = np.inf
+        np.save(tmp_path / "lo.npy", lo)
+        np.save(tmp_path / "hi.npy", hi)
+        args += ["-m", str(tmp_path / "lo.npy"), "-M", str(tmp_path / "hi.npy")]
+    # `-p census` with another distance differences the descriptor words as floats: NaN patterns beyond 24 bits (refused)
+    win = int(env["CENSUS_NCC_WIN"])
+    nan_words = args[args.index("-p") + 1] == "census" and args[args.index("-t") + 1] != "census" and nch * (win * win - 1) > 24
+    outs = {}
+    for tag, exe in (("ref", REF), ("ours", OURS)):
+        d = tmp_path / tag
+        d.mkdir()
+        cmd = [exe] + args + ["-l", str(d / "nolr.npy"), str(tmp_path / "u.npy"), str(tmp_path / "v.npy"), str(d / "disp.npy"),
+                              str(d / "cost.npy"), str(d / "back.npy")]
+        r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="2", **env), capture_output=True, text=True, timeout=600)
+        if nan_words and tag == "ours":
+            assert r.returncode == 2 and "NaN-valued" in r.stderr, (r.returncode, r.stderr)
+            return
+        assert r.returncode == 0, (tag, " ".join(args), env, r.stderr)
+        outs[tag] = (r.stdout, {f: np.load(d / f) for f in sorted(os.listdir(d))})
+    what = (" ".join(args), env, nx, ny, nch)
+    assert outs["ref"][0] == outs["ours"][0], ("stdout differs", what)
+    assert outs["ref"][1].keys() == outs["ours"][1].keys(), what
+    for f in outs["ref"][1]:
+        a, b = outs["ref"][1][f], outs["ours"][1][f]
+        assert a.shape == b.shape and ndiff(a, b) == 0, (f, what)
