@@ -168,6 +168,9 @@ def test_cli_random_options_match_reference(seed, tmp_path):
     nx, ny = int(rng.integers(8, 90)), int(rng.integers(6, 60))
     dmin = int(rng.integers(-20, 1))
     dmax = dmin + int(rng.integers(2, 40))
+    if rng.random() < 0.15:  # label counts across the kernel-selection thresholds (64, 128, 192, 256 ...)
+        dmin = int(rng.integers(-200, 1))
+        dmax = dmin + int(rng.choice([62, 63, 64, 100, 126, 127, 128, 150, 191, 192, 255, 256, 300]))
     u, v, gt = synth.stereo_pair(nx, ny, max(dmin, -16), min(dmax, 8) if min(dmax, 8) > max(dmin, -16) else max(dmin, -16) + 1,
                                  seed=int(rng.integers(0, 1000)), nch=nch)
     np.save(tmp_path / "u.npy", np.ascontiguousarray(u.transpose(1, 2, 0)) if nch > 1 else u[0])
