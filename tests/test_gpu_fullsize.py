@@ -1,6 +1,8 @@
-"""Full-size checks at BASELINE.json's shapes (1920x1080, 128 / 256 labels), where the
-CPU oracle is too slow to run whole: size-independent properties plus oracle checks on
-the parts of the result that only depend on a crop of the input."""
+"""Full-size checks at BASELINE.json's shapes (1920x1080, 128 / 256 labels): size-independent properties, oracle
+checks on the parts of the result that only depend on a crop of the input (single-threaded oracle), and the two
+bench workloads whole against the OpenMP oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -113,3 +115,26 @@ def test_full_size_batch_equals_single(ctx, vol256):
         assert ndiff(outs[b].download(), ref[b][0]) == 0 and ndiff(outcs[b].download(), ref[b][1]) == 0, b
     for cv in cvs:
         cv.free()
+
+
+@pytest.mark.parametrize("cfg", [("cfg3", -255, 0, 5, 8, 3, 1, 2.0, 20000.0), ("cfg2", -127, 0, 3, 4, 2, 0, 8.0, 32.0)], ids=lambda c: c[0])
+def test_full_size_workloads_vs_oracle(ctx, oracle, cfg):
+    """The bench workloads at their full size, 1920x1080, against the OpenMP oracle (every host core the box
+    gives the process): corrected S, labels, costs and the vfit refinement, bit for bit."""
+    _, dmin, dmax, win, NDIR, MGM, FH, P1, P2 = cfg
+    nx, ny = 1920, 1080
+    u, v, _ = synth.stereo_pair(nx, ny, dmin * 3 // 4, 0, seed=20150907)
+    du, dv = ctx.upload_image(u), ctx.upload_image(v)
+    cv = ctx.costvolume_dev(du, dv, dmin, dmax, "none", "census", float("inf"), win)
+    C = cv.download()
+    oracle.set_threads(min(32, len(os.sched_getaffinity(0))))
+    try:
+        Sa, oa, ca = oracle.mgm(C, dmin, P1, P2, NDIR, MGM, FH, 1)
+        ra, rca = oracle.refine(Sa, dmin, "vfit", oa, ca)
+    finally:
+        oracle.set_threads(1)
+    S, o, c = ctx.aggregate(cv, P1, P2, NDIR, MGM, FH, 1, None, "vfit", want_S=True)
+    assert ndiff(rca, c) == 0 and ndiff(ra, o) == 0
+    assert ndiff(Sa, S.download()) == 0
+    for h in (S, cv, du, dv):
+        h.free()
