@@ -81,15 +81,27 @@ constexpr int kR = 16;       // lines per band (waves per workgroup) of the pass
 constexpr int kCtrlWords = 4 + kMaxBatch * kMaxDirs * 4096;  // ticket, err, flag, pad, prog[volume*8 + pass][maxbands]
 constexpr int kMaxBands = 4096;
 
-long long lr_pad_floats()
+// Development switches (A/B timing, tests of the fall-back paths), read once per process; everything is on by default.
+struct DevSwitches {
+    bool c8;         // MGM_HIP_C8=0: never use the compact (1 byte per label) cost volumes
+    bool lazy_f32;   // MGM_HIP_LAZY_F32=0: always materialise the fp32 volume next to the compact one
+    bool pad;        // MGM_HIP_PAD=0: no padding of label counts to the next count of the second build
+    bool subv;       // MGM_HIP_SUBV=0: one volume per wave also at 128 / 64 labels
+    int wg_per_cu;   // MGM_HIP_WG_PER_CU=1|2: override the occupancy heuristic of the pass kernel (0 = heuristic)
+    int xflags;      // MGM_HIP_XFLAGS: experiment bits of development builds (mgm_device.h)
+    long long lr_pad;  // MGM_HIP_LR_PAD: floats between consecutive Lr volumes beyond their size, in 256-byte blocks (67)
+};
+static const DevSwitches &dev()
 {
-    static long long pad = -1;
-    if (pad < 0) {
-        const char *e = getenv("MGM_HIP_LR_PAD");  // in 256-byte blocks; default 67 (17 KiB + 256 B)
-        pad = 64ll * (e ? atoll(e) : 67);
-    }
-    return pad;
+    static const DevSwitches d = [] {
+        auto on = [](const char *n) { const char *e = getenv(n); return !(e && atoi(e) == 0); };
+        auto num = [](const char *n, long long dflt) { const char *e = getenv(n); return e ? atoll(e) : dflt; };
+        return DevSwitches{on("MGM_HIP_C8"), on("MGM_HIP_LAZY_F32"), on("MGM_HIP_PAD"), on("MGM_HIP_SUBV"),
+                           (int)num("MGM_HIP_WG_PER_CU", 0), (int)num("MGM_HIP_XFLAGS", 0), 64ll * num("MGM_HIP_LR_PAD", 67)};
+    }();
+    return d;
 }
+long long lr_pad_floats() { return dev().lr_pad; }
 
 int fail(mgm_ctx *c, int code, const std::string &msg)
 {
@@ -485,7 +497,7 @@ static int c8_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *use)
 {
     mgm_cv *cv = const_cast<mgm_cv *>(ccv);
     *use = false;
-    static const bool enabled = !(getenv("MGM_HIP_C8") && atoi(getenv("MGM_HIP_C8")) == 0);
+    const bool enabled = dev().c8;
     const int L = cv->dmax - cv->dmin + 1;
     if (!enabled || !c8_supported(L)) return MGM_OK;
     if (cv->c8_state == 0) {  // uploaded / externally written volume: make the compact copy now
@@ -571,7 +583,7 @@ static int costvolume_build(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int 
     }
     p.rlo = (*out)->rlo;
     p.rhi = (*out)->rhi;
-    if (c8_supported(dmax - dmin + 1) && !(getenv("MGM_HIP_C8") && atoi(getenv("MGM_HIP_C8")) == 0)) {
+    if (c8_supported(dmax - dmin + 1) && dev().c8) {
         if ((r = c8_alloc(c, *out))) return r;
         HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
         p.C8 = (*out)->d8;
@@ -660,7 +672,7 @@ static int costvolume_build(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int 
     // nor k_wta reads then -- is only materialised on demand (ensure_f32).
     if (p.C8 && !p.rlo && costfn == 2 && p.nch == 1 &&
         (p.trunc == __builtin_huge_valf() || (p.trunc >= 0.0f && p.trunc <= 254.0f && p.trunc == rintf(p.trunc))) &&
-        !(getenv("MGM_HIP_LAZY_F32") && atoi(getenv("MGM_HIP_LAZY_F32")) == 0)) {
+        dev().lazy_f32) {
         p.C = nullptr;
         (*out)->f32_state = 0;
     }
@@ -741,8 +753,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // uniform range has a finite minimum, so the added term is finite.
     int L = Lreal;
     bool padded = false;
-    if (allow_pad && c->force_build != 1 && pass2_lines(Lreal, false) == 0 &&
-        !(getenv("MGM_HIP_PAD") && atoi(getenv("MGM_HIP_PAD")) == 0)) {
+    if (allow_pad && c->force_build != 1 && pass2_lines(Lreal, false) == 0 && dev().pad) {
         const int lp = padded_labels(Lreal);
         if (lp) {
             L = lp;
@@ -818,7 +829,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         }
         HIPCHK(c, hipMemcpyAsync(c->h_words + 3, words + 3, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        use_c8 = c->h_words[3] == 0 && !(getenv("MGM_HIP_C8") && atoi(getenv("MGM_HIP_C8")) == 0);
+        use_c8 = c->h_words[3] == 0 && dev().c8;
         if (!use_c8)
             for (int v = 0; v < nb; v++) {
                 if ((r = reserve(c, c->padf[v], sizeof(float) * (size_t)npix * L))) return r;
@@ -838,8 +849,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // step is mostly fixed cost, so it may as well serve several volumes.  Compact costs, no weights, not FH with
     // TSGM = 2 (whose slabs travel with their minimum), and a volume count that divides.
     int subv = 1;
-    if (c->force_build != 1 && use_c8 && !weighted && !(fh && MGM == 2) && (L == 128 || L == 64) && nb % (256 / L) == 0 &&
-        !(getenv("MGM_HIP_SUBV") && atoi(getenv("MGM_HIP_SUBV")) == 0))
+    if (c->force_build != 1 && use_c8 && !weighted && !(fh && MGM == 2) && (L == 128 || L == 64) && nb % (256 / L) == 0 && dev().subv)
         subv = 256 / L;
     const int ngroups = nb / subv;  // work items address groups of `subv` volumes
     const int Lk = L * subv;        // label slots of a wave
@@ -929,8 +939,8 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         }
         p.wg_per_cu = (work / 256.0 > 1.8 * chain) ? 2 : 1;
     }
-    if (const char *e = getenv("MGM_HIP_WG_PER_CU")) p.wg_per_cu = atoi(e);
-    if (const char *e = getenv("MGM_HIP_XFLAGS")) p.xflags = atoi(e);
+    if (dev().wg_per_cu) p.wg_per_cu = dev().wg_per_cu;
+    p.xflags = dev().xflags;
     if ((p.xflags || c->debug_stats) && R2 && !pass2_devtools())
         return fail(c, MGM_ERR_UNSUPPORTED, "MGM_HIP_XFLAGS / MGM_HIP_DEBUG_STATS need a development build of the pass kernels "
                                             "(MGM_P2_DEFINES=-DMGM_P2_DEV=1 python -m mgm_amd.build --force)");
