@@ -541,11 +541,31 @@ int mgm_costvolume_build_ranged_dev(mgm_ctx *c, const mgm_img *u, const mgm_img 
     return costvolume_build(c, u, v, hull_min, hull_max, dminI, dmaxI, prefilter, distance, truncDist, census_win, out);
 }
 
+static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int dmin, int dmax, const mgm_img *rloI,
+                           const mgm_img *rhiI, const char *prefilter, const char *distance, float truncDist, int census_win,
+                           mgm_cv **out);
+
+// A volume this call created does not outlive a failure of the call (a caller-provided one stays the caller's).
 static int costvolume_build(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int dmin, int dmax, const mgm_img *rloI,
                             const mgm_img *rhiI, const char *prefilter, const char *distance, float truncDist, int census_win,
                             mgm_cv **out)
 {
     if (!c || !u || !v || !out) return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: null argument");
+    const bool provided = *out != nullptr;
+    const int r = costvolume_fill(c, u, v, dmin, dmax, rloI, rhiI, prefilter, distance, truncDist, census_win, out);
+    if (r != MGM_OK && !provided && *out) {
+        const std::string msg = c->err;  // (mgm_cv_free synchronises and may touch the message)
+        mgm_cv_free(c, *out);
+        *out = nullptr;
+        c->err = msg;
+    }
+    return r;
+}
+
+static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int dmin, int dmax, const mgm_img *rloI,
+                           const mgm_img *rhiI, const char *prefilter, const char *distance, float truncDist, int census_win,
+                           mgm_cv **out)
+{
     if (u->nch != v->nch) return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: channel counts differ");
     HIPCHK(c, hipSetDevice(c->device));
     int dist = distance_index(distance), pre = prefilter_index(prefilter);
@@ -553,6 +573,17 @@ static int costvolume_build(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int 
     if (dist == 2 || pre == 1) {  // 358-362
         dist = 2;
         pre = 1;
+    }
+
+    if (pre == 1) {
+        const int side = 2 * (census_win / 2) + 1, nbits = u->nch * (side * side - 1);
+        // `-p census` with a non-census distance makes the reference difference the descriptor words AS FLOATS
+        // (mgm_costvolume.h:355-362: the cost function is picked before both names are switched to census).  Up to 24
+        // bits those are denormals and the arithmetic is reproduced; from 25 bits on the words include NaN patterns and
+        // the outcome depends on operand order in the reference's comparisons -- refused rather than approximated.
+        if (costfn != 2 && nbits > 24)
+            return fail(c, MGM_ERR_UNSUPPORTED, "census prefilter with a non-census distance and a descriptor of more than 24 bits "
+                                                "(NaN-valued words): use -t census");
     }
 
     int r = MGM_OK;
@@ -609,13 +640,6 @@ static int costvolume_build(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int 
             return fail(c, MGM_ERR_INVALID, "census: nch*(win*win-1) must be a positive multiple of 8");
         const int nwords = (nbits / 8 + 3) / 4;
         if (nwords > kCensusMaxWords) return fail(c, MGM_ERR_UNSUPPORTED, "census descriptor longer than 256 bits");
-        // `-p census` with a non-census distance makes the reference difference the descriptor words AS FLOATS
-        // (mgm_costvolume.h:355-362: the cost function is picked before both names are switched to census).  Up to 24
-        // bits those are denormals and the arithmetic is reproduced; from 25 bits on the words include NaN patterns and
-        // the outcome depends on operand order in the reference's comparisons -- refused rather than approximated.
-        if (costfn != 2 && nbits > 24)
-            return fail(c, MGM_ERR_UNSUPPORTED, "census prefilter with a non-census distance and a descriptor of more than 24 bits "
-                                                "(NaN-valued words): use -t census");
         if ((r = reserve(c, c->census_u, sizeof(uint32_t) * (size_t)u->nx * u->ny * nwords))) return r;
         if ((r = reserve(c, c->census_v, sizeof(uint32_t) * (size_t)v->nx * v->ny * nwords))) return r;
         {
