@@ -359,8 +359,14 @@ int mgm_img_upload(mgm_ctx *c, const float *host, int nx, int ny, int nch, mgm_i
     if (!host) return fail(c, MGM_ERR_INVALID, "mgm_img_upload: null host pointer");
     int r = mgm_img_create(c, nx, ny, nch, out);
     if (r) return r;
-    HIPCHK(c, hipMemcpyAsync((*out)->d, host, sizeof(float) * (size_t)nx * ny * nch, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipMemcpyAsync((*out)->d, host, sizeof(float) * (size_t)nx * ny * nch, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {  // nothing this call created outlives its failure
+        r = hipfail(c, e, "mgm_img_upload: copy");
+        mgm_img_free(c, *out);
+        *out = nullptr;
+        return r;
+    }
     return MGM_OK;
 }
 int mgm_img_download(mgm_ctx *c, const mgm_img *im, float *host)
@@ -420,8 +426,14 @@ int mgm_cv_upload(mgm_ctx *c, const float *dense, int nx, int ny, int dmin, int 
     int r = mgm_cv_create(c, nx, ny, dmin, dmax, out);
     if (r) return r;
     const size_t n = (size_t)nx * ny * (size_t)(dmax - dmin + 1);
-    HIPCHK(c, hipMemcpyAsync((*out)->d, dense, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipMemcpyAsync((*out)->d, dense, sizeof(float) * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        r = hipfail(c, e, "mgm_cv_upload: copy");
+        mgm_cv_free(c, *out);
+        *out = nullptr;
+        return r;
+    }
     (*out)->c8_state = 0;
     return MGM_OK;
 }
@@ -746,7 +758,13 @@ int mgm_weights_dev(mgm_ctx *c, const mgm_img *u, float aP, float aThresh, mgm_i
     int r = mgm_img_create(c, u->nx, u->ny, 8, w8);
     if (r) return r;
     TimeScope t(c, "k_weights");
-    HIPCHK(c, launch_weights(u->d, u->nx, u->ny, u->nch, aP, aThresh, (*w8)->d, c->stream));
+    const hipError_t e = launch_weights(u->d, u->nx, u->ny, u->nch, aP, aThresh, (*w8)->d, c->stream);
+    if (e != hipSuccess) {
+        r = hipfail(c, e, "k_weights");
+        mgm_img_free(c, *w8);
+        *w8 = nullptr;
+        return r;
+    }
     return MGM_OK;
 }
 
@@ -1150,18 +1168,27 @@ int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm
     int r;
     if ((r = run_passes(c, C, (w8 && w8[0]) ? w8 : nullptr, n, P1, P2, MGM, use_fh, 0, NDIR, /*allow_pad=*/true))) return r;
     const long long npix = (long long)nx * ny;
-    for (int v = 0; v < n; v++) {
+    if (S)
+        for (int v = 0; v < n; v++) S[v] = nullptr;
+    for (int v = 0; v < n && !r; v++) {
         float *Sout = nullptr;
         if (S) {
-            if ((r = mgm_cv_create(c, nx, ny, C[v]->dmin, C[v]->dmax, &S[v]))) return r;
+            if ((r = mgm_cv_create(c, nx, ny, C[v]->dmin, C[v]->dmax, &S[v]))) break;
             Sout = S[v]->d;
         }
         const float *lr = (const float *)c->lr.p + (size_t)v * NDIR * c->last_stride;
-        if ((r = run_wta_refine(c, C[v], 0, npix, lr, c->last_stride, NDIR, fix_overcount, ridx, out[v]->d, outcost[v]->d, Sout, nullptr,
-                                nullptr, v)))
-            return r;
+        r = run_wta_refine(c, C[v], 0, npix, lr, c->last_stride, NDIR, fix_overcount, ridx, out[v]->d, outcost[v]->d, Sout, nullptr,
+                           nullptr, v);
     }
-    return MGM_OK;
+    if (r && S) {  // no S volume of a failed call is handed out
+        const std::string msg = c->err;
+        for (int v = 0; v < n; v++) {
+            if (S[v]) mgm_cv_free(c, S[v]);
+            S[v] = nullptr;
+        }
+        c->err = msg;
+    }
+    return r;
 }
 
 int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
