@@ -16,8 +16,9 @@
  *   - plain C: opaque handles, raw pointers, ints; every function returns an
  *     mgm_status (0 = MGM_OK) and never throws or aborts across the boundary;
  *     mgm_last_error(ctx) gives the text of the last failure on that context.
- *     A call that fails hands out nothing it created: its output handles are
- *     left NULL (a volume passed in to be refilled stays the caller's).
+ *     A call that fails hands out nothing it created: an output handle is
+ *     either not written at all or reset to NULL, never left pointing at a
+ *     half-made object (a volume passed in to be refilled stays the caller's).
  *   - images are the reference's `struct Img` layout (img.h:35-51): planar
  *     float32, data[x + y*nx + c*nx*ny].
  *   - cost volumes are the reference's per-pixel `Dvec` order (dvec.cc:49-131)
