@@ -218,4 +218,12 @@ def test_cli_random_options_match_reference(seed, tmp_path):
     assert outs["ref"][1].keys() == outs["ours"][1].keys(), what
     for f in outs["ref"][1]:
         a, b = outs["ref"][1][f], outs["ours"][1][f]
-        assert a.shape == b.shape and ndiff(a, b) == 0, (f, what)
+        assert a.shape == b.shape, (f, what)
+        if f == "cost.npy":
+            # A pixel without any finite S keeps the reference's UNINITIALISED label (mgm_core.cc:594 `float minP;`) and
+            # cost +INF; what the refinement then makes of that label is undefined (NaN or +INF, seen 2x in 3500 random
+            # command lines).  Here such a pixel gets a NaN label and keeps +INF: same pixels, no value to compare.
+            fa, fb = np.isfinite(a), np.isfinite(b)
+            assert np.array_equal(fa, fb), (f, what)
+            a, b = np.where(fa, a, 0), np.where(fb, b, 0)
+        assert ndiff(a, b) == 0, (f, what)
