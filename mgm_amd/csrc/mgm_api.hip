@@ -32,6 +32,10 @@ struct mgm_cv {
     // ragged volume: the per-pixel range images it was built from (device, nx*ny floats each), else nullptr.
     // dmin/dmax are then the hull of all ranges; labels outside a pixel's own range hold +INF.
     float *rlo = nullptr, *rhi = nullptr;
+    // built by `-p census` with a non-census distance from descriptors of more than 24 bits: costs are differences of
+    // descriptor WORDS read as floats (mgm_costvolume.h:355-362), NaN patterns included.  The volume itself is
+    // reproduced bit for bit; what the reference's aggregation makes of NaN costs depends on operand order.
+    bool nan_words = false;
 };
 
 namespace {
@@ -587,17 +591,6 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         pre = 1;
     }
 
-    if (pre == 1) {
-        const int side = 2 * (census_win / 2) + 1, nbits = u->nch * (side * side - 1);
-        // `-p census` with a non-census distance makes the reference difference the descriptor words AS FLOATS
-        // (mgm_costvolume.h:355-362: the cost function is picked before both names are switched to census).  Up to 24
-        // bits those are denormals and the arithmetic is reproduced; from 25 bits on the words include NaN patterns and
-        // the outcome depends on operand order in the reference's comparisons -- refused rather than approximated.
-        if (costfn != 2 && nbits > 24)
-            return fail(c, MGM_ERR_UNSUPPORTED, "census prefilter with a non-census distance and a descriptor of more than 24 bits "
-                                                "(NaN-valued words): use -t census");
-    }
-
     int r = MGM_OK;
     if (*out) {  // caller-provided volume to refill (must have the right geometry)
         if ((*out)->nx != u->nx || (*out)->ny != u->ny || (*out)->dmin != dmin || (*out)->dmax != dmax)
@@ -605,6 +598,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     } else if ((r = mgm_cv_create(c, u->nx, u->ny, dmin, dmax, out))) {
         return r;
     }
+    (*out)->nan_words = false;
     CostParams p{};
     p.C = (*out)->d;
     p.C8 = nullptr;
@@ -652,6 +646,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
             return fail(c, MGM_ERR_INVALID, "census: nch*(win*win-1) must be a positive multiple of 8");
         const int nwords = (nbits / 8 + 3) / 4;
         if (nwords > kCensusMaxWords) return fail(c, MGM_ERR_UNSUPPORTED, "census descriptor longer than 256 bits");
+        (*out)->nan_words = costfn != 2 && nbits > 24;
         if ((r = reserve(c, c->census_u, sizeof(uint32_t) * (size_t)u->nx * u->ny * nwords))) return r;
         if ((r = reserve(c, c->census_v, sizeof(uint32_t) * (size_t)v->nx * v->ny * nwords))) return r;
         {
@@ -787,6 +782,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     const mgm_cv *C = Cs[0];
     const int nx = C->nx, ny = C->ny, Lreal = C->dmax - C->dmin + 1;
     const int PEND = first + count;
+    for (int v = 0; v < nb; v++)
+        if (Cs[v]->nan_words)
+            return fail(c, MGM_ERR_UNSUPPORTED, "cost volume of a census prefilter with a non-census distance and a descriptor of "
+                                                "more than 24 bits (NaN-valued words): use -t census");
     HIPCHK(c, hipSetDevice(c->device));
 
     // A label count the second build does not take (not 64, 128, 192, 256, 384 or 512) runs PADDED: the kernels see
