@@ -227,3 +227,6 @@ def test_cli_random_options_match_reference(seed, tmp_path):
             assert np.array_equal(fa, fb), (f, what)
             a, b = np.where(fa, a, 0), np.where(fb, b, 0)
         assert ndiff(a, b) == 0, (f, what)
+    if FUZZ_N:  # long campaigns: do not let thousands of test directories pile up on the box
+        import shutil
+        shutil.rmtree(tmp_path, ignore_errors=True)
