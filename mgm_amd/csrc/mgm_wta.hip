@@ -190,13 +190,23 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
 hipError_t launch_wta(const WtaParams &p, hipStream_t s)
 {
     long long nb = (p.npix + 3) / 4;  // (an upper bound: waves take several pixels per iteration)
-    static int per_cu = 0;
-    if (!per_cu) {
+    static int per_cu = -1;  // MGM_HIP_WTA_WG_PER_CU=n overrides the grid bound (A/B timing)
+    if (per_cu < 0) {
         const char *e = getenv("MGM_HIP_WTA_WG_PER_CU");
-        per_cu = e ? atoi(e) : 16;
-        if (per_cu < 1) per_cu = 16;
+        per_cu = e ? atoi(e) : 0;
+        if (per_cu < 0) per_cu = 0;
     }
-    if (nb > 256ll * per_cu) nb = 256ll * per_cu;  // a bounded grid (workgroups of 4 waves), grid-stride beyond
+    static int packed = -1;  // MGM_HIP_WTA_PACKED=0: one pixel per slab also at 128 / 64 labels (A/B timing)
+    if (packed < 0) {
+        const char *e = getenv("MGM_HIP_WTA_PACKED");
+        packed = e ? atoi(e) != 0 : 1;
+    }
+    const bool use_packed = packed && p.Lreal == p.L && (p.L == 128 || p.L == 64) && p.npix % (256 / p.L) == 0;
+    // A bounded grid (workgroups of 4 waves), grid-stride beyond it.  Measured at 1920x1080 (8 / 4 directions): one
+    // pixel per slab is fastest at ~768 workgroups per CU (2.99 ms at 16 -> 2.73 ms: 6.4 TB/s, the read ceiling of the
+    // part), several pixels per slab at ~128 (0.83 -> 0.80 ms); far larger grids lose again.
+    const long long cap = 256ll * (per_cu ? per_cu : (use_packed ? 128 : 768));
+    if (nb > cap) nb = cap;
     const dim3 grid((unsigned)nb), block(256);
     static int wide4 = -1;  // MGM_HIP_WTA_WIDE4=0: the 8-direction instance also for NDIR <= 4 (A/B timing)
     if (wide4 < 0) {
@@ -204,12 +214,7 @@ hipError_t launch_wta(const WtaParams &p, hipStream_t s)
         wide4 = e ? atoi(e) != 0 : 1;
     }
     // 128 and 64 labels: two / four pixels per 256-float slab (16-byte loads, one butterfly for all of them)
-    static int packed = -1;
-    if (packed < 0) {
-        const char *e = getenv("MGM_HIP_WTA_PACKED");
-        packed = e ? atoi(e) != 0 : 1;
-    }
-    if (packed && p.Lreal == p.L && (p.L == 128 || p.L == 64) && p.npix % (256 / p.L) == 0) {
+    if (use_packed) {
         if (p.L == 128) {
             if (p.NDIR <= 4) hipLaunchKernelGGL((k_wta<4, 4, true, 4, 2>), grid, block, 0, s, p);
             else hipLaunchKernelGGL((k_wta<4, 2, true, kMaxDirs, 2>), grid, block, 0, s, p);
