@@ -104,7 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=None, choices=list(range(1, 17)),
                     help="pairs per step and GPU: their volumes share ONE launch of the pass kernel (pairs mode).  Default: "
-                         "8, or 16 for workloads of at most 128 labels (two / four of those volumes share every wave)")
+                         "12 (204 GB of Lr volumes at 1920x1080x256 x 8 directions), or 16 for workloads of at most 128 labels "
+                         "(two / four of those volumes share every wave)")
     ap.add_argument("--mode", default="pairs", choices=["pairs", "directions"],
                     help="N>1: 'pairs' = independent pairs, one per GPU (weak scaling, default); 'directions' = ONE "
                          "volume per step, its passes sharded over the GPUs with an ordered RCCL exchange (strong)")
@@ -135,7 +136,7 @@ def main():
     # pairs mode: every rank gets its own pair (different seed): independent units, no exchange.
     # directions mode: every rank holds the SAME pair and builds the full cost volume itself.
     if args.batch is None:
-        args.batch = 16 if L <= 128 else 8
+        args.batch = 16 if L <= 128 else 12
     B = args.batch if args.mode == "pairs" else 1
     dus, dvs, outs, outcs = [], [], [], []
     for b in range(B):

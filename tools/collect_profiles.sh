@@ -10,11 +10,11 @@ OUT=$ROOT/gpurun_out/profiles
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 W=${1:-cfg3}
-B=${2:-8}
+B=${2:-12}
 : > "$OUT/bench_lines.jsonl"
 timeout 900 python bench.py 2> "$OUT/bench_default.stderr" | tail -1 >> "$OUT/bench_lines.jsonl"
 for w in cfg3h cfg2; do timeout 300 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT/bench_lines.jsonl"; done
-for b in 4 1; do timeout 300 python bench.py --workload cfg3 --batch $b --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT/bench_lines.jsonl"; done
+for b in 8 4 1; do timeout 300 python bench.py --workload cfg3 --batch $b --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT/bench_lines.jsonl"; done
 
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python "$ROOT/bench.py" --workload $W --batch $B --steps 10 --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2> "$OUT/kt.stderr"
