@@ -53,6 +53,7 @@ typedef enum mgm_status {
 } mgm_status;
 
 /* ---- context ---------------------------------------------------------- */
+/* MGM_ERR_HIP if `device` does not exist or is not a gfx950 part. */
 int mgm_ctx_create(int device, mgm_ctx **ctx);
 int mgm_ctx_destroy(mgm_ctx *ctx);
 const char *mgm_last_error(const mgm_ctx *ctx);
@@ -89,8 +90,7 @@ int mgm_cv_free(mgm_ctx *ctx, mgm_cv *cv);
  * "ncc","btad","btsd"}; unknown names silently select the first entry, as the
  * reference does (mgm_costvolume.h:184-190, 201-207).  census_win is the value
  * of the reference's CENSUS_NCC_WIN environment parameter (mgm_costvolume.h:61).
- * Built: none/census x ad/sd/census.  sobelx, gblur, ncc, btad, btsd return
- * MGM_ERR_UNSUPPORTED.  *C must be NULL (a new volume is allocated) or a volume of
+ * Every entry of both tables is built on the device.  *C must be NULL (a new volume is allocated) or a volume of
  * the same geometry, which is then refilled in place (no allocation, no sync). */
 int mgm_costvolume_build_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, int dmin, int dmax,
                              const char *prefilter, const char *distance, float truncDist, int census_win,
@@ -116,7 +116,9 @@ int mgm_costvolume_build_ranged_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_im
 int mgm_weights_dev(mgm_ctx *ctx, const mgm_img *u, float aP, float aThresh, mgm_img **w8);
 
 /* ---- aggregation + WTA: mgm() ------------------------------------------ */
-/* C is not modified.  w8 may be NULL (all ones).  As in the reference
+/* C is not modified.  w8 may be NULL (all ones).  A volume that holds NaN costs (possible only in one uploaded with
+ * mgm_cv_upload or written through mgm_cv_device_ptr; it is scanned once per filling) is refused with
+ * MGM_ERR_UNSUPPORTED: what the reference's minima make of a NaN depends on operand order.  As in the reference
  * (mgm_core.cc:420-423) a single weight != 1.0 anywhere switches the whole run
  * to the weighted update functions.  P1/P2 are used as given (the caller has
  * already multiplied by the channel count, mgm.cc:356-357).

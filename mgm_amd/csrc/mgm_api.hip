@@ -36,7 +36,20 @@ struct mgm_cv {
     // descriptor WORDS read as floats (mgm_costvolume.h:355-362), NaN patterns included.  The volume itself is
     // reproduced bit for bit; what the reference's aggregation makes of NaN costs depends on operand order.
     bool nan_words = false;
+    // Does the volume hold NaN costs?  The scan-line kernels are compiled NaN-free (mgm_pass_common.h) and what the
+    // reference makes of a NaN cost depends on the operand order of its minima, so such a volume is refused by
+    // mgm_aggregate* instead of being aggregated into something unspecified.  0 not scanned (uploaded / written through
+    // mgm_cv_device_ptr), 1 flag word on the device is current but not read back, 2 clean, -1 holds NaN.
+    int nan_state = 0;
+    // bumped whenever the contents may have changed: contexts remember (pointer, generation) of the volumes of their
+    // last aggregation, so a refilled volume, or a new one at a recycled address, is not mistaken for one of them
+    unsigned long long gen = 0;
 };
+static unsigned long long next_cv_generation()
+{
+    static unsigned long long g = 0;
+    return ++g;
+}
 
 namespace {
 
@@ -72,8 +85,10 @@ struct mgm_ctx {
     int last_L = 0, last_Lk = 0;          // labels of the last aggregation, and the label stride its kernels ran with (>= last_L)
     Buf padf[kMaxBatch], pad8[kMaxBatch];  // padded copies of the cost volumes of a launch whose label count was padded
     bool last_pad_c8 = false;
-    const mgm_cv *last_cvs[kMaxBatch] = {};  // the volumes of the last aggregation (identity only, never dereferenced)
+    const mgm_cv *last_cvs[kMaxBatch] = {};  // the volumes of the last aggregation (identity only, never dereferenced) ...
+    unsigned long long last_gens[kMaxBatch] = {};  // ... and their generations at that time
     bool pending_check = false;
+    int num_cu = 256;  // hipDeviceProp_t::multiProcessorCount
     // timing
     bool timing = false;
     std::vector<Timing> tim;
@@ -244,6 +259,21 @@ bool make_geom(int pass, int nx, int ny, int R, int MGM, bool slope1_ok, PassGeo
 
 }  // namespace
 
+// The watchdog word of the last pass launch lands in h_words[1] with the stream's next synchronisation.  Every
+// internal synchronisation point and every new pass launch looks at it, so that a hand-off time-out of one
+// launch is reported by the next call at the latest, not overwritten by it.
+static int check_watchdog(mgm_ctx *c)
+{
+    if (!c->pending_check) return MGM_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pending_check = false;
+    if (c->h_words[1] != 0) {
+        c->h_words[1] = 0;
+        return fail(c, MGM_ERR_INTERNAL, "pass kernel watchdog: inter-band hand-off timed out");
+    }
+    return MGM_OK;
+}
+
 // ---------------------------------------------------------------------------
 extern "C" {
 
@@ -256,8 +286,12 @@ int mgm_ctx_create(int device, mgm_ctx **out)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return MGM_ERR_HIP;
     if (hipSetDevice(device) != hipSuccess) return MGM_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MGM_ERR_HIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MGM_ERR_HIP;  // the kernels exist for gfx950 only
     mgm_ctx *c = new mgm_ctx();
     c->device = device;
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return MGM_ERR_HIP;
@@ -305,14 +339,7 @@ int mgm_ctx_synchronize(mgm_ctx *c)
     if (!c) return MGM_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->pending_check) {
-        c->pending_check = false;
-        if (c->h_words[1] != 0) {
-            c->h_words[1] = 0;
-            return fail(c, MGM_ERR_INTERNAL, "pass kernel watchdog: inter-band hand-off timed out");
-        }
-    }
-    return MGM_OK;
+    return check_watchdog(c);
 }
 
 int mgm_timing_enable(mgm_ctx *c, int enable)
@@ -421,6 +448,12 @@ int mgm_cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, mgm_cv **out)
         delete cv;
         return fail(c, MGM_ERR_NOMEM, std::string("mgm_cv_create: ") + hipGetErrorString(e));
     }
+    if (hipMalloc((void **)&cv->bad8, 64) != hipSuccess) {
+        (void)hipFree(cv->d);
+        delete cv;
+        return fail(c, MGM_ERR_NOMEM, "mgm_cv_create: flag word");
+    }
+    cv->gen = next_cv_generation();
     *out = cv;
     return MGM_OK;
 }
@@ -439,6 +472,7 @@ int mgm_cv_upload(mgm_ctx *c, const float *dense, int nx, int ny, int dmin, int 
         return r;
     }
     (*out)->c8_state = 0;
+    (*out)->nan_state = 0;
     return MGM_OK;
 }
 // make cv->d current (see mgm_cv::f32_state); enqueued on the context's stream
@@ -475,6 +509,8 @@ void *mgm_cv_device_ptr(mgm_cv *cv)
     if (!cv) return nullptr;
     if (cv->owner && ensure_f32(cv->owner, cv)) return nullptr;
     cv->c8_state = 0;  // the caller may write through the pointer: re-derive the compact copy at the next use
+    cv->nan_state = 0;
+    cv->gen = next_cv_generation();
     return cv->d;
 }
 int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
@@ -484,6 +520,10 @@ int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
     }
+    for (mgm_ctx *o : {c, cv->owner})
+        if (o)
+            for (int v = 0; v < kMaxBatch; v++)
+                if (o->last_cvs[v] == cv) o->last_cvs[v] = nullptr;
     (void)hipFree(cv->d);
     if (cv->d8) (void)hipFree(cv->d8);
     if (cv->bad8) (void)hipFree(cv->bad8);
@@ -501,37 +541,44 @@ static int c8_alloc(mgm_ctx *c, mgm_cv *cv)
         cv->d8 = nullptr;
         return fail(c, MGM_ERR_NOMEM, "hipMalloc of the compact cost volume failed");
     }
-    if (!cv->bad8 && hipMalloc((void **)&cv->bad8, 64) != hipSuccess) {
-        cv->bad8 = nullptr;
-        return fail(c, MGM_ERR_NOMEM, "hipMalloc failed");
-    }
     return MGM_OK;
 }
-// Decide (once per filling of the volume) whether the compact copy can stand in for C.
-// Costs one 4-byte device->host read; MGM_HIP_C8=0 disables the compact path.
+// Decide (once per filling of the volume) whether the compact copy can stand in for C, and whether the volume
+// holds NaN costs (mgm_cv::nan_state).  Costs one 4-byte device->host read per filling; MGM_HIP_C8=0 disables the
+// compact path.  An uploaded volume is scanned here: by k_compact where it gets a compact copy, else by k_nanscan.
 static int c8_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *use)
 {
     mgm_cv *cv = const_cast<mgm_cv *>(ccv);
     *use = false;
-    const bool enabled = dev().c8;
     const int L = cv->dmax - cv->dmin + 1;
-    if (!enabled || !c8_supported(L)) return MGM_OK;
-    if (cv->c8_state == 0) {  // uploaded / externally written volume: make the compact copy now
+    const bool enabled = dev().c8 && c8_supported(L);
+    const long long n = (long long)cv->nx * cv->ny * L;
+    bool launched = false;
+    if (enabled && cv->c8_state == 0) {  // uploaded / externally written volume: make the compact copy now
         int r = c8_alloc(c, cv);
         if (r) return r;
         HIPCHK(c, hipMemsetAsync(cv->bad8, 0, 4, c->stream));
         TimeScope t(c, "k_compact");
-        HIPCHK(c, launch_compact(cv->d, (long long)cv->nx * cv->ny * L, cv->d8, cv->bad8, c->stream));
+        HIPCHK(c, launch_compact(cv->d, n, cv->d8, cv->bad8, c->stream));
         cv->c8_state = 1;
+        cv->nan_state = 1;
+        launched = true;
     }
-    if (cv->c8_state == 1) {
+    if (cv->nan_state == 0) {
+        if (!launched) HIPCHK(c, hipMemsetAsync(cv->bad8, 0, 4, c->stream));
+        TimeScope t(c, "k_nanscan");
+        HIPCHK(c, launch_nanscan(cv->d, n, cv->bad8, c->stream));
+        cv->nan_state = 1;
+    }
+    if (cv->c8_state == 1 || cv->nan_state == 1) {
         HIPCHK(c, hipMemcpyAsync(c->h_words + 3, cv->bad8, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        cv->c8_state = c->h_words[3] ? -1 : 2;
+        if (cv->c8_state == 1) cv->c8_state = (c->h_words[3] & 1u) ? -1 : 2;
+        if (cv->nan_state == 1) cv->nan_state = (c->h_words[3] & 2u) ? -1 : 2;
         if (cv->c8_state < 0 && !cv->f32_state)
             return fail(c, MGM_ERR_INTERNAL, "cost volume predicted to fit the compact form does not");
     }
-    *use = cv->c8_state == 2;
+    *use = enabled && cv->c8_state == 2;
     return MGM_OK;
 }
 
@@ -599,11 +646,14 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         return r;
     }
     (*out)->nan_words = false;
+    (*out)->gen = next_cv_generation();
     CostParams p{};
     p.C = (*out)->d;
     p.C8 = nullptr;
-    p.bad8 = nullptr;
+    p.bad8 = (*out)->bad8;
+    HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
     (*out)->c8_state = 0;
+    (*out)->nan_state = 1;  // K2 flags NaN costs as it writes them
     if (rloI) {  // the volume keeps its own copy of the range images: K4-K6 need them again
         const size_t nb = sizeof(float) * (size_t)u->nx * u->ny;
         for (float **q : {&(*out)->rlo, &(*out)->rhi})
@@ -622,9 +672,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     p.rhi = (*out)->rhi;
     if (c8_supported(dmax - dmin + 1) && dev().c8) {
         if ((r = c8_alloc(c, *out))) return r;
-        HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
         p.C8 = (*out)->d8;
-        p.bad8 = (*out)->bad8;
         (*out)->c8_state = 1;
     }
     (*out)->f32_state = 1;
@@ -787,6 +835,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
             return fail(c, MGM_ERR_UNSUPPORTED, "cost volume of a census prefilter with a non-census distance and a descriptor of "
                                                 "more than 24 bits (NaN-valued words): use -t census");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int r0 = check_watchdog(c)) return r0;  // (the control words are about to be reset)
 
     // A label count the second build does not take (not 64, 128, 192, 256, 384 or 512) runs PADDED: the kernels see
     // the next such count, the extra label slots hold +INF costs -- "no such label", exactly what a read past a Dvec
@@ -859,6 +908,15 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
 
     // compact costs (one byte per label) when the volume allows it
     bool use_c8 = true;
+    std::vector<char> c8ok(nb, 0);
+    for (int v = 0; v < nb; v++) {  // (also resolves mgm_cv::nan_state: one scan per filling of a volume)
+        bool u = false;
+        if ((r = c8_resolve(c, Cs[v], &u))) return r;
+        c8ok[v] = u;
+        if (Cs[v]->nan_state < 0)
+            return fail(c, MGM_ERR_UNSUPPORTED, "the cost volume holds NaN costs: what the reference's aggregation makes of them depends "
+                                                "on the operand order of its minima and is not reproduced");
+    }
     if (padded) {
         // padded copies of the costs: the compact form if every volume allows it, else fp32
         HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
@@ -878,11 +936,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
                 HIPCHK(c, launch_pad(Cs[v]->d, npix, Lreal, L, (float *)c->padf[v].p, nullptr, nullptr, c->stream));
             }
     } else {
-        for (int v = 0; v < nb; v++) {
-            bool u = false;
-            if ((r = c8_resolve(c, Cs[v], &u))) return r;
-            use_c8 = use_c8 && u;
-        }
+        for (int v = 0; v < nb; v++) use_c8 = use_c8 && c8ok[v];
     }
     if (c->force_build == 1) use_c8 = false;
     // second build (LDS-DMA loaders) whenever the slabs are whole DMA pieces
@@ -978,7 +1032,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
             work += (double)ngroups * g.nbands * (g.LL + g.slope * R);
             chain = std::max(chain, (double)g.slope * g.NL + g.LL + 10.0 * g.nbands);
         }
-        p.wg_per_cu = (work / 256.0 > 1.8 * chain) ? 2 : 1;
+        p.wg_per_cu = (work / (double)c->num_cu > 1.8 * chain) ? 2 : 1;
     }
     if (dev().wg_per_cu) p.wg_per_cu = dev().wg_per_cu;
     p.xflags = dev().xflags;
@@ -1065,7 +1119,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     c->last_L = Lreal;
     c->last_Lk = L;
     c->last_pad_c8 = padded && use_c8;
-    for (int v = 0; v < kMaxBatch; v++) c->last_cvs[v] = v < nb ? Cs[v] : nullptr;
+    for (int v = 0; v < kMaxBatch; v++) {
+        c->last_cvs[v] = v < nb ? Cs[v] : nullptr;
+        c->last_gens[v] = v < nb ? Cs[v]->gen : 0;
+    }
 
     return MGM_OK;
 }
@@ -1107,6 +1164,7 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
     w.whi = whi ? whi + pix0 : nullptr;
     w.clo = C->rlo ? C->rlo + pix0 : nullptr;
     w.chi = C->rhi ? C->rhi + pix0 : nullptr;
+    w.num_cu = c->num_cu;
     TimeScope t(c, "k_wta");
     HIPCHK(c, launch_wta(w, c->stream));
     return MGM_OK;
@@ -1299,7 +1357,7 @@ int mgm_wta_windowed_dev(mgm_ctx *c, const mgm_cv *C, int NDIR, int fix_overcoun
         if (im->nx != nx || im->ny != ny || im->nch != 1) return fail(c, MGM_ERR_INVALID, "mgm_wta_windowed: image size mismatch");
     int slot = -1;
     for (int v = 0; v < c->last_batch; v++)
-        if (c->last_cvs[v] == C) slot = v;
+        if (c->last_cvs[v] == C && c->last_gens[v] == C->gen) slot = v;
     if (!c->lr.p || slot < 0 || c->last_ndir != NDIR || c->last_L != L)
         return fail(c, MGM_ERR_INVALID, "mgm_wta_windowed: this volume was not part of the context's last aggregation with NDIR passes");
     HIPCHK(c, hipSetDevice(c->device));

@@ -84,19 +84,14 @@ __global__ void __launch_bounds__(256) k_filter2d(const float *__restrict__ u, i
     if (idx >= npix * nch) return;
     const int c = (int)(idx / npix);
     const long long p = idx % npix;
-    const int i = (int)(p % nx), j = (int)(p / nx);
-    const int hfnx = fnx / 2, hfny = fny / 2;
+    const int x0 = (int)(p % nx) - fnx / 2, y0 = (int)(p / nx) - fny / 2;  // top-left tap
     const float *pl = u + (long long)c * npix;
     float v = 0;
-    for (int jj = 0; jj < fny; jj++)
-        for (int ii = 0; ii < fnx; ii++) {
-            int x = i + ii - hfnx, y = j + jj - hfny;
-            x = x >= 0 ? x : 0;
-            x = x < nx ? x : nx - 1;
-            y = y >= 0 ? y : 0;
-            y = y < ny ? y : ny - 1;
-            v += pl[x + (long long)y * nx] * K.f[ii + jj * fnx];
-        }
+    for (int t = 0; t < fnx * fny; t++) {  // taps in row-major order, one rounded product + one rounded add each
+        const int x = min(max(x0 + t % fnx, 0), nx - 1);  // Neumann boundary: the nearest pixel
+        const int y = min(max(y0 + t / fnx, 0), ny - 1);
+        v += pl[x + (long long)y * nx] * K.f[t];
+    }
     out[idx] = v;
 }
 
@@ -112,28 +107,38 @@ hipError_t launch_filter2d(const float *u, int nx, int ny, int nch, const float 
 }
 
 // ---- the costs that look at more than one sample per image ------------------------
-// Birchfield-Tomasi dissimilarity of one channel (mgm_costvolume.h:82-110): half-sample interpolation along x --
-// the "/2.0" is a double division narrowed back to float -- then the symmetric interval distance.
-#define MGM_MIN3(a, b, c) (((a) < (b)) ? (((a) < (c)) ? (a) : (c)) : (((c) < (b)) ? (c) : (b)))
-#define MGM_MAX3(a, b, c) (((a) > (b)) ? (((a) > (c)) ? (a) : (c)) : (((c) > (b)) ? (c) : (b)))
+// Birchfield-Tomasi dissimilarity of one channel (mgm_costvolume.h:82-110).  Each sample spans the closed interval
+// between itself and its two half-way interpolants along x (at the image border the interpolant is the sample; the
+// halving is a double operation narrowed back to float, as compiled there); the dissimilarity is the smaller of
+// the two one-sided distances "sample of one image to the interval of the other".  The three-way selections keep
+// the reference's comparison tree, which decides what a NaN sample does.
+__device__ __forceinline__ float tri_low(float x, float y, float z)
+{
+    if (x < y) return x < z ? x : z;
+    return z < y ? z : y;
+}
+__device__ __forceinline__ float tri_high(float x, float y, float z)
+{
+    if (x > y) return x > z ? x : z;
+    return z > y ? z : y;
+}
+struct BtSpan {
+    float centre, lo, hi;
+};
+__device__ __forceinline__ BtSpan bt_span(const float *__restrict__ row, int width, int x)
+{
+    const float c = row[x];
+    float ahead = c, behind = c;
+    if (x + 1 < width) ahead = (float)((double)(c + row[x + 1]) * 0.5);
+    if (x > 0) behind = (float)((double)(c + row[x - 1]) * 0.5);
+    return BtSpan{c, tri_low(behind, ahead, c), tri_high(behind, ahead, c)};
+}
 __device__ __forceinline__ float btad1(const float *__restrict__ pu, int nx, int px, const float *__restrict__ pv, int vnx, int qx)
 {
-    const float IL = pu[px];
-    float ILp = IL, ILm = IL;
-    if (px < nx - 1) ILp = (float)((IL + pu[px + 1]) / 2.0);
-    if (px >= 1) ILm = (float)((IL + pu[px - 1]) / 2.0);
-    const float IR = pv[qx];
-    float IRp = IR, IRm = IR;
-    if (qx < vnx - 1) IRp = (float)((IR + pv[qx + 1]) / 2.0);
-    if (qx >= 1) IRm = (float)((IR + pv[qx - 1]) / 2.0);
-    const float IminR = MGM_MIN3(IRm, IRp, IR);
-    const float ImaxR = MGM_MAX3(IRm, IRp, IR);
-    const float IminL = MGM_MIN3(ILm, ILp, IL);
-    const float ImaxL = MGM_MAX3(ILm, ILp, IL);
-    const float dLR = MGM_MAX3(0, IL - ImaxR, IminR - IL);
-    const float dRL = MGM_MAX3(0, IR - ImaxL, IminL - IR);
-    const float BT = (dLR < dRL) ? dLR : dRL;
-    return (float)__builtin_fabs((double)BT);
+    const BtSpan a = bt_span(pu, nx, px), b = bt_span(pv, vnx, qx);
+    const float a_to_b = tri_high(0.0f, a.centre - b.hi, b.lo - a.centre);
+    const float b_to_a = tri_high(0.0f, b.centre - a.hi, a.lo - b.centre);
+    return __builtin_fabsf(a_to_b < b_to_a ? a_to_b : b_to_a);
 }
 
 // computeC_clippedNCC (mgm_costvolume.h:137-165): window sums in float, the normalisation in double (0.0000001 and
@@ -190,7 +195,7 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
     float *Cp = P.C ? P.C + pix * P.L : nullptr;  // nullptr: only the compact copy is wanted
     uint8_t *Cp8 = P.C8 ? P.C8 + pix * P.L : nullptr;
     const bool yin = (y < P.vny);  // q.y = p.y >= 0 always
-    bool anyfinite = false, bad8 = false;
+    bool anyfinite = false, bad8 = false, nanv = false;
     int rl = 0, rh = P.L - 1;  // the pixel's own label range (ragged volumes)
     if (P.rlo) {
         rl = (int)P.rlo[pix] - P.dmin;
@@ -237,6 +242,7 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
         e = (e < P.trunc) ? e : P.trunc;
         if (Cp) Cp[o] = e;
         anyfinite |= finite_bits(e);
+        nanv |= e != e;  // (only a NaN truncDist gets here: a NaN cost loses the comparison above)
         if (Cp8) {
             const unsigned b = c8_encode(e);
             bad8 |= b > 255u;
@@ -252,18 +258,22 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
         }
     else if (Cp8 && __builtin_amdgcn_ballot_w64(bad8) != 0ull && lane == 0)
         atomicOr(P.bad8, 1u);
+    if (P.bad8 && __builtin_amdgcn_ballot_w64(nanv) != 0ull && lane == 0) atomicOr(P.bad8, 2u);
 }
 
-// compact copy of an existing fp32 volume (uploaded by the caller)
+// compact copy of an existing fp32 volume (uploaded by the caller); flag bit 0: some cost has no compact form,
+// bit 1: some cost is NaN (the scan-line kernels are built NaN-free; see run_passes)
 __global__ void __launch_bounds__(256) k_compact(const float *__restrict__ C, long long n, uint8_t *__restrict__ C8,
                                                  unsigned *bad8)
 {
-    bool bad = false;
+    bool bad = false, nanv = false;
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
         unsigned w = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const unsigned b = (i + k < n) ? c8_encode(C[i + k]) : 0u;
+            const float x = (i + k < n) ? C[i + k] : 0.0f;
+            const unsigned b = c8_encode(x);
+            nanv |= x != x;
             bad |= b > 255u;
             w |= (b & 255u) << (8 * k);
         }
@@ -272,6 +282,25 @@ __global__ void __launch_bounds__(256) k_compact(const float *__restrict__ C, lo
             for (int k = 0; k < 4 && i + k < n; k++) C8[i + k] = (uint8_t)(w >> (8 * k));
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(bad8, 1u);
+    if (__builtin_amdgcn_ballot_w64(nanv) != 0ull && (threadIdx.x & 63) == 0) atomicOr(bad8, 2u);
+}
+
+// NaN scan alone, for volumes that get no compact copy (flag bit 1)
+__global__ void __launch_bounds__(256) k_nanscan(const float *__restrict__ C, long long n, unsigned *flag)
+{
+    bool nanv = false;
+    const long long n4 = n / 4, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 f = reinterpret_cast<const float4 *>(C)[i];
+        nanv |= f.x != f.x || f.y != f.y || f.z != f.z || f.w != f.w;
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) nanv |= C[i] != C[i];
+    if (__builtin_amdgcn_ballot_w64(nanv) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 2u);
+}
+hipError_t launch_nanscan(const float *C, long long n, unsigned *flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_nanscan, dim3(256 * 16), dim3(256), 0, s, C, n, flag);
+    return hipGetLastError();
 }
 
 // the fp32 volume back from its compact copy (exact: every byte decodes to the float it was made from)

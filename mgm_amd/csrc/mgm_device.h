@@ -79,6 +79,7 @@ struct WtaParams {
     const float *wlo, *whi;          // nullptr: the whole range
     // ragged C (CostParams::rlo/rhi): a disparity outside the pixel's own range does not exist in C either
     const float *clo, *chi;
+    int num_cu;                      // compute units of the device (grid sizing)
 };
 
 // launchers (one per translation unit)
@@ -94,6 +95,7 @@ hipError_t launch_pass2_lpl(const PassParams &p, int ntasks, bool fh, int wmode,
 // compact-cost support: labels per lane for which the C8 forms of K3 / k_wta exist
 inline bool c8_supported(int L) { return L == 64 || L == 128 || L == 192 || L == 256 || L == 384 || L == 512; }
 hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s);
+hipError_t launch_nanscan(const float *C, long long n, unsigned *flag, hipStream_t s);
 hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, unsigned *bad8, hipStream_t s);
 hipError_t launch_expand(const uint8_t *C8, long long n, float *C, hipStream_t s);
 hipError_t launch_wta(const WtaParams &p, hipStream_t s);

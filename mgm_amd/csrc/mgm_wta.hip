@@ -205,7 +205,7 @@ hipError_t launch_wta(const WtaParams &p, hipStream_t s)
     // A bounded grid (workgroups of 4 waves), grid-stride beyond it.  Measured at 1920x1080 (8 / 4 directions): one
     // pixel per slab is fastest at ~768 workgroups per CU (2.99 ms at 16 -> 2.73 ms: 6.4 TB/s, the read ceiling of the
     // part), several pixels per slab at ~128 (0.83 -> 0.80 ms); far larger grids lose again.
-    const long long cap = 256ll * (per_cu ? per_cu : (use_packed ? 128 : 768));
+    const long long cap = (long long)(p.num_cu > 0 ? p.num_cu : 256) * (per_cu ? per_cu : (use_packed ? 128 : 768));
     if (nb > cap) nb = cap;
     const dim3 grid((unsigned)nb), block(256);
     static int wide4 = -1;  // MGM_HIP_WTA_WIDE4=0: the 8-direction instance also for NDIR <= 4 (A/B timing)

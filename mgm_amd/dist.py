@@ -41,17 +41,21 @@ def owner_of_pass(p, NDIR, world):
     raise ValueError(p)
 
 
-def exchange_lr(lr_local, NDIR, ny, dist, group=None):
+def exchange_lr(lr_local, NDIR, ny, dist, group=None, like=None):
     """lr_local: list of [ny, nx, L] tensors, the Lr volumes of this rank's passes (in pass order).
-    Returns a [NDIR, my_rows, nx, L] tensor with every pass's slab of this rank's rows."""
+    Returns a [NDIR, my_rows, nx, L] tensor with every pass's slab of this rank's rows.
+    A rank beyond the NDIR-th runs no pass (world > NDIR) but still owns rows: it passes `like`, any tensor
+    whose last two dimensions, dtype and device are those of the Lr volumes."""
     import torch
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     first, count = passes_of_rank(NDIR, world, rank)
     assert len(lr_local) == count
     slabs = row_slabs(ny, world)
     r0, nr = slabs[rank]
-    ref = lr_local[0] if count else None
-    nx, L = ref.shape[1], ref.shape[2]
+    ref = lr_local[0] if count else like
+    if ref is None:
+        raise ValueError("exchange_lr: a rank without passes must say what the volumes look like (like=)")
+    nx, L = ref.shape[-2], ref.shape[-1]
     recv = torch.empty((NDIR, nr, nx, L), dtype=ref.dtype, device=ref.device)
     ops = []
     for p in range(NDIR):  # receives, in pass order per peer
@@ -108,10 +112,11 @@ def aggregate_direction_sharded(ctx, cv, P1, P2, NDIR, MGM, use_fh, fix_overcoun
         o.free(), c.free()
         return views[0], views[1]
     first, count = passes_of_rank(NDIR, world, rank)
-    ctx.aggregate_passes_dev(cv, P1, P2, MGM, use_fh, first, count, w8)
+    if count:  # (world > NDIR: the ranks beyond the NDIR-th run no pass; they still sum and search their rows)
+        ctx.aggregate_passes_dev(cv, P1, P2, MGM, use_fh, first, count, w8)
     ctx.synchronize()  # Lr volumes complete before RCCL reads them (different streams)
     lr_local = [device_view(ctx.lr_device_ptr(k), (ny, nx, L)) for k in range(count)]
-    recv = exchange_lr(lr_local, NDIR, ny, dist, group)
+    recv = exchange_lr(lr_local, NDIR, ny, dist, group, like=torch.empty((0, nx, L), dtype=torch.float32, device="cuda"))
     torch.cuda.synchronize()
     slabs = row_slabs(ny, world)
     r0, nr = slabs[rank]

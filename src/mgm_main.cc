@@ -9,7 +9,13 @@
 // reference's iio decodes them to -- and float TIFF, PFM or .npy out.
 //
 // Not supported (exit code 2, message on stderr): P2 = inf together with -m/-M range files that are not constant
-// (a ragged cost volume), WITH_MGM2=1, `-p census` with a non-census distance and a descriptor of more than 24 bits.
+// (a ragged cost volume), `-p census` with a non-census distance and a descriptor of more than 24 bits.
+//
+// WITH_MGM2=1 (mgm_naive_parallelism, mgm_core.cc:632-831): every pass on its own private Lr volume, all passes in
+// flight at once, then the volumes accumulated into S -- which is how the device path is organised anyway
+// (DESIGN.md 4).  The reference accumulates in thread-finish order (798-805); here the order is always 0, 1, ..., 7:
+// what its default build (Makefile:1, no OpenMP) and any run with one thread compute, and one member of the outcome
+// set of a threaded run.  So the flag is accepted and changes nothing.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -262,7 +268,7 @@ int main(int argc, char **argv)
     o.census_win = (int)env_param("CENSUS_NCC_WIN", 3);
     const double TSGM_ITER = env_param("TSGM_ITER", 1), TESTLRRL = env_param("TESTLRRL", 1);
     const double TAU = env_param("TESTLRRL_TAU", 1.0), MEDIAN = env_param("MEDIAN", 0);
-    if (env_param("WITH_MGM2", 0) != 0) { fprintf(stderr, "mgm: WITH_MGM2=1 is not supported (its result is thread-order dependent)\n"); return 2; }
+    (void)env_param("WITH_MGM2", 0);  // accepted: see the header comment
     if ((int)TSGM_ITER < 1) { fprintf(stderr, "mgm: TSGM_ITER < 1 is not supported\n"); return 2; }
 
     try {
@@ -302,8 +308,9 @@ int main(int argc, char **argv)
             mgm_img *Os[2] = {L.dout, R.dout}, *Cc[2] = {L.dcost, R.dcost};
             rc = mgm_aggregate_batch_dev(ctx, 2, Cs, Ws, o.P1, o.P2, o.NDIR, o.TSGM, o.FH, o.FIX, o.refine, Os, Cc, nullptr);
             if (rc == MGM_OK) together = true;
+            else if (rc == MGM_ERR_NOMEM) free_run(ctx, R);  // 2*NDIR Lr volumes do not fit: one run after the other, as the reference does
             else if (rc != MGM_ERR_UNSUPPORTED) die(ctx, rc, "mgm_aggregate_batch");
-            // (one image weighted, the other not: the two runs take different update functions)
+            // (UNSUPPORTED: one image weighted, the other not -- the two runs take different update functions)
         }
         if (!together) aggregate_run(ctx, o, L);
         report_run(o, L);

@@ -1,0 +1,50 @@
+"""A stand-in for mgm_amd.Context that computes NOTHING: bench.py's launcher, rendezvous, barrier / max-over-ranks timing
+and JSON contract can then be driven on CPU ranks (gloo) by tests/test_dist_cpu.py.  It is a test double, not a CPU
+path of the product: bench.py loads it only under MGM_BENCH_STUB=1 and labels the line `"data": "stub (no device work)"`."""
+import time
+
+
+class _Handle:
+    def __init__(self, shape=None):
+        self.shape = shape
+
+    def free(self):
+        pass
+
+
+class StubContext:
+    def __init__(self, device=0):
+        self.device, self._timing, self._t = device, False, []
+
+    def upload_image(self, a):
+        return _Handle(getattr(a, "shape", None))
+
+    def new_image(self, nx, ny, nch=1):
+        return _Handle((nch, ny, nx))
+
+    def costvolume_dev(self, u, v, dmin, dmax, prefilter="none", distance="ad", truncDist=float("inf"), census_win=3, into=None):
+        if self._timing:
+            self._t += [("k_census", 0.01), ("k_census", 0.01), ("k_cost", 0.1)]
+        return into if into is not None else _Handle()
+
+    def aggregate_batch_dev(self, Cvs, P1, P2, NDIR, MGM, use_fh=0, fix_overcount=1, w8s=None, refine=None, outs=None, outcosts=None,
+                            want_S=False):
+        time.sleep(0.002 * (1 + self.device))  # rank 1 is the slow one
+        if self._timing:
+            self._t += [("k_pass2", 1.0 * len(Cvs))] + [("k_wta", 0.5)] * len(Cvs)
+        return None, outs, outcosts
+
+    def synchronize(self):
+        pass
+
+    def timing(self, enable=True):
+        self._timing = bool(enable)
+
+    def timing_reset(self):
+        self._t = []
+
+    def timings(self):
+        return list(self._t)
+
+    def close(self):
+        pass

@@ -69,7 +69,7 @@ def _dir_worker(rank, world, port, q, NDIR):
     S, out, outc, lr = orc.mgm(C, -2, 8.0, 32.0, NDIR, 3, 0, 1, None, dump_lr=True)
     first, count = mdist.passes_of_rank(NDIR, world, rank)
     mine = [torch.from_numpy(np.ascontiguousarray(lr[p])) for p in range(first, first + count)]  # "my" passes only
-    recv = mdist.exchange_lr(mine, NDIR, ny, dist)
+    recv = mdist.exchange_lr(mine, NDIR, ny, dist, like=torch.empty((0, nx, L), dtype=torch.float32))
     r0, nr = mdist.row_slabs(ny, world)[rank]
     Srows = mdist.ordered_sum_numpy([recv[p].numpy() for p in range(NDIR)], C[r0:r0 + nr], 1)
     a, b = Srows.view(np.uint32), S[r0:r0 + nr].view(np.uint32)
@@ -79,7 +79,7 @@ def _dir_worker(rank, world, port, q, NDIR):
 
 
 def test_direction_sharding_exchange_is_bit_exact():
-    for NDIR in (8, 3):                                 # 3 passes over 2 ranks: uneven pass blocks
+    for NDIR in (8, 3, 1):                              # 3 passes over 2 ranks: uneven blocks; 1 pass: rank 1 runs none (world > NDIR)
         world, port = 2, _free_port()
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
@@ -103,3 +103,27 @@ def test_partitions():
             assert flat == list(range(NDIR))
             assert all(mdist.owner_of_pass(p, NDIR, world) == [r for r, (f, n) in enumerate(blocks) if f <= p < f + n][0]
                        for p in range(NDIR))
+
+
+# ---- bench.py's own launcher: `python bench.py --gpus 2` must start its two ranks itself -----------------------
+def test_bench_launches_its_own_ranks():
+    """The driver's command line, unchanged, on CPU: bench.py re-executes itself under torch.distributed.run with
+    two ranks (gloo here, RCCL on the GPU box), times K steps between barriers, and rank 0 prints the one JSON line
+    with the world size that was really initialised.  The context is a stub that computes nothing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGM_BENCH_STUB="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "cfg5",
+                        "--batch", "2", "--repeats", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = r.stdout.strip().splitlines()[-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["pairs_per_step"] == 2 and d["data"].startswith("stub")
+    # whole-job aggregate: 2 ranks x 4 steps x 2 volumes over the slowest rank's time
+    assert abs(d["value"] - 16 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    assert len(d["repeat_values"]) == 1 and d["roofline"]["per_kernel"]["k_pass2"]["GBps"] > 0

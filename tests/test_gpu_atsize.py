@@ -1,0 +1,192 @@
+"""The modes bench.py really runs, at BASELINE.json's sizes, against the OpenMP oracle:
+
+  cfg2  16 volumes of 1920x1080x128 in ONE pass launch (two volumes per wave, two bands per CU), census 3x3, -O 4, TSGM 2
+  cfg5  16 x 1024x1024x128 in one launch, with cfg2's settings (-O 4, TSGM 2) and with -O 8, TSGM 3
+  cfg4  4096x4096x192, -O 8, TSGM 3: the plain call on one GPU, and the direction-sharded entry points
+        (mgm_aggregate_passes_dev one pass per "rank" + mgm_wta_rows_dev on row slabs) emulating 8 ranks
+
+Every volume of every batch is compared with the oracle (refined disparity and cost maps, bit for bit; S too where
+the host has the memory), not with another run of the device code."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ndiff
+from mgm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def host_mem_available_gb():
+    gb = 1e9
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                gb = int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            t = open(path).read().strip()
+            if t != "max":
+                gb = min(gb, int(t) / 1e9)
+        except (OSError, ValueError):
+            pass
+    return gb
+
+
+@pytest.fixture
+def bigctx():
+    """A context of its own per test: its grow-only workspace (up to 204 GB here) is released when the test ends."""
+    import mgm_amd
+    c = mgm_amd.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_threads():
+    return min(32, len(os.sched_getaffinity(0)))
+
+
+def batch_against_oracle(ctx, oracle, nx, ny, dmin, dmax, win, NDIR, MGM, FH, P1, P2, nb, seed0):
+    dus, dvs, cvs = [], [], []
+    for b in range(nb):
+        u, v, _ = synth.stereo_pair(nx, ny, dmin * 3 // 4, 0, seed=seed0 + b)
+        dus.append(ctx.upload_image(u))
+        dvs.append(ctx.upload_image(v))
+        cvs.append(ctx.costvolume_dev(dus[-1], dvs[-1], dmin, dmax, "none", "census", float("inf"), win))
+    _, outs, outcs = ctx.aggregate_batch_dev(cvs, P1, P2, NDIR, MGM, FH, 1, None, "vfit")
+    ctx.synchronize()
+    oracle.set_threads(oracle_threads())
+    try:
+        for b in range(nb):
+            u, v, _ = synth.stereo_pair(nx, ny, dmin * 3 // 4, 0, seed=seed0 + b)
+            if b % 5 == 0:  # the cost volume itself, from the images, for a few of them (the others: the device's copy)
+                C = oracle.costvolume(u, v, dmin, dmax, "none", "census", np.inf, win)
+                assert ndiff(C, cvs[b].download()) == 0, "volume %d: cost volume" % b
+            else:
+                C = cvs[b].download()
+            Sa, oa, ca = oracle.mgm(C, dmin, P1, P2, NDIR, MGM, FH, 1)
+            ra, rca = oracle.refine(Sa, dmin, "vfit", oa, ca)
+            del Sa, C
+            assert ndiff(rca, outcs[b].download()[0]) == 0, "volume %d: costs" % b
+            assert ndiff(ra, outs[b].download()[0]) == 0, "volume %d: disparities" % b
+    finally:
+        oracle.set_threads(1)
+    for h in cvs + dus + dvs + outs + outcs:
+        h.free()
+
+
+def test_cfg2_sixteen_volumes_per_launch(bigctx, oracle):
+    """bench.py --workload cfg2: 16 pairs per step."""
+    batch_against_oracle(bigctx, oracle, 1920, 1080, -127, 0, 3, 4, 2, 0, 8.0, 32.0, 16, seed0=5000)
+
+
+@pytest.mark.parametrize("mode", [(4, 2, 0, 8.0, 32.0), (8, 3, 0, 8.0, 32.0), (8, 3, 1, 2.0, 20000.0)],
+                         ids=["O4-TSGM2", "O8-TSGM3", "O8-TSGM3-FH"])
+def test_cfg5_sixteen_pairs(bigctx, oracle, mode):
+    """BASELINE cfg5: a batch of 16 independent 1024x1024x128 pairs (here all on one GPU, one launch)."""
+    NDIR, MGM, FH, P1, P2 = mode
+    batch_against_oracle(bigctx, oracle, 1024, 1024, -127, 0, 3, NDIR, MGM, FH, P1, P2, 16, seed0=6000)
+
+
+def test_cfg3_twelve_volumes_per_launch_first_and_last(bigctx, oracle):
+    ctx = bigctx
+    """bench.py's default line: 12 pairs of cfg3 per launch (204 GB of Lr volumes); first and last volume vs the oracle."""
+    nx, ny, dmin, dmax, win, NDIR, MGM, FH, P1, P2 = 1920, 1080, -255, 0, 5, 8, 3, 1, 2.0, 20000.0
+    dus, dvs, cvs = [], [], []
+    for b in range(12):
+        u, v, _ = synth.stereo_pair(nx, ny, dmin * 3 // 4, 0, seed=synth.SEED + b)
+        dus.append(ctx.upload_image(u))
+        dvs.append(ctx.upload_image(v))
+        cvs.append(ctx.costvolume_dev(dus[-1], dvs[-1], dmin, dmax, "none", "census", float("inf"), win))
+    _, outs, outcs = ctx.aggregate_batch_dev(cvs, P1, P2, NDIR, MGM, FH, 1, None, "vfit")
+    oracle.set_threads(oracle_threads())
+    try:
+        for b in (0, 11):
+            C = cvs[b].download()
+            Sa, oa, ca = oracle.mgm(C, dmin, P1, P2, NDIR, MGM, FH, 1)
+            ra, rca = oracle.refine(Sa, dmin, "vfit", oa, ca)
+            del Sa, C
+            assert ndiff(rca, outcs[b].download()[0]) == 0 and ndiff(ra, outs[b].download()[0]) == 0, b
+    finally:
+        oracle.set_threads(1)
+    for h in cvs + dus + dvs + outs + outcs:
+        h.free()
+
+
+def test_cfg4_plain_and_eight_way_sharded(oracle):
+    """BASELINE cfg4: 4096x4096, 192 labels (three labels per lane: idle lanes in every compact DMA piece), -O 8, TSGM 3.
+    (a) eight emulated ranks: rank r runs pass r alone (mgm_aggregate_passes_dev), its Lr volume is cut into the eight
+    row slabs the ranks would exchange, every rank finishes its rows with mgm_wta_rows_dev; (b) the plain one-GPU call.
+    Both against the oracle if the host has the memory for it (3 volumes of 12.9 GB), else against each other plus the
+    row-crop property of pass 0."""
+    import torch
+    import mgm_amd
+    from mgm_amd import dist as mdist
+    nx = ny = 4096
+    dmin, dmax, L = -96, 95, 192
+    NDIR, MGM, FH, P1, P2 = 8, 3, 0, 8.0, 32.0
+    world = 8
+    c = mgm_amd.Context(0)  # its own context: the workspace (103 GB for the plain call) goes away with it
+    try:
+        u, v, _ = synth.stereo_pair(nx, ny, dmin * 3 // 4, dmax * 3 // 4, seed=4096)
+        du, dv = c.upload_image(u), c.upload_image(v)
+        cv = c.costvolume_dev(du, dv, dmin, dmax, "none", "census", float("inf"), 5)
+        slabs = mdist.row_slabs(ny, world)
+        out = torch.empty((ny, nx), dtype=torch.float32, device="cuda")
+        outc = torch.empty_like(out)
+        for half in range(2):  # the receive buffers of four ranks at a time (52 GB)
+            ranks = range(half * 4, half * 4 + 4)
+            recv = {g: torch.empty((NDIR, slabs[g][1], nx, L), dtype=torch.float32, device="cuda") for g in ranks}
+            for r in range(world):  # "rank r" runs its pass; the slabs travel
+                first, count = mdist.passes_of_rank(NDIR, world, r)
+                c.aggregate_passes_dev(cv, P1, P2, MGM, FH, first, count)
+                c.synchronize()
+                vol = mdist.device_view(c.lr_device_ptr(0), (ny, nx, L))
+                for g in ranks:
+                    recv[g][first].copy_(vol[slabs[g][0]:slabs[g][0] + slabs[g][1]])
+                torch.cuda.synchronize()
+            for g in ranks:
+                r0, n = slabs[g]
+                c.wta_rows_dev(cv, r0, n, recv[g].data_ptr(), NDIR, 1, "vfit", out[r0:].data_ptr(), outc[r0:].data_ptr())
+            c.synchronize()
+            del recv
+            torch.cuda.empty_cache()
+        sh_o, sh_c = out.cpu().numpy(), outc.cpu().numpy()
+        del out, outc
+        torch.cuda.empty_cache()
+        S, o, oc = c.aggregate(cv, P1, P2, NDIR, MGM, FH, 1, None, "vfit", want_S=True)
+        assert ndiff(sh_o, o) == 0 and ndiff(sh_c, oc) == 0, "sharded and plain results differ"
+        mem = host_mem_available_gb()
+        if mem >= 48:
+            C = cv.download()
+            oracle.set_threads(oracle_threads())
+            try:
+                Sa, oa, ca = oracle.mgm(C, dmin, P1, P2, NDIR, MGM, FH, 1)
+                ra, rca = oracle.refine(Sa, dmin, "vfit", oa, ca)
+            finally:
+                oracle.set_threads(1)
+            del C
+            assert ndiff(rca, oc) == 0 and ndiff(ra, o) == 0
+            if mem >= 64:
+                assert ndiff(Sa, S.download()) == 0
+            del Sa
+        else:  # pass 0 alone on the first rows equals pass 0 on the cropped volume (small enough for any host)
+            K = 24
+            c.aggregate_passes_dev(cv, P1, P2, MGM, FH, 0, 1)
+            c.synchronize()
+            lr0 = mdist.device_view(c.lr_device_ptr(0), (ny, nx, L))[:K].cpu().numpy()
+            Ck = mdist.device_view(c.lib.mgm_cv_device_ptr(cv.h), (ny, nx, L))[:K + 1].cpu().numpy()
+            oracle.set_threads(oracle_threads())
+            try:
+                _, _, _, lra = oracle.mgm(Ck, dmin, P1, P2, 1, MGM, FH, 1, None, dump_lr=True)
+            finally:
+                oracle.set_threads(1)
+            assert ndiff(lr0, lra[0][:K]) == 0
+            pytest.skip("host has %.0f GB available: cfg4 checked sharded == plain and by the pass-0 row crop, not against the whole-volume oracle" % mem)
+        for h in (S, cv, du, dv):
+            h.free()
+    finally:
+        c.close()

@@ -61,6 +61,11 @@ CASES = [
     ("ragged ranges, FH, TSGM=2 without weights, 3 channels, TSGM_ITER=2", 3,
      "-P1 1.5 -P2 40 -r -16 -R 8 -t ad -O 4 -m {ranges}/lo.npy -M {ranges}/hi.npy",
      dict(TSGM="2", TSGM_ITER="2", USE_TRUNCATED_LINEAR_POTENTIALS="1")),
+    # mgm_naive_parallelism (mgm_core.cc:632-831): with one thread the reference accumulates S in pass order
+    ("WITH_MGM2=1 (direction-parallel driver), census FH vfit, reference on one thread", 1, "-P1 2 -P2 20000 -r -16 -R 8 -t census -s vfit -O 8",
+     dict(TSGM="3", WITH_MGM2="1", OMP_NUM_THREADS="1", CENSUS_NCC_WIN="5", USE_TRUNCATED_LINEAR_POTENTIALS="1")),
+    ("WITH_MGM2=1, 3 channels, weights, TSGM=4, ad", 3, "-r -20 -R 12 -t ad -O 8 -aP2 4 -aThresh 12",
+     dict(TSGM="4", WITH_MGM2="1", OMP_NUM_THREADS="1")),
     ("parabolaOCV, census, median radius 3, tight tau", 1, "-r -16 -R 8 -t census -s parabolaOCV -O 8",
      dict(TSGM="3", MEDIAN="3", TESTLRRL_TAU="0.5", CENSUS_NCC_WIN="5")),
 ]
@@ -89,7 +94,7 @@ def test_cli_matches_reference(case, tmp_path):
         a = args.format(tmp=d, ranges=tmp_path).split()
         cmd = [exe] + a + [str(tmp_path / "u.npy"), str(tmp_path / "v.npy"), str(d / "disp.npy"), str(d / "cost.npy"),
                            str(d / "back.npy")]
-        e = dict(os.environ, OMP_NUM_THREADS="4", **env)
+        e = dict(os.environ, **dict(dict(OMP_NUM_THREADS="4"), **env))
         r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (tag, r.stderr)
         outs[tag] = (r.stdout, {f: np.load(d / f) for f in sorted(os.listdir(d))})
@@ -111,7 +116,7 @@ def test_cli_refuses_what_is_not_built(tmp_path):
     np.save(tmp_path / "lo.npy", lo)
     np.save(tmp_path / "hi.npy", lo + 6)
     ragged = ["-m", str(tmp_path / "lo.npy"), "-M", str(tmp_path / "hi.npy")]
-    for extra, env in (([], dict(TSGM_ITER="0")), ([], dict(WITH_MGM2="1")), (ragged + ["-P2", "inf"], {}),
+    for extra, env in (([], dict(TSGM_ITER="0")), (ragged + ["-P2", "inf"], {}),
                        (["-p", "census", "-t", "ad"], dict(CENSUS_NCC_WIN="7"))):
         r = subprocess.run(base[:1] + extra + base[1:], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 2 and r.stderr.startswith("mgm: "), (extra, env, r.stderr)

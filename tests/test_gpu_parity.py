@@ -214,3 +214,22 @@ def test_both_builds_of_the_pass_kernel_agree(oracle):
     Sa, oa, ca = oracle.mgm(C, 0, 8.0, 32.0, 8, 3)
     assert ndiff(res[0][0], res[1][0]) == 0 and ndiff(res[0][1], res[1][1]) == 0
     assert ndiff(res[0][0], Sa) == 0
+
+
+def test_uploaded_volume_with_nan_costs_is_refused(ctx):
+    """The scan-line kernels are compiled NaN-free; an uploaded volume is scanned once and a NaN cost refused
+    (what the reference makes of it depends on the operand order of its minima).  Both scan paths: a label count
+    with a compact copy (k_compact) and one without (k_nanscan); a refill through the device pointer is re-scanned."""
+    import mgm_amd
+    for L in (64, 50):
+        C = synth.raw_volume(40, 21, L, seed=5)
+        C[7, 11, 3] = np.nan
+        cv = ctx.upload_volume(C, 0)
+        with pytest.raises(mgm_amd.MgmError) as e:
+            ctx.aggregate(cv, 8.0, 32.0, 4, 2, 0, 1, None, None, want_S=False)
+        assert e.value.code == mgm_amd.MGM_ERR_UNSUPPORTED and "NaN" in str(e.value)
+        cv.free()
+        C[7, 11, 3] = 1.0
+        cv = ctx.upload_volume(C, 0)
+        ctx.aggregate(cv, 8.0, 32.0, 4, 2, 0, 1, None, None, want_S=False)  # clean: accepted
+        cv.free()
