@@ -88,6 +88,9 @@ struct mgm_ctx {
     const mgm_cv *last_cvs[kMaxBatch] = {};  // the volumes of the last aggregation (identity only, never dereferenced) ...
     unsigned long long last_gens[kMaxBatch] = {};  // ... and their generations at that time
     bool pending_check = false;
+    // self-validating hand-off slabs (k_pass2, TAGS): what the region was last cleared for, and the tag of its last launch
+    std::string hand_key;
+    unsigned hand_tag = 0;
     int num_cu = 256;  // hipDeviceProp_t::multiProcessorCount
     // timing
     bool timing = false;
@@ -269,6 +272,7 @@ static int check_watchdog(mgm_ctx *c)
     c->pending_check = false;
     if (c->h_words[1] != 0) {
         c->h_words[1] = 0;
+        c->hand_key.clear();  // (the launch may have left its hand-off slots half written)
         return fail(c, MGM_ERR_INTERNAL, "pass kernel watchdog: inter-band hand-off timed out");
     }
     return MGM_OK;
@@ -835,6 +839,9 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
             return fail(c, MGM_ERR_UNSUPPORTED, "cost volume of a census prefilter with a non-census distance and a descriptor of "
                                                 "more than 24 bits (NaN-valued words): use -t census");
     HIPCHK(c, hipSetDevice(c->device));
+    // The second build's unweighted kernels keep the sign bit of the slabs they hand from band to band for a validity
+    // tag, which needs E = T - m >= +0, i.e. non-negative penalties (mgm_pass2.hip, TAGS): anything else takes the first build.
+    const bool first_build = c->force_build == 1 || !(P1 >= 0.0f) || !(P2 >= 0.0f);
     if (int r0 = check_watchdog(c)) return r0;  // (the control words are about to be reset)
 
     // A label count the second build does not take (not 64, 128, 192, 256, 384 or 512) runs PADDED: the kernels see
@@ -843,7 +850,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // uniform range has a finite minimum, so the added term is finite.
     int L = Lreal;
     bool padded = false;
-    if (allow_pad && c->force_build != 1 && pass2_lines(Lreal, false) == 0 && dev().pad) {
+    if (allow_pad && !first_build && pass2_lines(Lreal, false) == 0 && dev().pad) {
         const int lp = padded_labels(Lreal);
         if (lp) {
             L = lp;
@@ -895,7 +902,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         // TSGM = 2 without weights is update_cost2_trunclinear with its boundary fix-up (166-186, 197-219): the second
         // build has it (combine_fh2_ragged); the first build does not
         fh2_ragged = MGM == 2;
-        if (fh2_ragged && (c->force_build == 1 || (pass2_lines(L, false) == 0)))
+        if (fh2_ragged && (first_build || (pass2_lines(L, false) == 0)))
             return fail(c, MGM_ERR_UNSUPPORTED, "FH potentials with TSGM=2 and no weights on a ragged cost volume need the second build");
         if ((r = reserve(c, c->ones8, sizeof(float) * (size_t)npix * 8))) return r;
         std::vector<float> one((size_t)npix * 8, 1.0f);
@@ -938,17 +945,17 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     } else {
         for (int v = 0; v < nb; v++) use_c8 = use_c8 && c8ok[v];
     }
-    if (c->force_build == 1) use_c8 = false;
+    if (first_build) use_c8 = false;
     // second build (LDS-DMA loaders) whenever the slabs are whole DMA pieces
     // 128 / 64 labels: 2 / 4 volumes of the launch share every wave of the 256-label kernels (k_pass2<..., SUBV>) -- a
     // step is mostly fixed cost, so it may as well serve several volumes.  Compact costs, no weights, not FH with
     // TSGM = 2 (whose slabs travel with their minimum), and a volume count that divides.
     int subv = 1;
-    if (c->force_build != 1 && use_c8 && !weighted && !(fh && MGM == 2) && (L == 128 || L == 64) && nb % (256 / L) == 0 && dev().subv)
+    if (!first_build && use_c8 && !weighted && !(fh && MGM == 2) && (L == 128 || L == 64) && nb % (256 / L) == 0 && dev().subv)
         subv = 256 / L;
     const int ngroups = nb / subv;  // work items address groups of `subv` volumes
     const int Lk = L * subv;        // label slots of a wave
-    const int R2 = c->force_build == 1 ? 0 : pass2_lines(Lk, use_c8);
+    const int R2 = first_build ? 0 : pass2_lines(Lk, use_c8);
     const int R = R2 ? R2 : kR;
     PassParams p{};
     int maxLL = 0, maxbands = 0;
@@ -964,7 +971,34 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     const long long lr_stride = nvol + lr_pad_floats();
     if ((r = reserve(c, c->lr, sizeof(float) * (size_t)lr_stride * count * nb))) return r;
     const int LPk = subv > 1 ? Lk : LP;  // floats per hand-off slab
-    if ((r = reserve(c, c->hand, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * LPk))) return r;
+    // The second build's unweighted kernels hand slabs from band to band that validate themselves (mgm_pass2.hip, TAGS):
+    // one slot per (volume, pass, band, pixel), written once per launch with the launch's tag in the sign bits.  The tag
+    // alternates between consecutive launches over the same slots; any other use of the region, or a different
+    // geometry, clears it first (all-ones words) and starts again with tag 0.
+    const bool tags = R2 && !weighted && !(fh && MGM == 2);
+    if (tags) {
+        long long per_vol = 0;
+        for (int q = first; q < PEND; q++) {
+            p.g[q].hand_base = per_vol;
+            per_vol += (long long)p.g[q].nbands * p.g[q].LL;
+        }
+        p.hand_vstride = per_vol;
+        const size_t bytes = sizeof(float) * (size_t)ngroups * per_vol * LPk;
+        const void *before = c->hand.p;
+        if ((r = reserve(c, c->hand, bytes))) return r;
+        char key[160];
+        snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d", nx, ny, LPk, ngroups, first, count, R, MGM <= 3 ? 1 : 0);
+        if (c->hand.p != before || c->hand_key != key) {
+            HIPCHK(c, hipMemsetAsync(c->hand.p, 0xff, bytes, c->stream));
+            c->hand_key = key;
+            c->hand_tag = 0x80000000u;  // (what the cleared words look like)
+        }
+        c->hand_tag ^= 0x80000000u;
+        p.hand_tag = c->hand_tag;
+    } else {
+        c->hand_key.clear();
+        if ((r = reserve(c, c->hand, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * LPk))) return r;
+    }
     if ((r = reserve(c, c->handm, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL))) return r;
 
     // task table: ticket -> (pass, band); item (p, b) always follows (p, b-1)

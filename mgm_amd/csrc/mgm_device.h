@@ -27,6 +27,7 @@ struct PassGeom {
     long long istep;   // pixel-index step along the line
     long long jstep;   // pixel-index step between lines
     int wplane[4];     // weight plane of neighbour k (mgm_core.cc:481-484)
+    long long hand_base;  // self-validating hand-off slabs (k_pass2, TAGS): first slab of this pass within a volume's region
 };
 
 // One launch of the pass kernel may aggregate several cost volumes of identical geometry (the
@@ -43,7 +44,10 @@ struct PassVolume {
 };
 struct PassParams {
     PassVolume vol[kMaxBatch];
-    float *hand;        // hand-off slabs  [volume*8 + pass][2][LLmax][NS*LP]
+    float *hand;        // hand-off slabs  [volume*8 + pass][2][LLmax][NS*LP]; the kernels with self-validating slabs (k_pass2,
+                        // TAGS): [volume][pass: g.hand_base][band][LL][LP], every slot written once per launch
+    long long hand_vstride;   // ... slabs per volume (group)
+    unsigned hand_tag;        // ... the launch's tag: sign bit every handed-over word carries (0 or 0x80000000)
     float *handm;       // hand-off minima [volume*8 + pass][2][LLmax]
     unsigned *prog;     // progress words  [volume*8 + pass][maxbands]
     unsigned *ticket;   // work-item ticket counter

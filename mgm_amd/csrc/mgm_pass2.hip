@@ -62,6 +62,15 @@ __device__ __forceinline__ unsigned lds_read_u32_opaque(const unsigned *p)
     return v;
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 lds_read_b128_opaque(const float *p)
+{
+    u32x4 v;
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float *)p;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+
 // Write-through (sc1) slab store in the widest pieces the slab allows: narrow sc1 stores are one
 // fabric write each, so 4 x dword costs ~6x the time of one dwordx4 (MI355X_MICROARCH.md).
 // Inline asm because clang has no 16-byte agent-scope store; the trailing s_nop keeps the data
@@ -138,9 +147,10 @@ struct Plan {
     static constexpr int NC = (LPL <= 4) ? (C8 ? 16 - MGM_P2_C8_NL : MGM_P2_NC) : 7;   // compute waves = lines per band
     static constexpr int NCA = (NL == 2) ? NC / 2 : NC;                               // lines served by loader A
     static constexpr int NDMA = C8 ? (NC + LPD - 1) / LPD : NCA * IPS;                // C pieces per step (loader A)
-    // DMA instructions per step: loader A = its C pieces + hand-off slabs [+ minimum] + progress word
+    // DMA instructions per step: loader A = its C pieces + hand-off slabs [+ minimum + progress word: the kernels whose
+    // hand-off slabs are not self-validating, see TAGS in k_pass2]
     // compact costs with two loaders: A = hand-off only, B = all C pieces
-    static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + NS * IPS + 1 + (HASM ? 1 : 0);
+    static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + NS * IPS + (HASM ? 2 : 0);
     static constexpr int nB = (C8 && NL == 2) ? NDMA : (NC - NCA) * IPS;
     // Ring geometry: RT = T-ring slots per line (2 with barriers), RDEPTH = steps of C / hand-off data the rings
     // hold, D = steps of DMA kept in flight (D <= RDEPTH-1).  The largest of a few candidates that fits in LDS.
@@ -221,6 +231,17 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     constexpr int LANES = 64 / SUBV;  // lanes per volume
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
     constexpr bool pubE = !WEIGHTED && !(FH && MGM == 2);  // slabs carry E = T - m; minima not needed
+    // Inter-band hand-off of the kernels that publish E.  E >= +0 always (T >= m; the host sends negative penalties to
+    // the first build), so the sign bit of every word is free: the last line of a band stores its slabs with the sign
+    // bits set to the LAUNCH's tag bit.  Every band has its own hand-off slots, written exactly once per launch, and
+    // consecutive launches on the same slots alternate the tag (the host clears the region whenever the geometry
+    // changes), so whatever a slot held before carries the other sign.  The consumer's loader simply DMAs the slab it
+    // needs next and looks at the signs of what landed: every word validates itself -- no progress word, no "stores
+    // have landed" wait on the producer side, no publication lag: a band trails its predecessor by the visibility
+    // latency of the stores plus the DMA depth (~4 steps instead of ~10).  A stale slab is fetched again until it is
+    // valid (slow path).  No assumption on timing or placement: a slot can only ever hold this launch's slab or an
+    // older launch's.
+    constexpr bool TAGS = pubE;
     using PL = Plan<LPL, NS, !pubE, C8>;
     constexpr int LP = PL::LP, NC = PL::NC, NCA = PL::NCA, D = PL::D, IPS = PL::IPS;
     constexpr int LPS = PL::LPS, LPD = PL::LPD, NDMA = PL::NDMA;
@@ -265,12 +286,18 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     const bool from_global = band > 0;
 
     constexpr int NSLP = NS * LP;
-    float *hand_out = P.hand + ((long long)(vp * 2 + (band & 1)) * P.LLmax) * NSLP;
+    // flag protocol: two slots per pass, alternating with the band's parity; TAGS: one slot per band
+    const long long hslab = (long long)(vp / kMaxDirs) * P.hand_vstride + g.hand_base;
+    float *hand_out = TAGS ? P.hand + (hslab + (long long)band * LL) * NSLP : P.hand + ((long long)(vp * 2 + (band & 1)) * P.LLmax) * NSLP;
     float *handm_out = P.handm + (long long)(vp * 2 + (band & 1)) * P.LLmax;
-    const float *hand_in = P.hand + ((long long)(vp * 2 + ((band + 1) & 1)) * P.LLmax) * NSLP;
+    // (band 0 has no predecessor; its loader still issues the DMAs -- every step the same count -- from its own slots)
+    const float *hand_in = TAGS ? P.hand + (hslab + (long long)(band > 0 ? band - 1 : 0) * LL) * NSLP
+                                : P.hand + ((long long)(vp * 2 + ((band + 1) & 1)) * P.LLmax) * NSLP;
     const float *handm_in = P.handm + (long long)(vp * 2 + ((band + 1) & 1)) * P.LLmax;
     unsigned *prog_out = P.prog + vp * P.maxbands + band;
     const unsigned *prog_in = from_global ? prog_out - 1 : prog_out;
+
+    const unsigned tag_in = P.hand_tag, tag_out = P.hand_tag;  // sign bits of the slabs handed over in this launch
 
     if (wave >= NC) {
         // =========================== loader waves ===========================
@@ -333,7 +360,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             }
             if (wl == 0) {
                 const int h = ht < 0 ? 0 : (ht < LL ? ht : LL - 1);
-                if (from_global && !dead && !(xflags & 4) && known < (unsigned)h + 1u) {
+                if (!TAGS && from_global && !dead && !(xflags & 4) && known < (unsigned)h + 1u) {
                     // slow path: the producer band is not far enough ahead.  Poll the word through
                     // LDS-DMA as well (no VGPR load, so nothing makes the compiler drain us elsewhere).
                     // Wait for a LEAD beyond the bare need: the producer publishes one pixel per step, so
@@ -369,9 +396,10 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     for (int c = 0; c < IPS; c++)
                         if (c * 64 + lane < LPL * 16)
                             dma16<AUX_SC1>(hptr + q * LP + c * 256, Hring + (slot * NS + q) * LP + c * 256);
-                if constexpr (!pubE)
+                if constexpr (!TAGS) {
                     if (lane == 0) dma4<AUX_SC1>(hmptr, Hm + slot);
-                if (lane == 0) dma4<AUX_SC1>(prog_in, Hprog + slot);
+                    if (lane == 0) dma4<AUX_SC1>(prog_in, Hprog + slot);
+                }
                 const bool adv = ht >= 0 && ht < LL - 1;
                 hptr += adv ? NSLP : 0;
                 hmptr += adv ? 1 : 0;
@@ -383,12 +411,54 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             else wait_vmcnt<PL::nB *(D - 1)>();
         };
 
+        // TAGS: the hand-off slab of step `t` (pixel t, or t-1 with slope 1) has landed in ring slot `vslot`; make sure
+        // it is the predecessor band's, fetching it again until it is
+        auto validate = [&](int t, int vslot) {
+            if constexpr (TAGS) {
+                const int h = SL == 2 ? t : t - 1;
+                if (wl != 0 || !from_global || h < 0 || h >= LL || dead || (xflags & 4)) return;
+                unsigned spins = 0;
+                const unsigned long long t0 = dbg ? wall_clock64() : 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int c = 0; c < IPS; c++)
+                        if (c * 64 + lane < LPL * 16) {
+                            const u32x4 v = lds_read_b128_opaque(Hring + vslot * NSLP + c * 256 + lane * 4);
+                            // all four sign bits must equal the expected tag
+                            ok = ok && (tag_in ? ((v.x & v.y & v.z & v.w) >> 31) != 0u : ((v.x | v.y | v.z | v.w) >> 31) == 0u);
+                        }
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                    if (spins == 0) n_slow++;
+                    n_spin++;
+                    __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+                    for (int c = 0; c < IPS; c++)
+                        if (c * 64 + lane < LPL * 16)
+                            dma16<AUX_SC1>(hand_in + (long long)h * NSLP + c * 256 + lane * 4, Hring + vslot * NSLP + c * 256);
+                    wait_vmcnt<0>();
+                    if (((++spins) & 255u) == 0) {
+                        if (lane == 0) dma4<AUX_SC1>(P.err, Hprog);
+                        wait_vmcnt<0>();
+                        const unsigned e = __builtin_amdgcn_readfirstlane(lds_read_u32_opaque(Hprog));
+                        if (spins > (SPIN_LIMIT >> 2) || e != 0) {
+                            if (lane == 0) __hip_atomic_store(P.err, 1u, RLX_AGENT);
+                            dead = true;
+                            break;
+                        }
+                    }
+                }
+                if (dbg) t_slow += wall_clock64() - t0;
+            }
+        };
+
         int slot = 0;
         for (int t = 0; t < D; t++) {  // prologue: steps 0..D-1
             issue(slot);
             slot = slot + 1 == RD ? 0 : slot + 1;
         }
         retire();
+        validate(0, 0);
         if (dbg && wl == 0 && lane == 0) {
             dbg[1] = wall_clock64();
             dbg[5] = t_slow;
@@ -396,7 +466,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
         step_barrier((xflags & 8) != 0);  // B0
         int uslot = 0;   // slot of the step that is about to run
         for (int s = 0; s < nsteps; s++) {
-            if (wl == 0 && from_global) {
+            if (!TAGS && wl == 0 && from_global) {
                 // freshest progress word that has landed: the one issued for step s
                 const unsigned k = __builtin_amdgcn_readfirstlane(lds_read_u32_opaque(Hprog + uslot));
                 known = k > known ? k : known;
@@ -407,6 +477,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             uslot = uslot + 1 == RD ? 0 : uslot + 1;
             const unsigned long long tb = dbg ? wall_clock64() : 0;
             retire();
+            validate(s + 1, uslot);  // what the compute waves read after this barrier
             const unsigned long long tc = dbg ? wall_clock64() : 0;
             step_barrier((xflags & 8) != 0);
             if (dbg) {
@@ -466,6 +537,11 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                 for (int q = 0; q < NS; q++)
 #pragma unroll
                     for (int k = 0; k < LPL; k++) X.w[q][k] = src[q * LP + k];
+                if constexpr (TAGS)
+                    if (r == 0) {  // (wave-uniform) the slab came from the previous band: E >= +0, drop the hand-off tag
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) X.w[0][k] = __builtin_fabsf(X.w[0][k]);
+                    }
                 if constexpr (!pubE) X.m = fwd_m0[sl];
             }
             if (line_ok && i >= 0 && i < LL) {
@@ -621,7 +697,15 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     ph[4] += clock64() - c4;  // LDS write retired
                 }
-                if (to_global) {
+                if constexpr (TAGS) {
+                    if (to_global) {
+                        float tagged[LPL];
+#pragma unroll
+                        for (int k = 0; k < LPL; k++)
+                            tagged[k] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, nb_i.w[0][k]) & 0x7fffffffu) | tag_out);  // (a NaN -- INF costs with P2 = INF -- may carry a sign of its own)
+                        store_slab_sc1_wide<LPL>(hand_out + (long long)i * LP, lane, tagged);
+                    }
+                } else if (to_global) {
 #pragma unroll
                     for (int q = 0; q < NS; q++)
                         store_slab_sc1_wide<LPL>(hand_out + ((long long)i * NS + q) * LP, lane, nb_i.w[q]);
