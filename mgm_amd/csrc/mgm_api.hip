@@ -111,6 +111,7 @@ struct DevSwitches {
     bool subv;       // MGM_HIP_SUBV=0: one volume per wave also at 128 / 64 labels
     int wg_per_cu;   // MGM_HIP_WG_PER_CU=1|2: override the occupancy heuristic of the pass kernel (0 = heuristic)
     int xflags;      // MGM_HIP_XFLAGS: experiment bits of development builds (mgm_device.h)
+    int strips;      // MGM_HIP_STRIPS=0|1: never / always walk the lines of passes 4-7 as two strips (default: chain-bound launches only)
     long long lr_pad;  // MGM_HIP_LR_PAD: floats between consecutive Lr volumes beyond their size, in 256-byte blocks (67)
 };
 static const DevSwitches &dev()
@@ -119,7 +120,7 @@ static const DevSwitches &dev()
         auto on = [](const char *n) { const char *e = getenv(n); return !(e && atoi(e) == 0); };
         auto num = [](const char *n, long long dflt) { const char *e = getenv(n); return e ? atoll(e) : dflt; };
         return DevSwitches{on("MGM_HIP_C8"), on("MGM_HIP_LAZY_F32"), on("MGM_HIP_PAD"), on("MGM_HIP_SUBV"),
-                           (int)num("MGM_HIP_WG_PER_CU", 0), (int)num("MGM_HIP_XFLAGS", 0), 64ll * num("MGM_HIP_LR_PAD", 67)};
+                           (int)num("MGM_HIP_WG_PER_CU", 0), (int)num("MGM_HIP_XFLAGS", 0), (int)num("MGM_HIP_STRIPS", -1), 64ll * num("MGM_HIP_LR_PAD", 67)};
     }();
     return d;
 }
@@ -257,6 +258,9 @@ bool make_geom(int pass, int nx, int ny, int R, int MGM, bool slope1_ok, PassGeo
     // form 0 sums inline, same, back, fwd: with MGM <= 3 the fwd neighbour (i+1, j-1) is never read,
     // so a line only has to stay ONE pixel behind the previous one (second K3 build only)
     g.slope = (slope1_ok && g.form == 0 && MGM <= 3) ? 1 : 2;
+    g.nstrips = 1;
+    g.split = g.LL;
+    g.hand_base = 0;
     return true;
 }
 
@@ -434,7 +438,20 @@ int mgm_img_free(mgm_ctx *c, mgm_img *im)
 }
 
 // ---- volumes --------------------------------------------------------------
-int mgm_cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, mgm_cv **out)
+// The fp32 array of a volume is allocated when somebody needs it: a volume K2 fills in the compact form only (single-word
+// census costs) never does on the hot path.
+static int cv_alloc_f32(mgm_ctx *c, mgm_cv *cv)
+{
+    if (cv->d) return MGM_OK;
+    const size_t n = (size_t)cv->nx * cv->ny * (size_t)(cv->dmax - cv->dmin + 1);
+    hipError_t e = hipMalloc((void **)&cv->d, sizeof(float) * n);
+    if (e != hipSuccess) {
+        cv->d = nullptr;
+        return fail(c, MGM_ERR_NOMEM, std::string("cost volume (fp32): ") + hipGetErrorString(e));
+    }
+    return MGM_OK;
+}
+static int cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, bool alloc_f32, mgm_cv **out)
 {
     if (!c || !out || nx <= 0 || ny <= 0 || dmax < dmin) return fail(c, MGM_ERR_INVALID, "mgm_cv_create: bad arguments");
     const long long L = (long long)dmax - dmin + 1;
@@ -442,18 +459,19 @@ int mgm_cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, mgm_cv **out)
         return fail(c, MGM_ERR_UNSUPPORTED, "more than 512 disparity labels per pixel are not supported");
     HIPCHK(c, hipSetDevice(c->device));
     mgm_cv *cv = new mgm_cv();
+    cv->d = nullptr;
     cv->nx = nx;
     cv->ny = ny;
     cv->dmin = dmin;
     cv->dmax = dmax;
     cv->owner = c;
-    hipError_t e = hipMalloc((void **)&cv->d, sizeof(float) * (size_t)nx * ny * (size_t)L);
-    if (e != hipSuccess) {
-        delete cv;
-        return fail(c, MGM_ERR_NOMEM, std::string("mgm_cv_create: ") + hipGetErrorString(e));
-    }
+    if (alloc_f32)
+        if (int r = cv_alloc_f32(c, cv)) {
+            delete cv;
+            return r;
+        }
     if (hipMalloc((void **)&cv->bad8, 64) != hipSuccess) {
-        (void)hipFree(cv->d);
+        if (cv->d) (void)hipFree(cv->d);
         delete cv;
         return fail(c, MGM_ERR_NOMEM, "mgm_cv_create: flag word");
     }
@@ -461,6 +479,7 @@ int mgm_cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, mgm_cv **out)
     *out = cv;
     return MGM_OK;
 }
+int mgm_cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, mgm_cv **out) { return cv_create(c, nx, ny, dmin, dmax, true, out); }
 int mgm_cv_upload(mgm_ctx *c, const float *dense, int nx, int ny, int dmin, int dmax, mgm_cv **out)
 {
     if (!dense) return fail(c, MGM_ERR_INVALID, "mgm_cv_upload: null host pointer");
@@ -485,6 +504,7 @@ static int ensure_f32(mgm_ctx *c, const mgm_cv *ccv)
     mgm_cv *cv = const_cast<mgm_cv *>(ccv);
     if (cv->f32_state) return MGM_OK;
     if (!cv->d8 || cv->c8_state < 1) return fail(c, MGM_ERR_INTERNAL, "cost volume has neither an fp32 nor a compact copy");
+    if (int r = cv_alloc_f32(c, cv)) return r;
     TimeScope t(c, "k_expand");
     HIPCHK(c, launch_expand(cv->d8, (long long)cv->nx * cv->ny * (cv->dmax - cv->dmin + 1), cv->d, c->stream));
     cv->f32_state = 1;
@@ -528,7 +548,7 @@ int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
         if (o)
             for (int v = 0; v < kMaxBatch; v++)
                 if (o->last_cvs[v] == cv) o->last_cvs[v] = nullptr;
-    (void)hipFree(cv->d);
+    if (cv->d) (void)hipFree(cv->d);
     if (cv->d8) (void)hipFree(cv->d8);
     if (cv->bad8) (void)hipFree(cv->bad8);
     if (cv->rlo) (void)hipFree(cv->rlo);
@@ -646,7 +666,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     if (*out) {  // caller-provided volume to refill (must have the right geometry)
         if ((*out)->nx != u->nx || (*out)->ny != u->ny || (*out)->dmin != dmin || (*out)->dmax != dmax)
             return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: *C is non-NULL but has a different geometry");
-    } else if ((r = mgm_cv_create(c, u->nx, u->ny, dmin, dmax, out))) {
+    } else if ((r = cv_create(c, u->nx, u->ny, dmin, dmax, false, out))) {
         return r;
     }
     (*out)->nan_words = false;
@@ -758,6 +778,9 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         dev().lazy_f32) {
         p.C = nullptr;
         (*out)->f32_state = 0;
+    } else {
+        if ((r = cv_alloc_f32(c, *out))) return r;
+        p.C = (*out)->d;
     }
     {
         TimeScope t(c, "k_cost");
@@ -1001,17 +1024,48 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     }
     if ((r = reserve(c, c->handm, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL))) return r;
 
-    // task table: ticket -> (pass, band); item (p, b) always follows (p, b-1)
-    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != ((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv || c->tk_r != R) {
+    {
+        // Two bands per CU pay when the launch is bound by throughput, not by the longest chain of bands: compare the
+        // band-steps one CU has to run with the critical path of the slowest pass (steps of slope*lines + line length
+        // + ~10 per band hand-off).  Measured break-even at a ratio of ~1.8: cfg3 needs 3 volumes per launch, one
+        // 4096x4096 volume is enough.
+        double work = 0, chain = 0;
+        for (int q = first; q < PEND; q++) {
+            const PassGeom &g = p.g[q];
+            work += (double)ngroups * g.nbands * (g.LL + g.slope * R);
+            chain = std::max(chain, (double)g.slope * g.NL + g.LL + 10.0 * g.nbands);
+        }
+        p.wg_per_cu = (work / (double)c->num_cu > 1.8 * chain) ? 2 : 1;
+    }
+    if (dev().wg_per_cu) p.wg_per_cu = dev().wg_per_cu;
+    // A single volume per launch (chain-bound, one band per CU) walks the lines of the passes without an in-line
+    // dependency -- form 1 with 2 or 3 neighbours -- as two strips, from both image edges inwards (mgm_pass2.hip): half
+    // the line length in the critical path of a pass, and bands that live half as long (measured, 1920x1080: K3 -5 % at
+    // 256 labels with Hirschmueller potentials and at 128 labels; nothing with FH potentials, whose single-volume launch
+    // is bound by the stalls of the min-convolution's repair path, and -5 % with two volumes).  A throughput-bound launch
+    // has nothing to gain from it (1-2 % of the pixels of such a pass are computed twice).
+    bool any_strips = false;
+    if (tags && (dev().strips == 1 || (dev().strips < 0 && p.wg_per_cu == 1 && ngroups == 1)))
+        for (int q = first; q < PEND; q++)
+            if (p.g[q].form == 1 && (MGM == 2 || MGM == 3) && p.g[q].LL >= 8 * R) {
+                p.g[q].nstrips = 2;
+                p.g[q].split = p.g[q].LL / 2;
+                any_strips = true;
+            }
+
+    // task table: ticket -> (pass, band [, strip]); item (p, b, .) always follows the items (p, b-1, .)
+    const int tk_key = (((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv) * 2 + (any_strips ? 1 : 0);
+    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != tk_key || c->tk_r != R) {
         // Passes with more bands (the column passes of a wide image) have the longer dependency
         // chain, so tickets are dealt by RELATIVE progress b / nbands(pass): every pass advances at
         // the rate that lets all of them finish together.  Within a pass the order is still by band.
         std::vector<int2> tasks;
         for (int v = 0; v < ngroups; v++)
             for (int q = first; q < PEND; q++)
-                for (int b = 0; b < p.g[q].nbands; b++) tasks.push_back(make_int2(v * kMaxDirs + q, b));
+                for (int b = 0; b < p.g[q].nbands; b++)
+                    for (int st = 0; st < p.g[q].nstrips; st++) tasks.push_back(make_int2(v * kMaxDirs + q, b + (st << 16)));
         std::stable_sort(tasks.begin(), tasks.end(), [&](const int2 &a, const int2 &b) {
-            const long long ka = (long long)a.y * p.g[b.x % kMaxDirs].nbands, kb = (long long)b.y * p.g[a.x % kMaxDirs].nbands;
+            const long long ka = (long long)(a.y & 0xffff) * p.g[b.x % kMaxDirs].nbands, kb = (long long)(b.y & 0xffff) * p.g[a.x % kMaxDirs].nbands;
             return ka != kb ? ka < kb : a.x < b.x;
         });
         if ((r = reserve(c, c->tasks, sizeof(int2) * tasks.size()))) return r;
@@ -1020,7 +1074,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         c->ntasks = (int)tasks.size();
         c->tk_nx = nx;
         c->tk_ny = ny;
-        c->tk_ndir = ((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv;
+        c->tk_ndir = tk_key;
         c->tk_r = R;
     }
 
@@ -1055,20 +1109,6 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.P2 = P2;
     p.dbg = nullptr;
     p.xflags = 0;
-    {
-        // Two bands per CU pay when the launch is bound by throughput, not by the longest chain of bands: compare the
-        // band-steps one CU has to run with the critical path of the slowest pass (steps of slope*lines + line length
-        // + ~10 per band hand-off).  Measured break-even at a ratio of ~1.8: cfg3 needs 3 volumes per launch, one
-        // 4096x4096 volume is enough.
-        double work = 0, chain = 0;
-        for (int q = first; q < PEND; q++) {
-            const PassGeom &g = p.g[q];
-            work += (double)ngroups * g.nbands * (g.LL + g.slope * R);
-            chain = std::max(chain, (double)g.slope * g.NL + g.LL + 10.0 * g.nbands);
-        }
-        p.wg_per_cu = (work / (double)c->num_cu > 1.8 * chain) ? 2 : 1;
-    }
-    if (dev().wg_per_cu) p.wg_per_cu = dev().wg_per_cu;
     p.xflags = dev().xflags;
     if ((p.xflags || c->debug_stats) && R2 && !pass2_devtools())
         return fail(c, MGM_ERR_UNSUPPORTED, "MGM_HIP_XFLAGS / MGM_HIP_DEBUG_STATS need a development build of the pass kernels "
@@ -1098,6 +1138,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         }
         const double tick = 1e-2;  // wall_clock64: 100 MHz -> 0.01 us
         fprintf(stderr, "[mgm stats] %d workgroups, kernel span %.1f us\n", c->ntasks, (t1 - t0) * tick);
+        if (c->debug_stats >= 2)  // one line per work item: pass, band, strip, ticket, start / first step / end (us), time in the slow path
+            for (int i = 0; i < c->ntasks; i++)
+                fprintf(stderr, "[mgm item] %d %d %d %d %.1f %.1f %.1f %.1f\n", tk[i].x % kMaxDirs, tk[i].y & 0xffff, tk[i].y >> 16, i,
+                        (d[i * 16 + 0] - t0) * tick, (d[i * 16 + 1] - t0) * tick, (d[i * 16 + 2] - t0) * tick, d[i * 16 + 6] * tick);
         for (int q = first; q < PEND; q++) {
             double run = 0, slow = 0, pro = 0, nslow = 0, nspin = 0, steps = 0, first = 1e30, last = 0;
             double ai = 0, ar = 0, ab = 0, bi = 0, br = 0, bb = 0, cb = 0, fsw = 0, fn = 0, fmx = 0, frep = 0;
@@ -1176,10 +1220,10 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
         w.C = c->last_pad_c8 ? nullptr : (const float *)c->padf[slot].p + pix0 * L;
         w.C8 = c->last_pad_c8 ? (const uint8_t *)c->pad8[slot].p + pix0 * L : nullptr;
     } else {
-        w.C = C->d + pix0 * L;
         w.C8 = (C->c8_state == 2 && c->force_build != 1) ? C->d8 + pix0 * L : nullptr;
         if (!w.C8)
             if (int r = ensure_f32(c, C)) return r;
+        w.C = C->d ? C->d + pix0 * L : nullptr;
     }
     w.Lr = lr;
     w.S = Sout;

@@ -27,6 +27,8 @@ struct PassGeom {
     long long istep;   // pixel-index step along the line
     long long jstep;   // pixel-index step between lines
     int wplane[4];     // weight plane of neighbour k (mgm_core.cc:481-484)
+    int nstrips, split;   // 2: the lines of this pass are walked as two strips [0, split) and [split, LL) by two workgroups per band
+                          // (k_pass2, TAGS, form 1 with 2 or 3 neighbours: no in-line dependency), both from the image edge inwards
     long long hand_base;  // self-validating hand-off slabs (k_pass2, TAGS): first slab of this pass within a volume's region
 };
 
@@ -52,7 +54,7 @@ struct PassParams {
     unsigned *prog;     // progress words  [volume*8 + pass][maxbands]
     unsigned *ticket;   // work-item ticket counter
     unsigned *err;      // watchdog word
-    const int2 *tasks;  // ticket -> (volume*8 + pass, band)
+    const int2 *tasks;  // ticket -> (volume*8 + pass, band + (strip << 16))
     int subv;                 // volumes per wave (1; 2 at 128 labels, 4 at 64: k_pass2<..., SUBV>); work items then address groups of volumes
     int wg_per_cu;            // 1 or 2 workgroups per compute unit (second build; see launch2_c8)
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA, 4 ignore

@@ -122,6 +122,9 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 
 #ifndef MGM_P2_C8_NL
 #define MGM_P2_C8_NL 1
 #endif
+#ifndef MGM_P2_C8_NC
+#define MGM_P2_C8_NC (16 - MGM_P2_C8_NL)   // lines per band with compact costs (tuning experiments: 7)
+#endif
 #ifndef MGM_P2_MAXD
 #define MGM_P2_MAXD 2
 #endif
@@ -144,7 +147,7 @@ struct Plan {
     static constexpr int LPS = LPL * 4;
     static constexpr int LPD = C8 ? 64 / LPS : 1;
     static constexpr int NL = (LPL <= 4 && MGM_P2_NC > 7) ? (C8 ? MGM_P2_C8_NL : 2) : 1;  // loader waves
-    static constexpr int NC = (LPL <= 4) ? (C8 ? 16 - MGM_P2_C8_NL : MGM_P2_NC) : 7;   // compute waves = lines per band
+    static constexpr int NC = (LPL <= 4) ? (C8 ? MGM_P2_C8_NC : MGM_P2_NC) : 7;   // compute waves = lines per band
     static constexpr int NCA = (NL == 2) ? NC / 2 : NC;                               // lines served by loader A
     static constexpr int NDMA = C8 ? (NC + LPD - 1) / LPD : NCA * IPS;                // C pieces per step (loader A)
     // DMA instructions per step: loader A = its C pieces + hand-off slabs [+ minimum + progress word: the kernels whose
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     __syncthreads();
     const int ticket = *s_task;
     const int2 tk = P.tasks[ticket];
-    const int vp = tk.x, band = tk.y;  // vp = volume*8 + pass
+    const int vp = tk.x, band = tk.y & 0xffff, strip = tk.y >> 16;  // vp = volume*8 + pass
     const int pass = vp & (kMaxDirs - 1);
     const int vgrp = (vp / kMaxDirs) * SUBV;  // first volume of this work item
     const PassVolume &V = P.vol[vgrp];
@@ -280,9 +283,22 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     const PassGeom &g = P.g[pass];
     const int NLn = g.NL, LL = g.LL, L = P.L, form = g.form;
     const float P1 = P.P1, P2 = P.P2;
-    const long long istep = g.istep;
     const int SL = g.slope;  // wave r is at pixel i = s - 1 - SL*r at step s
-    const int nsteps = ((LL + 1 + SL * (NC - 1)) + 2) / 3 * 3;
+    // Two strips per line (form 1 with 2 or 3 neighbours: a pixel depends on the previous line only): this workgroup walks
+    // strip `strip` of its band's lines, strip 0 = [0, split) upwards from pixel 0, strip 1 = [split, LL) downwards from
+    // pixel LL-1 -- in MIRRORED coordinates i' = LL-1-i, in which it is again a walk upwards from 0 (the two neighbours
+    // that swap roles, fwd and back, enter a commutative fp32 sum).  Both strips run from the image edge inwards and meet
+    // in the middle; so that neither ever needs the other's lines of the SAME band, line r of the band is walked over
+    // [0, W - r), W = strip length + NC-1: the last line covers exactly the strip, the lines above it a little more (the
+    // pixels both workgroups compute get the same values twice).  What a strip needs from the other comes from the
+    // previous band's hand-off slots, which are indexed by absolute pixel and validate themselves.  The chain of a pass
+    // is then 2 steps per line + HALF a line, and a band lives half as long.
+    const bool strips = TAGS && g.nstrips == 2;
+    const bool mirror = strips && strip == 1;
+    const long long istep = mirror ? -g.istep : g.istep;
+    const long long gbase = mirror ? g.base + (long long)(LL - 1) * g.istep : g.base;
+    const int W = !strips ? LL : min(LL, (strip == 0 ? g.split : LL - g.split) + NC - 1);  // pixels of the tile's first line
+    const int nsteps = ((W + 1 + SL * (NC - 1)) + 2) / 3 * 3;
     const bool from_global = band > 0;
 
     constexpr int NSLP = NS * LP;
@@ -328,16 +344,18 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                 constexpr int CPV = LPS / SUBV;  // 16-byte chunks of a line's slab that belong to one volume
                 const int chunk = lane % LPS;
                 const uint8_t *c8 = P.vol[vgrp + chunk / CPV].C8;
-                cptr[q] = reinterpret_cast<const float *>(c8 + (g.base + (long long)j * g.jstep) * L + (chunk % CPV) * 16);
+                cptr[q] = reinterpret_cast<const float *>(c8 + (gbase + (long long)j * g.jstep) * L + (chunk % CPV) * 16);
             } else if constexpr (C8)
-                cptr[q] = reinterpret_cast<const float *>(V.C8 + (g.base + (long long)j * g.jstep) * L + (lane % LPS) * 16);
+                cptr[q] = reinterpret_cast<const float *>(V.C8 + (gbase + (long long)j * g.jstep) * L + (lane % LPS) * 16);
             else
-                cptr[q] = V.C + (g.base + (long long)j * g.jstep) * L + lane * 4;
+                cptr[q] = V.C + (gbase + (long long)j * g.jstep) * L + lane * 4;
             ci[q] = -1 - SL * r;
         }
         // hand-off slab wanted by wave 0 at step t: pixel t (its fwd neighbour) with slope 2, pixel t-1
         // (its same neighbour) with slope 1; clamped to [0, LL-1]
-        const float *hptr = hand_in + lane * 4;
+        const int Hmax = W < LL ? W : LL - 1;  // last pixel of the previous band's last line this tile reads
+        const long long hstep = mirror ? -(long long)NSLP : (long long)NSLP;  // (slots are indexed by the absolute pixel)
+        const float *hptr = hand_in + (mirror ? (long long)(LL - 1) * NSLP : 0) + lane * 4;
         const float *hmptr = handm_in;
         int ht = SL == 2 ? 0 : -1;
 
@@ -354,12 +372,12 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     for (int c = 0; c < IPS; c++)
                         if (c * 64 + lane < ((xflags & 2) ? 1 : LPL * 16)) dma16<0>(cptr[q] + c * 256, dst + c * 256);
                 }
-                const bool adv = (ci[q] >= 0) && (ci[q] < LL - 1);
+                const bool adv = (ci[q] >= 0) && (ci[q] < W - 1);
                 cptr[q] += adv ? cstride : 0;
                 ci[q]++;
             }
             if (wl == 0) {
-                const int h = ht < 0 ? 0 : (ht < LL ? ht : LL - 1);
+                const int h = ht < 0 ? 0 : (ht <= Hmax ? ht : Hmax);
                 if (!TAGS && from_global && !dead && !(xflags & 4) && known < (unsigned)h + 1u) {
                     // slow path: the producer band is not far enough ahead.  Poll the word through
                     // LDS-DMA as well (no VGPR load, so nothing makes the compiler drain us elsewhere).
@@ -400,8 +418,8 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     if (lane == 0) dma4<AUX_SC1>(hmptr, Hm + slot);
                     if (lane == 0) dma4<AUX_SC1>(prog_in, Hprog + slot);
                 }
-                const bool adv = ht >= 0 && ht < LL - 1;
-                hptr += adv ? NSLP : 0;
+                const bool adv = ht >= 0 && ht < Hmax;
+                hptr += adv ? hstep : 0;
                 hmptr += adv ? 1 : 0;
                 ht++;
             }
@@ -416,7 +434,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
         auto validate = [&](int t, int vslot) {
             if constexpr (TAGS) {
                 const int h = SL == 2 ? t : t - 1;
-                if (wl != 0 || !from_global || h < 0 || h >= LL || dead || (xflags & 4)) return;
+                if (wl != 0 || !from_global || h < 0 || h > Hmax || dead || (xflags & 4)) return;
                 unsigned spins = 0;
                 const unsigned long long t0 = dbg ? wall_clock64() : 0;
                 for (;;) {
@@ -435,7 +453,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 #pragma unroll
                     for (int c = 0; c < IPS; c++)
                         if (c * 64 + lane < LPL * 16)
-                            dma16<AUX_SC1>(hand_in + (long long)h * NSLP + c * 256 + lane * 4, Hring + vslot * NSLP + c * 256);
+                            dma16<AUX_SC1>(hand_in + (long long)(mirror ? LL - 1 - h : h) * NSLP + c * 256 + lane * 4, Hring + vslot * NSLP + c * 256);
                     wait_vmcnt<0>();
                     if (((++spins) & 255u) == 0) {
                         if (lane == 0) dma4<AUX_SC1>(P.err, Hprog);
@@ -506,7 +524,9 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     const bool to_lds = (r < NC - 1) && (j + 1 < NLn);
     const bool to_global = (r == NC - 1) && (band + 1 < g.nbands);
     float *__restrict__ Lrb = P.vol[vgrp + (SUBV > 1 ? lane / LANES : 0)].Lr + (long long)(pass - P.pass0) * P.nvol;
-    const long long pix0 = g.base + (long long)j * g.jstep;
+    const long long pix0 = gbase + (long long)j * g.jstep;
+    const int Wr = strips ? W - r : LL;           // this line is walked over [0, Wr)
+    const int Wx = Wr + 1 < LL ? Wr + 1 : LL;     // ... and reads the slabs [0, Wx) of the line before it
     const float *fwd_src0 = r > 0 ? Tring + (r - 1) * RT * NSLP + lane * LPL : Hring + lane * LPL;
     const float *fwd_m0 = r > 0 ? Tm + (r - 1) * RT : Hm;
     // fp32: own ring [RD][LP]; compact: byte (r%LPD)*LPS*16 + lane*LPL of piece r/LPD of the step's slot
@@ -530,7 +550,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
         auto step = [&](int s, int cslot, NbT &X, const NbT &Y, const NbT &Z) {
             const int i = s - 1 - SLOPE * r;
             const unsigned long long c0 = prof ? clock64() : 0;
-            if (has_prev && i + NEWOFF >= 0 && i + NEWOFF < LL) {
+            if (has_prev && i + NEWOFF >= 0 && i + NEWOFF < Wx) {
                 const int sl = r > 0 ? ((i + NEWOFF) & (RT - 1)) : cslot;
                 const float *src = fwd_src0 + sl * NSLP;
 #pragma unroll
@@ -544,7 +564,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     }
                 if constexpr (!pubE) X.m = fwd_m0[sl];
             }
-            if (line_ok && i >= 0 && i < LL) {
+            if (line_ok && i >= 0 && i < Wr) {
                 const long long pix = pix0 + (long long)i * istep;
                 float Cv[LPL], Lv[LPL];
                 if constexpr (C8) {
@@ -703,7 +723,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 #pragma unroll
                         for (int k = 0; k < LPL; k++)
                             tagged[k] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, nb_i.w[0][k]) & 0x7fffffffu) | tag_out);  // (a NaN -- INF costs with P2 = INF -- may carry a sign of its own)
-                        store_slab_sc1_wide<LPL>(hand_out + (long long)i * LP, lane, tagged);
+                        store_slab_sc1_wide<LPL>(hand_out + (long long)(mirror ? LL - 1 - i : i) * LP, lane, tagged);
                     }
                 } else if (to_global) {
 #pragma unroll

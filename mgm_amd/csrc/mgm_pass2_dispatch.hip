@@ -5,6 +5,9 @@
 #ifndef MGM_P2_C8_NL
 #define MGM_P2_C8_NL 1
 #endif
+#ifndef MGM_P2_C8_NC
+#define MGM_P2_C8_NC (16 - MGM_P2_C8_NL)
+#endif
 #ifndef MGM_P2_DEV
 #define MGM_P2_DEV 0
 #endif
@@ -19,7 +22,7 @@ int pass2_lines(int L, bool c8)
 {
     if (L % 64) return 0;
     const int lpl = L / 64;
-    if (c8 && c8_supported(L)) return lpl <= 4 ? 16 - MGM_P2_C8_NL : 7;  // compact costs need fewer loader waves
+    if (c8 && c8_supported(L)) return lpl <= 4 ? MGM_P2_C8_NC : 7;  // compact costs need fewer loader waves
     if (lpl == 1 || lpl == 2 || lpl == 3 || lpl == 4) return 14;
     if (lpl == 6 || lpl == 8) return 7;
     return 0;

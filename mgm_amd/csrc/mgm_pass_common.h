@@ -230,6 +230,9 @@ __device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, uns
             // (e.g. over a stretch of +INF costs).  Plain sweeps would repair one lane per sweep.
             // Re-derive every carry as the exact image of its winning origin instead.
             boosted = true;
+#ifdef MGM_FH_NOREPAIR  // timing experiment (WRONG results): what do the repairs cost?
+            break;
+#endif
             c = fh_repair<LPL, FWD, GROUPS>(a, P1, lane);
         }
     }
