@@ -162,6 +162,30 @@ void *mgm_lr_device_ptr(mgm_ctx *ctx, int slot);
 int mgm_wta_rows_dev(mgm_ctx *ctx, const mgm_cv *C, int row0, int nrows, const void *lr_slabs, int NDIR,
                      int fix_overcount, const char *refine, void *out_rows, void *outcost_rows);
 
+/* ---- the same, driven from ONE host thread for n GPUs of a node: mgm_multi ---------------------------------------
+ * An mgm_ctx per device plus an RCCL communicator over the devices (librccl is loaded on first use).  The CPU analogue
+ * in the reference is mgm_naive_parallelism (mgm_core.cc:632-831, WITH_MGM2=1): passes in parallel on private Lr
+ * volumes, then accumulated -- here always in pass order, so the result is mgm()'s bit for bit.
+ *   mgm_multi_create     device_ids: n distinct HIP devices (gfx950).  MGM_ERR_HIP without librccl or a device.
+ *                        (MGM_MULTI_LOOPBACK=1 in the environment: a device may appear several times and slabs travel by
+ *                        device-to-device copies instead of ncclSend/ncclRecv -- the n-rank path on a one-GPU box, tests.)
+ *   mgm_multi_ctx        rank k's context: build C[k] on it (mgm_costvolume_build_dev from images uploaded there).
+ *   mgm_multi_aggregate  mgm() of ONE volume: C[k] = the same cost volume on every device (rebuilt there from the
+ *                        images: cheaper than moving it), w8 NULL or one weight image per device; rank k runs the
+ *                        passes of mgm_multi_plan's block k, grouped ncclSend/ncclRecv move the row slabs (one peer per
+ *                        xGMI link, all links at once), every rank sums its rows in pass order and searches them, and
+ *                        the rows are gathered into out0 / outcost0, images on device_ids[0].  Synchronous.
+ *   mgm_multi_plan       the partition as data: contiguous blocks of passes and of rows per rank (sizes differ by <= 1). */
+typedef struct mgm_multi mgm_multi;
+int mgm_multi_create(const int *device_ids, int n, mgm_multi **m);
+int mgm_multi_destroy(mgm_multi *m);
+int mgm_multi_size(const mgm_multi *m);
+mgm_ctx *mgm_multi_ctx(mgm_multi *m, int rank);
+const char *mgm_multi_last_error(const mgm_multi *m);
+int mgm_multi_plan(int n, int NDIR, int ny, int *first_pass, int *n_passes, int *row0, int *nrows);
+int mgm_multi_aggregate(mgm_multi *m, const mgm_cv *const *C, const mgm_img *const *w8, float P1, float P2, int NDIR, int MGM,
+                        int use_fh, int fix_overcount, const char *refine, mgm_img *out0, mgm_img *outcost0);
+
 /* Test/diagnostic aid: copy pass `pass`'s Lr volume of the LAST mgm_aggregate
  * call on this ctx into `dense` ([ny][nx][L]). */
 int mgm_debug_download_lr(mgm_ctx *ctx, int pass, float *dense);

@@ -28,6 +28,8 @@ ABI_SYMBOLS = [
     "mgm_selftest_div3", "mgm_aggregate_passes_dev", "mgm_lr_device_ptr", "mgm_wta_rows_dev",
     "mgm_aggregate_batch_dev", "mgm_median_dev", "mgm_leftright_dev", "mgm_backproject_dev",
     "mgm_wta_windowed_dev", "mgm_update_ranges_dev", "mgm_costvolume_build_ranged_dev",
+    "mgm_multi_create", "mgm_multi_destroy", "mgm_multi_size", "mgm_multi_ctx", "mgm_multi_last_error", "mgm_multi_plan",
+    "mgm_multi_aggregate",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -98,6 +100,16 @@ def load_library():
     L.mgm_lr_device_ptr.argtypes = [vp, i]
     L.mgm_lr_device_ptr.restype = vp
     L.mgm_wta_rows_dev.argtypes = [vp, vp, i, i, vp, i, i, cp, vp, vp]
+    ip = C.POINTER(i)
+    L.mgm_multi_create.argtypes = [ip, i, pp]
+    L.mgm_multi_destroy.argtypes = [vp]
+    L.mgm_multi_size.argtypes = [vp]
+    L.mgm_multi_ctx.argtypes = [vp, i]
+    L.mgm_multi_ctx.restype = vp
+    L.mgm_multi_last_error.argtypes = [vp]
+    L.mgm_multi_last_error.restype = cp
+    L.mgm_multi_plan.argtypes = [i, i, i, ip, ip, ip, ip]
+    L.mgm_multi_aggregate.argtypes = [vp, pp, pp, f, f, i, i, i, i, cp, vp, vp]
     _lib = L
     return L
 
@@ -160,8 +172,12 @@ class CostVolume:
 class Context:
     """One device + stream + workspace (``mgm_ctx``)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self.lib = load_library()
+        self.owned = _borrowed is None
+        if _borrowed is not None:  # a rank's context of an mgm_multi handle (destroyed with it)
+            self.h = C.c_void_p(_borrowed)
+            return
         h = C.c_void_p()
         r = self.lib.mgm_ctx_create(device, C.byref(h))
         if r:
@@ -169,9 +185,9 @@ class Context:
         self.h = h
 
     def close(self):
-        if self.h:
+        if self.h and self.owned:
             self.lib.mgm_ctx_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __enter__(self):
         return self
@@ -346,3 +362,48 @@ class Context:
             self._chk(self.lib.mgm_timing_get(self.h, k, C.byref(name), C.byref(ms)))
             res.append((name.value.decode(), ms.value))
         return res
+
+
+def multi_plan(n, NDIR, ny):
+    """mgm_multi_plan: [(first_pass, n_passes, row0, nrows)] per rank (no device needed)."""
+    L = load_library()
+    a = [(C.c_int * n)() for _ in range(4)]
+    r = L.mgm_multi_plan(n, NDIR, ny, *a)
+    if r:
+        raise MgmError(r, "mgm_multi_plan: bad arguments")
+    return [tuple(int(x[k]) for x in a) for k in range(n)]
+
+
+class Multi:
+    """n GPUs of one node behind one handle (``mgm_multi``): direction sharding of one volume with an RCCL slab exchange."""
+
+    def __init__(self, device_ids):
+        self.lib = load_library()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        r = self.lib.mgm_multi_create(ids, len(device_ids), C.byref(h))
+        if r:
+            raise MgmError(r, "mgm_multi_create(%s) failed" % (list(device_ids),))
+        self.h = h
+        self.n = len(device_ids)
+        self.ctx = [Context(_borrowed=self.lib.mgm_multi_ctx(h, k)) for k in range(self.n)]
+
+    def aggregate(self, Cvs, P1, P2, NDIR, MGM, use_fh=0, fix_overcount=1, refine=None, w8s=None):
+        """mgm_multi_aggregate: returns host arrays (out, outcost)."""
+        nx, ny, _, _ = Cvs[0].dims
+        out, outc = self.ctx[0].new_image(nx, ny), self.ctx[0].new_image(nx, ny)
+        arr = lambda hs: (C.c_void_p * self.n)(*hs)
+        r = self.lib.mgm_multi_aggregate(self.h, arr([cv.h for cv in Cvs]), arr([w.h for w in w8s]) if w8s is not None else None, P1, P2,
+                                         NDIR, MGM, use_fh, fix_overcount, refine.encode() if refine else None, out.h, outc.h)
+        if r:
+            raise MgmError(r, self.lib.mgm_multi_last_error(self.h).decode())
+        res = out.download()[0], outc.download()[0]
+        out.free(), outc.free()
+        return res
+
+    def close(self):
+        if self.h:
+            self.lib.mgm_multi_destroy(self.h)
+            self.h = None
+            for c in self.ctx:
+                c.h = None

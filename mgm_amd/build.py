@@ -24,7 +24,7 @@ UNITS = [("mgm_pass.hip", "", ["-fno-honor-nans"])]
 P2_EXTRA = os.environ.get("MGM_P2_DEFINES", "").split()  # e.g. "-DMGM_P2_MAXD=3" (tuning experiments)
 UNITS += [("mgm_pass2.hip", "_lpl%d" % n, ["-fno-honor-nans", "-DMGM_P2_LPL=%d" % n] + P2_EXTRA) for n in (1, 2, 3, 4, 6, 8)]
 UNITS += [("mgm_pass2_dispatch.hip", "", P2_EXTRA), ("mgm_cost.hip", "", []), ("mgm_wta.hip", "", []), ("mgm_post.hip", "", []),
-          ("mgm_api.hip", "", [])]
+          ("mgm_api.hip", "", []), ("mgm_multi.hip", "", [])]
 
 
 def hipcc():
@@ -69,7 +69,7 @@ def build(force=False, verbose=False):
                 if verbose and out.strip():
                     print(out)
     if jobs or force or _stale(LIB, objs):
-        run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB])
+        run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB])
     build_cli(force)
     return LIB
 

@@ -81,6 +81,9 @@ static HostImg median_filter(const HostImg &u, int radius)
     return M;
 }
 
+struct Run;
+static void free_run(mgm_ctx *ctx, Run &r);
+
 struct Opts {
     int dmin, dmax, NDIR;
     float P1, P2, aP2, aThresh, truncDist;
@@ -148,6 +151,30 @@ static void aggregate_run(mgm_ctx *ctx, const Opts &o, Run &r)
 {
     const int rc = mgm_aggregate_dev(ctx, r.C, r.dw, o.P1, o.P2, o.NDIR, o.TSGM, o.FH, o.FIX, o.refine, r.dout, r.dcost, nullptr);
     if (rc) die(ctx, rc, "mgm_aggregate");
+}
+
+// MGM_DEVICES=a,b,...: the passes of each mgm() run sharded over several GPUs of the node (mgm_multi_aggregate: every
+// device builds the cost volume from the images, runs its block of passes, row slabs travel over RCCL, ordered sum and
+// WTA per device, rows gathered on the first device).  `r` has been prepared on the first device.
+static void aggregate_run_multi(mgm_multi *m, const HostImg &u, const HostImg &v, int dmin, int dmax, const Opts &o, Run &r)
+{
+    const int n = mgm_multi_size(m);
+    std::vector<Run> shadow(n);
+    std::vector<const mgm_cv *> Cs(n);
+    std::vector<const mgm_img *> Ws(n);
+    Cs[0] = r.C;
+    Ws[0] = r.dw;
+    for (int k = 1; k < n; k++) {
+        prepare_run(mgm_multi_ctx(m, k), u, v, dmin, dmax, o, shadow[k]);
+        Cs[k] = shadow[k].C;
+        Ws[k] = shadow[k].dw;
+    }
+    const int rc = mgm_multi_aggregate(m, Cs.data(), Ws.data(), o.P1, o.P2, o.NDIR, o.TSGM, o.FH, o.FIX, o.refine, r.dout, r.dcost);
+    if (rc) {
+        fprintf(stderr, "mgm: mgm_multi_aggregate failed (%d): %s\n", rc, mgm_multi_last_error(m));
+        exit(rc == MGM_ERR_UNSUPPORTED ? 2 : 1);
+    }
+    for (int k = 1; k < n; k++) free_run(mgm_multi_ctx(m, k), shadow[k]);
 }
 
 // what mgm() and print_solution_energy put on stdout for one run (mgm_core.cc:420-423, 491; mgm_print_energy.h:109-111)
@@ -231,7 +258,7 @@ int main(int argc, char **argv)
                         "options: -r dmin(-30) -R dmax(30) -O NDIR(4) -P1 (8) -P2 (32) -p prefilter(none) -t distance(ad)\n"
                         "         -truncDist (inf) -s subpix(none) -aP1 (1) -aP2 (1) -aThresh (5) -m FILE -M FILE -l FILE\n"
                         "environment: CENSUS_NCC_WIN=3 TESTLRRL=1 TESTLRRL_TAU=1.0 MEDIAN=0 TSGM=4 TSGM_ITER=1\n"
-                        "             TSGM_FIX_OVERCOUNT=1 USE_TRUNCATED_LINEAR_POTENTIALS=0 MGM_DEVICE=0");
+                        "             TSGM_FIX_OVERCOUNT=1 USE_TRUNCATED_LINEAR_POTENTIALS=0 MGM_DEVICE=0 MGM_DEVICES=0,1,...");
     if (argc < 4) {
         fprintf(stderr, "too few parameters\n   usage: %s  [-r dmin -R dmax] [-m dminImg -M dmaxImg] [-O NDIR: 2, (4), 8] u v out "
                         "[cost [backflow]]\n", argv[0]);
@@ -293,14 +320,37 @@ int main(int argc, char **argv)
         o.P2 *= u.nch;
 
         mgm_ctx *ctx = nullptr;
-        int rc = mgm_ctx_create((int)env_param("MGM_DEVICE", 0), &ctx);
-        if (rc) { fprintf(stderr, "mgm: no usable MI355X device (mgm_ctx_create = %d); there is no CPU path\n", rc); return 1; }
+        mgm_multi *multi = nullptr;
+        int rc;
+        std::vector<int> devs;
+        if (const char *dl = getenv("MGM_DEVICES"))  // "0,1,2,3": several GPUs of this node
+            for (const char *q = dl; *q;) {
+                char *end;
+                const long d = strtol(q, &end, 10);
+                if (end == q) break;
+                devs.push_back((int)d);
+                q = *end == ',' ? end + 1 : end;
+            }
+        if (devs.size() > 1 && ((int)TSGM_ITER > 1 || plo)) {
+            fprintf(stderr, "mgm: MGM_DEVICES: TSGM_ITER > 1 and range images run on the first device only\n");
+            devs.resize(1);
+        }
+        if (devs.size() > 1) {
+            if ((rc = mgm_multi_create(devs.data(), (int)devs.size(), &multi))) {
+                fprintf(stderr, "mgm: MGM_DEVICES: cannot set up %d devices (mgm_multi_create = %d)\n", (int)devs.size(), rc);
+                return 1;
+            }
+            ctx = mgm_multi_ctx(multi, 0);
+        } else {
+            rc = mgm_ctx_create(devs.size() == 1 ? devs[0] : (int)env_param("MGM_DEVICE", 0), &ctx);
+            if (rc) { fprintf(stderr, "mgm: no usable MI355X device (mgm_ctx_create = %d); there is no CPU path\n", rc); return 1; }
+        }
 
         HostImg outoff, outcost;
         Run L, R;
         prepare_run(ctx, u, v, o.dmin, o.dmax, o, L, plo, phi);
         bool together = false;
-        if (TESTLRRL != 0 && !plo && u.nx == v.nx && u.ny == v.ny && env_param("MGM_BATCH_LR", 1) != 0) {
+        if (!multi && TESTLRRL != 0 && !plo && u.nx == v.nx && u.ny == v.ny && env_param("MGM_BATCH_LR", 1) != 0) {
             // both runs of the pair (mgm.cc:376-385 and 405-414) through ONE launch of the pass kernel
             prepare_run(ctx, v, u, -o.dmax, -o.dmin, o, R);  // mgm.cc:366, 405
             const mgm_cv *Cs[2] = {L.C, R.C};
@@ -312,14 +362,16 @@ int main(int argc, char **argv)
             else if (rc != MGM_ERR_UNSUPPORTED) die(ctx, rc, "mgm_aggregate_batch");
             // (UNSUPPORTED: one image weighted, the other not -- the two runs take different update functions)
         }
-        if (!together) aggregate_run(ctx, o, L);
+        if (multi) aggregate_run_multi(multi, u, v, o.dmin, o.dmax, o, L);
+        else if (!together) aggregate_run(ctx, o, L);
         report_run(o, L);
         iterate_run(ctx, o, L, (int)TSGM_ITER, o.dmin, o.dmax, plo, phi);
         if (MEDIAN != 0) median_run(ctx, L, (int)MEDIAN);
         if (nolr_file[0]) imgio::write(nolr_file, download(ctx, L.dout, L.nx, L.ny, 1));
         if (TESTLRRL != 0) {
             if (!R.C) prepare_run(ctx, v, u, -o.dmax, -o.dmin, o, R);  // mgm.cc:366, 405
-            if (!together) aggregate_run(ctx, o, R);
+            if (multi) aggregate_run_multi(multi, v, u, -o.dmax, -o.dmin, o, R);
+            else if (!together) aggregate_run(ctx, o, R);
             report_run(o, R);
             iterate_run(ctx, o, R, (int)TSGM_ITER, -o.dmax, -o.dmin);
             if (MEDIAN != 0) median_run(ctx, R, (int)MEDIAN);
@@ -348,7 +400,8 @@ int main(int argc, char **argv)
         }
         free_run(ctx, L);
         free_run(ctx, R);
-        mgm_ctx_destroy(ctx);
+        if (multi) mgm_multi_destroy(multi);
+        else mgm_ctx_destroy(ctx);
         imgio::write(f_out, outoff);
         if (f_cost) imgio::write(f_cost, outcost);
         if (f_back) imgio::write(f_back, syn);

@@ -106,6 +106,29 @@ def test_cli_matches_reference(case, tmp_path):
         assert ndiff(a, b) == 0, (name, f)
 
 
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference CLI (oracle/_ref/mgm) was not built")
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0"])
+def test_cli_on_several_devices_matches_reference(devices, tmp_path):
+    """MGM_DEVICES: both mgm() runs of the pair with their passes sharded over several "devices" (loopback ranks on the
+    one GPU of the box: mgm_multi_aggregate) -- stdout and outputs must still be the reference's."""
+    u, v, _ = synth.stereo_pair(112, 72, -16, 8, seed=42, nch=3)
+    np.save(tmp_path / "u.npy", np.ascontiguousarray(u.transpose(1, 2, 0)))
+    np.save(tmp_path / "v.npy", np.ascontiguousarray(v.transpose(1, 2, 0)))
+    args = "-P2 20000 -P1 2 -r -20 -R 12 -t census -s vfit -O 8 -aP2 4 -aThresh 12".split()
+    env = dict(MEDIAN="1", CENSUS_NCC_WIN="3", USE_TRUNCATED_LINEAR_POTENTIALS="1", TSGM="3")
+    outs = {}
+    for tag, exe, extra in (("ref", REF, {}), ("ours", OURS, dict(MGM_DEVICES=devices, MGM_MULTI_LOOPBACK="1"))):
+        d = tmp_path / tag
+        d.mkdir()
+        cmd = [exe] + args + [str(tmp_path / "u.npy"), str(tmp_path / "v.npy"), str(d / "disp.npy"), str(d / "cost.npy")]
+        r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="4", **env, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr)
+        outs[tag] = (r.stdout, {f: np.load(d / f) for f in sorted(os.listdir(d))})
+    assert outs["ref"][0] == outs["ours"][0], "stdout differs"
+    for f in outs["ref"][1]:
+        assert ndiff(outs["ref"][1][f], outs["ours"][1][f]) == 0, f
+
+
 def test_cli_refuses_what_is_not_built(tmp_path):
     u, v, _ = synth.stereo_pair(32, 16, -4, 4)
     np.save(tmp_path / "u.npy", u[0])

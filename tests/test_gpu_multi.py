@@ -1,0 +1,93 @@
+"""mgm_multi_*: several GPUs behind the C ABI (direction sharding of ONE volume, ordered row-slab exchange).  The box
+has one GPU, so the n-rank path runs in LOOPBACK mode (MGM_MULTI_LOOPBACK=1: the ranks are contexts on the same device and
+a slab travels by a device-to-device copy instead of an ncclSend/ncclRecv pair -- partition, buffers, ordering and the
+row-slab WTA are the code a real node runs); the RCCL transport itself is exercised with a communicator of one rank.
+Every result must equal the plain one-context aggregation bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ndiff
+from mgm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def loopback():
+    os.environ["MGM_MULTI_LOOPBACK"] = "1"
+    yield
+    os.environ.pop("MGM_MULTI_LOOPBACK", None)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 8])
+@pytest.mark.parametrize("mode", [(8, 3, 0, 8.0, 32.0), (8, 3, 1, 2.0, 20000.0), (4, 2, 0, 8.0, 32.0), (3, 4, 1, 2.0, 9.0)],
+                         ids=["O8-T3", "O8-T3-FH", "O4-T2", "O3-T4-FH"])
+def test_loopback_ranks_equal_one_context(ctx, loopback, n, mode):
+    import mgm_amd
+    NDIR, MGM, FH, P1, P2 = mode
+    nx, ny, dmin, dmax = 150, 61, -100, 27  # 128 labels; 61 rows over up to 8 ranks: uneven slabs
+    u, v, _ = synth.stereo_pair(nx, ny, -60, 10, seed=11)
+    du, dv = ctx.upload_image(u), ctx.upload_image(v)
+    cv = ctx.costvolume_dev(du, dv, dmin, dmax, "none", "census", float("inf"), 5)
+    _, o_ref, c_ref = ctx.aggregate(cv, P1, P2, NDIR, MGM, FH, 1, None, "vfit", want_S=False)
+    m = mgm_amd.Multi([0] * n)
+    try:
+        cvs = []
+        for k in range(n):  # every rank builds the volume itself, from the images
+            c = m.ctx[k]
+            cvs.append(c.costvolume_dev(c.upload_image(u), c.upload_image(v), dmin, dmax, "none", "census", float("inf"), 5))
+        for rep in range(2):  # (the second call reuses the workspaces and the hand-off slots)
+            o, oc = m.aggregate(cvs, P1, P2, NDIR, MGM, FH, 1, "vfit")
+            assert ndiff(o, o_ref) == 0 and ndiff(oc, c_ref) == 0, (n, mode, rep)
+    finally:
+        m.close()
+    for h in (cv, du, dv):
+        h.free()
+
+
+def test_loopback_weights_and_odd_labels(ctx, loopback):
+    """Per-edge weights (one weight image per rank) and a label count the second kernel build does not take."""
+    import mgm_amd
+    nx, ny, L, dmin = 90, 37, 100, -50
+    NDIR, MGM, FH, P1, P2 = 8, 3, 0, 8.0, 32.0
+    C = synth.raw_volume(nx, ny, L, seed=4, inf_frac=0.03)
+    rng = np.random.default_rng(3)
+    w = np.where(rng.random((8, ny, nx)) < 0.4, np.float32(0.25), np.float32(1.0)).astype(np.float32)
+    cv = ctx.upload_volume(C, dmin)
+    _, o_ref, c_ref = ctx.aggregate(cv, P1, P2, NDIR, MGM, FH, 1, w, None, want_S=False)
+    m = mgm_amd.Multi([0, 0, 0])
+    try:
+        cvs = [m.ctx[k].upload_volume(C, dmin) for k in range(3)]
+        ws = [m.ctx[k].upload_image(w) for k in range(3)]
+        o, oc = m.aggregate(cvs, P1, P2, NDIR, MGM, FH, 1, None, ws)
+        assert ndiff(oc, c_ref) == 0 and ndiff(o[np.isfinite(c_ref)], o_ref[np.isfinite(c_ref)]) == 0
+    finally:
+        m.close()
+    cv.free()
+
+
+def test_rccl_communicator_of_one_rank(ctx):
+    """librccl is found and initialised (ncclCommInitAll) and the whole path runs through it with n = 1."""
+    import mgm_amd
+    os.environ.pop("MGM_MULTI_LOOPBACK", None)
+    C = synth.raw_volume(70, 33, 64, seed=9)
+    cv0 = ctx.upload_volume(C, 0)
+    _, o_ref, c_ref = ctx.aggregate(cv0, 8.0, 32.0, 8, 3, 0, 1, None, "vfit", want_S=False)
+    m = mgm_amd.Multi([0])
+    try:
+        cv = m.ctx[0].upload_volume(C, 0)
+        o, oc = m.aggregate([cv], 8.0, 32.0, 8, 3, 0, 1, "vfit")
+        assert ndiff(o, o_ref) == 0 and ndiff(oc, c_ref) == 0
+    finally:
+        m.close()
+    cv0.free()
+
+
+def test_duplicate_devices_need_loopback_mode():
+    import mgm_amd
+    os.environ.pop("MGM_MULTI_LOOPBACK", None)
+    with pytest.raises(mgm_amd.MgmError) as e:
+        mgm_amd.Multi([0, 0])
+    assert e.value.code == mgm_amd.MGM_ERR_INVALID

@@ -33,3 +33,19 @@ def test_div3_sequence_matches_ieee_division(oracle):
 
 def test_usable_cpus():
     assert 1 <= usable_cpus() <= 64
+
+
+def test_multi_plan_partitions_passes_and_rows():
+    """mgm_multi_plan (C ABI, no device needed): contiguous blocks covering every pass and row exactly once, sizes
+    differing by at most one -- and the same partition as the Python launcher's (mgm_amd/dist.py)."""
+    import mgm_amd
+    from mgm_amd import dist as mdist
+    for n in (1, 2, 3, 4, 8):
+        for NDIR in (1, 3, 4, 8):
+            for ny in (5, 13, 1080, 4096):
+                plan = mgm_amd.multi_plan(n, NDIR, ny)
+                assert [p for f, c, _, _ in plan for p in range(f, f + c)] == list(range(NDIR))
+                assert [r for _, _, r0, nr in plan for r in range(r0, r0 + nr)] == list(range(ny))
+                assert max(c for _, c, _, _ in plan) - min(c for _, c, _, _ in plan) <= 1
+                assert [(f, c) for f, c, _, _ in plan] == [mdist.passes_of_rank(NDIR, n, k) for k in range(n)]
+                assert [(r0, nr) for _, _, r0, nr in plan] == mdist.row_slabs(ny, n)
