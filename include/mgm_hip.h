@@ -100,8 +100,8 @@ int mgm_costvolume_build_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, i
  * (-m/-M files) give a volume over the hull of all ranges in which a pixel only owns the disparities of its own
  * range -- the others read +INF, as Dvec::operator[] does (dvec.cc:129), and are exempt from the "no finite cost"
  * rule; mgm_aggregate* then searches the winner and gates the refinement inside each pixel's range.  One
- * combination returns MGM_ERR_UNSUPPORTED on a ragged volume: P2 = +INF.  The hull may span at most 512
- * labels; batched ragged volumes must share hull_min under FH potentials. */
+ * combination returns MGM_ERR_UNSUPPORTED on a ragged volume: P2 = +INF.  The hull may span at most 2048
+ * labels (up to 512 on the fast kernels); batched ragged volumes must share hull_min under FH potentials. */
 int mgm_costvolume_build(mgm_ctx *ctx, const float *u, const float *v, int nx, int ny, int nch, int vnx, int vny,
                          const float *dminI, const float *dmaxI, const char *prefilter, const char *distance,
                          float truncDist, int census_win, mgm_cv **C);

@@ -456,7 +456,7 @@ static int cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, bool alloc_
     if (!c || !out || nx <= 0 || ny <= 0 || dmax < dmin) return fail(c, MGM_ERR_INVALID, "mgm_cv_create: bad arguments");
     const long long L = (long long)dmax - dmin + 1;
     if (L > kMaxLPL * 64)
-        return fail(c, MGM_ERR_UNSUPPORTED, "more than 512 disparity labels per pixel are not supported");
+        return fail(c, MGM_ERR_UNSUPPORTED, "more than 2048 disparity labels per pixel are not supported");
     HIPCHK(c, hipSetDevice(c->device));
     mgm_cv *cv = new mgm_cv();
     cv->d = nullptr;
@@ -979,7 +979,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     const int ngroups = nb / subv;  // work items address groups of `subv` volumes
     const int Lk = L * subv;        // label slots of a wave
     const int R2 = first_build ? 0 : pass2_lines(Lk, use_c8);
-    const int R = R2 ? R2 : kR;
+    const int R = R2 ? R2 : (lpl > 8 ? 4 : kR);  // (more than 512 labels: the first build with bands of four lines)
     PassParams p{};
     int maxLL = 0, maxbands = 0;
     for (int q = 0; q < PEND; q++) {
@@ -1121,7 +1121,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     {
         TimeScope t(c, R2 ? "k_pass2" : "k_pass");
         if (R2) HIPCHK(c, launch_pass2(p, c->ntasks, fh, weighted ? 1 : 0, c->stream));
-        else HIPCHK(c, launch_pass(p, c->ntasks, kR, fh, weighted ? 1 : 0, c->stream));
+        else HIPCHK(c, launch_pass(p, c->ntasks, R, fh, weighted ? 1 : 0, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->h_words + 1, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     c->pending_check = true;

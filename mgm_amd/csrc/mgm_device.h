@@ -6,7 +6,7 @@
 namespace mgm {
 
 constexpr int kMaxDirs = 8;
-constexpr int kMaxLPL = 8;           // disparities per lane -> L <= 512
+constexpr int kMaxLPL = 32;          // disparities per lane -> L <= 2048 (the fast kernels stop at 8: 512 labels)
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kCensusMaxWords = 8;   // 32-bit census words per pixel
 

@@ -262,7 +262,8 @@ int pass_lpl(int L)
     const int lpl = (L + 63) / 64;
     if (lpl == 5) return 6;
     if (lpl == 7) return 8;
-    return lpl;
+    if (lpl <= 8) return lpl;
+    return lpl <= 12 ? 12 : (lpl <= 16 ? 16 : (lpl <= 24 ? 24 : 32));  // 513..2048 labels: bands of four lines
 }
 
 template <int LPL, bool FH, bool WEIGHTED, int R>
@@ -291,6 +292,14 @@ static hipError_t launch_lpl(const PassParams &p, int ntasks, bool fh, int wmode
 hipError_t launch_pass(const PassParams &p, int ntasks, int R, bool fh, int wmode, hipStream_t s)
 {
     const int lpl = pass_lpl(p.L);
+    if (R == 4)  // more than 512 labels (any label count up to 2048): the slabs of a line need most of a SIMD's registers
+        switch (lpl) {
+            case 12: return launch_lpl<12, 4>(p, ntasks, fh, wmode, s);
+            case 16: return launch_lpl<16, 4>(p, ntasks, fh, wmode, s);
+            case 24: return launch_lpl<24, 4>(p, ntasks, fh, wmode, s);
+            case 32: return launch_lpl<32, 4>(p, ntasks, fh, wmode, s);
+            default: return hipErrorInvalidValue;
+        }
     if (R != 16) return hipErrorInvalidValue;
     switch (lpl) {
         case 1: return launch_lpl<1, 16>(p, ntasks, fh, wmode, s);

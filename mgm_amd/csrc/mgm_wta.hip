@@ -238,6 +238,11 @@ hipError_t launch_wta(const WtaParams &p, hipStream_t s)
         WTA_CASE(6, 1)
         WTA_CASE(8, 1)
 #undef WTA_CASE
+        // 513..2048 labels: one pixel per wave and iteration, guarded loads
+        case 12: hipLaunchKernelGGL((k_wta<12, 1, false>), grid, block, 0, s, p); break;
+        case 16: hipLaunchKernelGGL((k_wta<16, 1, false>), grid, block, 0, s, p); break;
+        case 24: hipLaunchKernelGGL((k_wta<24, 1, false>), grid, block, 0, s, p); break;
+        case 32: hipLaunchKernelGGL((k_wta<32, 1, false>), grid, block, 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

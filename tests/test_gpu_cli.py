@@ -66,6 +66,7 @@ CASES = [
      dict(TSGM="3", WITH_MGM2="1", OMP_NUM_THREADS="1", CENSUS_NCC_WIN="5", USE_TRUNCATED_LINEAR_POTENTIALS="1")),
     ("WITH_MGM2=1, 3 channels, weights, TSGM=4, ad", 3, "-r -20 -R 12 -t ad -O 8 -aP2 4 -aThresh 12",
      dict(TSGM="4", WITH_MGM2="1", OMP_NUM_THREADS="1")),
+    ("601 labels (the reference's Dvec has no label limit), ad, 3 channels", 3, "-r -300 -R 300 -t ad -O 4 -s vfit", dict(TSGM="2")),
     ("parabolaOCV, census, median radius 3, tight tau", 1, "-r -16 -R 8 -t census -s parabolaOCV -O 8",
      dict(TSGM="3", MEDIAN="3", TESTLRRL_TAU="0.5", CENSUS_NCC_WIN="5")),
 ]

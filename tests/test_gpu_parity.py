@@ -233,3 +233,37 @@ def test_uploaded_volume_with_nan_costs_is_refused(ctx):
         cv = ctx.upload_volume(C, 0)
         ctx.aggregate(cv, 8.0, 32.0, 4, 2, 0, 1, None, None, want_S=False)  # clean: accepted
         cv.free()
+
+
+@pytest.mark.parametrize("L", [513, 600, 768, 1000, 1024, 1300, 1536, 2048])
+@pytest.mark.parametrize("mode", [(8, 3, 0, 8.0, 32.0, False), (8, 3, 1, 2.0, 20000.0, False), (4, 2, 1, 2.0, 9.0, False),
+                                  (8, 4, 0, 8.0, 32.0, True), (5, 1, 1, 1.5, 40.0, True)],
+                         ids=["O8-T3", "O8-T3-FH", "O4-T2-FH", "O8-T4-w", "O5-T1-FH-w"])
+def test_more_than_512_labels(ctx, oracle, L, mode):
+    """The reference's Dvec has no label limit (dvec.cc:55-64); 513..2048 labels take the first pass-kernel build with
+    bands of four lines (12 / 16 / 24 / 32 labels per lane) and the generic WTA instance."""
+    NDIR, MGM, FH, P1, P2, weighted = mode
+    nx, ny, dmin = 23, 19, -L // 3
+    C = synth.raw_volume(nx, ny, L, seed=L, inf_frac=0.04)
+    if L % 2:
+        C = (C * np.float32(1.0 / 3.0)).astype(np.float32)
+    w8 = None
+    if weighted:
+        rng = np.random.default_rng(L)
+        w8 = np.where(rng.random((8, ny, nx)) < 0.4, np.float32(0.3), np.float32(1.0)).astype(np.float32)
+    So, oo, co = oracle.mgm(C, dmin, P1, P2, NDIR, MGM, FH, 1, w8)
+    ro, rc = oracle.refine(So, dmin, "vfit", np.where(np.isfinite(co), oo, dmin).astype(np.float32), co)
+    cv = ctx.upload_volume(C, dmin)
+    S, o, c = ctx.aggregate(cv, P1, P2, NDIR, MGM, FH, 1, w8, "vfit", want_S=True)
+    assert ndiff(S.download(), So) == 0
+    assert ndiff(c, rc) == 0
+    fin = np.isfinite(co)
+    assert ndiff(o[fin], ro[fin]) == 0
+    S.free(), cv.free()
+
+
+def test_more_than_2048_labels_is_refused(ctx):
+    import mgm_amd
+    with pytest.raises(mgm_amd.MgmError) as e:
+        ctx.upload_volume(np.zeros((2, 2, 2049), np.float32), 0)
+    assert e.value.code == mgm_amd.MGM_ERR_UNSUPPORTED
