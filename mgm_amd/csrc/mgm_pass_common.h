@@ -116,6 +116,23 @@ __device__ __forceinline__ void neighbour_min(const float (&Lv)[LPL], float (&N)
 // exact sum: a min-plus scan in f64, which holds these sums exactly.  If the premise does not hold
 // the result is merely another guess; the caller's fixed-point sweeps remain the ground truth.
 // GROUPS: label ranges per wave (several volumes per wave): lane groups of 64/GROUPS lanes scan independently.
+// (The min-plus scan of the f64 sums runs on DPP moves -- two 32-bit moves per value -- with the same row / row-broadcast
+// structure as the fp32 guess in fh_scan: the first version used LDS-crossbar shuffles, ~2000 cycles per repair, and a
+// repair anywhere in a band stalls all its lock-stepped lines.  0.5-1 % of the slabs of real census data take this path.)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov_f64(double v, double fill)  // lanes without a source lane (or outside ROWMASK) get `fill`
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v), f = __builtin_bit_cast(unsigned long long, fill);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)f, (int)(unsigned)b, CTRL, ROWMASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(f >> 32), (int)(unsigned)(b >> 32), CTRL, ROWMASK, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 template <int LPL, bool FWD, int GROUPS = 1>
 __device__ __forceinline__ float fh_repair(float a, float P1, int lane_in)
 {
@@ -125,17 +142,38 @@ __device__ __forceinline__ float fh_repair(float a, float P1, int lane_in)
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     asm volatile("" : "+v"(P1));
-    auto from_prev = [&](double v, int d) { return FWD ? __shfl_up(v, d) : __shfl_down(v, d); };
-    auto has_prev = [&](int d) { return FWD ? (lane % GL) >= d : (lane % GL) + d < GL; };
     const double P1d = (double)P1, Rd = (double)LPL * (double)P1;
     const double inf = (double)f_inf();
+    const int li = lane & 15, row = lane >> 4, lg = lane % GL;
+    auto dmin = [](double x, double y) { return y < x ? y : x; };
     const double b = (double)(a + P1);  // first step of every chain that starts at this lane's carry-out
-    const double pb = from_prev(b, 1);           // (a shuffle must not sit under a divergent condition)
-    double s = has_prev(1) ? pb + Rd : inf;      // = origin' + LPL*P1; the surplus P1 comes off below
-#pragma unroll
-    for (int d = 1; d < GL; d <<= 1) {
-        const double t = from_prev(s, d) + (double)d * Rd;
-        if (has_prev(d)) s = t < s ? t : s;
+    // s = origin' + LPL*P1 from the neighbour lane (the surplus P1 comes off below); nothing enters a label range from outside
+    double s = FWD ? dpp_mov_f64<0x138, 0xf>(b, inf) : dpp_mov_f64<0x130, 0xf>(b, inf);  // wave_shr:1 / wave_shl:1
+    s = (FWD ? lg == 0 : lg == GL - 1) ? inf : s + Rd;
+    if constexpr (FWD) {
+        s = dmin(s, dpp_mov_f64<0x111, 0xf>(s, inf) + Rd);         // row_shr:1
+        s = dmin(s, dpp_mov_f64<0x112, 0xf>(s, inf) + 2.0 * Rd);   // row_shr:2
+        s = dmin(s, dpp_mov_f64<0x114, 0xf>(s, inf) + 4.0 * Rd);   // row_shr:4
+        s = dmin(s, dpp_mov_f64<0x118, 0xf>(s, inf) + 8.0 * Rd);   // row_shr:8
+        if constexpr (GROUPS <= 2)  // rows 1 and 3 take in the row before them (lane 15 of it) ...
+            s = dmin(s, dpp_mov_f64<0x142, 0xa>(s, inf) + (double)(li + 1) * Rd);
+        if constexpr (GROUPS == 1)  // ... rows 2 and 3 everything up to lane 31
+            s = dmin(s, dpp_mov_f64<0x143, 0xc>(s, inf) + (double)(li + 1 + (row == 3 ? 16 : 0)) * Rd);
+    } else {
+        s = dmin(s, dpp_mov_f64<0x101, 0xf>(s, inf) + Rd);         // row_shl:1
+        s = dmin(s, dpp_mov_f64<0x102, 0xf>(s, inf) + 2.0 * Rd);
+        s = dmin(s, dpp_mov_f64<0x104, 0xf>(s, inf) + 4.0 * Rd);
+        s = dmin(s, dpp_mov_f64<0x108, 0xf>(s, inf) + 8.0 * Rd);
+        if constexpr (GROUPS == 1) {  // the totals of the rows after this one sit at their first lanes
+            const double t3 = readlane_f64(s, 48);
+            const double t2 = dmin(readlane_f64(s, 32), t3 + 16.0 * Rd);
+            const double t1 = dmin(readlane_f64(s, 16), t2 + 16.0 * Rd);
+            const double tp = row == 0 ? t1 : (row == 1 ? t2 : t3);
+            s = dmin(s, row <= 2 ? tp + (double)(16 - li) * Rd : inf);
+        } else if constexpr (GROUPS == 2) {
+            const double t1 = readlane_f64(s, 16), t3 = readlane_f64(s, 48);
+            s = dmin(s, (row & 1) ? inf : (row == 0 ? t1 : t3) + (double)(16 - li) * Rd);
+        }
     }
     s -= P1d;
     if (P1 > 0.0f) {
