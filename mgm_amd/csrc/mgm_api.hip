@@ -1027,15 +1027,19 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     {
         // Two bands per CU pay when the launch is bound by throughput, not by the longest chain of bands: compare the
         // band-steps one CU has to run with the critical path of the slowest pass (steps of slope*lines + line length
-        // + ~10 per band hand-off).  Measured break-even at a ratio of ~1.8: cfg3 needs 3 volumes per launch, one
-        // 4096x4096 volume is enough.
+        // + the hand-off lag per band: ~3 steps with self-validating slabs, ~10 with progress words).  Measured on
+        // 1920x1080 (round 2, after the hand-off rewrite): the FH kernels -- long dependent instruction chains per step --
+        // gain from the second band from a ratio of ~1.8 on (three cfg3 volumes per launch; 12 volumes: 64 -> 51 ms); the
+        // Hirschmueller kernels only at large batches of 256 labels (+3 % at 12 volumes), and lose 3-10 % at 128 labels
+        // or small batches: their steps are short enough for one band to keep the CU's issue slots busy.
         double work = 0, chain = 0;
+        const double lag = tags ? 3.0 : 10.0;
         for (int q = first; q < PEND; q++) {
             const PassGeom &g = p.g[q];
             work += (double)ngroups * g.nbands * (g.LL + g.slope * R);
-            chain = std::max(chain, (double)g.slope * g.NL + g.LL + 10.0 * g.nbands);
+            chain = std::max(chain, (double)g.slope * g.NL + g.LL + lag * g.nbands);
         }
-        p.wg_per_cu = (work / (double)c->num_cu > 1.8 * chain) ? 2 : 1;
+        p.wg_per_cu = (work / (double)c->num_cu > (fh ? 1.8 : 8.0) * chain) ? 2 : 1;
     }
     if (dev().wg_per_cu) p.wg_per_cu = dev().wg_per_cu;
     // A single volume per launch (chain-bound, one band per CU) walks the lines of the passes without an in-line

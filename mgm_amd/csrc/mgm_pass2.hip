@@ -5,18 +5,27 @@
 //   * a workgroup = NC compute waves (one scan line each, lock-step on the
 //     slope-2 diagonal) + NL loader waves;
 //   * the loader waves stream every operand that comes from memory -- the C
-//     slab of each line D steps ahead, and the previous band's hand-off slabs,
-//     minima and progress word -- into LDS rings with LDS-DMA
-//     (global_load_lds_dwordx4, no VGPR round trip) and retire them with a
-//     COUNTED s_waitcnt vmcnt(n*(D-1)) followed by the step barrier, so D-1
-//     steps of loads stay in flight across every barrier;
+//     slab of each line D steps ahead, and the previous band's hand-off slabs
+//     -- into LDS rings with LDS-DMA (global_load_lds_dwordx4, no VGPR round
+//     trip) and retire them with a COUNTED s_waitcnt vmcnt(n*(D-1)) followed
+//     by the step barrier, so D-1 steps of loads stay in flight across every
+//     barrier;
 //   * compute waves only read LDS and issue stores (their Lr slab, and for the
 //     last line of the band the sc1 hand-off), so the compiler has no load to
 //     wait for: the first build lost ~1.5 us per step to vmcnt(0) drains the
-//     compiler placed on in-flight prefetch registers.
+//     compiler placed on in-flight prefetch registers;
+//   * between bands the unweighted kernels hand over SELF-VALIDATING slabs (the
+//     launch's tag in the sign bit of every word, one slot per band: see TAGS in
+//     k_pass2) -- no progress words, no publication lag; the weighted kernels
+//     keep the first build's progress-word protocol;
+//   * single-volume launches walk the lines of passes 4-7 (2 or 3 neighbours: no
+//     in-line dependency) as TWO strips from the image edges inwards (see
+//     `strips` in k_pass2).
 //
 // Used when every slab is a whole number of 16-byte DMA pieces (L == 64*LPL,
-// LPL in {1,2,3,4,6,8}); other label counts take the first build.
+// LPL in {1,2,3,4,6,8}); other label counts run padded to the next such count,
+// or -- direction-sharded odd label counts, more than 512 labels, negative
+// penalties -- take the first build.
 #include <type_traits>
 
 #include "mgm_pass_common.h"

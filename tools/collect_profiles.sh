@@ -1,43 +1,49 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh'): the round's measurement evidence.
-#   1. bench lines of the three workloads (default flags for the headline one: includes the CPU baseline)
-#   2. rocprofv3 --kernel-trace --stats of the default bench command        -> kernel_stats.csv
-#   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, counters only) -> hbm_counters.md, traffic.json
-# Everything lands in gpurun_out/profiles/; copy what is to be judged into profiles/ afterwards.
+#   1. bench lines: the default command (cfg3, 12 pairs per step; parity gate + CPU baseline), then the workload / batch matrix
+#   2. per (workload, batch) in $PROFILED: rocprofv3 --kernel-trace --stats of the bench command  -> <tag>_kernel_stats.csv
+#      and rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, counters only)          -> <tag>_hbm_counters.md, <tag>_traffic.json
+# Everything lands in gpurun_out/profiles/; copy what is to be judged into profiles/ afterwards (prefixed with the round).
 set -u
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-W=${1:-cfg3}
-B=${2:-12}
+PROFILED=${PROFILED:-"cfg3:12 cfg2:16 cfg3:1 cfg4:1 cfg5:16"}
+MATRIX=${MATRIX:-"cfg3h:12 cfg2:16 cfg5:16 cfg4:1 cfg3:8 cfg3:4 cfg3:2 cfg3:1 cfg3h:1 cfg2:1"}
 : > "$OUT/bench_lines.jsonl"
 timeout 900 python bench.py 2> "$OUT/bench_default.stderr" | tail -1 >> "$OUT/bench_lines.jsonl"
-for w in cfg3h cfg2; do timeout 300 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT/bench_lines.jsonl"; done
-for b in 8 4 1; do timeout 300 python bench.py --workload cfg3 --batch $b --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT/bench_lines.jsonl"; done
-
-cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python "$ROOT/bench.py" --workload $W --batch $B --steps 10 --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2> "$OUT/kt.stderr"
-timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- python "$ROOT/bench.py" --workload $W --batch $B --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/fetch.stderr"
-timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- python "$ROOT/bench.py" --workload $W --batch $B --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/write.stderr"
-cd "$ROOT"
-KS=$(find "$OUT/kt" -name "*kernel_stats.csv" | head -1)
-FC=$(find "$OUT/fetch" -name "*counter_collection.csv" | head -1)
-WC=$(find "$OUT/write" -name "*counter_collection.csv" | head -1)
-[ -n "$KS" ] && cp "$KS" "$OUT/kernel_stats.csv"
-tail -1 "$OUT/bench_under_rocprof.log" > "$OUT/bench_under_rocprof.json"
-if [ -n "$FC" ] && [ -n "$WC" ]; then
-  python tools/summarize_pmc.py "$FC" "$WC" $W $B "$OUT/hbm_counters.md" "$OUT/traffic.json" > /dev/null
-fi
-rm -rf "$OUT/kt" "$OUT/fetch" "$OUT/write"
+for wb in $MATRIX; do
+  w=${wb%%:*}; b=${wb##*:}
+  timeout 600 python bench.py --workload $w --batch $b --repeats 0 --no-cpu-baseline --no-parity 2>/dev/null | tail -1 >> "$OUT/bench_lines.jsonl"
+done
+for wb in $PROFILED; do
+  w=${wb%%:*}; b=${wb##*:}; tag=${w}_b${b}
+  cd /tmp
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python "$ROOT/bench.py" --workload $w --batch $b --steps 10 --repeats 0 --no-cpu-baseline --no-parity > "$OUT/${tag}_bench_under_rocprof.log" 2> "$OUT/kt.stderr"
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- python "$ROOT/bench.py" --workload $w --batch $b --steps 2 --warmup 1 --repeats 0 --no-cpu-baseline --no-parity > /dev/null 2> "$OUT/fetch.stderr"
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- python "$ROOT/bench.py" --workload $w --batch $b --steps 2 --warmup 1 --repeats 0 --no-cpu-baseline --no-parity > /dev/null 2> "$OUT/write.stderr"
+  cd "$ROOT"
+  KS=$(find "$OUT/kt" -name "*kernel_stats.csv" | head -1)
+  FC=$(find "$OUT/fetch" -name "*counter_collection.csv" | head -1)
+  WC=$(find "$OUT/write" -name "*counter_collection.csv" | head -1)
+  [ -n "$KS" ] && cp "$KS" "$OUT/${tag}_kernel_stats.csv"
+  tail -1 "$OUT/${tag}_bench_under_rocprof.log" > "$OUT/${tag}_bench_under_rocprof.json"; rm -f "$OUT/${tag}_bench_under_rocprof.log"
+  if [ -n "$FC" ] && [ -n "$WC" ]; then
+    python tools/summarize_pmc.py "$FC" "$WC" $w $b "$OUT/${tag}_hbm_counters.md" "$OUT/${tag}_traffic.json" > /dev/null
+  fi
+  rm -rf "$OUT/kt" "$OUT/fetch" "$OUT/write"
+done
 ls -la "$OUT"
-cat "$OUT/kernel_stats.csv" 2>/dev/null | head -12
-cat "$OUT/hbm_counters.md" 2>/dev/null
+for f in "$OUT"/*_kernel_stats.csv; do echo "== $f"; head -8 "$f" | cut -c1-200; done
+cat "$OUT"/*_hbm_counters.md 2>/dev/null | grep -E "^#|Aggregation|k_pass|k_wta"
 python - <<'PY'
 import json
 for l in open("gpurun_out/profiles/bench_lines.jsonl"):
     try: d = json.loads(l)
     except Exception: print("bad line", l[:100]); continue
+    a = d["roofline"]["avg_launch_ms"]
     print(d["config"]["workload"][:6], "B", d["config"].get("pairs_per_step"), "value", round(d["value"], 2), "ms/step", round(d["ms_per_step"], 2),
-          "frac", round(d["roofline"]["frac"], 3), "cpu", d.get("cpu_baseline", {}).get("value"))
+          "K3", round(a.get("k_pass2", a.get("k_pass", 0)), 2), "wta", round(a["k_wta"], 2), "frac", round(d["roofline"]["frac"], 3),
+          "parity", (d.get("parity") or {}).get("status"), "cpu", d.get("cpu_baseline", {}).get("value"))
 PY

@@ -1,10 +1,14 @@
-"""Turn the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of bench.py into profiles/r01_hbm_counters.md
-and profiles/r01_traffic.json.  FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B,
+"""Turn the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of bench.py into profiles/<tag>_hbm_counters.md
+and profiles/<tag>_traffic.json (which records the hash of the kernel sources it was measured on: bench.py
+reports the figure as roofline.traffic only while the kernels are still those).  FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B,
 MI355X_MICROARCH.md section HBM); WRITE_SIZE is used as reported (it reproduces k_cost's W*H*L*4 exactly)."""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 def per_kernel(path, counter):
@@ -36,7 +40,8 @@ with open(out_md, "w") as f:
         f.write("| `%s` | %d | %.4g | %.3f | %.4g | %.3f |\n" % r)
     f.write("\nAggregation of one batch of %d volumes (one pass-kernel launch + %d k_wta launches): %.2f GB of HBM traffic, %.2f GB per volume\n"
             % (B, B, total / 1e9, total / 1e9 / B))
-json.dump({"workload": workload, "pairs_per_step": B, "aggregation_hbm_bytes_per_step": total,
+from bench import kernel_source_hash
+json.dump({"workload": workload, "pairs_per_step": B, "kernel_source_sha": kernel_source_hash(), "aggregation_hbm_bytes_per_step": total,
            "aggregation_hbm_bytes_per_volume": total / B,
            "per_kernel": {r[0]: {"read_bytes": r[3] * 1e9, "write_bytes": r[5] * 1e9} for r in rows}},
           open(out_json, "w"), indent=1)
