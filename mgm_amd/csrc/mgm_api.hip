@@ -999,6 +999,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // alternates between consecutive launches over the same slots; any other use of the region, or a different
     // geometry, clears it first (all-ones words) and starts again with tag 0.
     const bool tags = R2 && !weighted && !(fh && MGM == 2);
+    std::string tag_key;
     if (tags) {
         long long per_vol = 0;
         for (int q = first; q < PEND; q++) {
@@ -1018,6 +1019,11 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         }
         c->hand_tag ^= 0x80000000u;
         p.hand_tag = c->hand_tag;
+        // The tag is only good for a launch that really rewrites every slot: until the pass kernel has been enqueued the
+        // region counts as unknown (the next call clears it), so an error return between here and the launch cannot
+        // leave slots behind that carry the tag of the launch after next.
+        tag_key = c->hand_key;
+        c->hand_key.clear();
     } else {
         c->hand_key.clear();
         if ((r = reserve(c, c->hand, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * LPk))) return r;
@@ -1127,6 +1133,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         if (R2) HIPCHK(c, launch_pass2(p, c->ntasks, fh, weighted ? 1 : 0, c->stream));
         else HIPCHK(c, launch_pass(p, c->ntasks, R, fh, weighted ? 1 : 0, c->stream));
     }
+    if (tags) c->hand_key = tag_key;  // enqueued: every slot of the region will carry this launch's tag
     HIPCHK(c, hipMemcpyAsync(c->h_words + 1, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     c->pending_check = true;
     if (p.dbg) {  // development aid: where does K3's time go?
