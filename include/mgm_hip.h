@@ -58,6 +58,9 @@ int mgm_ctx_create(int device, mgm_ctx **ctx);
 int mgm_ctx_destroy(mgm_ctx *ctx);
 const char *mgm_last_error(const mgm_ctx *ctx);
 int mgm_ctx_synchronize(mgm_ctx *ctx);
+/* Hand the context's grow-only workspace (Lr volumes of the largest aggregation so far, hand-off slots, ...) back to the
+ * device; it is allocated again on demand.  Synchronises. */
+int mgm_ctx_trim(mgm_ctx *ctx);
 void *mgm_ctx_stream(mgm_ctx *ctx); /* the hipStream_t everything is enqueued on */
 const char *mgm_version(void);
 

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("MGM_HIP_LIB") or os.path.join(_HERE, "lib", "libmgm_h
 
 # every symbol include/mgm_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "mgm_ctx_create", "mgm_ctx_destroy", "mgm_last_error", "mgm_ctx_synchronize", "mgm_ctx_stream", "mgm_version",
+    "mgm_ctx_create", "mgm_ctx_destroy", "mgm_last_error", "mgm_ctx_synchronize", "mgm_ctx_stream", "mgm_version", "mgm_ctx_trim",
     "mgm_timing_enable", "mgm_timing_reset", "mgm_timing_count", "mgm_timing_get",
     "mgm_img_create", "mgm_img_upload", "mgm_img_download", "mgm_img_dims", "mgm_img_device_ptr", "mgm_img_free",
     "mgm_cv_create", "mgm_cv_upload", "mgm_cv_download", "mgm_cv_dims", "mgm_cv_device_ptr", "mgm_cv_free",
@@ -60,6 +60,7 @@ def load_library():
     L.mgm_ctx_create.argtypes = [i, pp]
     L.mgm_ctx_destroy.argtypes = [vp]
     L.mgm_ctx_synchronize.argtypes = [vp]
+    L.mgm_ctx_trim.argtypes = [vp]
     L.mgm_ctx_stream.argtypes = [vp]
     L.mgm_ctx_stream.restype = vp
     L.mgm_timing_enable.argtypes = [vp, i]
@@ -201,6 +202,10 @@ class Context:
 
     def synchronize(self):
         self._chk(self.lib.mgm_ctx_synchronize(self.h))
+
+    def trim(self):
+        """Release the grow-only workspace (mgm_ctx_trim)."""
+        self._chk(self.lib.mgm_ctx_trim(self.h))
 
     # ---- containers ----
     def upload_image(self, a):

@@ -338,6 +338,32 @@ int mgm_ctx_destroy(mgm_ctx *c)
     return MGM_OK;
 }
 
+// The workspace (Lr volumes, hand-off slots, census images, ...) only ever grows with the largest call seen; this hands
+// it back to the device.  The next call allocates what it needs again; mgm_wta_windowed_dev / mgm_debug_download_lr /
+// mgm_lr_device_ptr have nothing to work on until the next aggregation.
+int mgm_ctx_trim(mgm_ctx *c)
+{
+    if (!c) return MGM_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int r = mgm_ctx_synchronize(c)) return r;
+    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->handm, &c->tasks, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
+    for (int v = 0; v < kMaxBatch; v++) {
+        bufs.push_back(&c->padf[v]);
+        bufs.push_back(&c->pad8[v]);
+    }
+    for (Buf *b : bufs) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    c->hand_key.clear();
+    c->tk_nx = c->tk_ny = c->tk_ndir = c->tk_r = -1;
+    c->ntasks = 0;
+    c->last_ndir = c->last_batch = 0;
+    for (int v = 0; v < kMaxBatch; v++) c->last_cvs[v] = nullptr;
+    return MGM_OK;
+}
+
 const char *mgm_last_error(const mgm_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 void *mgm_ctx_stream(mgm_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -1117,6 +1143,13 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.maxbands = kMaxBands;
     p.P1 = P1;
     p.P2 = P2;
+    // FH potentials, unweighted, compact costs: min(minconv(L)[o], m + P2) is minconv(L)[o] itself whenever P2 exceeds the
+    // longest ramp of a slab by a wide margin -- every label is reached from the slab's minimum in at most L-1 steps of
+    // P1, the costs are integers <= 254, so every value of a slab stays below 254 + (L-1)*P1 and the rounding of a ramp
+    // of L-1 additions at that magnitude is far below one step.  The kernels skip the cap for P2 = INF (wave-uniform),
+    // so it is passed as INF then: same bits, five instructions of the FH step fewer (the reference's own example,
+    // P1 = 2, P2 = 20000, is such a case).
+    if (fh && tags && use_c8 && P1 >= 0.0f && P2 >= 4.0f * (float)Lk * P1 + 4096.0f) p.P2 = __builtin_huge_valf();
     p.dbg = nullptr;
     p.xflags = 0;
     p.xflags = dev().xflags;

@@ -11,6 +11,7 @@ import os
 
 import numpy as np
 import pytest
+import torch  # (before libmgm_hip.so is loaded: torch brings its own HIP runtime and must initialise first)
 
 from helpers import ndiff
 from mgm_amd import synth
@@ -37,9 +38,11 @@ def host_mem_available_gb():
 
 
 @pytest.fixture
-def bigctx():
-    """A context of its own per test: its grow-only workspace (up to 204 GB here) is released when the test ends."""
+def bigctx(ctx):
+    """A context of its own per test: its grow-only workspace (up to 204 GB here) is released when the test ends -- and
+    the session's shared context gives back what earlier tests made it grow to (mgm_ctx_trim)."""
     import mgm_amd
+    ctx.trim()
     c = mgm_amd.Context(0)
     yield c
     c.close()
@@ -116,19 +119,19 @@ def test_cfg3_twelve_volumes_per_launch_first_and_last(bigctx, oracle):
         h.free()
 
 
-def test_cfg4_plain_and_eight_way_sharded(oracle):
+def test_cfg4_plain_and_eight_way_sharded(ctx, oracle):
     """BASELINE cfg4: 4096x4096, 192 labels (three labels per lane: idle lanes in every compact DMA piece), -O 8, TSGM 3.
     (a) eight emulated ranks: rank r runs pass r alone (mgm_aggregate_passes_dev), its Lr volume is cut into the eight
     row slabs the ranks would exchange, every rank finishes its rows with mgm_wta_rows_dev; (b) the plain one-GPU call.
     Both against the oracle if the host has the memory for it (3 volumes of 12.9 GB), else against each other plus the
     row-crop property of pass 0."""
-    import torch
     import mgm_amd
     from mgm_amd import dist as mdist
     nx = ny = 4096
     dmin, dmax, L = -96, 95, 192
     NDIR, MGM, FH, P1, P2 = 8, 3, 0, 8.0, 32.0
     world = 8
+    ctx.trim()
     c = mgm_amd.Context(0)  # its own context: the workspace (103 GB for the plain call) goes away with it
     try:
         u, v, _ = synth.stereo_pair(nx, ny, dmin * 3 // 4, dmax * 3 // 4, seed=4096)

@@ -88,3 +88,20 @@ def test_windowed_needs_the_last_aggregation(ctx):
         ctx.wta_windowed_dev(b, 8, 1, None, lo, hi)
     assert e.value.code == mgm_amd.MGM_ERR_INVALID
     a.free(), b.free()
+
+
+def test_trim_releases_the_workspace_and_the_next_call_regrows_it(ctx):
+    """mgm_ctx_trim: results after it are the same; the windowed WTA has nothing to work on until the next aggregation."""
+    import mgm_amd
+    C = synth.raw_volume(60, 40, 64, seed=77)
+    cv = ctx.upload_volume(C, -10)
+    _, o1, c1 = ctx.aggregate(cv, 8.0, 32.0, 8, 3, 0, 1, None, "vfit", want_S=False)
+    ctx.trim()
+    lo, hi = ctx.upload_image(np.full((40, 60), -10, np.float32)), ctx.upload_image(np.full((40, 60), 53, np.float32))
+    with pytest.raises(mgm_amd.MgmError) as e:
+        ctx.wta_windowed_dev(cv, 8, 1, "vfit", lo, hi)
+    assert e.value.code == mgm_amd.MGM_ERR_INVALID
+    _, o2, c2 = ctx.aggregate(cv, 8.0, 32.0, 8, 3, 0, 1, None, "vfit", want_S=False)
+    assert ndiff(o1, o2) == 0 and ndiff(c1, c2) == 0
+    for h in (cv, lo, hi):
+        h.free()
