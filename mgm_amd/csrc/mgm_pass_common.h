@@ -190,6 +190,76 @@ __device__ __forceinline__ float fh_repair(float a, float P1, int lane_in)
     return fminf(a, (float)s);
 }
 
+// Second guess after a rejected one, still in fp32 (cold path, ~25 instructions): what makes the first guess fail is
+// ONE addition that crosses three or more binades -- in practice a hop that starts from the near-zero value at the
+// winning label -- because a single rounding of x + n*P1 then differs from the reference's rounding at every binade on
+// the way (crossing one or two binades in one addition gives the same bits: the two roundings cannot disagree).  So:
+// every lane first advances its carry-out by one whole lane with LPL exact unit steps (the value is then >= LPL*P1 = R),
+// and the min-plus scan over those cuts every hop into pieces that cross at most two binades from there: 4R at a time
+// from a value >= R, then 12R from >= 5R, then 16R.  Exact under fh_repair's premise (additions inside a binade exact);
+// emulated on the CPU against the sequential recurrence on 3*10^6 slabs of census data for P1 in {0.75, 2, 2.5, 3, 8}:
+// no miss (tools/fh_emul.py).  The caller verifies it like any guess; fh_repair remains behind it.
+template <int LPL, bool FWD, int GROUPS = 1>
+__device__ __forceinline__ float fh_careful(float a, float P1, int lane_in)
+{
+    constexpr int GL = 64 / GROUPS;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));  // (cold path: keep its per-lane constants out of the caller's hot loop)
+    asm volatile("" : "+v"(P1));
+    const float R = (float)LPL * P1, inf = f_inf();
+    const int li = lane & 15, row = lane >> 4, lg = lane % GL;
+    float b = a;
+#pragma unroll
+    for (int q = 0; q < LPL; q++) b = b + P1;  // the chain out of this lane, through the whole next lane
+    float s = FWD ? dpp_shr1(b, inf) : dpp_shl1(b, inf);
+    s = (FWD ? lg == 0 : lg == GL - 1) ? inf : s;
+    auto cut2 = [&](float off, float &p1, float &p2) {  // off = p1 + p2, p1 <= 4R
+        p1 = fminf(off, 4.0f * R);
+        p2 = off - p1;
+    };
+    if constexpr (FWD) {
+        s = dpp_min_row_shr1(s, s + R);
+        s = dpp_min_row_shr2(s, s + 2.0f * R);
+        s = dpp_min_row_shr4(s, s + 4.0f * R);
+        s = dpp_min_row_shr8(s, (s + 4.0f * R) + 4.0f * R);
+        if constexpr (GROUPS <= 2) {  // rows 1 and 3 take in lane 15 of the row before them, (li+1) lanes away
+            float p1, p2;
+            cut2((float)(li + 1) * R, p1, p2);
+            const bool on = GROUPS == 1 ? row >= 1 : (row & 1);
+            float t = dpp_add_bcast15(s, on ? p1 : inf);
+            t = t + (on ? p2 : 0.0f);
+            s = fminf(s, t);
+        }
+        if constexpr (GROUPS == 1) {  // rows 2 and 3 take in lane 31
+            const float off = (float)(li + 1 + (row == 3 ? 16 : 0)) * R;
+            const float p1 = fminf(off, 4.0f * R), p2 = fminf(off - p1, 12.0f * R), p3 = (off - p1) - p2;
+            const bool on = row >= 2;
+            float t = dpp_add_bcast31(s, on ? p1 : inf);
+            t = (t + (on ? p2 : 0.0f)) + (on ? p3 : 0.0f);
+            s = fminf(s, t);
+        }
+    } else {
+        s = dpp_min_row_shl1(s, s + R);
+        s = dpp_min_row_shl2(s, s + 2.0f * R);
+        s = dpp_min_row_shl4(s, s + 4.0f * R);
+        s = dpp_min_row_shl8(s, (s + 4.0f * R) + 4.0f * R);
+        auto add16 = [&](float x) { return (x + 4.0f * R) + 12.0f * R; };  // sixteen lanes further
+        float p1, p2;
+        cut2((float)(16 - li) * R, p1, p2);
+        if constexpr (GROUPS == 1) {
+            const float t3 = readlane_f(s, 48);
+            const float t2 = fminf(readlane_f(s, 32), add16(t3));
+            const float t1 = fminf(readlane_f(s, 16), add16(t2));
+            const float tp = row == 0 ? t1 : (row == 1 ? t2 : t3);
+            s = fminf(s, row <= 2 ? (tp + p1) + p2 : inf);
+        } else if constexpr (GROUPS == 2) {
+            const float t1 = readlane_f(s, 16), t3 = readlane_f(s, 48);
+            s = fminf(s, (row & 1) ? inf : ((row == 0 ? t1 : t3) + p1) + p2);
+        }
+    }
+    return fminf(a, s);
+}
+
 // One direction of minConvTruncatedLinear.  FWD: M[o] = min(M[o-1] + P1, M[o]) for rising o.
 // Written for the VALU issue budget (four waves share a SIMD: every slot costs 16 cycles): the
 // guess is a min-plus scan of fused DPP instructions, 2 slots per log-step.
@@ -252,7 +322,7 @@ __device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, uns
     // no carry into the first lane of a label range
     const float p1edge = (FWD ? lane % GL == 0 : lane % GL == GL - 1) ? f_inf() : P1;
     float f[LPL];
-    bool boosted = false;
+    int boosted = 0;
     for (int it = 0; it < 70; it++) {
         // exact in-lane recurrence given the neighbour's carry
         const float cin = FWD ? dpp_add_wave_shr1(c, p1edge) : dpp_add_wave_shl1(c, p1edge);  // carry + P1
@@ -263,14 +333,18 @@ __device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, uns
         c = f[K1];
         sweeps++;
         if (__builtin_amdgcn_ballot_w64(!same) == 0ull) break;
-        if (!boosted) {
-            // The guess was wrong somewhere: a ramp long enough to cross binades more than once
-            // (e.g. over a stretch of +INF costs).  Plain sweeps would repair one lane per sweep.
-            // Re-derive every carry as the exact image of its winning origin instead.
-            boosted = true;
+        if (boosted == 0) {
+            // The guess was wrong somewhere: one of its hops crossed binades more than twice (a ramp from the near-zero
+            // value at the winning label, or over a stretch of +INF costs).  Plain sweeps would repair one lane per
+            // sweep.  Second guess: the same scan with carries advanced by a lane and cut hops, exact whenever the
+            // additions inside a binade are; and if the next sweep rejects that too, every carry is re-derived in f64.
+            boosted = 1;
 #ifdef MGM_FH_NOREPAIR  // timing experiment (WRONG results): what do the repairs cost?
             break;
 #endif
+            c = fh_careful<LPL, FWD, GROUPS>(a, P1, lane);
+        } else if (boosted == 1) {
+            boosted = 2;
             c = fh_repair<LPL, FWD, GROUPS>(a, P1, lane);
         }
     }
