@@ -173,7 +173,8 @@ struct Plan {
                + NC * rt               // T minima
                + rdepth * NS * LP      // hand-off ring
                + 2 * rdepth + 8 + 32   // hand-off minima, progress words, task word (+ spare)
-               + cring_floats(rdepth); // C ring
+               + cring_floats(rdepth)  // C ring
+               + (C8 ? rdepth * 16 : 0);  // per line and ring slot: does the compact slab hold a +INF code?
     }
     static constexpr bool fits(int rt, int rdepth, int d)
     {
@@ -254,6 +255,10 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     // valid (slow path).  No assumption on timing or placement: a slot can only ever hold this launch's slab or an
     // older launch's.
     constexpr bool TAGS = pubE;
+    // Loader-side +INF flags of the compact cost slabs (see flag_inf): only where the step is long enough for the loader to
+    // have the time -- the FH kernels (cfg3 x 12: K3 50.1 -> 48.9 ms); the Hirschmueller kernels, whose loader is on the
+    // critical path of a short step, lose 8-25 % with it (cfg2 x 16, cfg4) and keep decoding every byte.
+    constexpr bool CFLAG = C8 && FH;
     using PL = Plan<LPL, NS, !pubE, C8>;
     constexpr int LP = PL::LP, NC = PL::NC, NCA = PL::NCA, D = PL::D, IPS = PL::IPS;
     constexpr int LPS = PL::LPS, LPD = PL::LPD, NDMA = PL::NDMA;
@@ -270,6 +275,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     float *Hm = Tm + NC * RT;                     // [RD]
     unsigned *Hprog = reinterpret_cast<unsigned *>(Hm + RD);  // [RD]
     int *s_task = reinterpret_cast<int *>(Hprog + RD);
+    unsigned *Cflag = reinterpret_cast<unsigned *>(s_task + 40);  // [RD][16] (compact costs; behind the spare words)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -479,6 +485,25 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             }
         };
 
+        // Compact costs: 255 stands for +INF, and turning it back costs the compute waves two instructions per label.
+        // Most slabs hold no such code (labels whose right pixel lies outside the image, padded label slots), so the
+        // loader -- which in the FH kernels has issue slots to spare -- looks at every compact piece once it has landed and leaves one
+        // flag per line: the compute wave then converts the bytes alone (mgm_device.h, c8_decode).
+        auto flag_inf = [&](int vslot) {
+            if constexpr (CFLAG) {
+                if (!(!(C8 && PL::NL == 2) || wl == 1)) return;  // (the loader that fetches the compact pieces)
+#pragma unroll
+                for (int q = 0; q < NDMA; q++) {
+                    const u32x4 v = lds_read_b128_opaque(Cring + (vslot * NDMA + q) * 256 + lane * 4);
+                    auto ff = [](unsigned w) { return ((~w) - 0x01010101u) & w & 0x80808080u; };  // != 0 iff a byte of w is 0xFF
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64((ff(v.x) | ff(v.y) | ff(v.z) | ff(v.w)) != 0u);
+                    const int line = q * LPD + lane;
+                    if (lane < LPD && line < NC)
+                        Cflag[vslot * 16 + line] = ((bal >> (lane * LPS)) & ((1ull << LPS) - 1ull)) != 0ull ? 1u : 0u;
+                }
+            }
+        };
+
         int slot = 0;
         for (int t = 0; t < D; t++) {  // prologue: steps 0..D-1
             issue(slot);
@@ -486,6 +511,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
         }
         retire();
         validate(0, 0);
+        flag_inf(0);
         if (dbg && wl == 0 && lane == 0) {
             dbg[1] = wall_clock64();
             dbg[5] = t_slow;
@@ -505,6 +531,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             const unsigned long long tb = dbg ? wall_clock64() : 0;
             retire();
             validate(s + 1, uslot);  // what the compute waves read after this barrier
+            flag_inf(uslot);
             const unsigned long long tc = dbg ? wall_clock64() : 0;
             step_barrier((xflags & 8) != 0);
             if (dbg) {
@@ -578,7 +605,27 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                 float Cv[LPL], Lv[LPL];
                 if constexpr (C8) {
                     const unsigned char *src = reinterpret_cast<const unsigned char *>(c_src0 + cslot * NDMA * 256) + c8_byte;
-                    if constexpr (LPL == 1) {
+                    // (wave-uniform) no +INF code in this slab: the bytes are the costs
+                    const bool plain = CFLAG && __builtin_amdgcn_readfirstlane((int)Cflag[cslot * 16 + r]) == 0;
+                    if (plain) {
+                        if constexpr (LPL == 1) {
+                            Cv[0] = (float)*src;
+                        } else if constexpr (LPL == 2) {
+                            const unsigned w = *reinterpret_cast<const unsigned short *>(src);
+                            Cv[0] = (float)(w & 255u);
+                            Cv[1] = (float)(w >> 8);
+                        } else if constexpr (LPL % 4 == 0) {
+#pragma unroll
+                            for (int h = 0; h < LPL / 4; h++) {
+                                const unsigned w = reinterpret_cast<const unsigned *>(src)[h];
+#pragma unroll
+                                for (int k = 0; k < 4; k++) Cv[h * 4 + k] = (float)((w >> (8 * k)) & 255u);
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < LPL; k++) Cv[k] = (float)src[k];
+                        }
+                    } else if constexpr (LPL == 1) {
                         Cv[0] = c8_decode(*src);
                     } else if constexpr (LPL == 2) {
                         const unsigned w = *reinterpret_cast<const unsigned short *>(src);
