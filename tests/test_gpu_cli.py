@@ -255,6 +255,23 @@ def test_cli_random_options_match_reference(seed, tmp_path):
             fa, fb = np.isfinite(a), np.isfinite(b)
             assert np.array_equal(fa, fb), (f, what)
             a, b = np.where(fa, a, 0), np.where(fb, b, 0)
+        else:
+            # ... and the LABEL of such a pixel is the uninitialised `float minP` itself (seen as -111 in one of 4000 random
+            # command lines): not compared where both sides report no finite cost
+            nofin = ~(np.isfinite(outs["ref"][1]["cost.npy"]) | np.isfinite(outs["ours"][1]["cost.npy"])).reshape(ny, nx)
+            m = np.broadcast_to(nofin[:, :, None], a.reshape(ny, nx, -1).shape).reshape(a.shape)
+            a, b = np.where(m, 0, a), np.where(m, 0, b)
+        if f == "back.npy":
+            # The reference indexes v with a FLOAT expression, x + d + y*nx + c*npix (mgm.cc:437): in the last row of the
+            # last channel a sub-pixel disparity just below the image border rounds up to npix*nch, one element past the end
+            # of its vector -- it copies whatever the heap holds there (seen once in 2500 random command lines); the
+            # library reads the last element instead.  Same pixels from the same formula; not compared.
+            d32 = outs["ref"][1]["disp.npy"].reshape(ny, nx).astype(np.float32)
+            with np.errstate(invalid="ignore"):
+                k = (np.arange(nx, dtype=np.float32)[None, :] + d32) + (np.arange(ny, dtype=np.float32)[:, None] * np.float32(nx))
+                past = np.stack([(k + np.float32(c * nx * ny)) >= np.float32(nx * ny * nch) for c in range(nch)], axis=-1)
+            a = np.where(past.reshape(a.shape), 0, a)
+            b = np.where(past.reshape(b.shape), 0, b)
         assert ndiff(a, b) == 0, (f, what)
     if FUZZ_N:  # long campaigns: do not let thousands of test directories pile up on the box
         import shutil
