@@ -583,8 +583,15 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
         unsigned long long fh_sweeps = 0, fh_n = 0, fh_rep = 0;
         unsigned fh_max = 0;
         const bool prof = dbg && r == NC / 2;
+        // where this lane's part of the Lr slab of step s goes: a running pointer (one 64-bit add per step instead of
+        // rebuilding pixel index * label stride from half a dozen scalars that would otherwise have to stay live -- the FH
+        // kernels spill SGPRs, and every restore is a VALU slot)
+        float *qs = Lrb + (pix0 + (long long)(-1 - SLOPE * r) * istep) * L + (lane % LANES) * LPL;
+        const long long dq = istep * L;
         auto step = [&](int s, int cslot, NbT &X, const NbT &Y, const NbT &Z) {
             const int i = s - 1 - SLOPE * r;
+            float *const q_here = qs;
+            qs += dq;
             const unsigned long long c0 = prof ? clock64() : 0;
             if (has_prev && i + NEWOFF >= 0 && i + NEWOFF < Wx) {
                 const int sl = r > 0 ? ((i + NEWOFF) & (RT - 1)) : cslot;
@@ -601,7 +608,8 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                 if constexpr (!pubE) X.m = fwd_m0[sl];
             }
             if (line_ok && i >= 0 && i < Wr) {
-                const long long pix = pix0 + (long long)i * istep;
+                long long pix = 0;
+                if constexpr (WEIGHTED || MGM_P2_DEV) pix = pix0 + (long long)i * istep;
                 float Cv[LPL], Lv[LPL];
                 if constexpr (C8) {
                     const unsigned char *src = reinterpret_cast<const unsigned char *>(c_src0 + cslot * NDMA * 256) + c8_byte;
@@ -706,7 +714,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 #ifdef MGM_P2_XFLAG16  // xflags & 16 (timing experiment, wrong results): every Lr store lands in a small cache-resident window
                     float *q = Lrb + ((xflags & 16) ? (pix & 255) : pix) * L + (lane % LANES) * LPL;
 #else
-                    float *q = Lrb + pix * L + (lane % LANES) * LPL;
+                    float *q = q_here;
 #endif
 #pragma unroll
                     for (int k = 0; k < LPL; k++) q[k] = Lv[k];
