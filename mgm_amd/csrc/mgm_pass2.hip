@@ -199,29 +199,21 @@ struct Plan {
     static_assert((RT & (RT - 1)) == 0, "RT must be a power of two");
 };
 
-// unit weights, slabs hold E = T - m (every unit-weight case but FH with MGM == 2)
+// unit weights, slabs hold E = T - m (every unit-weight case but FH with MGM == 2).  E >= +0, so the reference's
+// `e = 0; e += ...` needs no addition for its first term (+0 + x == x bit for bit when x >= +0).  With MGM == 2
+// (update_cost2: (t_1 - m_1)/2 + (t_2 - m_2)/2) the slabs hold the HALVES, taken once by the line that publishes them
+// instead of once per reader -- the same correctly rounded value either way.
 template <int LPL, int MGM, bool FH>
 __device__ __forceinline__ void combine_unit_E(const float (&C)[LPL], const float (&e1)[LPL], const float (&e2)[LPL],
                                                const float (&e3)[LPL], const float (&e4)[LPL], float (&out)[LPL])
 {
     if constexpr (MGM == 2) {  // update_cost2 (FH with MGM == 2 never gets here)
 #pragma unroll
-        for (int k = 0; k < LPL; k++) {
-            float e = 0.0f;
-            e += e1[k] * 0.5f;
-            e += e2[k] * 0.5f;
-            out[k] = C[k] + e;
-        }
+        for (int k = 0; k < LPL; k++) out[k] = C[k] + (e1[k] + e2[k]);
     } else {
 #pragma unroll
         for (int k = 0; k < LPL; k++) {
-            float e;
-            if constexpr (!FH) {
-                e = 0.0f;
-                e += e1[k];
-            } else {
-                e = e1[k];
-            }
+            float e = e1[k];
             if constexpr (MGM >= 3) e += e2[k];
             if constexpr (MGM >= 3) e += e3[k];
             if constexpr (MGM >= 4) e += e4[k];
@@ -615,7 +607,15 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     const unsigned char *src = reinterpret_cast<const unsigned char *>(c_src0 + cslot * NDMA * 256) + c8_byte;
                     // (wave-uniform) no +INF code in this slab: the bytes are the costs
                     const bool plain = CFLAG && __builtin_amdgcn_readfirstlane((int)Cflag[cslot * 16 + r]) == 0;
-                    if (plain) {
+                    if constexpr (CFLAG && LPL == 4) {  // convert the bytes, then patch the +INF codes in where the slab has any
+                        const unsigned w = reinterpret_cast<const unsigned *>(src)[0];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) Cv[k] = (float)((w >> (8 * k)) & 255u);
+                        if (!plain) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) Cv[k] = ((w >> (8 * k)) & 255u) == 255u ? f_inf() : Cv[k];
+                        }
+                    } else if (plain) {
                         if constexpr (LPL == 1) {
                             Cv[0] = (float)*src;
                         } else if constexpr (LPL == 2) {
@@ -640,11 +640,19 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                         Cv[0] = c8_decode(w & 255u);
                         Cv[1] = c8_decode(w >> 8);
                     } else if constexpr (LPL % 4 == 0) {
+                        // (kernels whose loader leaves no flags) convert the bytes; the +INF code is patched in only if
+                        // some lane of the wave holds one -- 4 slots for the test instead of 2 per label
+                        unsigned w[LPL / 4], any = 0u;
 #pragma unroll
                         for (int h = 0; h < LPL / 4; h++) {
-                            const unsigned w = reinterpret_cast<const unsigned *>(src)[h];
+                            w[h] = reinterpret_cast<const unsigned *>(src)[h];
+                            any |= (0xFEFEFEFEu - w[h]) & w[h] & 0x80808080u;  // != 0 iff a byte of w is 0xFF
 #pragma unroll
-                            for (int k = 0; k < 4; k++) Cv[h * 4 + k] = c8_decode((w >> (8 * k)) & 255u);
+                            for (int k = 0; k < 4; k++) Cv[h * 4 + k] = (float)((w[h] >> (8 * k)) & 255u);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) {
+#pragma unroll
+                            for (int k = 0; k < LPL; k++) Cv[k] = ((w[k / 4] >> (8 * (k % 4))) & 255u) == 255u ? f_inf() : Cv[k];
                         }
                     } else {  // 3 or 6 labels per lane: the lane's bytes are not word-aligned
 #pragma unroll
@@ -756,7 +764,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                     }
                     if constexpr (pubE) {
 #pragma unroll
-                        for (int k = 0; k < LPL; k++) nb_i.w[0][k] = nb_i.w[0][k] - m;
+                        for (int k = 0; k < LPL; k++) nb_i.w[0][k] = MGM == 2 ? (nb_i.w[0][k] - m) * 0.5f : nb_i.w[0][k] - m;
                     }
                 } else {
 #pragma unroll

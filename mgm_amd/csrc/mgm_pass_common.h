@@ -273,9 +273,17 @@ __device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, uns
     constexpr int DK = FWD ? 1 : -1;
     const float rampP = (float)LPL * P1;
 
-    float a = M[K0];  // carry-out ignoring carry-in: exact for the first lane, a candidate origin elsewhere
+    // carry-out ignoring carry-in: exact for the first lane, a candidate origin elsewhere.  (The cold paths below compute
+    // it again -- `again` keeps that from being merged with the hot path's value, whose register the scan can then
+    // overwrite in place instead of copying it first.)
+    auto origin = [&](bool again) {
+        float a = M[K0];
+        if (again) asm volatile("" : "+v"(a));
 #pragma unroll
-    for (int q = 1; q < LPL; q++) a = fminf(M[K0 + q * DK], a + P1);  // (compile-time indices: no scratch)
+        for (int q = 1; q < LPL; q++) a = fminf(M[K0 + q * DK], a + P1);  // (compile-time indices: no scratch)
+        return a;
+    };
+    const float a = origin(false);
 
     // cheap guess of the 64 carries: min-plus scan with single-rounded ramps.  Inside each row of
     // 16 lanes with DPP row shifts; across rows FWD with the row broadcasts, BWD through the row
@@ -305,12 +313,14 @@ __device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, uns
         c = dpp_min_row_shl4(c, c + r4);
         c = dpp_min_row_shl8(c, c + r8);
         if constexpr (GROUPS == 1) {
-            const float t3 = readlane_f(c, 48);                   // total of row 3 (at its first lane)
-            const float t2 = fminf(readlane_f(c, 32), t3 + r16);  // rows 2..3
-            const float t1 = fminf(readlane_f(c, 16), t2 + r16);  // rows 1..3
-            const float tp = row == 0 ? t1 : (row == 1 ? t2 : t3);
-            const float offD = row <= 2 ? (float)(16 - li) * rampP : f_inf();
-            c = fminf(c, tp + offD);
+            // the mirror image of the forward scan's two row broadcasts: rows 0 and 2 take in the first lane of the row
+            // after them, then rows 0 and 1 take in lane 32, which by then covers rows 2..3.  Per-lane offsets (+INF
+            // where a hop does not apply); 5 VALU slots where chaining the three row totals first took 9.
+            const float offA0 = row == 0 ? (float)(16 - li) * rampP : f_inf();
+            const float offA2 = row == 2 ? (float)(16 - li) * rampP : f_inf();
+            const float offB = row <= 1 ? (float)(32 - lane) * rampP : f_inf();
+            c = fminf(fminf(c, readlane_f(c, 16) + offA0), readlane_f(c, 48) + offA2);
+            c = fminf(c, readlane_f(c, 32) + offB);
         } else if constexpr (GROUPS == 2) {  // rows 0 and 2 take in the row after them (same label range)
             const float t1 = readlane_f(c, 16), t3 = readlane_f(c, 48);
             const float tp = row == 0 ? t1 : t3;
@@ -342,10 +352,10 @@ __device__ __forceinline__ void fh_scan(float (&M)[LPL], float P1, int lane, uns
 #ifdef MGM_FH_NOREPAIR  // timing experiment (WRONG results): what do the repairs cost?
             break;
 #endif
-            c = fh_careful<LPL, FWD, GROUPS>(a, P1, lane);
+            c = fh_careful<LPL, FWD, GROUPS>(origin(true), P1, lane);
         } else if (boosted == 1) {
             boosted = 2;
-            c = fh_repair<LPL, FWD, GROUPS>(a, P1, lane);
+            c = fh_repair<LPL, FWD, GROUPS>(origin(true), P1, lane);
         }
     }
 #pragma unroll
