@@ -496,6 +496,86 @@ __global__ void __launch_bounds__(256) k_cost_census8w(const uint32_t *__restric
     }
 }
 
+// The same again with FOUR consecutive pixels of a row per lane (image widths that are multiples of four): the sixteen
+// labels of a lane slide along the right image by one word per pixel, so the four pixels share 19 census words where
+// four separate lanes load 64 -- the kernel above is bound by those (L1-resident, unaligned) loads, not by its stores.
+template <int L>
+__global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restrict__ cu, const uint32_t *__restrict__ cv,
+                                                       int nx, int ny, int vnx, int vny, int dmin, unsigned tb,
+                                                       uint8_t *__restrict__ C8)
+{
+    static_assert(L == 64 || L == 128 || L == 256 || L == 512, "whole pixels per KiB");
+    constexpr int LP = L / 16;    // lanes per pixel group
+    constexpr int G = 64 / LP;    // groups of four pixels per wave and iteration
+    const long long npix = (long long)nx * ny;  // (a multiple of four)
+    const long long nchunk = (npix + 4 * G - 1) / (4 * G);
+    const int lane = threadIdx.x & 63, sub = lane / LP, part = lane % LP;
+    const unsigned long long group = (LP == 64 ? ~0ull : ((1ull << (LP % 64)) - 1ull)) << (sub * LP);
+    for (long long chunk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < nchunk; chunk += (long long)gridDim.x * 4) {
+        const long long pix0 = (chunk * G + sub) * 4;
+        const bool live = pix0 < npix;
+        const unsigned p32 = live ? (unsigned)pix0 : 0u;  // (npix < 2^31: checked by the caller)
+        const int y = (int)(p32 / (unsigned)nx), x = (int)(p32 - (unsigned)y * (unsigned)nx);  // x .. x+3: one row
+        const uint4 wu4 = *reinterpret_cast<const uint4 *>(cu + p32);
+        const unsigned wu[4] = {wu4.x, wu4.y, wu4.z, wu4.w};
+        const int q0 = x + dmin + part * 16;
+        const bool yin = y < vny;
+        const uint32_t *row = cv + (long long)(yin ? y : 0) * vnx;
+        unsigned w[4][4];
+        bool fin[4] = {false, false, false, false};
+        if (yin && q0 >= 0 && q0 + 20 <= vnx) {  // every word the four pixels need lies inside the right image
+            unsigned v[20];
+#pragma unroll
+            for (int h = 0; h < 5; h++) {
+                const u32x4_a4 t = *reinterpret_cast<const u32x4_a4 *>(row + q0 + 4 * h);
+                v[4 * h] = t.x; v[4 * h + 1] = t.y; v[4 * h + 2] = t.z; v[4 * h + 3] = t.w;
+            }
+            // (a bit count is at most 32: never the +INF code, and clipped only by a truncation below 32 -- wave-uniform)
+            const bool clip = tb < 32u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                fin[i] = true;
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    unsigned b[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) b[k] = (unsigned)__builtin_popcount(wu[i] ^ v[i + 4 * h + k]);
+                    if (clip) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) b[k] = b[k] < tb ? b[k] : tb;
+                    }
+                    w[i][h] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    unsigned b[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int q = q0 + i + 4 * h + k;
+                        const bool in = yin && q >= 0 && q < vnx;
+                        const unsigned pc = (unsigned)__builtin_popcount(wu[i] ^ row[in ? q : 0]);
+                        b[k] = in ? (pc < tb ? pc : tb) : tb;
+                        fin[i] |= b[k] != 255u;
+                    }
+                    w[i][h] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool anyfinite = (__builtin_amdgcn_ballot_w64(fin[i]) & group) != 0ull;  // of this pixel's labels
+            if (live) {
+                uint4 o;
+                o.x = anyfinite ? w[i][0] : 0u; o.y = anyfinite ? w[i][1] : 0u; o.z = anyfinite ? w[i][2] : 0u; o.w = anyfinite ? w[i][3] : 0u;
+                *reinterpret_cast<uint4 *>(C8 + (pix0 + i) * L + part * 16) = o;
+            }
+        }
+    }
+}
+
 hipError_t launch_cost(const CostParams &p, hipStream_t s)
 {
     const long long npix = (long long)p.nx * p.ny;
@@ -504,6 +584,18 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
         long long nb = (npix + 3) / 4;
         if (nb > 256 * 32) nb = 256 * 32;
         const dim3 block(256);
+        if ((p.L == 64 || p.L == 128 || p.L == 256 || p.L == 512) && npix < 0x7fffffffll && p.nx % 4 == 0) {
+            long long nw = (npix * p.L / 4096 + 3) / 4 + 1;
+            if (nw > 256 * 32) nw = 256 * 32;
+            const dim3 gridw((unsigned)nw);
+            switch (p.L) {
+                case 64: hipLaunchKernelGGL(k_cost_census8x<64>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                case 128: hipLaunchKernelGGL(k_cost_census8x<128>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                case 256: hipLaunchKernelGGL(k_cost_census8x<256>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                default: hipLaunchKernelGGL(k_cost_census8x<512>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+            }
+            return hipGetLastError();
+        }
         if ((p.L == 64 || p.L == 128 || p.L == 256 || p.L == 512) && npix < 0x7fffffffll) {
             long long nw = (npix * p.L / 1024 + 3) / 4 + 1;
             if (nw > 256 * 32) nw = 256 * 32;
