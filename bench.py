@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- disparity-volumes/s of the MGM hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3] [--batch B] [--mode pairs|directions]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3] [--batch B] [--mode pairs|directions] [--extras auto|on|off]
 
 One "step" = one full pass of the hot path over one batch of synthetic stereo pairs whose images are
 already resident in HBM: census transform + W*H*L cost volume (K1, K2), all-direction MGM
@@ -9,31 +9,45 @@ aggregation (K3), ordered sum + over-count fix + WTA + V-fit (K4-K6).  Outputs s
 
 N > 1: one process per GPU.  `python bench.py --gpus N` started WITHOUT a torch.distributed.run environment
 launches itself under it (N ranks on 127.0.0.1); started by `python -m torch.distributed.run ... bench.py --gpus N`
-it is one of the ranks.  In the default `pairs` mode every rank processes its own independent pairs -- the
-reference has no cross-pair coupling, so there is no data-path collective -- and the job rate is all volumes of
-all ranks over the slowest rank's time (weak scaling).  `--mode directions` shards the passes of ONE volume over
-the ranks (strong scaling, cfg4-size volumes).  torch is used for the process group, the barrier and the
-max-reduction only.
+it is one of the ranks.  The HEADLINE (`value`) is always the `pairs` mode on the chosen workload: every rank
+processes its own independent pairs -- the reference has no cross-pair coupling, so there is no data-path collective
+-- and the job rate is all volumes of all ranks over the slowest rank's time (weak scaling).
+
+With the driver's plain command line (no --workload / --batch / --mode) two more legs run after the headline and
+land in the SAME json line (`--extras`):
+    "cfg5_replicas"   BASELINE config 5: 16 independent 1024x1024x128 pairs per step and GPU, replicas only
+    "directions"      BASELINE config 4: ONE 4096x4096x192 volume, its 8 passes sharded over the N GPUs with the ordered
+                      row-slab exchange (mgm_amd/dist.py over RCCL: "rccl"; the same plan driven by ONE process through
+                      mgm_multi_* with device-to-device peer copies: "peer"), next to the same volume on one GPU
+                      ("single", rank 0) -- strong scaling, and a bit-for-bit comparison of the three results.
+The extras are guarded: a leg that fails records its error, every exchange is time-boxed (mgm_amd/dist.py), and a
+watchdog prints the line with whatever has been measured if the extras overrun `--extras-timeout` (a hung peer cannot
+take the headline with it).  `--mode directions` runs the direction-sharded leg alone and makes it the headline.
 
 Workload matrix (BASELINE.json configs; cfg1 is the reference's CPU-runnable case and a parity test, not a bench line):
     --workload cfg3   (default; the configuration the metric is quoted on)   1920x1080x256, census 5x5, -O 8, TSGM 3, FH
     --workload cfg3h  the same with Hirschmueller potentials
     --workload cfg2   1920x1080x128, census 3x3, -O 4, TSGM 2
-    --workload cfg4 [--mode directions]   4096x4096x192, census 5x5, -O 8, TSGM 3 (one volume per step)
+    --workload cfg4   4096x4096x192, census 5x5, -O 8, TSGM 3 (one volume per step)
     --workload cfg5   1024x1024x128, census 3x3, -O 4, TSGM 2, 16 pairs per step and GPU (throughput mode)
 
 Rank 0 prints ONE JSON line, the last thing on stdout; fields `roofline`, `cpu_baseline` and `parity` are described
 in DESIGN.md.  PARITY GATE: the disparity and cost maps of pair 0 computed by the LAST timed step are compared, bit for
 bit, with the CPU oracle run on the same seeded pair in the same process; a mismatch fails the run (exit code 3).
+torch is used for the process group, the barrier and the max-reduction only.
 """
 import argparse
 import hashlib
+import importlib.util
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
+from datetime import timedelta
 
 import numpy as np
 
@@ -55,6 +69,10 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PARITY_MAX_CELLS = 1.2e9  # the in-run oracle takes whole volumes up to this size (cfg4: see tests/test_gpu_fullsize.py)
+
+
+def labels_of(w):
+    return w["dmax"] - w["dmin"] + 1
 
 
 def pair_of(w, seed_offset=0):
@@ -83,15 +101,13 @@ def cpu_model():
     return "unknown"
 
 
-def run_step(ctx, dus, dvs, w, outs, outcs, cvs=None):
-    """One step = one batch: the cost volume of every pair, ONE pass launch over the batch, WTA+vfit per volume."""
-    cvs = cvs or [None] * len(dus)
-    cvs = [ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", "census", float("inf"), w["win"], into=cv)
-           for du, dv, cv in zip(dus, dvs, cvs)]
-    ctx.aggregate_batch_dev(cvs, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, None, "vfit", outs, outcs, want_S=False)
-    return cvs
+def compact_costs(w):
+    """Do this workload's costs travel as one byte per label?  (single-word census costs at a label count the compact
+    kernels take: mgm_api.hip, costvolume_fill / c8_supported)"""
+    return labels_of(w) in (64, 128, 192, 256, 384, 512) and os.environ.get("MGM_HIP_C8", "1") != "0"
 
 
+# ---- the CPU legs (rank 0 only; never inside a timed GPU region) --------------------------------------------------------
 def oracle_whole_volume(w, threads):
     """Pair 0 through the CPU oracle (oracle/mgm_oracle.c), whole volume, `threads` OpenMP threads (the reference
     parallelises each diagonal of a pass the same way, mgm_core.cc:505-579).  Returns (disp, cost, seconds)."""
@@ -105,14 +121,55 @@ def oracle_whole_volume(w, threads):
     return ro, rc, time.perf_counter() - t0
 
 
-def cpu_baseline(w, whole, seconds_target=15.0):
-    """The CPU oracle (plain-C port of the reference path) timed on the GPU box's host cores: one thread on a row band of
-    the same workload sized to about `seconds_target` seconds, and -- `whole` = (seconds, threads), measured by the
-    parity leg -- one whole volume on every core the process may use.  The better of the two is the headline figure."""
+def reference_whole_volume(w, threads, want=None):
+    """The REAL reference (oracle/_ref/libmgm_ref.so: gfacciol/mgm compiled from its own sources behind
+    oracle/ref_harness.cc) on pair 0: allocate_and_fill_sgm_costvolume + mgm() + subpixel_refinement_sgm, timed INSIDE
+    the harness around those three calls (the dense <-> Dvec container copies of the harness are not the reference's
+    work).  Returns seconds, or None where the library is not there / the census window cannot be set."""
+    from oracle.oracle import Oracle, Reference
+    if not Reference.available():
+        return None
+    os.environ["CENSUS_NCC_WIN"] = str(w["win"])  # a smart parameter of the reference, cached on first use per process
+    ref = Reference()
+    if ref.census_win() != w["win"] or not hasattr(ref.lib, "ref_seconds"):
+        return None
+    Oracle(threads=threads)  # (sets the OpenMP thread count of the process: both libraries share libgomp)
+    u, v, _ = pair_of(w)
+    os.environ["USE_TRUNCATED_LINEAR_POTENTIALS"] = "1" if w["FH"] else "0"
+    C = ref.costvolume(u, v, w["dmin"], w["dmax"], "none", "census", np.inf)
+    t = ref.seconds()
+    S, o, c = ref.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1)
+    t += ref.seconds()
+    ro, rc = ref.refine(S, w["dmin"], "vfit", o, c)
+    t += ref.seconds()
+    if want is not None:
+        want["o"], want["c"] = ro, rc
+    return t
+
+
+def cpu_baseline(w, whole_first, threads, seconds_target=12.0):
+    """The CPU path timed on the GPU box's host cores (rank 0, N = 1): bounded samples of the same workload.
+      reference  the REAL reference's three calls on the whole pair, `threads` OpenMP threads, median of 3 (where
+                 oracle/_ref/libmgm_ref.so travelled to this box)
+      port       oracle/mgm_oracle.c: the whole pair on `threads` threads, median of 3 (the parity leg's run is the first of
+                 them), and ONE thread on a row band sized to ~`seconds_target` s, extrapolated linearly in rows
+    The top-level value is the reference's where it exists (kind "reference"), else the port's best."""
     from mgm_amd import synth
     from oracle.oracle import Oracle
+    nx, L = w["nx"], labels_of(w)
+    cells = float(nx) * w["ny"] * L
+    res = {"unit": "disparity-volumes/s", "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
+    # -- port, all threads: median of 3 whole volumes
+    runs = [whole_first] if whole_first is not None else []
+    while len(runs) < 3:
+        runs.append(oracle_whole_volume(w, threads)[2])
+    med = float(np.median(runs))
+    port = {"value": 1.0 / med, "cores": threads, "kind": "port", "runs_s": [round(t, 3) for t in runs],
+            "sample": "one whole %dx%dx%d volume (cost volume + %d-direction mgm + vfit), oracle/mgm_oracle.c on %d OpenMP threads, "
+                      "median of %d runs" % (nx, w["ny"], L, w["NDIR"], threads, len(runs)),
+            "mcell_updates_per_s": cells * w["NDIR"] / med / 1e6}
+    # -- port, one thread, on a band of rows
     orc = Oracle(threads=1)
-    nx, L = w["nx"], w["dmax"] - w["dmin"] + 1
 
     def band(rows):
         u, v, _ = synth.stereo_pair(nx, rows, w["dmin"] * 3 // 4, max(0, w["dmax"] * 3 // 4))
@@ -125,22 +182,40 @@ def cpu_baseline(w, whole, seconds_target=15.0):
     per_row = band(8) / 8  # calibrate on a thin band, then size the sample
     rows = int(max(16, min(w["ny"], seconds_target / per_row)))
     dt = band(rows)
-    vol_per_s = (rows / w["ny"]) / dt  # linear in the number of rows
-    res = {"value": vol_per_s, "unit": "disparity-volumes/s", "cores": 1, "kind": "port",
-           "sample": "%dx%dx%d band (%d of %d rows) of the same workload, %.1f s of CPU time, extrapolated "
-                     "linearly in rows; oracle/mgm_oracle.c, 1 thread" % (nx, rows, L, rows, w["ny"], dt),
-           "mcell_updates_per_s": nx * rows * L * w["NDIR"] / dt / 1e6}
-    if whole is not None:
-        dto, T = whole
-        res["openmp"] = {"value": 1.0 / dto, "cores": T, "sample": "one whole %dx%dx%d volume, %.1f s wall" % (nx, w["ny"], L, dto)}
-        if 1.0 / dto > res["value"]:
-            res.update({"value": 1.0 / dto, "cores": T, "mcell_updates_per_s": nx * w["ny"] * L * w["NDIR"] / dto / 1e6,
-                        "sample": res["openmp"]["sample"] + " on %d OpenMP threads; 1 thread: %.4f volumes/s (%s)" % (T, vol_per_s, res["sample"])})
-    res["host_cpus"] = os.cpu_count()
-    res["cpu_model"] = cpu_model()
-    return res
+    port["one_thread"] = {"value": (rows / w["ny"]) / dt, "cores": 1,
+                          "sample": "%dx%dx%d band (%d of %d rows), %.1f s, extrapolated linearly in rows" % (nx, rows, L, rows, w["ny"], dt),
+                          "mcell_updates_per_s": nx * rows * L * w["NDIR"] / dt / 1e6}
+    res["port"] = port
+    # -- the reference itself
+    ref_runs, ref_out = [], {}
+    try:
+        for _ in range(3):
+            t = reference_whole_volume(w, threads, ref_out if not ref_runs else None)
+            if t is None:
+                break
+            ref_runs.append(t)
+    except Exception as e:  # noqa: BLE001 -- a baseline that cannot run is reported, it does not fail the bench
+        res["reference_error"] = repr(e)[:300]
+    if ref_runs:
+        rmed = float(np.median(ref_runs))
+        res["reference"] = {"value": 1.0 / rmed, "cores": threads, "kind": "reference", "runs_s": [round(t, 3) for t in ref_runs],
+                            "sample": "one whole %dx%dx%d volume: the reference's allocate_and_fill_sgm_costvolume + mgm() + "
+                                      "subpixel_refinement_sgm (oracle/_ref/libmgm_ref.so, compiled from gfacciol/mgm's sources, -O3 "
+                                      "-fopenmp) on %d OpenMP threads, median of %d runs, timed around the three calls"
+                                      % (nx, w["ny"], L, threads, len(ref_runs)),
+                            "mcell_updates_per_s": cells * w["NDIR"] / rmed / 1e6}
+    top = res.get("reference") or port
+    res.update({"value": top["value"], "cores": top["cores"], "kind": top["kind"], "sample": top["sample"]})
+    return res, ref_out
 
 
+def nd(a, b):
+    """Differing float32 words of two arrays, NaN == NaN."""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return int(np.sum((a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))))
+
+
+# ---- launcher -----------------------------------------------------------------------------------------------------------
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -167,106 +242,150 @@ def relaunch_under_torchrun(args):
     sys.exit(p.returncode if p.returncode or js else 1)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity gate (profiling runs)")
-    ap.add_argument("--repeats", type=int, default=None,
-                    help="further timed blocks of K steps after the reported one (their rates go to `repeat_values`); "
-                         "default: as many as make the GPU phase last about 10 s, at most 8")
-    ap.add_argument("--batch", type=int, default=None, choices=list(range(1, 17)),
-                    help="pairs per step and GPU: their volumes share ONE launch of the pass kernel (pairs mode).  Default: "
-                         "12 (204 GB of Lr volumes at 1920x1080x256 x 8 directions), 16 for workloads of at most 128 labels "
-                         "(two / four of those volumes share every wave), 1 for cfg4")
-    ap.add_argument("--mode", default="pairs", choices=["pairs", "directions"],
-                    help="N>1: 'pairs' = independent pairs, one per GPU (weak scaling, default); 'directions' = ONE "
-                         "volume per step, its passes sharded over the GPUs with an ordered RCCL exchange (strong)")
-    args = ap.parse_args()
-    w = WORKLOADS[args.workload]
-    stub = os.environ.get("MGM_BENCH_STUB") == "1"  # tests/test_dist_cpu.py: gloo ranks on CPU, a context that computes nothing
+class OneLine:
+    """The ONE json line of rank 0, printed exactly once -- by the main thread at the end, or by the watchdog if the
+    guarded extras overrun (every rank then leaves through os._exit: a process group with a transfer pending on the device
+    cannot be torn down in an orderly way)."""
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        relaunch_under_torchrun(args)
-    import torch
-    dist = None
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        sys.exit("bench.py --gpus %d runs inside a torch.distributed.run job of %d ranks" % (args.gpus, world))
-    if not stub:
-        if not torch.cuda.is_available():
-            sys.exit("bench.py needs an MI355X: there is no CPU path in mgm_amd")
-        torch.cuda.set_device(local)
-    if world > 1 or args.mode == "directions":
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if stub:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+    def __init__(self, rank):
+        self.rank, self.lock, self.done, self.res, self.code = rank, threading.Lock(), False, None, 0
+        self.guard_deadline = None
+
+    def emit(self, hard, note=None):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.rank == 0 and self.res is not None:
+                if note:
+                    self.res.setdefault("extras_note", note)
+                sys.stdout.flush()
+                print(json.dumps(self.res), flush=True)
+        if hard:
+            os._exit(self.code)
+
+    def guard(self, seconds):
+        """From now on the process has `seconds` to call emit(); past that the watchdog does."""
+        self.guard_deadline = time.monotonic() + seconds
+
+        def run():
+            while not self.done:
+                if time.monotonic() > self.guard_deadline + (0.0 if self.rank == 0 else 2.0):
+                    self.emit(True, "watchdog: the extras did not finish within %.0f s; the line holds what had been measured" % seconds)
+                time.sleep(0.25)
+        threading.Thread(target=run, daemon=True).start()
+        # torch.distributed.run sends SIGTERM to the surviving ranks when one dies: rank 0 still prints what it has.  The
+        # C-level handler writes the signal number to a pipe at once, whatever the main thread is blocked in.
+        try:
+            r, wfd = os.pipe()
+            os.set_blocking(wfd, False)
+            signal.signal(signal.SIGTERM, lambda *_: None)
+            signal.set_wakeup_fd(wfd)
+
+            def on_term():
+                os.read(r, 1)
+                self.emit(True, "SIGTERM during the extras (a rank died): the line holds what had been measured")
+            threading.Thread(target=on_term, daemon=True).start()
+        except (ValueError, OSError):
+            pass
+
+
+# ---- legs -------------------------------------------------------------------------------------------------------------
+class Env:
+    """What every leg needs: the process's rank, its groups and its context."""
+
+    def __init__(self, args, stub):
+        self.args, self.stub = args, stub
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist, self.ctrl, self.torch = None, None, None
+
+    def setup(self):
+        import torch
+        self.torch = torch
+        args = self.args
+        if self.world != args.gpus:
+            sys.exit("bench.py --gpus %d runs inside a torch.distributed.run job of %d ranks" % (args.gpus, self.world))
+        if not self.stub:
+            if not torch.cuda.is_available():
+                sys.exit("bench.py needs an MI355X: there is no CPU path in mgm_amd")
+            torch.cuda.set_device(self.local)
+        if self.world > 1 or args.mode == "directions":
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            if self.stub:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=timedelta(seconds=600))
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local))
+                if self.world > 1:
+                    # control plane of the guarded legs: CPU collectives (agreement, "rank 0 is busy" barriers) that neither
+                    # occupy a GPU nor hang without a time-out
+                    self.ctrl = dist.new_group(backend="gloo", timeout=timedelta(seconds=900))
+            self.dist = dist
+        self.n_ranks = self.dist.get_world_size() if self.dist is not None else 1  # the world RCCL actually initialised
+        if self.stub:
+            spec = importlib.util.spec_from_file_location("bench_stub", os.environ["MGM_BENCH_STUB"])
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            self.ctx = mod.StubContext(self.local)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    n_ranks = dist.get_world_size() if dist is not None else 1  # the world RCCL actually initialised
+            import mgm_amd
+            self.ctx = mgm_amd.Context(self.local)
 
-    if stub:
-        from tests.bench_stub import StubContext
-        ctx = StubContext(local)
-    else:
-        import mgm_amd
-        ctx = mgm_amd.Context(local)
-    from mgm_amd import shard
-    nx, ny, L = w["nx"], w["ny"], w["dmax"] - w["dmin"] + 1
-    # pairs mode: every rank gets its own pairs (different seeds): independent units, no exchange.
-    # directions mode: every rank holds the SAME pair and builds the full cost volume itself.
-    if args.batch is None:
-        args.batch = 1 if args.workload == "cfg4" else (16 if L <= 128 else 12)
-    B = args.batch if args.mode == "pairs" else 1
+    def sync_all(self):
+        if not self.stub:
+            self.torch.cuda.synchronize()
+        self.ctx.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            if not self.stub:
+                self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        from mgm_amd import shard
+        return shard.max_over_ranks(x, self.dist if self.world > 1 else None, device="cpu" if self.stub else "cuda")
+
+    def ctrl_barrier(self):
+        if self.world > 1:
+            self.dist.barrier(group=self.ctrl)  # (stub: the default group is gloo)
+
+
+def pairs_leg(env, w, B, steps, warmup, repeats, keep=False):
+    """Independent pairs, B per step and GPU: W warm-up steps, then EXACTLY K timed steps between barrier + synchronize
+    brackets, MAX over ranks.  Returns the measurement (and, with `keep`, the device outputs of the last step)."""
+    ctx, rank = env.ctx, env.rank
+    nx, ny = w["nx"], w["ny"]
     dus, dvs, outs, outcs = [], [], [], []
     for b in range(B):
-        u, v, _ = pair_of(w, (rank * B + b) if args.mode == "pairs" else 0)
+        u, v, _ = pair_of(w, rank * B + b)  # every rank gets its own pairs (different seeds): independent units, no exchange
         dus.append(ctx.upload_image(u))
         dvs.append(ctx.upload_image(v))
         outs.append(ctx.new_image(nx, ny))
         outcs.append(ctx.new_image(nx, ny))
-    du, dv = dus[0], dvs[0]
 
-    def sync_all():
-        if not stub:
-            torch.cuda.synchronize()
-        ctx.synchronize()
-        if world > 1:
-            dist.barrier()
-            if not stub:
-                torch.cuda.synchronize()
-
-    last = {}
-    if args.mode == "directions":
-        from mgm_amd import dist as mdist
-
-        def step(cv):
-            cv = ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", "census", float("inf"), w["win"], into=cv)
-            last["o"], last["c"] = mdist.aggregate_direction_sharded(ctx, cv, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, "vfit", dist)
-            return cv
-    else:
-        def step(cvs):
-            return run_step(ctx, dus, dvs, w, outs, outcs, cvs)
-
-    def timed_block():
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(cv)  # pairs mode: enqueue only, nothing synchronises inside the timed region
-        sync_all()
-        return shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, device="cpu" if stub else "cuda")
+    def step(cvs):
+        # one step = one batch: the cost volume of every pair, ONE pass launch over the batch, WTA + vfit per volume
+        cvs = cvs or [None] * B
+        cvs = [ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", "census", float("inf"), w["win"], into=cv)
+               for du, dv, cv in zip(dus, dvs, cvs)]
+        ctx.aggregate_batch_dev(cvs, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, None, "vfit", outs, outcs, want_S=False)
+        return cvs
 
     cv = None  # the W*H*L volumes are allocated once and refilled every step
-    for _ in range(max(1, args.warmup)):
+
+    def timed_block():
+        env.sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(cv)  # enqueue only: nothing synchronises inside the timed region
+        env.sync_all()
+        return env.max_over_ranks(time.perf_counter() - t0)
+
+    for _ in range(max(1, warmup)):
         cv = step(cv)
-    sync_all()
+    env.sync_all()
     ctx.timing(True)
     ctx.timing_reset()
     dt = timed_block()  # the reported measurement: exactly K steps between two barrier + synchronize brackets
@@ -276,102 +395,376 @@ def main():
     ctx.timing(False)
     # further blocks of K steps: the same measurement again (stability), and a GPU phase long enough for a coarse
     # utilisation sampler to see
-    reps = args.repeats if args.repeats is not None else int(min(8, max(0, np.ceil(10.0 / max(dt, 1e-3)) - 1)))
+    reps = repeats if repeats is not None else int(min(8, max(0, np.ceil(10.0 / max(dt, 1e-3)) - 1)))
     rep_dt = [timed_block() for _ in range(reps)]
-
-    # ---- parity gate: pair 0 of the last timed step against the CPU oracle --------------------------------------
-    cells = float(nx) * ny * L
-    parity, whole = None, None
-    if rank == 0 and not args.no_parity and not stub:
-        if cells > PARITY_MAX_CELLS:
-            parity = {"status": "skipped", "why": "%.1f G cells: beyond the in-run oracle (covered by tests/test_gpu_fullsize.py)" % (cells / 1e9)}
-        else:
-            if args.mode == "directions":
-                got_o, got_c = last["o"].cpu().numpy(), last["c"].cpu().numpy()
-            else:
-                got_o, got_c = outs[0].download()[0], outcs[0].download()[0]
-            from oracle.oracle import usable_cpus
-            T = min(32, usable_cpus())
-            ref_o, ref_c, secs = oracle_whole_volume(w, T)
-            whole = (secs, T)
-
-            def nd(a, b):
-                a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
-                return int(np.sum((a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))))
-            bad = nd(ref_o, got_o.reshape(ref_o.shape)) + nd(ref_c, got_c.reshape(ref_c.shape))
-            parity = {"status": "bit-exact" if bad == 0 else "FAILED", "differing_words": bad,
-                      "what": "refined disparity and cost maps (2 x %dx%d float32) of pair 0 from the last timed step vs oracle/mgm_oracle.c "
-                              "on the same pair (%d threads, %.1f s)" % (nx, ny, T, secs)}
-    for x in (cv if isinstance(cv, list) else [cv]):
+    m = {"dt": dt, "rep_dt": rep_dt, "avg": {k: float(np.mean(vs)) for k, vs in kern.items()},
+         "per_step": {k: float(np.sum(vs)) / steps for k, vs in kern.items()}, "B": B, "steps": steps}
+    if keep:
+        m["outs"], m["outcs"] = outs, outcs
+    for x in cv:
         x.free()
+    for h in dus + dvs + ([] if keep else outs + outcs):
+        h.free()
+    return m
 
+
+def roofline_of(w, B, avg, workload):
+    """SURVEY.md 8(d): the aggregation = K3 (pass kernel, one launch per batch) + K4-K6 (k_wta, one launch per volume);
+    ALGORITHMIC bytes = 12 B per cell per direction (read C, read S, write S in fp32).  `frac` is that figure over the
+    measured launch times; `frac_counter` prices the same time against the HBM bytes the PMC counters saw (committed summary
+    of THESE kernels, else null); per-kernel figures use the bytes each kernel's DATA FORMAT implies (compact costs: C is
+    one byte per label), so that none of them can exceed the peak."""
+    nx, ny, L = w["nx"], w["ny"], labels_of(w)
+    cells = float(nx) * ny * L
+    pass_name = "k_pass2" if "k_pass2" in avg else "k_pass"
+    agg_ms = avg[pass_name] + B * avg["k_wta"]
+    alg_bytes = 12.0 * w["NDIR"] * cells * B
+    achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
+    cbytes = 1.0 if compact_costs(w) else 4.0
+    traffic, traffic_src = None, None
+    for prof in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
+        tj = json.load(open(os.path.join(ROOT, "profiles", prof)))
+        if tj.get("workload") == workload and tj.get("pairs_per_step") == B and tj.get("kernel_source_sha") == kernel_source_hash():
+            traffic, traffic_src = tj.get("aggregation_hbm_bytes_per_step"), "profiles/" + prof
+            break
+    fmt = {pass_name: (cbytes + 4.0) * w["NDIR"] * cells * B,          # reads C once per direction, writes one Lr volume per direction
+           "k_wta": (4.0 * w["NDIR"] + cbytes) * cells + 8.0 * nx * ny,  # reads NDIR Lr volumes + C, writes two W*H maps
+           "k_cost": cbytes * cells}                                     # writes C (the images are negligible)
+    per_kernel = {k: {"format_bytes": b, "GBps": b / (avg[k] * 1e-3) / 1e9, "frac": b / (avg[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                  for k, b in fmt.items() if k in avg}
+    return {"bound": "hbm", "kernel": "%s (one launch per batch of %d volumes) + k_wta (one launch per volume): the %d-direction aggregation" % (pass_name, B, w["NDIR"]),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "achieved_counter": (traffic / (agg_ms * 1e-3) / 1e9) if traffic else None,
+            "frac_counter": (traffic / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "algorithmic_bytes_per_launch": alg_bytes, "aggregation_ms": agg_ms,
+            "avg_launch_ms": {k: avg[k] for k in sorted(avg)}, "per_kernel": per_kernel}
+
+
+def replicas_leg(env, name, steps, warmup):
+    """BASELINE config 5: replicas only -- 16 independent pairs per step and GPU, no communication."""
+    w = WORKLOADS[name]
+    B = 16
+    m = pairs_leg(env, w, B, steps, warmup, 0)
+    from mgm_amd import shard
+    rf = roofline_of(w, B, m["avg"], name)
+    pass_name = "k_pass2" if "k_pass2" in m["avg"] else "k_pass"
+    return {"workload": "%s: %s" % (name, w["desc"]), "value": shard.job_rate([steps * B] * env.n_ranks, m["dt"]), "unit": "disparity-volumes/s",
+            "n_gpus": env.n_ranks, "pairs_per_step_per_gpu": B, "steps": steps, "warmup": warmup, "ms_per_step": m["dt"] / steps * 1e3,
+            "scaling": "weak", "parallelism": "replicas only: independent pairs, no data-path collective",
+            "k2_ms": m["avg"].get("k_cost"), "k3_ms": m["avg"][pass_name], "wta_ms": m["avg"]["k_wta"], "roofline_frac": rf["frac"]}
+
+
+def directions_legs(env, name, steps, warmup, timeout_s, transports=("single", "peer", "rccl")):
+    """BASELINE config 4: ONE volume, its passes sharded by direction over the ranks.  Sub-legs, each guarded:
+      single  the whole aggregation on rank 0's GPU (the N = 1 figure of the strong-scaling curve, and the result the
+              others are compared with, bit for bit)
+      peer    rank 0's process drives ALL N GPUs through mgm_multi_* with device-to-device copies for the exchange
+      rccl    one process per GPU, mgm_amd/dist.py: agree, then the ordered slab exchange over RCCL, time-boxed
+    Every rank must call this (the control barriers keep the idle ranks off the GPUs while rank 0 works alone)."""
+    from mgm_amd import dist as mdist
+    w = WORKLOADS[name]
+    ctx, rank, world, torch, dist = env.ctx, env.rank, env.n_ranks, env.torch, env.dist
+    nx, ny, L, NDIR = w["nx"], w["ny"], labels_of(w), w["NDIR"]
+    res = {"workload": "%s: %s" % (name, w["desc"]), "ranks": world, "unit": "disparity-volumes/s", "scaling": "strong",
+           "steps": steps, "warmup": warmup}
+    if env.stub:
+        return stub_directions(env, res, steps)
+    u, v, _ = pair_of(w, 0)  # every rank holds the SAME pair and builds the full cost volume itself
+    du, dv = ctx.upload_image(u), ctx.upload_image(v)
+
+    def build(c, a, b, into=None):
+        return c.costvolume_dev(a, b, w["dmin"], w["dmax"], "none", "census", float("inf"), w["win"], into=into)
+
+    def stage_ms(c):
+        t = {}
+        for n, ms in c.timings():
+            t.setdefault(n, []).append(ms)
+        return {k: float(np.mean(x)) for k, x in t.items()}
+
+    ref = {}
+    # ---- single ----
+    if "single" in transports:
+        if rank == 0:
+            try:
+                cv, o, c = None, None, None
+                for it in range(warmup + 1):
+                    if it == warmup:
+                        ctx.synchronize()
+                        ctx.timing(True)
+                        ctx.timing_reset()
+                        t0 = time.perf_counter()
+                    for _ in range(steps if it == warmup else 1):
+                        cv = build(ctx, du, dv, cv)
+                        _, o, c = ctx.aggregate_dev(cv, w["P1"], w["P2"], NDIR, w["MGM"], w["FH"], 1, None, "vfit", out=o, outcost=c)
+                ctx.synchronize()
+                dt = time.perf_counter() - t0
+                a = stage_ms(ctx)
+                ctx.timing(False)
+                pn = "k_pass2" if "k_pass2" in a else "k_pass"
+                agg = a[pn] + a["k_wta"]
+                res["single"] = {"value": steps / dt, "ms_per_volume": dt / steps * 1e3, "k2_ms": a.get("k_cost"), "k3_ms": a[pn], "wta_ms": a["k_wta"],
+                                 "roofline_frac": 12.0 * NDIR * float(nx) * ny * L / (agg * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                ref["o"], ref["c"] = o.download()[0], c.download()[0]
+                for h in (cv, o, c):
+                    h.free()
+            except Exception as e:  # noqa: BLE001
+                res["single"] = {"error": repr(e)[:300]}
+            ctx.trim()
+        env.ctrl_barrier()
+    # ---- peer: one process, all GPUs, device-to-device copies ----
+    if "peer" in transports and world > 1:
+        if rank == 0:
+            try:
+                import mgm_amd
+                os.environ["MGM_MULTI_TRANSPORT"] = "peer"
+                m = mgm_amd.Multi(list(range(world)))
+                try:
+                    ims = [(m.ctx[k].upload_image(u), m.ctx[k].upload_image(v)) for k in range(world)]
+                    cvs = [None] * world
+                    o, c = m.ctx[0].new_image(nx, ny), m.ctx[0].new_image(nx, ny)
+                    for it in range(warmup + 1):
+                        if it == warmup:
+                            for k in range(world):
+                                m.ctx[k].synchronize()
+                            m.ctx[0].timing(True)
+                            m.ctx[0].timing_reset()
+                            t0 = time.perf_counter()
+                        for _ in range(steps if it == warmup else 1):
+                            cvs = [build(m.ctx[k], ims[k][0], ims[k][1], cvs[k]) for k in range(world)]
+                            m.aggregate_dev(cvs, w["P1"], w["P2"], NDIR, w["MGM"], w["FH"], 1, "vfit", o, c)  # returns when the result is on device 0
+                    dt = time.perf_counter() - t0
+                    a = stage_ms(m.ctx[0])
+                    pn = "k_pass2" if "k_pass2" in a else "k_pass"
+                    res["peer"] = {"value": steps / dt, "ms_per_volume": dt / steps * 1e3, "transport": m.transport(), "k2_ms": a.get("k_cost"),
+                                   "k3_ms": a.get(pn), "wta_ms": a.get("k_wta"), "what": "ONE process drives all %d GPUs (mgm_multi_*), slabs by device-to-device copies" % world}
+                    po, pc = o.download()[0], c.download()[0]
+                    if ref:
+                        res["peer"]["differs_from_single"] = nd(po, ref["o"]) + nd(pc, ref["c"])
+                    else:
+                        ref["o"], ref["c"] = po, pc
+                finally:
+                    m.close()
+            except Exception as e:  # noqa: BLE001
+                res["peer"] = {"error": repr(e)[:300]}
+        env.ctrl_barrier()
+    # ---- rccl: one process per GPU ----
+    if "rccl" in transports and world > 1:
+        variants = [("rccl", False)] + ([("rccl_overlap", True)] if mdist.n_rounds(NDIR, world) > 1 else [])
+        cv = None
+        for key, overlap in variants:
+            stats, err, got = {}, None, None
+            try:
+                for it in range(warmup + 1):
+                    if it == warmup:
+                        env.sync_all()
+                        stats.clear()
+                        ctx.timing(True)
+                        ctx.timing_reset()
+                        t0 = time.perf_counter()
+                    for _ in range(steps if it == warmup else 1):
+                        cv = build(ctx, du, dv, cv)
+                        got = mdist.aggregate_direction_sharded(ctx, cv, w["P1"], w["P2"], NDIR, w["MGM"], w["FH"], 1, "vfit", dist, None, None,
+                                                                env.ctrl, timeout_s, overlap, stats)
+                env.sync_all()
+                dt = env.max_over_ranks(time.perf_counter() - t0)
+                a = stage_ms(ctx)
+                ctx.timing(False)
+            except Exception as e:  # noqa: BLE001 -- ExchangeTimeout: the group is wedged, no further collective on it
+                err = e
+            if err is not None:
+                res[key] = {"error": repr(err)[:300]}
+                if isinstance(err, mdist.ExchangeTimeout) or not isinstance(err, mdist.ExchangeError):
+                    res[key]["fatal"] = True
+                    break
+                continue
+            n = max(1, stats.get("steps", 1))
+            pn = "k_pass2" if "k_pass2" in a else "k_pass"
+            res[key] = {"value": steps / dt, "ms_per_volume": dt / steps * 1e3, "rccl_ranks": world, "overlap": overlap, "k2_ms": a.get("k_cost"),
+                        "k3_ms": a.get(pn), "passes_ms": stats.get("passes_ms", 0.0) / n, "exchange_ms": stats.get("exchange_ms", 0.0) / n,
+                        "wta_ms": stats.get("wta_ms", 0.0) / n, "gather_ms": stats.get("gather_ms", 0.0) / n,
+                        "what": "one process per GPU; rank 0's stage times (torch events on the library's stream): its passes, the wait for the "
+                                "slabs after them, its rows' ordered sum + WTA + vfit, the all-gather of the rows"}
+            if rank == 0 and ref:
+                res[key]["differs_from_single"] = nd(got[0].cpu().numpy(), ref["o"]) + nd(got[1].cpu().numpy(), ref["c"])
+        if cv is not None:
+            cv.free()
+    du.free(), dv.free()
+    best = [(res[k]["value"], k) for k in ("rccl", "rccl_overlap", "peer", "single") if isinstance(res.get(k), dict) and "value" in res[k]
+            and (world == 1 or k != "single")]
+    if best:
+        res["value"], res["transport"] = max(best)
+        if "single" in res and "value" in res["single"]:
+            res["speedup_vs_single"] = res["value"] / res["single"]["value"]
+    return res
+
+
+def stub_directions(env, res, steps):
+    """MGM_BENCH_STUB: the control flow of the direction-sharded leg on CPU ranks -- agreement and the ordered slab
+    exchange over gloo on small host tensors (mgm_amd/dist.py, the code the RCCL leg runs), no device work."""
+    from mgm_amd import dist as mdist
+    torch, dist = env.torch, env.dist
+    world, rank = env.n_ranks, env.rank
+    NDIR, ny, nx, L = 8, 13, 21, 10
+    if world == 1:
+        res["single"] = {"value": 1.0, "stub": True}
+        res["value"], res["transport"] = 1.0, "single"
+        return res
+    t0 = time.perf_counter()
+    bad = 0
+    for s in range(steps):
+        first, count = mdist.passes_of_rank(NDIR, world, rank)
+        gen = torch.Generator().manual_seed(1234 + s)
+        vols = torch.rand((NDIR, ny, nx, L), generator=gen)  # (every rank can regenerate every pass: the check below)
+        if not mdist.agree(True, dist, None, env.ctrl, "cpu"):
+            raise RuntimeError("stub agreement failed")
+        recv = mdist.exchange_lr([vols[p] for p in range(first, first + count)], NDIR, ny, dist, like=vols[0, :0], timeout_s=60.0)
+        r0, nr = mdist.row_slabs(ny, world)[rank]
+        bad += int((recv != vols[:, r0:r0 + nr]).sum())
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    res["rccl"] = {"value": steps / dt, "ms_per_volume": dt / steps * 1e3, "rccl_ranks": world, "overlap": False, "stub": True,
+                   "differs_from_single": bad}
+    res["value"], res["transport"] = res["rccl"]["value"], "rccl"
+    return res
+
+
+# ---- main ---------------------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity gate (profiling runs)")
+    ap.add_argument("--repeats", type=int, default=None,
+                    help="further timed blocks of K steps after the reported one (their rates go to `repeat_values`); "
+                         "default: as many as make the GPU phase last about 10 s, at most 8")
+    ap.add_argument("--batch", type=int, default=None, choices=list(range(1, 17)),
+                    help="pairs per step and GPU: their volumes share ONE launch of the pass kernel.  Default: "
+                         "12 (204 GB of Lr volumes at 1920x1080x256 x 8 directions), 16 for workloads of at most 128 labels "
+                         "(two / four of those volumes share every wave), 1 for cfg4")
+    ap.add_argument("--mode", default="pairs", choices=["pairs", "directions"],
+                    help="'pairs' = independent pairs (weak scaling, the headline); 'directions' = only the direction-sharded "
+                         "leg: ONE volume per step, its passes sharded over the GPUs with the ordered slab exchange (strong)")
+    ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
+                    help="the cfg5-replicas and cfg4-directions legs after the headline; auto = on for the plain command line")
+    ap.add_argument("--extras-timeout", type=float, default=420.0, help="seconds the guarded extras may take altogether")
+    ap.add_argument("--exchange-timeout", type=float, default=90.0, help="seconds one direction-sharded step may take")
+    args = ap.parse_args()
+    plain = args.workload is None and args.batch is None and args.mode == "pairs"
+    extras = args.extras == "on" or (args.extras == "auto" and plain)
+    wname = args.workload or ("cfg4" if args.mode == "directions" else "cfg3")
+    w = WORKLOADS[wname]
+    stub = bool(os.environ.get("MGM_BENCH_STUB"))  # tests/test_dist_cpu.py: gloo ranks on CPU, a context that computes nothing
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
+    env = Env(args, stub)
+    env.setup()
+    rank, n_ranks, ctx = env.rank, env.n_ranks, env.ctx
+    line = OneLine(rank)
+    nx, ny, L = w["nx"], w["ny"], labels_of(w)
+    cells = float(nx) * ny * L
+
+    if args.mode == "directions":  # the direction-sharded leg alone, as the headline
+        line.guard(args.extras_timeout)
+        d = directions_legs(env, wname, args.steps, args.warmup, args.exchange_timeout, ("single", "rccl") if n_ranks > 1 else ("single",))
+        if rank == 0:
+            key = d.get("transport", "single")
+            sub = d.get(key, {})
+            line.res = {"metric": "disparity-volumes/sec (W*H*L cost volume -> 8-dir MGM -> WTA+vfit)", "value": d.get("value"),
+                        "unit": "disparity-volumes/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
+                        "ms_per_step": sub.get("ms_per_volume"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                        "data": "synthetic" if not stub else "stub (no device work)",
+                        "config": {"workload": "%s: %s" % (wname, w["desc"]), "W": nx, "H": ny, "L": L, "pairs_per_step": 1,
+                                   "parallelism": "one volume, %d-way direction sharding, ordered slab exchange (%s)" % (n_ranks, key)},
+                        "directions": d}
+        line.emit(env.dist is not None)
+        ctx.close()
+        return 0
+
+    if args.batch is None:
+        args.batch = 1 if wname == "cfg4" else (16 if L <= 128 else 12)
+    B = args.batch
+    m = pairs_leg(env, w, B, args.steps, args.warmup, args.repeats, keep=True)
+    dt = m["dt"]
     if rank == 0:
-        vols_per_block = args.steps * (n_ranks * B if args.mode == "pairs" else 1)
-        if args.mode == "pairs":
-            value = shard.job_rate([args.steps * B] * n_ranks, dt)  # whole-job aggregate: every rank did K batches of B volumes
-        else:
-            value = args.steps / dt                                # K volumes, each computed by all ranks together
-        avg = {k: float(np.mean(vs)) for k, vs in kern.items()}
-        per_step = {k: float(np.sum(vs)) / args.steps for k, vs in kern.items()}
-        pass_name = "k_pass2" if "k_pass2" in avg else "k_pass"
-        # in directions mode rank 0 ran NDIR/world passes and summed ny/world rows per launch
-        frac_pass = (mdist.passes_of_rank(w["NDIR"], n_ranks, 0)[1] / w["NDIR"]) if args.mode == "directions" else 1.0
-        frac_rows = (mdist.row_slabs(ny, n_ranks)[0][1] / ny) if args.mode == "directions" else 1.0
-        # Aggregation stage = K3 (pass kernel) + K4-K6 (k_wta): the two launches together do what the
-        # reference's aggregation loop does; SURVEY.md 8(d): 12 B per cell per direction.
-        # With a batch of B volumes per step the pass kernel is launched once (over all of them) and k_wta B times.
-        agg_ms = avg[pass_name] + B * avg["k_wta"]
-        alg_bytes = 12.0 * w["NDIR"] * cells * (float(B) if args.mode == "pairs" else (2.0 / 3.0) * frac_pass + (1.0 / 3.0) * frac_rows)
-        achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
-        # HBM bytes from PMC counters: a committed summary counts only if it was measured on THESE kernels
-        traffic, traffic_src = None, None
-        for prof in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
-            tj = json.load(open(os.path.join(ROOT, "profiles", prof)))
-            if tj.get("workload") == args.workload and tj.get("pairs_per_step") == B and tj.get("kernel_source_sha") == kernel_source_hash():
-                traffic, traffic_src = tj.get("aggregation_hbm_bytes_per_step"), "profiles/" + prof
-                break
-        roofline = {"bound": "hbm", "kernel": "%s (one launch per batch of %d volumes) + k_wta (one launch per volume): the %d-direction aggregation" % (pass_name, B, w["NDIR"]),
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
-                    "avg_launch_ms": {k: avg[k] for k in sorted(avg)},
-                    "per_kernel": {
-                        pass_name: {"alg_bytes": 8.0 * w["NDIR"] * cells * B,
-                                    "GBps": 8.0 * w["NDIR"] * cells * B / (avg[pass_name] * 1e-3) / 1e9},
-                        "k_wta": {"alg_bytes": (4.0 * w["NDIR"] + 4.0) * cells + 8.0 * nx * ny,
-                                  "GBps": ((4.0 * w["NDIR"] + 4.0) * cells) / (avg["k_wta"] * 1e-3) / 1e9},
-                        # single-word census costs are written once, as one byte per label (the fp32 volume is never made)
-                        "k_cost": {"alg_bytes": 1.0 * cells, "GBps": 1.0 * cells / (avg["k_cost"] * 1e-3) / 1e9}}}
-        res = {"metric": "disparity-volumes/sec (W*H*L cost volume -> 8-dir MGM -> WTA+vfit)", "value": value,
-               "unit": "disparity-volumes/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.mode == "pairs" else "strong",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not stub else "stub (no device work)",
-               "config": {"workload": "%s: %s" % (args.workload, w["desc"]), "W": nx, "H": ny, "L": L, "pairs_per_step": B,
-                          "NDIR": w["NDIR"], "TSGM": w["MGM"], "potential": "FH" if w["FH"] else "Hirschmueller",
-                          "P1": w["P1"], "P2": w["P2"], "census_win": w["win"], "refine": "vfit",
-                          "parallelism": ("independent pairs, %d per step and GPU, no data-path collective" % B if args.mode == "pairs" else
-                                          "one volume, %d-way direction sharding, ordered RCCL slab exchange" % n_ranks)
-                          if n_ranks > 1 or args.mode == "directions" else "1 GPU"},
-               "roofline": roofline,
-               "kernel_ms_per_step": per_step,
-               "repeat_values": [vols_per_block / t for t in rep_dt],
-               "parity": parity,
-               "mcell_updates_per_s": vols_per_block * cells * w["NDIR"] / dt / 1e6}
-        if n_ranks == 1 and not args.no_cpu_baseline and not stub:
-            res["cpu_baseline"] = cpu_baseline(w, whole)
+        from mgm_amd import shard
+        vols_per_block = args.steps * n_ranks * B
+        line.res = res = {
+            "metric": "disparity-volumes/sec (W*H*L cost volume -> 8-dir MGM -> WTA+vfit)",
+            "value": shard.job_rate([args.steps * B] * n_ranks, dt),  # whole-job aggregate: every rank did K batches of B volumes
+            "unit": "disparity-volumes/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not stub else "stub (no device work)",
+            "config": {"workload": "%s: %s" % (wname, w["desc"]), "W": nx, "H": ny, "L": L, "pairs_per_step": B,
+                       "NDIR": w["NDIR"], "TSGM": w["MGM"], "potential": "FH" if w["FH"] else "Hirschmueller",
+                       "P1": w["P1"], "P2": w["P2"], "census_win": w["win"], "refine": "vfit",
+                       "parallelism": ("independent pairs, %d per step and GPU, no data-path collective" % B) if n_ranks > 1 else "1 GPU"},
+            "roofline": roofline_of(w, B, m["avg"], wname),
+            "kernel_ms_per_step": m["per_step"],
+            "repeat_values": [vols_per_block / t for t in m["rep_dt"]],
+            "parity": None,
+            "mcell_updates_per_s": vols_per_block * cells * w["NDIR"] / dt / 1e6}
+
+    # ---- parity gate: pair 0 of the last timed step against the CPU oracle; CPU baseline --------------------------------
+    parity, whole_s, T = None, None, 1
+    if rank == 0 and not stub:
+        from oracle.oracle import usable_cpus
+        T = min(32, usable_cpus())
+        if not args.no_parity:
+            if cells > PARITY_MAX_CELLS:
+                parity = {"status": "skipped", "why": "%.1f G cells: beyond the in-run oracle (covered by tests/test_gpu_fullsize.py)" % (cells / 1e9)}
+            else:
+                got_o, got_c = m["outs"][0].download()[0], m["outcs"][0].download()[0]
+                ref_o, ref_c, whole_s = oracle_whole_volume(w, T)
+                bad = nd(ref_o, got_o.reshape(ref_o.shape)) + nd(ref_c, got_c.reshape(ref_c.shape))
+                parity = {"status": "bit-exact" if bad == 0 else "FAILED", "differing_words": bad,
+                          "what": "refined disparity and cost maps (2 x %dx%d float32) of pair 0 from the last timed step vs oracle/mgm_oracle.c "
+                                  "on the same pair (%d threads, %.1f s)" % (nx, ny, T, whole_s)}
+                if bad:
+                    line.code = 3
+            res["parity"] = parity
+        if n_ranks == 1 and not args.no_cpu_baseline and cells <= PARITY_MAX_CELLS:
+            res["cpu_baseline"], ref_out = cpu_baseline(w, whole_s, T)
+            if ref_out and parity is not None and parity.get("status") != "skipped":  # the reference's own maps, while we have them
+                got_o, got_c = m["outs"][0].download()[0], m["outcs"][0].download()[0]
+                parity["vs_reference_differing_words"] = nd(ref_out["o"], got_o.reshape(ref_out["o"].shape)) + nd(ref_out["c"], got_c.reshape(ref_out["c"].shape))
+                if parity["vs_reference_differing_words"]:
+                    parity["status"], line.code = "FAILED", 3
+    for h in m["outs"] + m["outcs"]:
+        h.free()
+
+    # ---- the extra legs (guarded) ------------------------------------------------------------------------------------
+    if extras:
+        line.guard(args.extras_timeout)
+        ctx.trim()
+        env.ctrl_barrier()  # (rank 0 may have spent a minute in the CPU legs)
+        try:
+            r5 = replicas_leg(env, "cfg5", max(5, args.steps), min(args.warmup, 2))
+            if rank == 0:
+                res["cfg5_replicas"] = r5
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                res["cfg5_replicas"] = {"error": repr(e)[:300]}
+        ctx.trim()
+        try:
+            d = directions_legs(env, "cfg4", max(2, min(args.steps, 5)), 1, args.exchange_timeout)
+            if rank == 0:
+                res["directions"] = d
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                res["directions"] = {"error": repr(e)[:300]}
+    failed = line.code != 0
+    if rank == 0 and failed:
+        print("bench.py: PARITY GATE FAILED: %s" % json.dumps(res.get("parity")), file=sys.stderr, flush=True)
+    if env.dist is not None:
+        line.emit(True)  # (os._exit: librccl leaves a version banner in the C stdio buffer that would be flushed after the json)
+    line.emit(False)
     ctx.close()
-    if dist is not None and dist.is_initialized():
-        dist.destroy_process_group()
-    failed = False
-    if rank == 0:
-        sys.stdout.flush()
-        print(json.dumps(res), flush=True)  # the ONE json line, last thing on stdout
-        failed = parity is not None and parity["status"] == "FAILED"
-        if failed:
-            print("bench.py: PARITY GATE FAILED: %d words differ from the oracle" % parity["differing_words"], file=sys.stderr, flush=True)
-    if dist is not None:
-        os._exit(3 if failed else 0)  # librccl leaves a version banner in the C stdio buffer that would be flushed after the json
-    sys.exit(3 if failed else 0)
+    return line.code
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -61,6 +61,10 @@ int mgm_ctx_synchronize(mgm_ctx *ctx);
 /* Hand the context's grow-only workspace (Lr volumes of the largest aggregation so far, hand-off slots, ...) back to the
  * device; it is allocated again on demand.  Synchronises. */
 int mgm_ctx_trim(mgm_ctx *ctx);
+/* Cap, in bytes, on the workspace ONE pass launch may take (the NDIR Lr volumes of every batched volume and the
+ * hand-off slots; 0 = no cap, the default).  mgm_aggregate_batch_dev runs a batch that exceeds it -- or that the
+ * device cannot hold -- as several launches over the largest sub-batches that fit instead of returning MGM_ERR_NOMEM. */
+int mgm_ctx_set_workspace_limit(mgm_ctx *ctx, unsigned long long bytes);
 void *mgm_ctx_stream(mgm_ctx *ctx); /* the hipStream_t everything is enqueued on */
 const char *mgm_version(void);
 
@@ -78,6 +82,7 @@ int mgm_img_upload(mgm_ctx *ctx, const float *host, int nx, int ny, int nch, mgm
 int mgm_img_download(mgm_ctx *ctx, const mgm_img *img, float *host);
 int mgm_img_dims(const mgm_img *img, int *nx, int *ny, int *nch);
 void *mgm_img_device_ptr(mgm_img *img);
+int mgm_img_device(const mgm_img *img); /* HIP device ordinal the pixels live on (-1: NULL) */
 int mgm_img_free(mgm_ctx *ctx, mgm_img *img);
 
 /* ---- volumes (costvolume_t, mgm_costvolume.h:311-327) ------------------ */
@@ -86,6 +91,7 @@ int mgm_cv_upload(mgm_ctx *ctx, const float *dense, int nx, int ny, int dmin, in
 int mgm_cv_download(mgm_ctx *ctx, const mgm_cv *cv, float *dense);
 int mgm_cv_dims(const mgm_cv *cv, int *nx, int *ny, int *dmin, int *dmax);
 void *mgm_cv_device_ptr(mgm_cv *cv);
+int mgm_cv_device(const mgm_cv *cv); /* HIP device ordinal of the context that made the volume (-1: NULL) */
 int mgm_cv_free(mgm_ctx *ctx, mgm_cv *cv);
 
 /* ---- cost volume: allocate_and_fill_sgm_costvolume --------------------- */
@@ -161,30 +167,49 @@ int mgm_aggregate_batch_dev(mgm_ctx *ctx, int n, const mgm_cv *const *C, const m
  * out_rows / outcost_rows are device buffers of nrows*nx floats. */
 int mgm_aggregate_passes_dev(mgm_ctx *ctx, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int MGM, int use_fh,
                              int first_pass, int n_passes);
+/* The same with the caller placing the Lr volumes: pass first_pass+k lands in workspace slot slot0+k of n_slots, and
+ * the hand-off region is laid out once for the passes [0, NDIR_total).  For callers that launch the passes of a
+ * volume ONE AT A TIME so that pass k's slabs travel while pass k+1 runs (mgm_multi_aggregate, mgm_amd/dist.py). */
+int mgm_aggregate_passes_at_dev(mgm_ctx *ctx, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int MGM, int use_fh,
+                                int first_pass, int n_passes, int slot0, int n_slots, int NDIR_total);
 void *mgm_lr_device_ptr(mgm_ctx *ctx, int slot);
 int mgm_wta_rows_dev(mgm_ctx *ctx, const mgm_cv *C, int row0, int nrows, const void *lr_slabs, int NDIR,
                      int fix_overcount, const char *refine, void *out_rows, void *outcost_rows);
 
 /* ---- the same, driven from ONE host thread for n GPUs of a node: mgm_multi ---------------------------------------
- * An mgm_ctx per device plus an RCCL communicator over the devices (librccl is loaded on first use).  The CPU analogue
- * in the reference is mgm_naive_parallelism (mgm_core.cc:632-831, WITH_MGM2=1): passes in parallel on private Lr
- * volumes, then accumulated -- here always in pass order, so the result is mgm()'s bit for bit.
- *   mgm_multi_create     device_ids: n distinct HIP devices (gfx950).  MGM_ERR_HIP without librccl or a device.
- *                        (MGM_MULTI_LOOPBACK=1 in the environment: a device may appear several times and slabs travel by
- *                        device-to-device copies instead of ncclSend/ncclRecv -- the n-rank path on a one-GPU box, tests.)
+ * An mgm_ctx per device plus a transport for the row slabs.  The CPU analogue in the reference is
+ * mgm_naive_parallelism (mgm_core.cc:632-831, WITH_MGM2=1): passes in parallel on private Lr volumes, then accumulated
+ * -- here always in pass order, so the result is mgm()'s bit for bit.
+ *   mgm_multi_create     device_ids: n distinct HIP devices (gfx950).  Transport (mgm_multi_transport tells which):
+ *                          "rccl"      grouped ncclSend/ncclRecv on a communicator over the devices (librccl is loaded on
+ *                                      first use) -- the default;
+ *                          "peer"      the receiving device PULLS each slab with a device-to-device copy on a second
+ *                                      stream, ordered by events: MGM_MULTI_TRANSPORT=peer, and what the handle falls back
+ *                                      to when librccl cannot be loaded or its communicator cannot be made;
+ *                          "loopback"  a device id appears several times (allowed only with MGM_MULTI_LOOPBACK=1): the
+ *                                      ranks are contexts on one GPU, copies as for "peer" -- the n-rank path on a one-GPU
+ *                                      box (tests).
+ *                        On failure *m is NULL and mgm_multi_last_error(NULL) holds the reason.
  *   mgm_multi_ctx        rank k's context: build C[k] on it (mgm_costvolume_build_dev from images uploaded there).
  *   mgm_multi_aggregate  mgm() of ONE volume: C[k] = the same cost volume on every device (rebuilt there from the
- *                        images: cheaper than moving it), w8 NULL or one weight image per device; rank k runs the
- *                        passes of mgm_multi_plan's block k, grouped ncclSend/ncclRecv move the row slabs (one peer per
- *                        xGMI link, all links at once), every rank sums its rows in pass order and searches them, and
- *                        the rows are gathered into out0 / outcost0, images on device_ids[0].  Synchronous.
+ *                        images: cheaper than moving it; MGM_ERR_INVALID if C[k] or w8[k] does not live on device k, or
+ *                        out0 / outcost0 not on device_ids[0]), w8 NULL or one weight image per device; rank k runs the
+ *                        passes of mgm_multi_plan's block k, the row slabs move (one peer per xGMI link, all links at
+ *                        once), every rank sums its rows in pass order and searches them, and the rows are gathered into
+ *                        out0 / outcost0.  Synchronous; an exchange that does not complete within
+ *                        MGM_MULTI_TIMEOUT_S (default 120) seconds returns MGM_ERR_HIP after aborting the transport (the
+ *                        handle is then only good for mgm_multi_destroy).  A rank's failure is reported after EVERY
+ *                        rank's queued work has drained, never in the middle of a transfer group.
+ *                        MGM_MULTI_OVERLAP=1: ranks with several passes launch them one per launch and each pass's
+ *                        slabs leave behind it, while the next pass runs.
  *   mgm_multi_plan       the partition as data: contiguous blocks of passes and of rows per rank (sizes differ by <= 1). */
 typedef struct mgm_multi mgm_multi;
 int mgm_multi_create(const int *device_ids, int n, mgm_multi **m);
 int mgm_multi_destroy(mgm_multi *m);
 int mgm_multi_size(const mgm_multi *m);
 mgm_ctx *mgm_multi_ctx(mgm_multi *m, int rank);
-const char *mgm_multi_last_error(const mgm_multi *m);
+const char *mgm_multi_last_error(const mgm_multi *m); /* m == NULL: why the last mgm_multi_create of this thread failed */
+const char *mgm_multi_transport(const mgm_multi *m);  /* "rccl", "peer" or "loopback" */
 int mgm_multi_plan(int n, int NDIR, int ny, int *first_pass, int *n_passes, int *row0, int *nrows);
 int mgm_multi_aggregate(mgm_multi *m, const mgm_cv *const *C, const mgm_img *const *w8, float P1, float P2, int NDIR, int MGM,
                         int use_fh, int fix_overcount, const char *refine, mgm_img *out0, mgm_img *outcost0);

@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "mgm_aggregate_batch_dev", "mgm_median_dev", "mgm_leftright_dev", "mgm_backproject_dev",
     "mgm_wta_windowed_dev", "mgm_update_ranges_dev", "mgm_costvolume_build_ranged_dev",
     "mgm_multi_create", "mgm_multi_destroy", "mgm_multi_size", "mgm_multi_ctx", "mgm_multi_last_error", "mgm_multi_plan",
-    "mgm_multi_aggregate",
+    "mgm_multi_aggregate", "mgm_multi_transport", "mgm_img_device", "mgm_cv_device", "mgm_aggregate_passes_at_dev",
+    "mgm_ctx_set_workspace_limit",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -107,10 +108,16 @@ def load_library():
     L.mgm_multi_size.argtypes = [vp]
     L.mgm_multi_ctx.argtypes = [vp, i]
     L.mgm_multi_ctx.restype = vp
-    L.mgm_multi_last_error.argtypes = [vp]
+    L.mgm_multi_last_error.argtypes = [vp]  # (NULL: why the last mgm_multi_create failed)
     L.mgm_multi_last_error.restype = cp
     L.mgm_multi_plan.argtypes = [i, i, i, ip, ip, ip, ip]
     L.mgm_multi_aggregate.argtypes = [vp, pp, pp, f, f, i, i, i, i, cp, vp, vp]
+    L.mgm_multi_transport.argtypes = [vp]
+    L.mgm_multi_transport.restype = cp
+    L.mgm_img_device.argtypes = [vp]
+    L.mgm_cv_device.argtypes = [vp]
+    L.mgm_aggregate_passes_at_dev.argtypes = [vp, vp, vp, f, f, i, i, i, i, i, i, i]
+    L.mgm_ctx_set_workspace_limit.argtypes = [vp, C.c_ulonglong]
     _lib = L
     return L
 
@@ -206,6 +213,14 @@ class Context:
     def trim(self):
         """Release the grow-only workspace (mgm_ctx_trim)."""
         self._chk(self.lib.mgm_ctx_trim(self.h))
+
+    def set_workspace_limit(self, nbytes):
+        """Cap on the workspace of one pass launch; larger batches run as several launches (mgm_ctx_set_workspace_limit)."""
+        self._chk(self.lib.mgm_ctx_set_workspace_limit(self.h, int(nbytes)))
+
+    def stream_ptr(self):
+        """The hipStream_t everything is enqueued on (for torch.cuda.ExternalStream)."""
+        return int(self.lib.mgm_ctx_stream(self.h) or 0)
 
     # ---- containers ----
     def upload_image(self, a):
@@ -340,6 +355,10 @@ class Context:
         self._chk(self.lib.mgm_aggregate_passes_dev(self.h, Cv.h, w8.h if w8 is not None else None, P1, P2, MGM, use_fh,
                                                     first_pass, n_passes))
 
+    def aggregate_passes_at_dev(self, Cv, P1, P2, MGM, use_fh, first_pass, n_passes, slot0, n_slots, NDIR_total, w8=None):
+        self._chk(self.lib.mgm_aggregate_passes_at_dev(self.h, Cv.h, w8.h if w8 is not None else None, P1, P2, MGM, use_fh,
+                                                       first_pass, n_passes, slot0, n_slots, NDIR_total))
+
     def lr_device_ptr(self, slot):
         return self.lib.mgm_lr_device_ptr(self.h, slot)
 
@@ -388,20 +407,28 @@ class Multi:
         h = C.c_void_p()
         r = self.lib.mgm_multi_create(ids, len(device_ids), C.byref(h))
         if r:
-            raise MgmError(r, "mgm_multi_create(%s) failed" % (list(device_ids),))
+            raise MgmError(r, "mgm_multi_create(%s) failed: %s" % (list(device_ids), self.lib.mgm_multi_last_error(None).decode()))
         self.h = h
         self.n = len(device_ids)
         self.ctx = [Context(_borrowed=self.lib.mgm_multi_ctx(h, k)) for k in range(self.n)]
 
-    def aggregate(self, Cvs, P1, P2, NDIR, MGM, use_fh=0, fix_overcount=1, refine=None, w8s=None):
-        """mgm_multi_aggregate: returns host arrays (out, outcost)."""
-        nx, ny, _, _ = Cvs[0].dims
-        out, outc = self.ctx[0].new_image(nx, ny), self.ctx[0].new_image(nx, ny)
+    def transport(self):
+        """"rccl", "peer" or "loopback" (mgm_multi_transport)."""
+        return self.lib.mgm_multi_transport(self.h).decode()
+
+    def aggregate_dev(self, Cvs, P1, P2, NDIR, MGM, use_fh, fix_overcount, refine, out, outc, w8s=None):
+        """mgm_multi_aggregate into images on device 0 (returns when they are complete)."""
         arr = lambda hs: (C.c_void_p * self.n)(*hs)
         r = self.lib.mgm_multi_aggregate(self.h, arr([cv.h for cv in Cvs]), arr([w.h for w in w8s]) if w8s is not None else None, P1, P2,
                                          NDIR, MGM, use_fh, fix_overcount, refine.encode() if refine else None, out.h, outc.h)
         if r:
             raise MgmError(r, self.lib.mgm_multi_last_error(self.h).decode())
+
+    def aggregate(self, Cvs, P1, P2, NDIR, MGM, use_fh=0, fix_overcount=1, refine=None, w8s=None):
+        """mgm_multi_aggregate: returns host arrays (out, outcost)."""
+        nx, ny, _, _ = Cvs[0].dims
+        out, outc = self.ctx[0].new_image(nx, ny), self.ctx[0].new_image(nx, ny)
+        self.aggregate_dev(Cvs, P1, P2, NDIR, MGM, use_fh, fix_overcount, refine, out, outc, w8s)
         res = out.download()[0], outc.download()[0]
         out.free(), outc.free()
         return res

@@ -17,6 +17,7 @@ using namespace mgm;
 struct mgm_img {
     float *d;
     int nx, ny, nch;
+    int device;  // the device the pixels live on (mgm_img_device)
 };
 struct mgm_cv {
     float *d;
@@ -70,11 +71,19 @@ struct mgm_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // workspace
-    Buf lr, hand, handm, words, tasks, census_u, census_v, dbg, stmp, ones8;
+    Buf lr, hand, hand2, handm, words, tasks, census_u, census_v, dbg, stmp, ones8;  // hand: self-validating slabs (TAGS); hand2: the other kernels' slots
+    size_t ws_limit = 0;  // mgm_ctx_set_workspace_limit: cap on the Lr + hand-off workspace of one pass launch (0 = none)
     int debug_stats = 0;  // MGM_HIP_DEBUG_STATS=1: per-workgroup timing summary of K3 on stderr
     unsigned *h_words = nullptr;  // pinned mirror of the control words
     // cached task table key
     int tk_nx = -1, tk_ny = -1, tk_ndir = -1, tk_r = -1;
+    // task tables of earlier launch shapes (a caller that launches the passes of a volume one by one alternates between
+    // eight of them): {nx, ny, key, R} -> device table; `tasks` is the one in use
+    struct TaskTab {
+        int nx, ny, key, R, ntasks;
+        Buf buf;
+    };
+    std::vector<TaskTab> ttabs;
     int force_build = 0;  // 0 auto, 1 first build only (MGM_HIP_PASS_BUILD=1)
     int ntasks = 0;
     // last aggregate (for mgm_debug_download_lr)
@@ -90,7 +99,7 @@ struct mgm_ctx {
     bool pending_check = false;
     // self-validating hand-off slabs (k_pass2, TAGS): what the region was last cleared for, and the tag of its last launch
     std::string hand_key;
-    unsigned hand_tag = 0;
+    unsigned hand_tags[kMaxDirs] = {};  // per pass: the tag its slots carry after its last launch
     int num_cu = 256;  // hipDeviceProp_t::multiProcessorCount
     // timing
     bool timing = false;
@@ -159,6 +168,10 @@ int reserve(mgm_ctx *c, Buf &b, size_t bytes)
     return MGM_OK;
 }
 
+// the control words of the pass kernel (and a little scratch for others): zeroed when they come into being -- word 1, the
+// watchdog word, is never reset by a launch (check_watchdog)
+int ensure_words(mgm_ctx *c);
+
 struct TimeScope {  // brackets one kernel launch with events when timing is on
     mgm_ctx *c;
     Timing t{};
@@ -180,6 +193,14 @@ struct TimeScope {  // brackets one kernel launch with events when timing is on
         c->tim.push_back(t);
     }
 };
+
+int ensure_words(mgm_ctx *c)
+{
+    const void *before = c->words.p;
+    if (int r = reserve(c, c->words, sizeof(unsigned) * (4 + (size_t)kMaxBatch * kMaxDirs * 4096))) return r;
+    if (c->words.p != before) HIPCHK(c, hipMemsetAsync(c->words.p, 0, c->words.cap, c->stream));
+    return MGM_OK;
+}
 
 // name tables with the reference's silent fall-back to entry 0
 int distance_index(const char *n)  // mgm_costvolume.h:170-190
@@ -266,16 +287,20 @@ bool make_geom(int pass, int nx, int ny, int R, int MGM, bool slope1_ok, PassGeo
 
 }  // namespace
 
-// The watchdog word of the last pass launch lands in h_words[1] with the stream's next synchronisation.  Every
-// internal synchronisation point and every new pass launch looks at it, so that a hand-off time-out of one
-// launch is reported by the next call at the latest, not overwritten by it.
-static int check_watchdog(mgm_ctx *c)
+// The watchdog word of the pass kernel is STICKY on the device: no launch resets it, a copy of it follows every pass
+// launch into h_words[1], and only the host clears it, once it has seen it set.  A hand-off time-out of one launch is
+// therefore reported by whichever call next finds the stream idle (block = false: pass launches look without waiting --
+// nothing on the hot path synchronises for it) or synchronises anyway (block = true), and cannot be overwritten by a
+// later launch's copy.
+static int check_watchdog(mgm_ctx *c, bool block = true)
 {
     if (!c->pending_check) return MGM_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (block) HIPCHK(c, hipStreamSynchronize(c->stream));
+    else if (hipStreamQuery(c->stream) != hipSuccess) return MGM_OK;  // still running: the word is looked at later
     c->pending_check = false;
     if (c->h_words[1] != 0) {
         c->h_words[1] = 0;
+        if (c->words.p) (void)hipMemsetAsync((unsigned *)c->words.p + 1, 0, sizeof(unsigned), c->stream);
         c->hand_key.clear();  // (the launch may have left its hand-off slots half written)
         return fail(c, MGM_ERR_INTERNAL, "pass kernel watchdog: inter-band hand-off timed out");
     }
@@ -321,11 +346,13 @@ int mgm_ctx_destroy(mgm_ctx *c)
     if (!c) return MGM_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->handm, &c->words, &c->tasks, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
+    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->words, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);
         bufs.push_back(&c->pad8[v]);
     }
+    for (auto &t : c->ttabs)
+        if (t.buf.p) (void)hipFree(t.buf.p);
     for (Buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &t : c->tim) {
@@ -346,7 +373,7 @@ int mgm_ctx_trim(mgm_ctx *c)
     if (!c) return MGM_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     if (int r = mgm_ctx_synchronize(c)) return r;
-    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->handm, &c->tasks, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
+    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);
         bufs.push_back(&c->pad8[v]);
@@ -359,8 +386,19 @@ int mgm_ctx_trim(mgm_ctx *c)
     c->hand_key.clear();
     c->tk_nx = c->tk_ny = c->tk_ndir = c->tk_r = -1;
     c->ntasks = 0;
+    for (auto &t : c->ttabs)
+        if (t.buf.p) (void)hipFree(t.buf.p);
+    c->ttabs.clear();
+    c->tasks = Buf{};
     c->last_ndir = c->last_batch = 0;
     for (int v = 0; v < kMaxBatch; v++) c->last_cvs[v] = nullptr;
+    return MGM_OK;
+}
+
+int mgm_ctx_set_workspace_limit(mgm_ctx *c, unsigned long long bytes)
+{
+    if (!c) return MGM_ERR_INVALID;
+    c->ws_limit = (size_t)bytes;
     return MGM_OK;
 }
 
@@ -410,7 +448,7 @@ int mgm_img_create(mgm_ctx *c, int nx, int ny, int nch, mgm_img **out)
 {
     if (!c || !out || nx <= 0 || ny <= 0 || nch <= 0) return fail(c, MGM_ERR_INVALID, "mgm_img_create: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    mgm_img *im = new mgm_img{nullptr, nx, ny, nch};
+    mgm_img *im = new mgm_img{nullptr, nx, ny, nch, c->device};
     hipError_t e = hipMalloc((void **)&im->d, sizeof(float) * (size_t)nx * ny * nch);
     if (e != hipSuccess) {
         delete im;
@@ -451,6 +489,7 @@ int mgm_img_dims(const mgm_img *im, int *nx, int *ny, int *nch)
     return MGM_OK;
 }
 void *mgm_img_device_ptr(mgm_img *im) { return im ? im->d : nullptr; }
+int mgm_img_device(const mgm_img *im) { return im ? im->device : -1; }
 int mgm_img_free(mgm_ctx *c, mgm_img *im)
 {
     if (!im) return MGM_OK;
@@ -554,6 +593,7 @@ int mgm_cv_dims(const mgm_cv *cv, int *nx, int *ny, int *dmin, int *dmax)
     if (dmax) *dmax = cv->dmax;
     return MGM_OK;
 }
+int mgm_cv_device(const mgm_cv *cv) { return (cv && cv->owner) ? cv->owner->device : -1; }
 void *mgm_cv_device_ptr(mgm_cv *cv)
 {
     if (!cv) return nullptr;
@@ -804,6 +844,10 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         dev().lazy_f32) {
         p.C = nullptr;
         (*out)->f32_state = 0;
+        // these kernels (k_cost_census8*) compute min(popcount, trunc) in integers: every cost has a compact form and none
+        // is NaN BY CONSTRUCTION, so there is no flag to read back -- a refilled volume costs no synchronisation
+        (*out)->c8_state = 2;
+        (*out)->nan_state = 2;
     } else {
         if ((r = cv_alloc_f32(c, *out))) return r;
         p.C = (*out)->d;
@@ -877,9 +921,14 @@ static int padded_labels(int L)
     return 0;
 }
 
+// slot0 / nslots: pass p's Lr volume goes to workspace slot slot0 + (p - first) of nslots (a caller that launches the
+// passes of one volume one at a time keeps them all: mgm_aggregate_passes_at_dev); layout_ndir: the hand-off region is
+// laid out for the passes [0, layout_ndir) whichever of them this launch runs, so that such a caller's launches share it.
 static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int nb, float P1, float P2, int MGM,
-                      int use_fh, int first, int count, bool allow_pad = false)
+                      int use_fh, int first, int count, bool allow_pad = false, int slot0 = 0, int nslots = 0, int layout_ndir = 0)
 {
+    if (nslots <= 0) nslots = slot0 + count;
+    if (layout_ndir < first + count) layout_ndir = first + count;
     const mgm_cv *C = Cs[0];
     const int nx = C->nx, ny = C->ny, Lreal = C->dmax - C->dmin + 1;
     const int PEND = first + count;
@@ -891,7 +940,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // The second build's unweighted kernels keep the sign bit of the slabs they hand from band to band for a validity
     // tag, which needs E = T - m >= +0, i.e. non-negative penalties (mgm_pass2.hip, TAGS): anything else takes the first build.
     const bool first_build = c->force_build == 1 || !(P1 >= 0.0f) || !(P2 >= 0.0f);
-    if (int r0 = check_watchdog(c)) return r0;  // (the control words are about to be reset)
+    if (int r0 = check_watchdog(c, false)) return r0;  // (without waiting: the word is sticky on the device)
 
     // A label count the second build does not take (not 64, 128, 192, 256, 384 or 512) runs PADDED: the kernels see
     // the next such count, the extra label slots hold +INF costs -- "no such label", exactly what a read past a Dvec
@@ -909,9 +958,9 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     const long long npix = (long long)nx * ny, nvol = npix * L;
     const int lpl = pass_lpl(L), LP = lpl * 64;
     int r;
-    if ((r = reserve(c, c->words, sizeof(unsigned) * kCtrlWords))) return r;
+    if ((r = ensure_words(c))) return r;
     unsigned *words = (unsigned *)c->words.p;
-    HIPCHK(c, hipMemsetAsync(words, 0, sizeof(unsigned) * kCtrlWords, c->stream));
+    HIPCHK(c, hipMemsetAsync(words, 0, sizeof(unsigned), c->stream));  // the ticket (the progress words: below, where they are used)
 
     // weighted? (mgm_core.cc:420-423: any value != 1.0 switches every update)
     bool weighted = false;
@@ -1008,7 +1057,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     const int R = R2 ? R2 : (lpl > 8 ? 4 : kR);  // (more than 512 labels: the first build with bands of four lines)
     PassParams p{};
     int maxLL = 0, maxbands = 0;
-    for (int q = 0; q < PEND; q++) {
+    for (int q = 0; q < std::max(PEND, layout_ndir); q++) {
         if (!make_geom(q, nx, ny, R, MGM, R2 != 0, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
         maxLL = std::max(maxLL, p.g[q].LL);
         maxbands = std::max(maxbands, p.g[q].nbands);
@@ -1018,17 +1067,20 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // Consecutive passes' volumes are staggered by an odd number of 256-byte blocks so that the
     // NDIR slabs of one pixel (read together by k_wta) do not fall on the same HBM channel.
     const long long lr_stride = nvol + lr_pad_floats();
-    if ((r = reserve(c, c->lr, sizeof(float) * (size_t)lr_stride * count * nb))) return r;
+    if ((r = reserve(c, c->lr, sizeof(float) * (size_t)lr_stride * nslots * nb))) return r;
     const int LPk = subv > 1 ? Lk : LP;  // floats per hand-off slab
     // The second build's unweighted kernels hand slabs from band to band that validate themselves (mgm_pass2.hip, TAGS):
-    // one slot per (volume, pass, band, pixel), written once per launch with the launch's tag in the sign bits.  The tag
-    // alternates between consecutive launches over the same slots; any other use of the region, or a different
-    // geometry, clears it first (all-ones words) and starts again with tag 0.
+    // one slot per (volume, pass, band, pixel), written once per launch OF THAT PASS with the tag in the sign bits.  A
+    // pass's tag alternates between its consecutive launches over the same slots; a different geometry clears the region
+    // first (all-ones words) and starts every pass again with tag 0.  The region is laid out for the passes
+    // [0, layout_ndir) and is this protocol's alone (the other kernels' slots live in `hand2`), so neither a caller that
+    // launches the passes one by one nor one that alternates weighted and unweighted runs makes it be cleared again.
     const bool tags = R2 && !weighted && !(fh && MGM == 2);
     std::string tag_key;
+    float *hand_ptr = nullptr;
     if (tags) {
         long long per_vol = 0;
-        for (int q = first; q < PEND; q++) {
+        for (int q = 0; q < layout_ndir; q++) {
             p.g[q].hand_base = per_vol;
             per_vol += (long long)p.g[q].nbands * p.g[q].LL;
         }
@@ -1037,22 +1089,27 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         const void *before = c->hand.p;
         if ((r = reserve(c, c->hand, bytes))) return r;
         char key[160];
-        snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d", nx, ny, LPk, ngroups, first, count, R, MGM <= 3 ? 1 : 0);
+        snprintf(key, sizeof key, "%d %d %d %d %d %d %d", nx, ny, LPk, ngroups, layout_ndir, R, MGM <= 3 ? 1 : 0);
         if (c->hand.p != before || c->hand_key != key) {
             HIPCHK(c, hipMemsetAsync(c->hand.p, 0xff, bytes, c->stream));
             c->hand_key = key;
-            c->hand_tag = 0x80000000u;  // (what the cleared words look like)
+            for (int q = 0; q < kMaxDirs; q++) c->hand_tags[q] = 0x80000000u;  // (what the cleared words look like)
         }
-        c->hand_tag ^= 0x80000000u;
-        p.hand_tag = c->hand_tag;
-        // The tag is only good for a launch that really rewrites every slot: until the pass kernel has been enqueued the
-        // region counts as unknown (the next call clears it), so an error return between here and the launch cannot
-        // leave slots behind that carry the tag of the launch after next.
+        for (int q = first; q < PEND; q++) {
+            c->hand_tags[q] ^= 0x80000000u;
+            p.hand_tag[q] = c->hand_tags[q];
+        }
+        // The tags are only good for a launch that really rewrites every slot of its passes: until the pass kernel has
+        // been enqueued the region counts as unknown (the next call clears it), so an error return between here and the
+        // launch cannot leave slots behind that carry the tag of the launch after next.
         tag_key = c->hand_key;
         c->hand_key.clear();
+        hand_ptr = (float *)c->hand.p;
     } else {
-        c->hand_key.clear();
-        if ((r = reserve(c, c->hand, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * LPk))) return r;
+        if ((r = reserve(c, c->hand2, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * LPk))) return r;
+        hand_ptr = (float *)c->hand2.p;
+        // progress words of this protocol: [volume*8 + pass][band]
+        HIPCHK(c, hipMemsetAsync(words + 4, 0, sizeof(unsigned) * (size_t)nb * kMaxDirs * kMaxBands, c->stream));
     }
     if ((r = reserve(c, c->handm, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL))) return r;
 
@@ -1091,6 +1148,14 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
 
     // task table: ticket -> (pass, band [, strip]); item (p, b, .) always follows the items (p, b-1, .)
     const int tk_key = (((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv) * 2 + (any_strips ? 1 : 0);
+    if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != tk_key || c->tk_r != R)
+        for (auto &t : c->ttabs)
+            if (t.nx == nx && t.ny == ny && t.key == tk_key && t.R == R) {  // a shape seen before: its table is still on the device
+                c->tasks = t.buf;
+                c->ntasks = t.ntasks;
+                c->tk_nx = nx, c->tk_ny = ny, c->tk_ndir = tk_key, c->tk_r = R;
+                break;
+            }
     if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != tk_key || c->tk_r != R) {
         // Passes with more bands (the column passes of a wide image) have the longer dependency
         // chain, so tickets are dealt by RELATIVE progress b / nbands(pass): every pass advances at
@@ -1104,7 +1169,14 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
             const long long ka = (long long)(a.y & 0xffff) * p.g[b.x % kMaxDirs].nbands, kb = (long long)(b.y & 0xffff) * p.g[a.x % kMaxDirs].nbands;
             return ka != kb ? ka < kb : a.x < b.x;
         });
+        if (c->ttabs.size() >= 24) {  // (bounded: drop the oldest; the stream is synchronised below before anything is reused)
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->ttabs.front().buf.p) (void)hipFree(c->ttabs.front().buf.p);
+            c->ttabs.erase(c->ttabs.begin());
+        }
+        c->tasks = Buf{};
         if ((r = reserve(c, c->tasks, sizeof(int2) * tasks.size()))) return r;
+        c->ttabs.push_back(mgm_ctx::TaskTab{nx, ny, tk_key, R, (int)tasks.size(), c->tasks});
         HIPCHK(c, hipMemcpyAsync(c->tasks.p, tasks.data(), sizeof(int2) * tasks.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->ntasks = (int)tasks.size();
@@ -1118,12 +1190,12 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         if (!use_c8 && (r = ensure_f32(c, Cs[v]))) return r;
         p.vol[v].C = padded ? (const float *)c->padf[v].p : Cs[v]->d;
         p.vol[v].C8 = use_c8 ? (padded ? (const uint8_t *)c->pad8[v].p : Cs[v]->d8) : nullptr;
-        p.vol[v].Lr = (float *)c->lr.p + (size_t)v * count * lr_stride;
+        p.vol[v].Lr = (float *)c->lr.p + ((size_t)v * nslots + slot0) * lr_stride;
         p.vol[v].w8 = ones8 ? ones8 : (weighted ? w8s[v]->d : nullptr);
         p.vol[v].rlo = (fh && ragged) ? Cs[v]->rlo : nullptr;
         p.vol[v].rhi = (fh && ragged) ? Cs[v]->rhi : nullptr;
     }
-    p.hand = (float *)c->hand.p;
+    p.hand = hand_ptr;
     p.handm = (float *)c->handm.p;
     p.ticket = words + 0;
     p.err = words + 1;
@@ -1236,7 +1308,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     }
     c->last_nvol = nvol;
     c->last_stride = lr_stride;
-    c->last_ndir = count;
+    c->last_ndir = nslots;
     c->last_batch = nb;
     c->last_L = Lreal;
     c->last_Lk = L;
@@ -1344,20 +1416,42 @@ int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm
     }
     const int ridx = refinement_index(refine);
     HIPCHK(c, hipSetDevice(c->device));
-    int r;
-    if ((r = run_passes(c, C, (w8 && w8[0]) ? w8 : nullptr, n, P1, P2, MGM, use_fh, 0, NDIR, /*allow_pad=*/true))) return r;
+    int r = MGM_OK;
     const long long npix = (long long)nx * ny;
     if (S)
         for (int v = 0; v < n; v++) S[v] = nullptr;
-    for (int v = 0; v < n && !r; v++) {
-        float *Sout = nullptr;
-        if (S) {
-            if ((r = mgm_cv_create(c, nx, ny, C[v]->dmin, C[v]->dmax, &S[v]))) break;
-            Sout = S[v]->d;
+    // The Lr volumes of a launch take NDIR x W x H x L floats per volume.  A batch that does not fit the caller's
+    // workspace limit (mgm_ctx_set_workspace_limit), or the device (hipMalloc fails), is run as several launches over
+    // the largest sub-batches that do -- multiples of four / two volumes first, so that volumes keep sharing waves at
+    // 64 / 128 labels -- instead of failing with MGM_ERR_NOMEM: same results, the later volumes just wait their turn.
+    int chunk = n;
+    if (c->ws_limit) {
+        const int Lk = padded_labels(L) ? padded_labels(L) : L;
+        const double per_vol = 4.0 * ((double)npix * Lk + (double)lr_pad_floats()) * NDIR * 1.07;  // (+ the hand-off slots: ~7 %)
+        while (chunk > 1 && per_vol * chunk > (double)c->ws_limit) chunk--;
+        if (chunk >= 4) chunk -= chunk % 4;
+        else if (chunk == 3) chunk = 2;
+    }
+    for (int v0 = 0; v0 < n && !r;) {
+        int m = std::min(chunk, n - v0);
+        r = run_passes(c, C + v0, (w8 && w8[0]) ? w8 + v0 : nullptr, m, P1, P2, MGM, use_fh, 0, NDIR, /*allow_pad=*/true);
+        if (r == MGM_ERR_NOMEM && m > 1) {  // does not fit the device either: halve and try again
+            chunk = m > 4 ? (m / 2) - (m / 2) % 2 : m / 2;
+            chunk = std::max(chunk, 1);
+            r = MGM_OK;
+            continue;
         }
-        const float *lr = (const float *)c->lr.p + (size_t)v * NDIR * c->last_stride;
-        r = run_wta_refine(c, C[v], 0, npix, lr, c->last_stride, NDIR, fix_overcount, ridx, out[v]->d, outcost[v]->d, Sout, nullptr,
-                           nullptr, v);
+        for (int v = 0; v < m && !r; v++) {
+            float *Sout = nullptr;
+            if (S) {
+                if ((r = mgm_cv_create(c, nx, ny, C[v0 + v]->dmin, C[v0 + v]->dmax, &S[v0 + v]))) break;
+                Sout = S[v0 + v]->d;
+            }
+            const float *lr = (const float *)c->lr.p + (size_t)v * NDIR * c->last_stride;
+            r = run_wta_refine(c, C[v0 + v], 0, npix, lr, c->last_stride, NDIR, fix_overcount, ridx, out[v0 + v]->d, outcost[v0 + v]->d,
+                               Sout, nullptr, nullptr, v);
+        }
+        v0 += m;
     }
     if (r && S) {  // no S volume of a failed call is handed out
         const std::string msg = c->err;
@@ -1389,6 +1483,24 @@ int mgm_aggregate_passes_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, flo
         return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes: weights must be nx*ny*8");
     HIPCHK(c, hipSetDevice(c->device));
     return run_passes(c, &C, w8 ? &w8 : nullptr, 1, P1, P2, MGM, use_fh, first_pass, n_passes);
+}
+
+// The same with the caller saying where the Lr volumes go: pass p lands in workspace slot slot0 + (p - first_pass) of
+// n_slots, and the context lays its hand-off region out for the passes [0, NDIR_total).  A caller that launches the
+// passes of one volume one at a time (to send pass k's slabs while pass k+1 runs) keeps all of them this way.
+int mgm_aggregate_passes_at_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int MGM, int use_fh,
+                                int first_pass, int n_passes, int slot0, int n_slots, int NDIR_total)
+{
+    if (!c || !C) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes_at: null argument");
+    if (first_pass < 0 || n_passes < 1 || first_pass + n_passes > kMaxDirs || NDIR_total > kMaxDirs)
+        return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes_at: passes must lie in 0..7");
+    if (slot0 < 0 || n_slots < slot0 + n_passes || n_slots > kMaxDirs)
+        return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes_at: the passes do not fit the slots");
+    if (MGM < 1 || MGM > 4) return fail(c, MGM_ERR_INVALID, "MGM (TSGM) must be 1..4");
+    if (w8 && (w8->nx != C->nx || w8->ny != C->ny || w8->nch != 8))
+        return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes_at: weights must be nx*ny*8");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_passes(c, &C, w8 ? &w8 : nullptr, 1, P1, P2, MGM, use_fh, first_pass, n_passes, false, slot0, n_slots, NDIR_total);
 }
 
 void *mgm_lr_device_ptr(mgm_ctx *c, int slot)
@@ -1446,8 +1558,8 @@ int mgm_selftest_div3(mgm_ctx *c, unsigned long long *nbad)
     if (!c || !nbad) return fail(c, MGM_ERR_INVALID, "mgm_selftest_div3: null argument");
     HIPCHK(c, hipSetDevice(c->device));
     int r;
-    if ((r = reserve(c, c->words, sizeof(unsigned) * kCtrlWords))) return r;
-    unsigned long long *d = (unsigned long long *)c->words.p;
+    if ((r = ensure_words(c))) return r;
+    unsigned long long *d = (unsigned long long *)c->words.p + 1;  // (words 2 and 3: scratch; word 1 is the sticky watchdog word)
     HIPCHK(c, hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
     HIPCHK(c, launch_selftest_div3(d, c->stream));
     HIPCHK(c, hipMemcpyAsync(nbad, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1496,7 +1608,7 @@ int mgm_update_ranges_dev(mgm_ctx *c, const mgm_img *outoff, mgm_img *dminI, mgm
     if (radius < 0 || radius > 16) return fail(c, MGM_ERR_INVALID, "mgm_update_ranges: radius must be 0..16");
     HIPCHK(c, hipSetDevice(c->device));
     int r;
-    if ((r = reserve(c, c->words, sizeof(unsigned) * kCtrlWords))) return r;
+    if ((r = ensure_words(c))) return r;
     TimeScope t(c, "k_update_ranges");
     // (the two words of the global minimum / maximum live at the end of the control block, which K3 does not use)
     HIPCHK(c, launch_update_ranges(outoff->d, outoff->nx, outoff->ny, slack, radius, dminI->d, dmaxI->d,

@@ -496,7 +496,8 @@ __global__ void __launch_bounds__(256) k_cost_census8w(const uint32_t *__restric
     }
 }
 
-// The same again with FOUR consecutive pixels of a row per lane (image widths that are multiples of four): the sixteen
+// The same again with FOUR consecutive pixels of a row per lane (image widths that are multiples of four; any compact
+// label count -- at 192 / 384 labels a pixel group takes 12 / 24 lanes and the last 4 / 16 lanes of the wave idle): the sixteen
 // labels of a lane slide along the right image by one word per pixel, so the four pixels share 19 census words where
 // four separate lanes load 64 -- the kernel above is bound by those (L1-resident, unaligned) loads, not by its stores.
 template <int L>
@@ -504,16 +505,16 @@ __global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restric
                                                        int nx, int ny, int vnx, int vny, int dmin, unsigned tb,
                                                        uint8_t *__restrict__ C8)
 {
-    static_assert(L == 64 || L == 128 || L == 256 || L == 512, "whole pixels per KiB");
+    static_assert(L % 16 == 0 && L >= 16 && L <= 1024, "sixteen labels per lane");
     constexpr int LP = L / 16;    // lanes per pixel group
-    constexpr int G = 64 / LP;    // groups of four pixels per wave and iteration
+    constexpr int G = 64 / LP;    // groups of four pixels per wave and iteration (192 / 384 labels: 4 / 16 lanes of the wave idle)
     const long long npix = (long long)nx * ny;  // (a multiple of four)
     const long long nchunk = (npix + 4 * G - 1) / (4 * G);
     const int lane = threadIdx.x & 63, sub = lane / LP, part = lane % LP;
-    const unsigned long long group = (LP == 64 ? ~0ull : ((1ull << (LP % 64)) - 1ull)) << (sub * LP);
+    const unsigned long long group = (LP == 64 ? ~0ull : ((1ull << (LP % 64)) - 1ull)) << ((sub * LP) & 63);
     for (long long chunk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < nchunk; chunk += (long long)gridDim.x * 4) {
         const long long pix0 = (chunk * G + sub) * 4;
-        const bool live = pix0 < npix;
+        const bool live = sub < G && pix0 < npix;
         const unsigned p32 = live ? (unsigned)pix0 : 0u;  // (npix < 2^31: checked by the caller)
         const int y = (int)(p32 / (unsigned)nx), x = (int)(p32 - (unsigned)y * (unsigned)nx);  // x .. x+3: one row
         const uint4 wu4 = *reinterpret_cast<const uint4 *>(cu + p32);
@@ -584,14 +585,16 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
         long long nb = (npix + 3) / 4;
         if (nb > 256 * 32) nb = 256 * 32;
         const dim3 block(256);
-        if ((p.L == 64 || p.L == 128 || p.L == 256 || p.L == 512) && npix < 0x7fffffffll && p.nx % 4 == 0) {
+        if (npix < 0x7fffffffll && p.nx % 4 == 0) {  // (every compact label count is a multiple of 16)
             long long nw = (npix * p.L / 4096 + 3) / 4 + 1;
             if (nw > 256 * 32) nw = 256 * 32;
             const dim3 gridw((unsigned)nw);
             switch (p.L) {
                 case 64: hipLaunchKernelGGL(k_cost_census8x<64>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
                 case 128: hipLaunchKernelGGL(k_cost_census8x<128>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                case 192: hipLaunchKernelGGL(k_cost_census8x<192>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
                 case 256: hipLaunchKernelGGL(k_cost_census8x<256>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                case 384: hipLaunchKernelGGL(k_cost_census8x<384>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
                 default: hipLaunchKernelGGL(k_cost_census8x<512>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
             }
             return hipGetLastError();

@@ -49,7 +49,9 @@ struct PassParams {
     float *hand;        // hand-off slabs  [volume*8 + pass][2][LLmax][NS*LP]; the kernels with self-validating slabs (k_pass2,
                         // TAGS): [volume][pass: g.hand_base][band][LL][LP], every slot written once per launch
     long long hand_vstride;   // ... slabs per volume (group)
-    unsigned hand_tag;        // ... the launch's tag: sign bit every handed-over word carries (0 or 0x80000000)
+    unsigned hand_tag[kMaxDirs];  // ... per pass, the tag of this launch: sign bit every handed-over word carries (0 or 0x80000000).
+                              // A pass's slots are written once per launch OF THAT PASS, so the tag alternates per pass
+                              // (direction-sharded callers launch the passes of one volume one at a time)
     float *handm;       // hand-off minima [volume*8 + pass][2][LLmax]
     unsigned *prog;     // progress words  [volume*8 + pass][maxbands]
     unsigned *ticket;   // work-item ticket counter

@@ -4,22 +4,35 @@
 // (mgm_core.cc:632-831): passes in parallel on private Lr volumes (710-717), then accumulated (798-805) -- there in
 // thread-finish order, here always in pass order, which keeps the result bit-identical to mgm().
 //
-// One host thread drives all devices: every device has its own mgm_ctx (device + stream + workspace), all calls are
-// asynchronous on those streams, and the exchange is ONE grouped set of ncclSend / ncclRecv per device (RCCL keeps one
-// xGMI link per peer busy: an all-to-all, 7 x 1/8 of a volume out and in per GPU at 8 GPUs).  An all-reduce is not
-// used: it would fix neither the order of the fp32 additions nor use more than one link at a time (ring).
+// One host thread drives all devices: every device has its own mgm_ctx (device + stream + workspace) and a second
+// stream for the exchange; all calls are asynchronous, ordered by events.  The exchange runs in ROUNDS -- round r moves
+// the r-th pass of every rank -- over one of three transports:
+//   rccl      ONE grouped set of ncclSend / ncclRecv per round (RCCL keeps one xGMI link per peer busy: an all-to-all,
+//             7 x 1/8 of a volume out and in per GPU at 8 GPUs).  An all-reduce is not used: it would fix neither the
+//             order of the fp32 additions nor use more than one link at a time (ring);
+//   peer      the RECEIVING device pulls each slab with hipMemcpyPeerAsync on its exchange stream once the owner's
+//             "pass done" event has fired -- no communicator, no IPC; what a handle falls back to when librccl or its
+//             communicator is not to be had (MGM_MULTI_TRANSPORT=peer asks for it);
+//   loopback  a device appears several times in the list (MGM_MULTI_LOOPBACK=1, tests): the "ranks" are contexts on one
+//             GPU and a slab is a device-to-device copy.  Partition, buffers, ordering and the row-slab WTA are the code
+//             that runs on a real node; only the copy call differs from `peer`.
+// With MGM_MULTI_OVERLAP=1 a rank that owns several passes launches them one per launch (mgm_aggregate_passes_at_dev)
+// and round r is posted right behind pass r, so its slabs travel while pass r+1 runs.
+//
+// Failure discipline: every buffer is sized BEFORE anything is enqueued; a transfer group is closed on every path that
+// opened it (GroupGuard); when a rank's launch fails nothing further is posted, every rank's queued work is drained, and
+// only then is the error returned; the final wait polls the streams against MGM_MULTI_TIMEOUT_S and aborts the
+// communicators (ncclCommAbort) instead of blocking forever on a peer that never delivers.
 //
 // librccl is loaded on first use (dlopen), so that single-GPU users of libmgm_hip.so do not carry it; everything here
 // is written against the public ABI of mgm_hip.h only.
-//
-// Loopback mode (MGM_MULTI_LOOPBACK=1, tests): the same device may appear several times in the list; the "ranks" are
-// then contexts on one GPU and a transfer is a device-to-device copy ordered by events instead of a send/recv pair.
-// Partition, buffers, ordering and the row-slab WTA are the code that runs on a real node; only the transport differs.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +47,8 @@ struct Rccl {  // the entry points used, resolved from librccl.so at run time
     void *lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -53,6 +68,8 @@ struct Rccl {  // the entry points used, resolved from librccl.so at run time
         auto sym = [&](const char *n) { return dlsym(lib, n); };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
+        CommGetAsyncError = (decltype(CommGetAsyncError))sym("ncclCommGetAsyncError");
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         Send = (decltype(Send))sym("ncclSend");
@@ -60,28 +77,40 @@ struct Rccl {  // the entry points used, resolved from librccl.so at run time
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
         if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
             err = "librccl lacks an entry point";
+            dlclose(lib);
+            lib = nullptr;
             return false;
         }
         return true;
     }
 };
 Rccl g_rccl;
+thread_local std::string g_create_err = "no mgm_multi_create has failed on this thread";
 
 struct Grow {  // grow-only device buffer on one device
     void *p = nullptr;
     size_t cap = 0;
 };
 
+enum Transport { T_RCCL = 0, T_PEER = 1, T_LOOPBACK = 2 };
+const char *const kTransportName[] = {"rccl", "peer", "loopback"};
+constexpr int kRounds = 8;
+
 }  // namespace
 
 struct mgm_multi {
     int n = 0;
-    bool loopback = false;
+    Transport tr = T_RCCL;
+    bool dead = false;     // a transfer timed out and the transport was aborted: only mgm_multi_destroy is left
+    bool overlap = false;  // MGM_MULTI_OVERLAP=1
+    double timeout_s = 120.0;
     std::vector<int> dev;
     std::vector<mgm_ctx *> ctx;
     std::vector<ncclComm_t> comm;
-    std::vector<Grow> recv, rows;        // per rank: [NDIR][nrows][nx][L] slabs received; [2][nrows][nx] results of its rows
-    std::vector<hipEvent_t> passes_done;  // per rank: its Lr volumes are complete (loopback transport)
+    std::vector<Grow> recv, rows;          // per rank: [NDIR][nrows][nx][L] slabs received; its rows' results (rank 0: + the gather staging)
+    std::vector<hipStream_t> xs;           // per rank: the exchange stream
+    std::vector<hipEvent_t> pass_done;     // [rank * kRounds + round]: that pass's Lr volume is complete
+    std::vector<hipEvent_t> xdone, rows_done;  // per rank: all its slabs have arrived; its rows are searched
     std::string err;
 };
 
@@ -98,6 +127,7 @@ int reserve(mgm_multi *m, int k, Grow &b, size_t bytes)
     if (hipSetDevice(m->dev[k]) != hipSuccess) return fail(m, MGM_ERR_HIP, "hipSetDevice");
     if (b.p) {
         (void)hipStreamSynchronize((hipStream_t)mgm_ctx_stream(m->ctx[k]));
+        (void)hipStreamSynchronize(m->xs[k]);
         (void)hipFree(b.p);
         b.p = nullptr;
         b.cap = 0;
@@ -108,6 +138,70 @@ int reserve(mgm_multi *m, int k, Grow &b, size_t bytes)
     }
     b.cap = bytes;
     return MGM_OK;
+}
+
+struct GroupGuard {  // an RCCL group that is closed on every path out of its scope
+    bool open = false;
+    bool start()
+    {
+        open = g_rccl.GroupStart() == ncclSuccess;
+        return open;
+    }
+    ncclResult_t end()
+    {
+        if (!open) return ncclSuccess;
+        open = false;
+        return g_rccl.GroupEnd();
+    }
+    ~GroupGuard()
+    {
+        if (open) (void)g_rccl.GroupEnd();
+    }
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Everything queued on every rank's streams has run (or the deadline passed: false).
+bool drain(mgm_multi *m, double deadline, std::string &why)
+{
+    for (;;) {
+        bool busy = false;
+        for (int k = 0; k < m->n && !busy; k++) {
+            (void)hipSetDevice(m->dev[k]);
+            for (hipStream_t s : {(hipStream_t)mgm_ctx_stream(m->ctx[k]), m->xs[k]}) {
+                const hipError_t e = hipStreamQuery(s);
+                if (e == hipErrorNotReady) busy = true;
+                else if (e != hipSuccess) {
+                    why = std::string("device ") + std::to_string(m->dev[k]) + ": " + hipGetErrorString(e);
+                    return false;
+                }
+            }
+            if (m->tr == T_RCCL && k < (int)m->comm.size() && m->comm[k] && g_rccl.CommGetAsyncError) {
+                ncclResult_t ae = ncclSuccess;
+                if (g_rccl.CommGetAsyncError(m->comm[k], &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) {
+                    why = std::string("RCCL asynchronous error on rank ") + std::to_string(k) + ": " + g_rccl.GetErrorString(ae);
+                    return false;
+                }
+            }
+        }
+        if (!busy) return true;
+        if (now_s() > deadline) {
+            why = "the exchange did not complete within " + std::to_string((int)m->timeout_s) + " s (MGM_MULTI_TIMEOUT_S)";
+            return false;
+        }
+        usleep(100);
+    }
+}
+
+void abort_transport(mgm_multi *m)
+{
+    m->dead = true;
+    if (m->tr == T_RCCL && g_rccl.CommAbort)
+        for (auto &c : m->comm)
+            if (c) {
+                (void)g_rccl.CommAbort(c);
+                c = nullptr;
+            }
 }
 
 }  // namespace
@@ -136,37 +230,77 @@ int mgm_multi_create(const int *device_ids, int n, mgm_multi **out)
 {
     if (!out) return MGM_ERR_INVALID;
     *out = nullptr;
-    if (!device_ids || n < 1 || n > 64) return MGM_ERR_INVALID;
+    if (!device_ids || n < 1 || n > 64) {
+        g_create_err = "mgm_multi_create: 1..64 device ids";
+        return MGM_ERR_INVALID;
+    }
     bool dup = false;
     for (int a = 0; a < n; a++)
         for (int b = 0; b < a; b++) dup |= device_ids[a] == device_ids[b];
     const char *lb = getenv("MGM_MULTI_LOOPBACK");
-    if (dup && !(lb && atoi(lb) == 1)) return MGM_ERR_INVALID;  // RCCL needs distinct devices
+    if (dup && !(lb && atoi(lb) == 1)) {
+        g_create_err = "mgm_multi_create: a device id appears twice (loopback ranks need MGM_MULTI_LOOPBACK=1)";
+        return MGM_ERR_INVALID;
+    }
     mgm_multi *m = new mgm_multi();
     m->n = n;
-    m->loopback = dup || (lb && atoi(lb) == 1);
+    // loopback only where the caller really passed one device several times: distinct devices never take it silently
+    const char *tr = getenv("MGM_MULTI_TRANSPORT");
+    m->tr = dup ? T_LOOPBACK : ((tr && !strcmp(tr, "peer")) ? T_PEER : T_RCCL);
+    if (const char *e = getenv("MGM_MULTI_OVERLAP")) m->overlap = atoi(e) == 1;
+    if (const char *e = getenv("MGM_MULTI_TIMEOUT_S")) m->timeout_s = std::max(1.0, atof(e));
     m->dev.assign(device_ids, device_ids + n);
     m->ctx.assign(n, nullptr);
     m->recv.resize(n);
     m->rows.resize(n);
-    m->passes_done.assign(n, nullptr);
+    m->xs.assign(n, nullptr);
+    m->pass_done.assign((size_t)n * kRounds, nullptr);
+    m->xdone.assign(n, nullptr);
+    m->rows_done.assign(n, nullptr);
     int r = MGM_OK;
+    std::string why;
     for (int k = 0; k < n && !r; k++) {
         r = mgm_ctx_create(device_ids[k], &m->ctx[k]);
-        if (!r && hipEventCreateWithFlags(&m->passes_done[k], hipEventDisableTiming) != hipSuccess) r = MGM_ERR_HIP;
+        if (r) {
+            why = "mgm_ctx_create(" + std::to_string(device_ids[k]) + ") failed: no usable gfx950 device of that ordinal";
+            break;
+        }
+        bool ok = hipSetDevice(device_ids[k]) == hipSuccess && hipStreamCreateWithFlags(&m->xs[k], hipStreamNonBlocking) == hipSuccess;
+        for (int q = 0; q < kRounds && ok; q++) ok = hipEventCreateWithFlags(&m->pass_done[(size_t)k * kRounds + q], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&m->xdone[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&m->rows_done[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            r = MGM_ERR_HIP;
+            why = "stream / event creation on device " + std::to_string(device_ids[k]);
+        }
     }
-    if (!r && !m->loopback) {
+    if (!r && m->tr == T_RCCL) {
         std::string e;
-        if (!g_rccl.load(e)) r = MGM_ERR_HIP;
-        else {
+        if (!g_rccl.load(e)) {
+            m->tr = T_PEER;  // degrade: the exchange does not need a communicator
+            m->err = "transport peer (" + e + ")";
+        } else {
             m->comm.assign(n, nullptr);
-            if (g_rccl.CommInitAll(m->comm.data(), n, device_ids) != ncclSuccess) {
+            const ncclResult_t ne = g_rccl.CommInitAll(m->comm.data(), n, device_ids);
+            if (ne != ncclSuccess) {
                 m->comm.clear();
-                r = MGM_ERR_HIP;
+                m->tr = T_PEER;
+                m->err = std::string("transport peer (ncclCommInitAll: ") + g_rccl.GetErrorString(ne) + ")";
             }
         }
     }
+    if (!r && m->tr == T_PEER && n > 1)  // direct copies over xGMI where the devices can see each other (else the runtime stages them)
+        for (int a = 0; a < n; a++)
+            for (int b = 0; b < n; b++) {
+                int can = 0;
+                if (a == b || hipDeviceCanAccessPeer(&can, device_ids[a], device_ids[b]) != hipSuccess || !can) continue;
+                if (hipSetDevice(device_ids[a]) == hipSuccess) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(device_ids[b], 0);
+                    if (pe != hipSuccess) (void)hipGetLastError();  // (already enabled: fine)
+                }
+            }
     if (r) {
+        g_create_err = why;
         mgm_multi_destroy(m);
         return r;
     }
@@ -179,12 +313,19 @@ int mgm_multi_destroy(mgm_multi *m)
     if (!m) return MGM_OK;
     for (int k = 0; k < m->n; k++) {
         (void)hipSetDevice(m->dev[k]);
-        if (m->ctx[k]) (void)mgm_ctx_synchronize(m->ctx[k]);
+        if (!m->dead) {
+            if (m->ctx[k]) (void)mgm_ctx_synchronize(m->ctx[k]);
+            if (m->xs[k]) (void)hipStreamSynchronize(m->xs[k]);
+        }
         if (k < (int)m->comm.size() && m->comm[k]) (void)g_rccl.CommDestroy(m->comm[k]);
         if (m->recv[k].p) (void)hipFree(m->recv[k].p);
         if (m->rows[k].p) (void)hipFree(m->rows[k].p);
-        if (m->passes_done[k]) (void)hipEventDestroy(m->passes_done[k]);
-        if (m->ctx[k]) (void)mgm_ctx_destroy(m->ctx[k]);
+        for (int q = 0; q < kRounds; q++)
+            if (m->pass_done[(size_t)k * kRounds + q]) (void)hipEventDestroy(m->pass_done[(size_t)k * kRounds + q]);
+        if (m->xdone[k]) (void)hipEventDestroy(m->xdone[k]);
+        if (m->rows_done[k]) (void)hipEventDestroy(m->rows_done[k]);
+        if (m->xs[k]) (void)hipStreamDestroy(m->xs[k]);
+        if (m->ctx[k] && !m->dead) (void)mgm_ctx_destroy(m->ctx[k]);  // (a dead handle's contexts may still have a transfer pending: leaked)
     }
     delete m;
     return MGM_OK;
@@ -192,12 +333,14 @@ int mgm_multi_destroy(mgm_multi *m)
 
 int mgm_multi_size(const mgm_multi *m) { return m ? m->n : 0; }
 mgm_ctx *mgm_multi_ctx(mgm_multi *m, int rank) { return (m && rank >= 0 && rank < m->n) ? m->ctx[rank] : nullptr; }
-const char *mgm_multi_last_error(const mgm_multi *m) { return m ? m->err.c_str() : "null handle"; }
+const char *mgm_multi_last_error(const mgm_multi *m) { return m ? m->err.c_str() : g_create_err.c_str(); }
+const char *mgm_multi_transport(const mgm_multi *m) { return m ? kTransportName[m->tr] : ""; }
 
 int mgm_multi_aggregate(mgm_multi *m, const mgm_cv *const *C, const mgm_img *const *w8, float P1, float P2, int NDIR, int MGM,
                         int use_fh, int fix_overcount, const char *refine, mgm_img *out0, mgm_img *outcost0)
 {
     if (!m || !C || !out0 || !outcost0) return fail(m, MGM_ERR_INVALID, "mgm_multi_aggregate: null argument");
+    if (m->dead) return fail(m, MGM_ERR_HIP, "mgm_multi_aggregate: the transport of this handle was aborted after a time-out");
     if (NDIR < 1 || NDIR > 8) return fail(m, MGM_ERR_INVALID, "NDIR must be 1..8");
     const int n = m->n;
     int nx = 0, ny = 0, dmin = 0, dmax = 0;
@@ -206,141 +349,191 @@ int mgm_multi_aggregate(mgm_multi *m, const mgm_cv *const *C, const mgm_img *con
         if (!C[k] || mgm_cv_dims(C[k], &a, &b, &c, &d)) return fail(m, MGM_ERR_INVALID, "mgm_multi_aggregate: one cost volume per device");
         if (k == 0) nx = a, ny = b, dmin = c, dmax = d;
         else if (a != nx || b != ny || c != dmin || d != dmax) return fail(m, MGM_ERR_INVALID, "mgm_multi_aggregate: the devices' cost volumes differ in geometry");
+        // a volume or weight image on another rank's device would fault in that rank's kernels: refuse it here
+        if (mgm_cv_device(C[k]) != m->dev[k]) return fail(m, MGM_ERR_INVALID, "mgm_multi_aggregate: C[" + std::to_string(k) + "] does not live on device " + std::to_string(m->dev[k]));
+        if (w8 && w8[k] && mgm_img_device(w8[k]) != m->dev[k])
+            return fail(m, MGM_ERR_INVALID, "mgm_multi_aggregate: w8[" + std::to_string(k) + "] does not live on device " + std::to_string(m->dev[k]));
     }
     {
         int a, b, c;
         if (mgm_img_dims(out0, &a, &b, &c) || a != nx || b != ny || mgm_img_dims(outcost0, &a, &b, &c) || a != nx || b != ny)
             return fail(m, MGM_ERR_INVALID, "mgm_multi_aggregate: output image size mismatch");
+        if (mgm_img_device(out0) != m->dev[0] || mgm_img_device(outcost0) != m->dev[0])
+            return fail(m, MGM_ERR_INVALID, "mgm_multi_aggregate: out0 / outcost0 must live on device_ids[0]");
     }
     const size_t L = (size_t)(dmax - dmin + 1), rowf = (size_t)nx * L;  // floats per image row of a volume
     std::vector<int> first(n), cnt(n), row0(n), nrows(n);
     mgm_multi_plan(n, NDIR, ny, first.data(), cnt.data(), row0.data(), nrows.data());
-    auto owner = [&](int p) {
-        for (int k = 0; k < n; k++)
-            if (p >= first[k] && p < first[k] + cnt[k]) return k;
-        return -1;
-    };
+    int rounds = 0;
+    for (int k = 0; k < n; k++) rounds = std::max(rounds, cnt[k]);
+    const bool per_pass = m->overlap && rounds > 1;  // one launch per pass, each round posted behind its pass
     int r;
-    // 1. every device runs its block of passes (asynchronous: the devices work concurrently)
-    for (int k = 0; k < n; k++) {
-        if (!cnt[k]) continue;  // more devices than passes: this one only sums and searches its rows
-        if ((r = mgm_aggregate_passes_dev(m->ctx[k], C[k], w8 ? w8[k] : nullptr, P1, P2, MGM, use_fh, first[k], cnt[k])))
-            return fail(m, r, std::string("device ") + std::to_string(m->dev[k]) + ": " + mgm_last_error(m->ctx[k]));
-        if (m->loopback) {
-            if (hipSetDevice(m->dev[k]) != hipSuccess || hipEventRecord(m->passes_done[k], (hipStream_t)mgm_ctx_stream(m->ctx[k])) != hipSuccess)
-                return fail(m, MGM_ERR_HIP, "hipEventRecord");
-        }
-    }
-    // 2. receive buffers: all passes of this device's rows, in pass order
+    // 0. every buffer, before anything is enqueued: all passes of this device's rows in pass order; its rows' two result
+    //    images -- on rank 0 also the staging area of the RCCL gather
+    size_t staging = 0;
+    for (int k = 1; k < n; k++) staging += 2 * (size_t)nrows[k] * nx;
     for (int k = 0; k < n; k++) {
         if ((r = reserve(m, k, m->recv[k], sizeof(float) * (size_t)NDIR * std::max(nrows[k], 1) * rowf))) return r;
-        if ((r = reserve(m, k, m->rows[k], sizeof(float) * 2 * (size_t)std::max(nrows[k], 1) * nx))) return r;
+        const size_t own = 2 * (size_t)std::max(nrows[k], 1) * nx;
+        if ((r = reserve(m, k, m->rows[k], sizeof(float) * (k == 0 ? std::max(own, std::max<size_t>(staging, 1)) : own)))) return r;
     }
-    // 3. the exchange.  Rank k sends, for each of its passes, rank g's rows to g; and receives its own rows of every other
-    //    rank's passes.  Between any two ranks the messages are posted in pass order on both sides.
+    auto ctx_stream = [&](int k) { return (hipStream_t)mgm_ctx_stream(m->ctx[k]); };
     auto lr_of = [&](int k, int p) { return (const float *)mgm_lr_device_ptr(m->ctx[k], p - first[k]); };
-    for (int k = 0; k < n; k++)
-        for (int p = first[k]; p < first[k] + cnt[k]; p++)
-            if (!lr_of(k, p)) return fail(m, MGM_ERR_INTERNAL, "mgm_multi_aggregate: no Lr volume (padded label count?)");
-    if (!m->loopback && n > 1)
-        if (g_rccl.GroupStart() != ncclSuccess) return fail(m, MGM_ERR_HIP, "ncclGroupStart");
-    for (int k = 0; k < n; k++) {
-        if (hipSetDevice(m->dev[k]) != hipSuccess) return fail(m, MGM_ERR_HIP, "hipSetDevice");
-        hipStream_t sk = (hipStream_t)mgm_ctx_stream(m->ctx[k]);
-        float *rk = (float *)m->recv[k].p;
-        const size_t slab_k = (size_t)nrows[k] * rowf;
-        for (int p = 0; p < NDIR; p++) {  // what lands in rank k's buffer
-            const int g = owner(p);
-            if (!nrows[k]) continue;
-            if (g == k) {
-                if (hipMemcpyAsync(rk + (size_t)p * slab_k, lr_of(k, p) + (size_t)row0[k] * rowf, sizeof(float) * slab_k, hipMemcpyDeviceToDevice, sk) != hipSuccess)
-                    return fail(m, MGM_ERR_HIP, "hipMemcpyAsync (own slab)");
-            } else if (m->loopback) {
-                if (hipStreamWaitEvent(sk, m->passes_done[g], 0) != hipSuccess ||
-                    hipMemcpyAsync(rk + (size_t)p * slab_k, lr_of(g, p) + (size_t)row0[k] * rowf, sizeof(float) * slab_k, hipMemcpyDeviceToDevice, sk) != hipSuccess)
-                    return fail(m, MGM_ERR_HIP, "hipMemcpyAsync (loopback slab)");
-            } else {
-                const ncclResult_t e = g_rccl.Recv(rk + (size_t)p * slab_k, slab_k, ncclFloat, g, m->comm[k], sk);
-                if (e != ncclSuccess) return fail(m, MGM_ERR_HIP, std::string("ncclRecv: ") + g_rccl.GetErrorString(e));
+    auto ev_of = [&](int k, int round) { return m->pass_done[(size_t)k * kRounds + (per_pass ? round : 0)]; };
+    int rc = MGM_OK;      // first failure; nothing further is posted once it is set, and it is returned after the drain
+    std::string rc_msg;
+    auto hipbad = [&](const char *what) {
+        if (!rc) rc = MGM_ERR_HIP, rc_msg = std::string(what) + ": " + hipGetErrorString(hipGetLastError());
+    };
+
+    // 1. + 3. passes and exchange, round by round
+    auto launch_round = [&](int round) {  // every rank's pass(es) of this round (all of them when !per_pass)
+        for (int k = 0; k < n && !rc; k++) {
+            if (cnt[k] <= round) continue;  // (more devices than passes: such a rank only sums and searches its rows)
+            int e = per_pass ? mgm_aggregate_passes_at_dev(m->ctx[k], C[k], w8 ? w8[k] : nullptr, P1, P2, MGM, use_fh, first[k] + round, 1, round, cnt[k], NDIR)
+                             : mgm_aggregate_passes_dev(m->ctx[k], C[k], w8 ? w8[k] : nullptr, P1, P2, MGM, use_fh, first[k], cnt[k]);
+            if (e) {
+                rc = e;
+                rc_msg = std::string("device ") + std::to_string(m->dev[k]) + ": " + mgm_last_error(m->ctx[k]);
+                return;
             }
+            if (hipSetDevice(m->dev[k]) != hipSuccess || hipEventRecord(ev_of(k, round), ctx_stream(k)) != hipSuccess) hipbad("hipEventRecord (pass done)");
         }
-        if (!m->loopback)
-            for (int p = first[k]; p < first[k] + cnt[k]; p++)  // what rank k sends
-                for (int g = 0; g < n; g++) {
-                    if (g == k || !nrows[g]) continue;
-                    const ncclResult_t e = g_rccl.Send(lr_of(k, p) + (size_t)row0[g] * rowf, (size_t)nrows[g] * rowf, ncclFloat, g, m->comm[k], sk);
-                    if (e != ncclSuccess) return fail(m, MGM_ERR_HIP, std::string("ncclSend: ") + g_rccl.GetErrorString(e));
+    };
+    auto post_round = [&](int round) {  // the slabs of every rank's `round`-th pass go to the rows' owners
+        if (rc) return;
+        for (int k = 0; k < n; k++)
+            if (cnt[k] > round && !lr_of(k, first[k] + round)) {
+                rc = MGM_ERR_INTERNAL, rc_msg = "mgm_multi_aggregate: no Lr volume (padded label count?)";
+                return;
+            }
+        GroupGuard grp;
+        if (m->tr == T_RCCL && n > 1 && !grp.start()) {
+            rc = MGM_ERR_HIP, rc_msg = "ncclGroupStart";
+            return;
+        }
+        for (int k = 0; k < n && !rc; k++) {
+            if (hipSetDevice(m->dev[k]) != hipSuccess) {
+                hipbad("hipSetDevice");
+                break;
+            }
+            hipStream_t xk = m->xs[k];
+            float *rk = (float *)m->recv[k].p;
+            const size_t slab_k = (size_t)nrows[k] * rowf;
+            // (the exchange stream of a rank that sends this round starts behind its pass)
+            if (cnt[k] > round && hipStreamWaitEvent(xk, ev_of(k, round), 0) != hipSuccess) hipbad("hipStreamWaitEvent (own pass)");
+            for (int g = 0; g < n && !rc; g++) {  // what lands in rank k's buffer: rank g's pass of this round
+                if (cnt[g] <= round || !nrows[k]) continue;
+                const int p = first[g] + round;
+                float *dst = rk + (size_t)p * slab_k;
+                const float *src = lr_of(g, p) + (size_t)row0[k] * rowf;
+                if (g == k) {
+                    if (hipMemcpyAsync(dst, src, sizeof(float) * slab_k, hipMemcpyDeviceToDevice, xk) != hipSuccess) hipbad("hipMemcpyAsync (own slab)");
+                } else if (m->tr == T_RCCL) {
+                    const ncclResult_t e = g_rccl.Recv(dst, slab_k, ncclFloat, g, m->comm[k], xk);
+                    if (e != ncclSuccess && !rc) rc = MGM_ERR_HIP, rc_msg = std::string("ncclRecv: ") + g_rccl.GetErrorString(e);
+                } else {  // pull it: ordered behind the owner's pass by its event
+                    hipError_t e = hipStreamWaitEvent(xk, ev_of(g, round), 0);
+                    if (e == hipSuccess)
+                        e = m->tr == T_PEER ? hipMemcpyPeerAsync(dst, m->dev[k], src, m->dev[g], sizeof(float) * slab_k, xk)
+                                            : hipMemcpyAsync(dst, src, sizeof(float) * slab_k, hipMemcpyDeviceToDevice, xk);
+                    if (e != hipSuccess) hipbad("slab copy");
                 }
+            }
+            if (m->tr == T_RCCL && cnt[k] > round)  // what rank k sends
+                for (int g = 0; g < n && !rc; g++) {
+                    if (g == k || !nrows[g]) continue;
+                    const ncclResult_t e = g_rccl.Send(lr_of(k, first[k] + round) + (size_t)row0[g] * rowf, (size_t)nrows[g] * rowf, ncclFloat, g, m->comm[k], xk);
+                    if (e != ncclSuccess) rc = MGM_ERR_HIP, rc_msg = std::string("ncclSend: ") + g_rccl.GetErrorString(e);
+                }
+        }
+        const ncclResult_t ge = grp.end();  // (closed whatever happened inside)
+        if (ge != ncclSuccess && !rc) rc = MGM_ERR_HIP, rc_msg = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge);
+    };
+    if (per_pass) {
+        for (int round = 0; round < rounds && !rc; round++) {
+            launch_round(round);
+            post_round(round);
+        }
+    } else {
+        launch_round(0);
+        for (int round = 0; round < rounds && !rc; round++) post_round(round);
     }
-    if (!m->loopback && n > 1)
-        if (g_rccl.GroupEnd() != ncclSuccess) return fail(m, MGM_ERR_HIP, "ncclGroupEnd");
-    // 4. every device finishes its rows: ordered sum over the passes, over-count fix, WTA, refinement
+    // 4. every device finishes its rows: ordered sum over the passes, over-count fix, WTA, refinement -- behind its slabs
     float *o0 = (float *)mgm_img_device_ptr(out0), *c0 = (float *)mgm_img_device_ptr(outcost0);
-    for (int k = 0; k < n; k++) {
+    for (int k = 0; k < n && !rc; k++) {
+        if (hipSetDevice(m->dev[k]) != hipSuccess || hipEventRecord(m->xdone[k], m->xs[k]) != hipSuccess ||
+            hipStreamWaitEvent(ctx_stream(k), m->xdone[k], 0) != hipSuccess) {
+            hipbad("exchange-done event");
+            break;
+        }
         if (!nrows[k]) continue;
         float *ok = k == 0 ? o0 + (size_t)row0[0] * nx : (float *)m->rows[k].p;
         float *ck = k == 0 ? c0 + (size_t)row0[0] * nx : (float *)m->rows[k].p + (size_t)nrows[k] * nx;
-        if ((r = mgm_wta_rows_dev(m->ctx[k], C[k], row0[k], nrows[k], m->recv[k].p, NDIR, fix_overcount, refine, ok, ck)))
-            return fail(m, r, std::string("device ") + std::to_string(m->dev[k]) + ": " + mgm_last_error(m->ctx[k]));
-        if (m->loopback && k > 0)
-            if (hipSetDevice(m->dev[k]) != hipSuccess || hipEventRecord(m->passes_done[k], (hipStream_t)mgm_ctx_stream(m->ctx[k])) != hipSuccess)
-                return fail(m, MGM_ERR_HIP, "hipEventRecord");
+        if ((r = mgm_wta_rows_dev(m->ctx[k], C[k], row0[k], nrows[k], m->recv[k].p, NDIR, fix_overcount, refine, ok, ck))) {
+            rc = r, rc_msg = std::string("device ") + std::to_string(m->dev[k]) + ": " + mgm_last_error(m->ctx[k]);
+            break;
+        }
+        if (k > 0 && hipEventRecord(m->rows_done[k], ctx_stream(k)) != hipSuccess) hipbad("hipEventRecord (rows)");
     }
     // 5. the rows travel to device 0 (two W x nrows images per device)
-    if (n > 1) {
-        if (!m->loopback && g_rccl.GroupStart() != ncclSuccess) return fail(m, MGM_ERR_HIP, "ncclGroupStart");
-        for (int k = 1; k < n; k++) {
-            if (!nrows[k]) continue;
-            const size_t cntk = (size_t)nrows[k] * nx;
-            hipStream_t s0 = (hipStream_t)mgm_ctx_stream(m->ctx[0]), sk = (hipStream_t)mgm_ctx_stream(m->ctx[k]);
-            if (m->loopback) {
-                if (hipSetDevice(m->dev[0]) != hipSuccess || hipStreamWaitEvent(s0, m->passes_done[k], 0) != hipSuccess ||
-                    hipMemcpyAsync(o0 + (size_t)row0[k] * nx, m->rows[k].p, sizeof(float) * cntk, hipMemcpyDeviceToDevice, s0) != hipSuccess ||
-                    hipMemcpyAsync(c0 + (size_t)row0[k] * nx, (float *)m->rows[k].p + cntk, sizeof(float) * cntk, hipMemcpyDeviceToDevice, s0) != hipSuccess)
-                    return fail(m, MGM_ERR_HIP, "hipMemcpyAsync (loopback rows)");
-            } else {
-                if (hipSetDevice(m->dev[k]) != hipSuccess) return fail(m, MGM_ERR_HIP, "hipSetDevice");
-                if (g_rccl.Send(m->rows[k].p, 2 * cntk, ncclFloat, 0, m->comm[k], sk) != ncclSuccess) return fail(m, MGM_ERR_HIP, "ncclSend (rows)");
-            }
-        }
-        if (!m->loopback) {
-            // device 0 receives each rank's two images back to back into a staging area, then places them
-            if (hipSetDevice(m->dev[0]) != hipSuccess) return fail(m, MGM_ERR_HIP, "hipSetDevice");
-            hipStream_t s0 = (hipStream_t)mgm_ctx_stream(m->ctx[0]);
-            size_t total = 0;
-            for (int k = 1; k < n; k++) total += 2 * (size_t)nrows[k] * nx;
-            // (the staging area follows rank 0's own receive buffer use: a separate allocation)
-            static_assert(sizeof(float) == 4, "");
-            Grow &st = m->rows[0];
-            if ((r = reserve(m, 0, st, sizeof(float) * std::max<size_t>(total, 1)))) {
-                (void)g_rccl.GroupEnd();
-                return r;
-            }
-            size_t off = 0;
-            for (int k = 1; k < n; k++) {
+    if (n > 1 && !rc) {
+        hipStream_t s0 = ctx_stream(0);
+        if (m->tr != T_RCCL) {
+            for (int k = 1; k < n && !rc; k++) {
                 if (!nrows[k]) continue;
                 const size_t cntk = (size_t)nrows[k] * nx;
-                if (g_rccl.Recv((float *)st.p + off, 2 * cntk, ncclFloat, k, m->comm[0], s0) != ncclSuccess) {
-                    (void)g_rccl.GroupEnd();
-                    return fail(m, MGM_ERR_HIP, "ncclRecv (rows)");
-                }
+                const float *src = (const float *)m->rows[k].p;
+                hipError_t e = hipSetDevice(m->dev[0]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(s0, m->rows_done[k], 0);
+                if (e == hipSuccess)
+                    e = m->tr == T_PEER ? hipMemcpyPeerAsync(o0 + (size_t)row0[k] * nx, m->dev[0], src, m->dev[k], sizeof(float) * cntk, s0)
+                                        : hipMemcpyAsync(o0 + (size_t)row0[k] * nx, src, sizeof(float) * cntk, hipMemcpyDeviceToDevice, s0);
+                if (e == hipSuccess)
+                    e = m->tr == T_PEER ? hipMemcpyPeerAsync(c0 + (size_t)row0[k] * nx, m->dev[0], src + cntk, m->dev[k], sizeof(float) * cntk, s0)
+                                        : hipMemcpyAsync(c0 + (size_t)row0[k] * nx, src + cntk, sizeof(float) * cntk, hipMemcpyDeviceToDevice, s0);
+                if (e != hipSuccess) hipbad("row copy");
+            }
+        } else {
+            // device 0 receives each rank's two images back to back into its staging area (sized in step 0), then places them
+            GroupGuard grp;
+            if (!grp.start()) rc = MGM_ERR_HIP, rc_msg = "ncclGroupStart (rows)";
+            float *st = (float *)m->rows[0].p;
+            size_t off = 0;
+            for (int k = 1; k < n && !rc; k++) {
+                if (!nrows[k]) continue;
+                const size_t cntk = (size_t)nrows[k] * nx;
+                if (hipSetDevice(m->dev[k]) != hipSuccess) hipbad("hipSetDevice");
+                else if (g_rccl.Send(m->rows[k].p, 2 * cntk, ncclFloat, 0, m->comm[k], ctx_stream(k)) != ncclSuccess) rc = MGM_ERR_HIP, rc_msg = "ncclSend (rows)";
+                if (!rc && hipSetDevice(m->dev[0]) != hipSuccess) hipbad("hipSetDevice");
+                else if (!rc && g_rccl.Recv(st + off, 2 * cntk, ncclFloat, k, m->comm[0], s0) != ncclSuccess) rc = MGM_ERR_HIP, rc_msg = "ncclRecv (rows)";
                 off += 2 * cntk;
             }
-            if (g_rccl.GroupEnd() != ncclSuccess) return fail(m, MGM_ERR_HIP, "ncclGroupEnd");
+            const ncclResult_t ge = grp.end();
+            if (ge != ncclSuccess && !rc) rc = MGM_ERR_HIP, rc_msg = std::string("ncclGroupEnd (rows): ") + g_rccl.GetErrorString(ge);
             off = 0;
-            for (int k = 1; k < n; k++) {
+            if (!rc && hipSetDevice(m->dev[0]) != hipSuccess) hipbad("hipSetDevice");
+            for (int k = 1; k < n && !rc; k++) {
                 if (!nrows[k]) continue;
                 const size_t cntk = (size_t)nrows[k] * nx;
-                if (hipMemcpyAsync(o0 + (size_t)row0[k] * nx, (float *)st.p + off, sizeof(float) * cntk, hipMemcpyDeviceToDevice, s0) != hipSuccess ||
-                    hipMemcpyAsync(c0 + (size_t)row0[k] * nx, (float *)st.p + off + cntk, sizeof(float) * cntk, hipMemcpyDeviceToDevice, s0) != hipSuccess)
-                    return fail(m, MGM_ERR_HIP, "hipMemcpyAsync (rows)");
+                if (hipMemcpyAsync(o0 + (size_t)row0[k] * nx, st + off, sizeof(float) * cntk, hipMemcpyDeviceToDevice, s0) != hipSuccess ||
+                    hipMemcpyAsync(c0 + (size_t)row0[k] * nx, st + off + cntk, sizeof(float) * cntk, hipMemcpyDeviceToDevice, s0) != hipSuccess)
+                    hipbad("hipMemcpyAsync (rows)");
                 off += 2 * cntk;
             }
         }
     }
-    // 6. everything has been enqueued; the call returns when the result is on device 0 (and no watchdog fired anywhere)
+    // 6. everything has been enqueued (or a failure stopped the posting: whatever was posted is complete on both sides,
+    //    one host thread posts for every rank).  Wait for all of it against the deadline; the call returns when the result
+    //    is on device 0, no watchdog fired anywhere, and no rank's stream has anything left that touches a buffer.
+    std::string why;
+    if (!drain(m, now_s() + m->timeout_s, why)) {
+        abort_transport(m);
+        return fail(m, MGM_ERR_HIP, "mgm_multi_aggregate: " + why + (rc ? " (after: " + rc_msg + ")" : ""));
+    }
     for (int k = n - 1; k >= 0; k--)
-        if ((r = mgm_ctx_synchronize(m->ctx[k]))) return fail(m, r, std::string("device ") + std::to_string(m->dev[k]) + ": " + mgm_last_error(m->ctx[k]));
+        if ((r = mgm_ctx_synchronize(m->ctx[k])) && !rc) rc = r, rc_msg = std::string("device ") + std::to_string(m->dev[k]) + ": " + mgm_last_error(m->ctx[k]);
+    if (rc) return fail(m, rc, rc_msg);
     return MGM_OK;
 }
 

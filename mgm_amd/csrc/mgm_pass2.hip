@@ -320,7 +320,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     unsigned *prog_out = P.prog + vp * P.maxbands + band;
     const unsigned *prog_in = from_global ? prog_out - 1 : prog_out;
 
-    const unsigned tag_in = P.hand_tag, tag_out = P.hand_tag;  // sign bits of the slabs handed over in this launch
+    const unsigned tag_in = P.hand_tag[pass], tag_out = tag_in;  // sign bits of the slabs this pass hands over in this launch
 
     if (wave >= NC) {
         // =========================== loader waves ===========================

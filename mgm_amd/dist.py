@@ -1,18 +1,47 @@
-"""One volume sharded by DIRECTION over the GPUs of a node (BASELINE cfg4).
+"""One volume sharded by DIRECTION over the GPUs of a node (BASELINE cfg4), one process per GPU.
 
 Every rank builds the full cost volume from the images (cheaper than broadcasting 13 GB), runs
-its contiguous share of the passes with ``mgm_aggregate_passes_dev`` and keeps their Lr volumes.
+its contiguous share of the passes with ``mgm_aggregate_passes[_at]_dev`` and keeps their Lr volumes.
 The per-pixel sum over directions must be taken in PASS ORDER in fp32 (a different order flips
 argmins), so an all-reduce is out: instead the image rows are cut into one slab per
 rank and the ranks exchange slabs with grouped point-to-point transfers (``batch_isend_irecv`` =
 ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd on RCCL; every GPU talks to every other GPU at
 once, one peer per xGMI link).  Each rank then owns all directions of its rows and finishes
-them locally with ``mgm_wta_rows_dev`` (ordered sum, over-count fix, WTA, V-fit).
+them locally with ``mgm_wta_rows_dev`` (ordered sum, over-count fix, WTA, V-fit).  The CPU analogue in
+the reference is mgm_naive_parallelism (mgm_core.cc:710-805): passes in parallel on private Lr volumes,
+then accumulated -- there in thread-finish order, here in pass order.
 
-The exchange code is backend-agnostic (torch tensors): the CPU test runs it over gloo with
-host tensors, the GPU path runs it over RCCL with zero-copy views of the workspace.
+How a step is ordered (no host synchronisation inside it): the library's stream is made torch's current
+stream (``torch.cuda.ExternalStream``), so RCCL's transfers wait for the pass kernels through stream
+events and the row-slab WTA waits for the transfers the same way.  The exchange is cut into ROUNDS --
+round k carries the k-th pass of every rank -- and with ``overlap=True`` a rank launches its passes one
+per launch and posts round k right behind pass k, so that the slabs of pass k travel while pass k+1 runs.
+
+What keeps a failure from becoming a hang:
+  * AGREE, THEN EXCHANGE: whether its pass launch succeeded is something every rank knows when the launch
+    returns; the ranks MIN-reduce that flag (on the control group, gloo if the caller has one: CPU only)
+    BEFORE any transfer is posted, so either all of them enter the exchange or none does, and every rank
+    reaches that small collective whatever happened to its launch;
+  * TIME-BOXED: the end of the step is an event polled against a deadline (`timeout_s`); a peer that never
+    delivers raises :class:`ExchangeTimeout` instead of blocking in ``synchronize`` forever.  After a
+    time-out the process group is unusable (a transfer is still pending on the device): abort it
+    (:func:`abort_group`) and tear the process down.
+
+The exchange code is backend-agnostic (torch tensors): the CPU tests run it over gloo with host tensors,
+the GPU path runs it over RCCL with zero-copy views of the workspace.
 """
+import time
+from datetime import timedelta
+
 import numpy as np
+
+
+class ExchangeError(RuntimeError):
+    """Some rank could not run its passes: no rank entered the exchange."""
+
+
+class ExchangeTimeout(RuntimeError):
+    """The slab exchange (or the step around it) did not complete in time on this rank."""
 
 
 def row_slabs(ny, world):
@@ -41,38 +70,150 @@ def owner_of_pass(p, NDIR, world):
     raise ValueError(p)
 
 
-def exchange_lr(lr_local, NDIR, ny, dist, group=None, like=None):
+def n_rounds(NDIR, world):
+    """Rounds of the exchange: the largest number of passes any rank runs."""
+    return max(passes_of_rank(NDIR, world, g)[1] for g in range(world))
+
+
+def agree(ok, dist, group=None, ctrl=None, device=None):
+    """True iff `ok` on EVERY rank.  Every rank must call it (it is a collective): the point is that a rank whose
+    own work failed still gets here, so the others learn of it instead of waiting for its slabs."""
+    import torch
+    g = ctrl if ctrl is not None else group
+    on_cpu = ctrl is not None or device is None or torch.device(device).type == "cpu"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if on_cpu else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=g)
+    return bool(int(t.item()) == 1)
+
+
+def abort_group(dist, group=None):
+    """Best effort: abort the communicator of a wedged process group so that teardown does not block on it."""
+    try:
+        pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        for name in ("abort", "_abort"):
+            f = getattr(pg, name, None)
+            if f is not None:
+                f()
+                return True
+        b = pg._get_backend(__import__("torch").device("cuda"))
+        for name in ("abort", "_abort"):
+            f = getattr(b, name, None)
+            if f is not None:
+                f()
+                return True
+    except Exception:  # noqa: BLE001 -- nothing more can be done for a dead communicator
+        pass
+    return False
+
+
+class SlabExchange:
+    """The ordered all-to-all of Lr row slabs, round by round.
+
+        ex = SlabExchange(NDIR, ny, nx, L, dist, ...)
+        for k in range(ex.rounds):
+            ex.post(k, lr_k)        # lr_k: [ny, nx, L] volume of this rank's k-th pass, or None if it has fewer passes
+        recv = ex.finish()          # [NDIR, my_rows, nx, L]: every pass's slab of this rank's rows, in pass order
+
+    Between any two ranks the messages are posted in round order on both sides, so they match without tags."""
+
+    def __init__(self, NDIR, ny, nx, L, dist, group=None, dtype=None, device="cpu", timeout_s=None):
+        import torch
+        self.dist, self.group, self.NDIR, self.ny = dist, group, NDIR, ny
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.slabs = row_slabs(ny, self.world)
+        self.r0, self.nr = self.slabs[self.rank]
+        self.first, self.count = passes_of_rank(NDIR, self.world, self.rank)
+        self.rounds = n_rounds(NDIR, self.world)
+        self.device = torch.device(device)
+        self.recv = torch.empty((NDIR, self.nr, nx, L), dtype=dtype or torch.float32, device=self.device)
+        self.reqs = []
+        self.deadline = (time.monotonic() + timeout_s) if timeout_s else None
+        self.posted = 0
+
+    def post(self, k, vol):
+        dist = self.dist
+        assert k == self.posted and k < self.rounds, "rounds are posted in order"
+        assert (vol is not None) == (k < self.count), "a volume for each of this rank's passes, None beyond them"
+        self.posted += 1
+        ops = []
+        for g in range(self.world):  # receives: the k-th pass of every rank that has one
+            f, n = passes_of_rank(self.NDIR, self.world, g)
+            if k >= n:
+                continue
+            p = f + k
+            if g == self.rank:
+                if self.nr:
+                    self.recv[p].copy_(vol[self.r0:self.r0 + self.nr])
+            elif self.nr:
+                ops.append(dist.P2POp(dist.irecv, self.recv[p], g, self.group))
+        if vol is not None:  # sends: every other rank's rows of my k-th pass
+            for g in range(self.world):
+                g0, gn = self.slabs[g]
+                if g != self.rank and gn:
+                    ops.append(dist.P2POp(dist.isend, vol[g0:g0 + gn], g, self.group))
+        if ops:
+            self.reqs += dist.batch_isend_irecv(ops)
+
+    def _remaining(self):
+        if self.deadline is None:
+            return None
+        left = self.deadline - time.monotonic()
+        if left <= 0:
+            raise ExchangeTimeout("slab exchange: rank %d of %d ran out of time" % (self.rank, self.world))
+        return left
+
+    def finish(self, block=True):
+        """Wait for every transfer.  Device tensors: the CURRENT stream is ordered behind the transfers; with `block`
+        the host also waits, polling an event against the deadline.  Host tensors (gloo): each request is waited for
+        with what is left of the deadline."""
+        import torch
+        assert self.posted == self.rounds, "every round must be posted (ranks without a pass post None)"
+        if self.device.type == "cuda":
+            for req in self.reqs:
+                req.wait()  # (RCCL: enqueues a stream wait, does not block the host)
+            if block:
+                ev = torch.cuda.Event()
+                ev.record()
+                poll_event(ev, self.deadline, "slab exchange: rank %d of %d" % (self.rank, self.world))
+        else:
+            for req in self.reqs:
+                left = self._remaining()
+                try:
+                    if left is None:
+                        req.wait()
+                    else:
+                        req.wait(timedelta(seconds=left))
+                except RuntimeError as e:
+                    if "ime" in str(e) and "out" in str(e):  # gloo: "Timed out waiting ..."
+                        raise ExchangeTimeout(str(e)) from e
+                    raise
+        self.reqs = []
+        return self.recv
+
+
+def poll_event(ev, deadline, what="step"):
+    """Host-side wait for a torch.cuda.Event that gives up at `deadline` (time.monotonic() seconds; None = never)."""
+    while not ev.query():
+        if deadline is not None and time.monotonic() > deadline:
+            raise ExchangeTimeout("%s: not complete after the time allowed" % what)
+        time.sleep(0.0002)
+
+
+def exchange_lr(lr_local, NDIR, ny, dist, group=None, like=None, timeout_s=None):
     """lr_local: list of [ny, nx, L] tensors, the Lr volumes of this rank's passes (in pass order).
     Returns a [NDIR, my_rows, nx, L] tensor with every pass's slab of this rank's rows.
     A rank beyond the NDIR-th runs no pass (world > NDIR) but still owns rows: it passes `like`, any tensor
     whose last two dimensions, dtype and device are those of the Lr volumes."""
-    import torch
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     first, count = passes_of_rank(NDIR, world, rank)
     assert len(lr_local) == count
-    slabs = row_slabs(ny, world)
-    r0, nr = slabs[rank]
     ref = lr_local[0] if count else like
     if ref is None:
         raise ValueError("exchange_lr: a rank without passes must say what the volumes look like (like=)")
-    nx, L = ref.shape[-2], ref.shape[-1]
-    recv = torch.empty((NDIR, nr, nx, L), dtype=ref.dtype, device=ref.device)
-    ops = []
-    for p in range(NDIR):  # receives, in pass order per peer
-        o = owner_of_pass(p, NDIR, world)
-        if o == rank:
-            recv[p].copy_(lr_local[p - first][r0:r0 + nr])
-        elif nr:
-            ops.append(dist.P2POp(dist.irecv, recv[p], o, group))
-    for k in range(count):  # sends, in pass order per peer
-        for g in range(world):
-            g0, gn = slabs[g]
-            if g != rank and gn:
-                ops.append(dist.P2POp(dist.isend, lr_local[k][g0:g0 + gn], g, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    return recv
+    ex = SlabExchange(NDIR, ny, ref.shape[-2], ref.shape[-1], dist, group, ref.dtype, ref.device, timeout_s)
+    for k in range(ex.rounds):
+        ex.post(k, lr_local[k] if k < count else None)
+    return ex.finish()
 
 
 def ordered_sum_numpy(slabs, C_rows, fix_overcount):
@@ -98,9 +239,16 @@ def device_view(ptr, shape):
     return torch.as_tensor(_DevMem(ptr, shape), device="cuda")
 
 
-def aggregate_direction_sharded(ctx, cv, P1, P2, NDIR, MGM, use_fh, fix_overcount, refine, dist, group=None, w8=None):
+def aggregate_direction_sharded(ctx, cv, P1, P2, NDIR, MGM, use_fh, fix_overcount, refine, dist, group=None, w8=None,
+                                ctrl=None, timeout_s=120.0, overlap=False, stats=None):
     """The whole aggregation of ONE volume across the ranks of `group`.  Returns (out, outcost) as torch
-    tensors [ny, nx] on every rank (all-gathered rows)."""
+    tensors [ny, nx] on every rank (all-gathered rows).
+
+    ctrl: a CPU (gloo) group of the same ranks for the agreement step (default: `group` itself, device tensors).
+    overlap: launch this rank's passes one per launch and post each pass's slabs right behind it.
+    stats: a dict that receives this rank's stage times in ms (passes / exchange / wta / gather), torch events on the
+    library's stream.  Raises ExchangeError (no rank exchanged anything; the group is still usable) or ExchangeTimeout
+    (the group is wedged)."""
     import torch
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     nx, ny, dmin, dmax = cv.dims
@@ -111,26 +259,78 @@ def aggregate_direction_sharded(ctx, cv, P1, P2, NDIR, MGM, use_fh, fix_overcoun
         views = [device_view(ctx.lib.mgm_img_device_ptr(im.h), (ny, nx)).clone() for im in (o, c)]
         o.free(), c.free()
         return views[0], views[1]
+    deadline = (time.monotonic() + timeout_s) if timeout_s else None
     first, count = passes_of_rank(NDIR, world, rank)
-    if count:  # (world > NDIR: the ranks beyond the NDIR-th run no pass; they still sum and search their rows)
-        ctx.aggregate_passes_dev(cv, P1, P2, MGM, use_fh, first, count, w8)
-    ctx.synchronize()  # Lr volumes complete before RCCL reads them (different streams)
-    lr_local = [device_view(ctx.lr_device_ptr(k), (ny, nx, L)) for k in range(count)]
-    recv = exchange_lr(lr_local, NDIR, ny, dist, group, like=torch.empty((0, nx, L), dtype=torch.float32, device="cuda"))
-    torch.cuda.synchronize()
+    rounds = n_rounds(NDIR, world)
     slabs = row_slabs(ny, world)
     r0, nr = slabs[rank]
-    out = torch.empty((max(nr, 1), nx), dtype=torch.float32, device="cuda")
-    outc = torch.empty_like(out)
-    if nr:
-        ctx.wta_rows_dev(cv, r0, nr, recv.data_ptr(), NDIR, fix_overcount, refine, out.data_ptr(), outc.data_ptr())
-    ctx.synchronize()
     maxr = max(n for _, n in slabs)
-    pad = lambda t: torch.cat([t[:nr], t.new_zeros((maxr - nr, nx))]) if nr < maxr else t[:nr]
-    go = [torch.empty((maxr, nx), dtype=torch.float32, device="cuda") for _ in range(world)]
-    gc = [torch.empty_like(go[0]) for _ in range(world)]
-    dist.all_gather(go, pad(out).contiguous(), group)
-    dist.all_gather(gc, pad(outc).contiguous(), group)
-    full_o = torch.cat([go[g][:slabs[g][1]] for g in range(world)])
-    full_c = torch.cat([gc[g][:slabs[g][1]] for g in range(world)])
+    lib_stream = torch.cuda.ExternalStream(ctx.stream_ptr())
+    marks = []
+
+    def mark():
+        if stats is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
+
+    def launch(fn):  # a launch error is known when the call returns: remember it, and go on to the agreement
+        try:
+            fn()
+            return None
+        except Exception as e:  # noqa: BLE001 -- reported after every rank has been told
+            return e
+
+    with torch.cuda.stream(lib_stream):
+        mark()
+        err = None
+        ex = None
+        if not overlap:
+            if count:  # (world > NDIR: the ranks beyond the NDIR-th run no pass; they still sum and search their rows)
+                err = launch(lambda: ctx.aggregate_passes_dev(cv, P1, P2, MGM, use_fh, first, count, w8))
+            mark()
+            if not agree(err is None, dist, group, ctrl, "cuda"):
+                raise ExchangeError("rank %d: %s" % (rank, err) if err is not None else "another rank could not run its passes")
+            ex = SlabExchange(NDIR, ny, nx, L, dist, group, torch.float32, "cuda", None)
+            ex.deadline = deadline
+            for k in range(rounds):
+                ex.post(k, device_view(ctx.lr_device_ptr(k), (ny, nx, L)) if k < count else None)
+        else:
+            for k in range(rounds):
+                if k < count and err is None:
+                    err = launch(lambda: ctx.aggregate_passes_at_dev(cv, P1, P2, MGM, use_fh, first + k, 1, k, count, NDIR, w8))
+                if k == rounds - 1:
+                    mark()
+                if not agree(err is None, dist, group, ctrl, "cuda"):
+                    if ex is not None:  # earlier rounds are in flight: let them land before anybody frees a buffer
+                        ex.posted = ex.rounds
+                        ex.finish()
+                    raise ExchangeError("rank %d: %s" % (rank, err) if err is not None else "another rank could not run its passes")
+                if ex is None:
+                    ex = SlabExchange(NDIR, ny, nx, L, dist, group, torch.float32, "cuda", None)
+                    ex.deadline = deadline
+                ex.post(k, device_view(ctx.lr_device_ptr(k), (ny, nx, L)) if k < count else None)
+        recv = ex.finish(block=False)
+        mark()
+        out = torch.zeros((maxr, nx), dtype=torch.float32, device="cuda")  # (padded to the longest slab for the gather)
+        outc = torch.zeros_like(out)
+        if nr:
+            ctx.wta_rows_dev(cv, r0, nr, recv.data_ptr(), NDIR, fix_overcount, refine, out.data_ptr(), outc.data_ptr())
+        mark()
+        go = [torch.empty((maxr, nx), dtype=torch.float32, device="cuda") for _ in range(world)]
+        gc = [torch.empty_like(go[0]) for _ in range(world)]
+        dist.all_gather(go, out, group)
+        dist.all_gather(gc, outc, group)
+        full_o = torch.cat([go[g][:slabs[g][1]] for g in range(world)])
+        full_c = torch.cat([gc[g][:slabs[g][1]] for g in range(world)])
+        mark()
+        done = torch.cuda.Event()
+        done.record()
+        poll_event(done, deadline, "direction-sharded step: rank %d of %d" % (rank, world))
+    ctx.synchronize()  # the stream is idle: this only looks at the pass kernel's watchdog word
+    if stats is not None:
+        names = ["passes_ms", "exchange_ms", "wta_ms", "gather_ms"]
+        for i, n in enumerate(names):
+            stats[n] = stats.get(n, 0.0) + marks[i].elapsed_time(marks[i + 1])
+        stats["steps"] = stats.get("steps", 0) + 1
     return full_o, full_c

@@ -1,6 +1,8 @@
-"""A stand-in for mgm_amd.Context that computes NOTHING: bench.py's launcher, rendezvous, barrier / max-over-ranks timing
-and JSON contract can then be driven on CPU ranks (gloo) by tests/test_dist_cpu.py.  It is a test double, not a CPU
-path of the product: bench.py loads it only under MGM_BENCH_STUB=1 and labels the line `"data": "stub (no device work)"`."""
+"""A stand-in for mgm_amd.Context that computes NOTHING: bench.py's launcher, rendezvous, barrier / max-over-ranks timing,
+extra legs and JSON contract can then be driven on CPU ranks (gloo) by tests/test_dist_cpu.py.  It is a test double, not a
+CPU path of the product: bench.py does not know this file -- the test INJECTS it (MGM_BENCH_STUB=<path of this file>) -- and
+labels the line `"data": "stub (no device work)"`."""
+import os
 import time
 
 
@@ -30,11 +32,16 @@ class StubContext:
     def aggregate_batch_dev(self, Cvs, P1, P2, NDIR, MGM, use_fh=0, fix_overcount=1, w8s=None, refine=None, outs=None, outcosts=None,
                             want_S=False):
         time.sleep(0.002 * (1 + self.device))  # rank 1 is the slow one
+        if os.environ.get("MGM_STUB_HANG_AT") == "cfg5" and len(Cvs) == 16 and self.device == 1:
+            time.sleep(3600)  # (tests/test_dist_cpu.py: a rank that never comes back from the cfg5 leg)
         if self._timing:
             self._t += [("k_pass2", 1.0 * len(Cvs))] + [("k_wta", 0.5)] * len(Cvs)
         return None, outs, outcosts
 
     def synchronize(self):
+        pass
+
+    def trim(self):
         pass
 
     def timing(self, enable=True):

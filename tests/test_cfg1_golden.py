@@ -4,6 +4,7 @@
 
 CPU: the oracle restatement (cost volume + mgm() for both runs) plus a numpy restatement of main()'s left-right check.
 GPU: the `mgm` host program over libmgm_hip.so on the same files, stdout and both maps bit for bit."""
+import ast
 import os
 import subprocess
 
@@ -58,7 +59,7 @@ def test_cli_reproduces_config1(cfg1, tmp_path):
     for s in "LR":
         np.save(tmp_path / (s + ".npy"), cfg1["u" + s].astype(np.float32))
     cmd = [OURS] + str(cfg1["args"]).split() + [str(tmp_path / "L.npy"), str(tmp_path / "R.npy"), str(tmp_path / "disp.npy"), str(tmp_path / "cost.npy")]
-    r = subprocess.run(cmd, env=dict(os.environ, **eval(str(cfg1["env"]))), capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, env=dict(os.environ, **ast.literal_eval(str(cfg1["env"]))), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     assert r.stdout == str(cfg1["stdout"])
     assert ndiff(np.load(tmp_path / "disp.npy").reshape(500, 700), cfg1["disp"]) == 0

@@ -114,7 +114,7 @@ def test_bench_launches_its_own_ranks():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MGM_BENCH_STUB="1")
+    env = dict(os.environ, MGM_BENCH_STUB=os.path.join(root, "tests", "bench_stub.py"))  # the stub is injected by path
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "cfg5",
@@ -127,3 +127,100 @@ def test_bench_launches_its_own_ranks():
     # whole-job aggregate: 2 ranks x 4 steps x 2 volumes over the slowest rank's time
     assert abs(d["value"] - 16 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
     assert len(d["repeat_values"]) == 1 and d["roofline"]["per_kernel"]["k_pass2"]["GBps"] > 0
+    assert d["roofline"]["per_kernel"]["k_pass2"]["format_bytes"] > 0 and "cfg5_replicas" not in d  # (explicit workload: no extra legs)
+
+
+def _run_bench(args, extra_env=None, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGM_BENCH_STUB=os.path.join(root, "tests", "bench_stub.py"), **(extra_env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None), lines
+
+
+def test_driver_command_line_runs_the_extra_legs():
+    """`python bench.py --gpus 2 --steps K --warmup W` and nothing else -- the driver's command: after the cfg3 headline the
+    SAME json line carries the cfg5 replicas and the direction-sharded leg (here: agreement + ordered slab exchange over
+    gloo on the stub's host tensors), and it is still ONE line."""
+    r, d, lines = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["workload"].startswith("cfg3")
+    c5 = d["cfg5_replicas"]
+    assert c5["n_gpus"] == 2 and c5["pairs_per_step_per_gpu"] == 16 and c5["value"] > 0 and c5["scaling"] == "weak"
+    dr = d["directions"]
+    assert dr["ranks"] == 2 and dr["scaling"] == "strong" and dr["transport"] == "rccl"
+    assert dr["rccl"]["rccl_ranks"] == 2 and dr["rccl"]["differs_from_single"] == 0 and dr["value"] == dr["rccl"]["value"]
+    assert "extras_note" not in d
+
+
+def test_extras_watchdog_prints_the_headline_when_a_leg_hangs():
+    """A leg that never returns (the stub sleeps in the cfg5 leg when told to) must not take the headline with it: the
+    watchdog prints the one line with what had been measured and ends every rank."""
+    r, d, lines = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "0", "--extras-timeout", "6"],
+                             {"MGM_STUB_HANG_AT": "cfg5"}, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and d["value"] > 0 and d["config"]["workload"].startswith("cfg3")
+    assert "watchdog" in d["extras_note"] and "directions" not in d
+
+
+def test_single_rank_default_line_has_both_legs():
+    r, d, lines = _run_bench(["--steps", "2", "--warmup", "1", "--repeats", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and d["n_gpus"] == 1
+    assert d["cfg5_replicas"]["n_gpus"] == 1 and d["directions"]["ranks"] == 1 and d["directions"]["transport"] == "single"
+
+
+def test_exchange_rounds_and_timeout():
+    """SlabExchange posts round by round (the overlap schedule) and gives the same slabs; a peer that never posts makes
+    the receiver raise ExchangeTimeout instead of blocking forever."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rounds_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=180) for _ in ps]
+    [p.join(60) for p in ps]
+    assert sorted(res) == [(0, 0, "timeout"), (1, 0, "absent")], res
+
+
+def _rounds_worker(rank, world, port, q):
+    from datetime import timedelta
+    from mgm_amd import dist as mdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=120))
+    NDIR, ny, nx, L = 5, 11, 7, 6  # 5 passes over 2 ranks: 3 rounds, rank 1 has no pass in the last one
+    vols = torch.rand((NDIR, ny, nx, L), generator=torch.Generator().manual_seed(5))
+    first, count = mdist.passes_of_rank(NDIR, world, rank)
+    ex = mdist.SlabExchange(NDIR, ny, nx, L, dist, None, torch.float32, "cpu", 60.0)
+    assert ex.rounds == 3
+    for k in range(ex.rounds):
+        assert mdist.agree(True, dist)  # (what the overlapped schedule does between launches)
+        ex.post(k, vols[first + k] if k < count else None)
+    recv = ex.finish()
+    r0, nr = mdist.row_slabs(ny, world)[rank]
+    bad = int((recv != vols[:, r0:r0 + nr]).sum())
+    assert mdist.agree(rank == 0, dist) is False  # one rank reporting a failure is every rank's failure
+    # rank 1 goes away without posting: rank 0's exchange must time out, not hang
+    what = "absent"
+    if rank == 0:
+        ex2 = mdist.SlabExchange(NDIR, ny, nx, L, dist, None, torch.float32, "cpu", 3.0)
+        try:
+            for k in range(ex2.rounds):
+                ex2.post(k, vols[first + k] if k < count else None)
+            ex2.finish()
+            what = "completed?"
+        except mdist.ExchangeTimeout:
+            what = "timeout"
+    q.put((rank, bad, what))
+    q.close()
+    q.join_thread()  # (os._exit below does not flush the queue's feeder thread)
+    if rank == 1:
+        import time
+        time.sleep(8)  # stay alive (connected) while rank 0 waits in vain
+    os._exit(0)  # (a process group with a dead exchange is not torn down in an orderly way)
