@@ -71,6 +71,7 @@ struct mgm_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // workspace
+    Buf exact_mins;  // slab minima of the operand-order-faithful pass kernel (mgm_pass_exact.hip)
     Buf lr, hand, hand2, handm, words, tasks, census_u, census_v, dbg, stmp, ones8;  // hand: self-validating slabs (TAGS); hand2: the other kernels' slots
     size_t ws_limit = 0;  // mgm_ctx_set_workspace_limit: cap on the Lr + hand-off workspace of one pass launch (0 = none)
     int debug_stats = 0;  // MGM_HIP_DEBUG_STATS=1: per-workgroup timing summary of K3 on stderr
@@ -117,7 +118,8 @@ struct DevSwitches {
     bool c8;         // MGM_HIP_C8=0: never use the compact (1 byte per label) cost volumes
     bool lazy_f32;   // MGM_HIP_LAZY_F32=0: always materialise the fp32 volume next to the compact one
     bool pad;        // MGM_HIP_PAD=0: no padding of label counts to the next count of the second build
-    bool subv;       // MGM_HIP_SUBV=0: one volume per wave also at 128 / 64 labels
+    int subv;        // MGM_HIP_SUBV=0: one volume per wave also at 128 / 64 labels; 2: volumes share waves whenever they can
+    int deep;        // MGM_HIP_DEEP=0|1: never / always the pass kernels with deep DMA rings (default: by the launch's shape)
     int wg_per_cu;   // MGM_HIP_WG_PER_CU=1|2: override the occupancy heuristic of the pass kernel (0 = heuristic)
     int xflags;      // MGM_HIP_XFLAGS: experiment bits of development builds (mgm_device.h)
     int strips;      // MGM_HIP_STRIPS=0|1: never / always walk the lines of passes 4-7 as two strips (default: chain-bound launches only)
@@ -128,7 +130,7 @@ static const DevSwitches &dev()
     static const DevSwitches d = [] {
         auto on = [](const char *n) { const char *e = getenv(n); return !(e && atoi(e) == 0); };
         auto num = [](const char *n, long long dflt) { const char *e = getenv(n); return e ? atoll(e) : dflt; };
-        return DevSwitches{on("MGM_HIP_C8"), on("MGM_HIP_LAZY_F32"), on("MGM_HIP_PAD"), on("MGM_HIP_SUBV"),
+        return DevSwitches{on("MGM_HIP_C8"), on("MGM_HIP_LAZY_F32"), on("MGM_HIP_PAD"), (int)num("MGM_HIP_SUBV", 1), (int)num("MGM_HIP_DEEP", -1),
                            (int)num("MGM_HIP_WG_PER_CU", 0), (int)num("MGM_HIP_XFLAGS", 0), (int)num("MGM_HIP_STRIPS", -1), 64ll * num("MGM_HIP_LR_PAD", 67)};
     }();
     return d;
@@ -346,7 +348,7 @@ int mgm_ctx_destroy(mgm_ctx *c)
     if (!c) return MGM_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->words, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
+    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->words, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);
         bufs.push_back(&c->pad8[v]);
@@ -373,7 +375,7 @@ int mgm_ctx_trim(mgm_ctx *c)
     if (!c) return MGM_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     if (int r = mgm_ctx_synchronize(c)) return r;
-    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
+    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);
         bufs.push_back(&c->pad8[v]);
@@ -921,6 +923,65 @@ static int padded_labels(int L)
     return 0;
 }
 
+// K3 for the volumes whose aggregation can meet NaNs: the slow, operand-order-faithful kernel (mgm_pass_exact.hip) --
+// the reference's own update functions and schedule, one launch per diagonal, every minimum as the reference writes it.
+static int run_passes_exact(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int nb, float P1, float P2, int MGM,
+                            bool fh, bool weighted, int first, int count, int slot0, int nslots)
+{
+    const mgm_cv *C = Cs[0];
+    const int nx = C->nx, ny = C->ny, L = C->dmax - C->dmin + 1;
+    const long long npix = (long long)nx * ny, nvol = npix * L;
+    const long long lr_stride = nvol + lr_pad_floats();
+    int r;
+    if ((r = reserve(c, c->lr, sizeof(float) * (size_t)lr_stride * nslots * nb))) return r;
+    if ((r = reserve(c, c->exact_mins, sizeof(float) * (size_t)npix))) return r;
+    ExactParams p{};
+    p.nx = nx;
+    p.ny = ny;
+    p.L = L;
+    p.P1 = P1;
+    p.P2 = P2;
+    p.MGM = MGM;
+    // which of the four update functions (mgm_core.cc:548-571)
+    p.mode = weighted ? (fh ? 3 : 1) : (fh ? (MGM == 2 ? 2 : 3) : (MGM == 2 ? 0 : 1));
+    p.mins = (float *)c->exact_mins.p;
+    for (int v = 0; v < nb; v++) {
+        if ((r = ensure_f32(c, Cs[v]))) return r;
+        p.C = Cs[v]->d;
+        p.dmin = Cs[v]->dmin;
+        p.w8 = weighted ? w8s[v]->d : nullptr;
+        p.rlo = Cs[v]->rlo;
+        p.rhi = Cs[v]->rhi;
+        for (int q = first; q < first + count; q++) {
+            const RefPass &rp = kPasses[q];
+            for (int k = 0; k < 4; k++) {
+                p.d[k][0] = rp.d[k][0];
+                p.d[k][1] = rp.d[k][1];
+                p.wplane[k] = kPassToChannel[k][q];
+            }
+            p.inc_x = rp.inc_x;
+            p.inc_y = rp.inc_y;
+            p.row_major = rp.row_major;
+            p.Lr = (float *)c->lr.p + ((size_t)v * nslots + slot0 + (q - first)) * lr_stride;
+            HIPCHK(c, hipMemcpyAsync(p.Lr, p.C, sizeof(float) * (size_t)nvol, hipMemcpyDeviceToDevice, c->stream));  // Lr = CC (495-498)
+            TimeScope t(c, "k_pass_exact");
+            HIPCHK(c, launch_pass_exact(p, c->stream));
+        }
+    }
+    c->last_nvol = nvol;
+    c->last_stride = lr_stride;
+    c->last_ndir = nslots;
+    c->last_batch = nb;
+    c->last_L = L;
+    c->last_Lk = L;
+    c->last_pad_c8 = false;
+    for (int v = 0; v < kMaxBatch; v++) {
+        c->last_cvs[v] = v < nb ? Cs[v] : nullptr;
+        c->last_gens[v] = v < nb ? Cs[v]->gen : 0;
+    }
+    return MGM_OK;
+}
+
 // slot0 / nslots: pass p's Lr volume goes to workspace slot slot0 + (p - first) of nslots (a caller that launches the
 // passes of one volume one at a time keeps them all: mgm_aggregate_passes_at_dev); layout_ndir: the hand-off region is
 // laid out for the passes [0, layout_ndir) whichever of them this launch runs, so that such a caller's launches share it.
@@ -932,10 +993,6 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     const mgm_cv *C = Cs[0];
     const int nx = C->nx, ny = C->ny, Lreal = C->dmax - C->dmin + 1;
     const int PEND = first + count;
-    for (int v = 0; v < nb; v++)
-        if (Cs[v]->nan_words)
-            return fail(c, MGM_ERR_UNSUPPORTED, "cost volume of a census prefilter with a non-census distance and a descriptor of "
-                                                "more than 24 bits (NaN-valued words): use -t census");
     HIPCHK(c, hipSetDevice(c->device));
     // The second build's unweighted kernels keep the sign bit of the slabs they hand from band to band for a validity
     // tag, which needs E = T - m >= +0, i.e. non-negative penalties (mgm_pass2.hip, TAGS): anything else takes the first build.
@@ -978,6 +1035,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         weighted = wv;
     }
     const bool fh = use_fh > 0;
+    const bool weighted_given = weighted;  // (before the ragged FH path borrows the weighted kernels below)
     // FH potentials on a ragged volume: the min-convolution runs over the RECEIVING pixel's range (mgm_core.cc:242-271), so
     // it cannot be done once by the producer.  The weighted FH kernels convolve on the consumer side anyway: use them,
     // with all-ones weights if the caller has none (update_costW_trunclinear with DeltaI = 1 is what the reference calls
@@ -985,12 +1043,16 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // boundary fix-up (166-186, 197-219) and is not built.
     bool ragged = false;
     for (int v = 0; v < nb; v++) ragged |= Cs[v]->rlo != nullptr;
-    // The dense layout of a ragged volume relies on every slab keeping a finite minimum, which a finite P2 guarantees
-    // (every term is capped at m + P2).  With P2 = +INF a pixel whose neighbours' ranges miss its own gets an all-INF
-    // slab and the next one INF - INF = NaN; from there on the result depends on which operand of the reference's
-    // `a < b ? a : b` minima holds the NaN, which v_min_f32 does not reproduce.
-    if (ragged && !(P2 < __builtin_huge_valf()))
-        return fail(c, MGM_ERR_UNSUPPORTED, "a ragged cost volume with P2 = +INF is not built (NaN propagation of the reference's minima)");
+    // Volumes whose aggregation can meet NaNs take the slow kernel that keeps the operand order of the reference's minima
+    // (mgm_pass_exact.hip; the fast builds are compiled NaN-free):
+    //   * costs that are descriptor WORDS differenced as floats (-p census with a non-census distance, > 24 bits);
+    //   * a ragged volume with P2 = +INF: the dense layout relies on every slab keeping a finite minimum, which a finite
+    //     P2 guarantees (every term is capped at m + P2); with P2 = +INF a pixel whose neighbours' ranges miss its own gets
+    //     an all-INF slab and the next one INF - INF = NaN;
+    //   * (found below, by the scan of an uploaded volume) NaN costs.
+    bool exact = ragged && !(P2 < __builtin_huge_valf());
+    for (int v = 0; v < nb; v++) exact |= Cs[v]->nan_words;
+    if (exact) return run_passes_exact(c, Cs, w8s, nb, P1, P2, MGM, fh, weighted_given, first, count, slot0, nslots);
     const float *ones8 = nullptr;
     if (fh && ragged)
         for (int v = 1; v < nb; v++)
@@ -1018,10 +1080,9 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         bool u = false;
         if ((r = c8_resolve(c, Cs[v], &u))) return r;
         c8ok[v] = u;
-        if (Cs[v]->nan_state < 0)
-            return fail(c, MGM_ERR_UNSUPPORTED, "the cost volume holds NaN costs: what the reference's aggregation makes of them depends "
-                                                "on the operand order of its minima and is not reproduced");
+        exact |= Cs[v]->nan_state < 0;
     }
+    if (exact) return run_passes_exact(c, Cs, w8s, nb, P1, P2, MGM, fh, weighted_given, first, count, slot0, nslots);
     if (padded) {
         // padded copies of the costs: the compact form if every volume allows it, else fp32
         HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
@@ -1048,8 +1109,12 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // 128 / 64 labels: 2 / 4 volumes of the launch share every wave of the 256-label kernels (k_pass2<..., SUBV>) -- a
     // step is mostly fixed cost, so it may as well serve several volumes.  Compact costs, no weights, not FH with
     // TSGM = 2 (whose slabs travel with their minimum), and a volume count that divides.
+    // Only from two such groups on, though: sharing a wave halves the band-steps but makes every step the longer step of
+    // the 256-label kernels, and a launch of one group is bound by its chain of bands, i.e. by the step (round 3,
+    // 1920x1080x128 x 2: K3 3.74 ms sharing, 3.11 ms as two plain work items; x 4: the same either way).
     int subv = 1;
-    if (!first_build && use_c8 && !weighted && !(fh && MGM == 2) && (L == 128 || L == 64) && nb % (256 / L) == 0 && dev().subv)
+    if (!first_build && use_c8 && !weighted && !(fh && MGM == 2) && (L == 128 || L == 64) && nb % (256 / L) == 0 &&
+        (dev().subv == 2 || (dev().subv == 1 && nb / (256 / L) >= 2)))
         subv = 256 / L;
     const int ngroups = nb / subv;  // work items address groups of `subv` volumes
     const int Lk = L * subv;        // label slots of a wave
@@ -1129,7 +1194,13 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
             chain = std::max(chain, (double)g.slope * g.NL + g.LL + lag * g.nbands);
         }
         p.wg_per_cu = (work / (double)c->num_cu > (fh ? 1.8 : 8.0) * chain) ? 2 : 1;
+        // Deep DMA rings (k_pass2, DEEP) wherever a band's step may have to wait for its loads: everything but the
+        // launches of many 128-label volumes, which lose with them (round 3: 1920x1080x128 x 16, ratio 5.1: K3 16.2 ->
+        // 19.1 ms; 1024x1024x128 x 16, ratio 4.0, and twelve 256-label volumes, ratio 10: no change).
+        const double ratio = work / (double)c->num_cu / chain;
+        p.deep = (tags && use_c8 && !(Lk <= 256 && subv > 1 && ratio > 4.5)) ? 1 : 0;
     }
+    if (dev().deep >= 0) p.deep = (tags && use_c8 && dev().deep) ? 1 : 0;
     if (dev().wg_per_cu) p.wg_per_cu = dev().wg_per_cu;
     // A single volume per launch (chain-bound, one band per CU) walks the lines of the passes without an in-line
     // dependency -- form 1 with 2 or 3 neighbours -- as two strips, from both image edges inwards (mgm_pass2.hip): half

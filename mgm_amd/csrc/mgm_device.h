@@ -59,6 +59,7 @@ struct PassParams {
     const int2 *tasks;  // ticket -> (volume*8 + pass, band + (strip << 16))
     int subv;                 // volumes per wave (1; 2 at 128 labels, 4 at 64: k_pass2<..., SUBV>); work items then address groups of volumes
     int wg_per_cu;            // 1 or 2 workgroups per compute unit (second build; see launch2_c8)
+    int deep;                 // 1: the build with deeper DMA rings (k_pass2, DEEP; compact unweighted kernels)
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA, 4 ignore
                               // inter-band waits, 8 skip step barriers, 16 Lr stores into a cache-resident window (-DMGM_P2_XFLAG16 builds only); all of them need a -DMGM_P2_DEV=1 build
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
@@ -89,6 +90,23 @@ struct WtaParams {
     const float *clo, *chi;
     int num_cu;                      // compute units of the device (grid sizing)
 };
+
+// the slow, operand-order-faithful pass kernel (mgm_pass_exact.hip): one pass of one volume
+struct ExactParams {
+    const float *C;      // [npix][L]
+    float *Lr;           // this pass's volume [npix][L], initialised to C by the caller
+    float *mins;         // [npix] slab minima of the pixels visited so far
+    const float *w8;     // 8 planes or nullptr
+    const float *rlo, *rhi;  // ragged volume: per-pixel range images, or nullptr
+    int nx, ny, L, dmin;
+    float P1, P2;
+    int MGM, mode;       // mode: 0 update_cost2, 1 update_costW, 2 update_cost2_trunclinear, 3 update_costW_trunclinear
+    int d[4][2];         // the pass's neighbour offsets (mgm_core.cc:463-471)
+    int inc_x, inc_y, row_major;
+    int wplane[4];       // weight plane of neighbour k (481-484)
+    int ii, jj0;         // diagonal; first jj of it that lies inside the image
+};
+hipError_t launch_pass_exact(const ExactParams &p, hipStream_t s);
 
 // launchers (one per translation unit)
 hipError_t launch_pass(const PassParams &p, int ntasks, int R, bool fh, int wmode, hipStream_t s);

@@ -135,7 +135,10 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 
 #define MGM_P2_C8_NC (16 - MGM_P2_C8_NL)   // lines per band with compact costs (tuning experiments: 7)
 #endif
 #ifndef MGM_P2_MAXD
-#define MGM_P2_MAXD 2
+#define MGM_P2_MAXD 2   // steps of DMA in flight, the shallow build (throughput-bound launches of many volumes)
+#endif
+#ifndef MGM_P2_DEEPD
+#define MGM_P2_DEEPD 4  // ... the deep build: launches in which a band's step waits for its DMA (see DEEP in k_pass2)
 #endif
 #ifndef MGM_P2_PUBLAG
 #define MGM_P2_PUBLAG 3
@@ -147,7 +150,7 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 
 #define MGM_P2_LEAD 2
 #endif
 // ---- geometry of the build --------------------------------------------------------
-template <int LPL, int NS, bool HASM, bool C8>
+template <int LPL, int NS, bool HASM, bool C8, int MAXD = MGM_P2_MAXD>
 struct Plan {
     static constexpr int LP = LPL * 64;
     static constexpr int IPS = (LPL * 16 + 63) / 64;  // DMA pieces per fp32 slab
@@ -184,10 +187,10 @@ struct Plan {
     static constexpr int pick(int what)  // 0: RT, 1: RDEPTH, 2: D
     {
         const int rts[2] = {2, 2};
-        const int rds[3] = {MGM_P2_MAXD + 1, 4, 3};
+        const int rds[3] = {MAXD + 1, 4, 3};
         for (int a = 0; a < 2; a++)
             for (int b = 0; b < 3; b++)
-                for (int d = MGM_P2_MAXD; d >= 2; d--)
+                for (int d = MAXD; d >= 2; d--)
                     if (fits(rts[a], rds[b], d)) return what == 0 ? rts[a] : (what == 1 ? rds[b] : d);
         return 0;
     }
@@ -228,10 +231,16 @@ __device__ __forceinline__ void combine_unit_E(const float (&C)[LPL], const floa
 // slabs and the compact-cost pieces simply carry [volume 0 | volume 1 | ...]; what differs per lane group is the base
 // pointers, the slab minimum and the edge lanes of the label neighbourhood / of the FH scans.  LPL = 4, compact
 // costs, no weights, the kernels that publish E (everything but FH with TSGM = 2).
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1>
+// DEEP: the rings hold MGM_P2_DEEPD steps of DMA instead of MGM_P2_MAXD.  With two steps in flight a load has ONE step to
+// land, and a step that is shorter than the memory latency (~0.8 us under load) waits for it: measured (round 3, same
+// box, shallow -> deep) 4096x4096x192 x 1: K3 32.5 -> 27.7 ms; 1920x1080x128 x 1: 2.69 -> 2.34; 256 labels x 1: 5.71 -> 5.50
+// (Hirschmueller), 7.23 -> 7.03 (FH); x 2: 11.24 -> 10.95; twelve volumes: nothing -- and sixteen 128-label volumes LOSE
+// (16.2 -> 19.1 ms), so the host picks per launch (mgm_api.hip, run_passes).  Compact unweighted kernels only.
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false>
 __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, true, C8>::NL) * 64,
                                   ((C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
 {
+    static_assert(!DEEP || (C8 && !WEIGHTED && !(FH && MGM == 2)), "the deep rings exist for the compact kernels that publish E");
     static_assert(SUBV == 1 || (LPL == 4 && C8 && !WEIGHTED && !(FH && MGM == 2)), "volumes share a wave only in the compact unweighted kernels that publish E");
     constexpr int LANES = 64 / SUBV;  // lanes per volume
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
@@ -251,7 +260,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     // have the time -- the FH kernels (cfg3 x 12: K3 50.1 -> 48.9 ms); the Hirschmueller kernels, whose loader is on the
     // critical path of a short step, lose 8-25 % with it (cfg2 x 16, cfg4) and keep decoding every byte.
     constexpr bool CFLAG = C8 && FH;
-    using PL = Plan<LPL, NS, !pubE, C8>;
+    using PL = Plan<LPL, NS, !pubE, C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD>;
     constexpr int LP = PL::LP, NC = PL::NC, NCA = PL::NCA, D = PL::D, IPS = PL::IPS;
     constexpr int LPS = PL::LPS, LPD = PL::LPD, NDMA = PL::NDMA;
     constexpr int LPW = NCA;   // C lines per loader wave (NC - NCA == NCA when there are two loaders)
@@ -851,18 +860,18 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 }
 
 // ---- launcher (one translation unit per LPL: -DMGM_P2_LPL=n) -----------------------
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false>
 static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 {
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
-    using PL = Plan<LPL, NS, WEIGHTED || (FH && MGM == 2), C8>;
+    using PL = Plan<LPL, NS, WEIGHTED || (FH && MGM == 2), C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD>;
     size_t shmem = sizeof(float) * (size_t)PL::lds_floats(PL::D);
     // Occupancy is chosen per launch through the LDS request: the compact unweighted kernels are built for two
     // workgroups per CU (<= 64 VGPRs, < 80 KB of LDS).  Two bands per CU hide each other's barrier and LDS stalls --
     // right when the launch is throughput-bound (a batch of volumes); a single volume is bound by the chain of
     // bands, where the doubled step latency costs more than it gives, so it asks for > half the LDS and runs alone.
     if (p.wg_per_cu < 2 && shmem < 81 * 1024) shmem = 81 * 1024;
-    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8, SUBV>;
+    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
@@ -874,10 +883,14 @@ template <int LPL, bool FH, bool WEIGHTED, int MGM>
 static hipError_t launch2_one(const PassParams &p, int ntasks, hipStream_t s)
 {
     if constexpr (LPL == 4 && !WEIGHTED && !(FH && MGM == 2)) {  // several volumes per wave (128 / 64 labels)
-        if (p.subv == 2 && p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 2>(p, ntasks, s);
-        if (p.subv == 4 && p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 4>(p, ntasks, s);
+        if (p.subv == 2 && p.vol[0].C8)
+            return p.deep ? launch2_c8<LPL, FH, WEIGHTED, MGM, true, 2, true>(p, ntasks, s) : launch2_c8<LPL, FH, WEIGHTED, MGM, true, 2>(p, ntasks, s);
+        if (p.subv == 4 && p.vol[0].C8)
+            return p.deep ? launch2_c8<LPL, FH, WEIGHTED, MGM, true, 4, true>(p, ntasks, s) : launch2_c8<LPL, FH, WEIGHTED, MGM, true, 4>(p, ntasks, s);
     }
     if (p.subv > 1) return hipErrorInvalidValue;
+    if constexpr (!WEIGHTED && !(FH && MGM == 2))
+        if (p.vol[0].C8 && p.deep) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 1, true>(p, ntasks, s);
     if (p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true>(p, ntasks, s);
     return launch2_c8<LPL, FH, WEIGHTED, MGM, false>(p, ntasks, s);
 }

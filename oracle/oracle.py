@@ -36,8 +36,8 @@ def build(force=False):
         os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "mgm_oracle.c"))
     ):
         subprocess.check_call(["make", "-C", HERE, "libmgm_oracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference") and (force or not os.path.exists(REF_SO)):
-        subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference"):  # (make is incremental: a newer ref_harness.cc rebuilds _ref/libmgm_ref.so)
+        subprocess.check_call(["make", "-C", HERE, "ref"] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
 
 
 def usable_cpus(cap=64):
@@ -167,6 +167,12 @@ class Reference:
         L.ref_mgm.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float,
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, _f32p, _f32p]
         L.ref_refine.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _f32p, _f32p]
+        if hasattr(L, "ref_seconds"):
+            L.ref_seconds.restype = C.c_double
+
+    def seconds(self):
+        """Wall time of the reference function inside the last costvolume / mgm / refine call (not the container copies)."""
+        return float(self.lib.ref_seconds())
 
     def census_win(self):
         """CENSUS_NCC_WIN as cached by the reference (one value per process)."""

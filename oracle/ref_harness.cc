@@ -22,6 +22,7 @@
 #include <cstring>
 #include <cmath>
 #include "assert.h"
+#include <chrono>
 
 #include "smartparameter.h"
 #include "img.h"
@@ -47,7 +48,18 @@ static Img const_img(float value, int nx, int ny)
     return I;
 }
 
+/* Wall time of the reference's OWN work inside the last ref_costvolume / ref_mgm / ref_refine call: the bracket is put
+ * around the reference function alone, not around this harness's dense <-> Dvec container copies (bench.py's
+ * cpu_baseline.reference leg reads it through ref_seconds()). */
+static double g_last_seconds = 0.0;
+struct RefTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~RefTimer() { g_last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 extern "C" {
+
+double ref_seconds(void) { return g_last_seconds; }
 
 /* CENSUS_NCC_WIN is an env-backed smart parameter cached on first use
  * (smartparameter.h:26-50, mgm_costvolume.h:61): one value per process. */
@@ -59,8 +71,10 @@ int ref_costvolume(const float *u, const float *v, int nx, int ny, int nch, int 
 {
     Img U = make_img(u, nx, ny, nch), V = make_img(v, vnx, vny, nch);
     Img dminI = const_img((float)dmin, nx, ny), dmaxI = const_img((float)dmax, nx, ny);
+    RefTimer *tm = new RefTimer();
     struct costvolume_t CC = allocate_and_fill_sgm_costvolume(U, V, dminI, dmaxI, (char *)prefilter,
                                                               (char *)distance, truncDist);
+    delete tm;
     int L = dmax - dmin + 1;
     for (int i = 0; i < nx * ny; i++)
         for (int o = 0; o < L; o++) C[(size_t)i * L + o] = CC[i][o + dmin];
@@ -99,7 +113,9 @@ int ref_mgm(const float *C, int nx, int ny, int dmin, int dmax, const float *w8,
     Img W(nx, ny, 8);
     for (int i = 0; i < nx * ny * 8; i++) W[i] = w8 ? w8[i] : 1.0f;
     Img O(nx, ny), OC(nx, ny);
+    RefTimer *tm = new RefTimer();
     struct costvolume_t SS = mgm(CC, W, dminI, dmaxI, &O, &OC, P1, P2, NDIR, MGM, FH, FIX);
+    delete tm;
     if (S)
         for (int i = 0; i < nx * ny; i++)
             for (int o = 0; o < L; o++) S[(size_t)i * L + o] = SS[i][o + dmin];
@@ -117,7 +133,9 @@ int ref_refine(const float *S, int nx, int ny, int dmin, int dmax, const char *m
     for (int i = 0; i < nx * ny; i++)
         for (int o = 0; o < L; o++) SS[i].set_nolock(o + dmin, S[(size_t)i * L + o]);
     std::vector<float> O(out, out + (size_t)nx * ny), OC(outcost, outcost + (size_t)nx * ny);
+    RefTimer *tm = new RefTimer();
     subpixel_refinement_sgm(SS, O, OC, (char *)method);
+    delete tm;
     memcpy(out, &O[0], sizeof(float) * (size_t)nx * ny);
     memcpy(outcost, &OC[0], sizeof(float) * (size_t)nx * ny);
     return 0;

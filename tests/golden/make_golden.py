@@ -94,6 +94,23 @@ def worker(win):
             ("raw20_h_o2_t2", Cr2, -7, None, 1.3, 7.7, 2, 2, 0, 1),
             ("raw20_fh_o3_t1", Cr2, -7, None, 2.0, 9.0, 3, 1, 1, 1),
         ]
+        # ---- NaN costs: what the reference makes of them turns on the operand order of its minima (`a < b ? a : b`,
+        # fmin3, the strict `<` scan of Dvec::get_minvalue) -- the library's operand-order-faithful kernel
+        # (mgm_pass_exact.hip) and the oracle are pinned on these.  All four update functions, every TSGM.
+        Cn = synth.raw_volume(31, 23, 24, seed=11, inf_frac=0.03)
+        Cn[rng.random(Cn.shape) < 0.01] = np.nan
+        Cn[5, 7, :] = np.nan          # a pixel without any comparable cost
+        Cn[9, 3:6, 0] = -0.0          # (and signed zeros: of equal minima the scan keeps the first)
+        wn = np.where(rng.random((8, 23, 31)) < 0.5, 4.0, 1.0).astype(np.float32)
+        agg += [
+            ("nan24_h_o4_t2", Cn, -9, None, 8.0, 32.0, 4, 2, 0, 1),
+            ("nan24_h_o8_t3", Cn, -9, None, 8.0, 32.0, 8, 3, 0, 1),
+            ("nan24_h_o8_t4_w", Cn, -9, wn, 8.0, 32.0, 8, 4, 0, 1),
+            ("nan24_h_o8_t1_p2inf", Cn, -9, None, 8.0, np.inf, 8, 1, 0, 0),
+            ("nan24_fh_o4_t2", Cn, -9, None, 2.0, 9.0, 4, 2, 1, 1),
+            ("nan24_fh_o8_t3", Cn, -9, None, 2.0, 20000.0, 8, 3, 1, 1),
+            ("nan24_fh_o8_t4_w", Cn, -9, wn, 1.5, np.inf, 8, 4, 1, 1),
+        ]
         for name, C, dmin, w8, P1, P2, NDIR, MGM, FH, FIX in agg:
             S, out, outc = ref.mgm(C, dmin, P1, P2, NDIR, MGM, FH, FIX, w8)
             d = dict(kind="agg", C=C, dmin=dmin, P1=P1, P2=P2, NDIR=NDIR, MGM=MGM, FH=FH, FIX=FIX, S=S, out=out,

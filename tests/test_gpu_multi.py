@@ -21,10 +21,26 @@ def loopback():
     os.environ.pop("MGM_MULTI_LOOPBACK", None)
 
 
+_ORACLE = {}
+
+
+def oracle_maps(oracle, u, v, dmin, dmax, mode):
+    """The CPU oracle's refined maps for one of the modes below (cached: every rank count compares with the same ones)."""
+    if mode not in _ORACLE:
+        NDIR, MGM, FH, P1, P2 = mode
+        C = oracle.costvolume(u, v, dmin, dmax, "none", "census", np.inf, 5)
+        S, o, c = oracle.mgm(C, dmin, P1, P2, NDIR, MGM, FH, 1)
+        _ORACLE[mode] = oracle.refine(S, dmin, "vfit", o, c)
+    return _ORACLE[mode]
+
+
+@pytest.mark.parametrize("overlap", [0, 1], ids=["one-launch", "pass-by-pass"])
 @pytest.mark.parametrize("n", [2, 3, 4, 8])
 @pytest.mark.parametrize("mode", [(8, 3, 0, 8.0, 32.0), (8, 3, 1, 2.0, 20000.0), (4, 2, 0, 8.0, 32.0), (3, 4, 1, 2.0, 9.0)],
                          ids=["O8-T3", "O8-T3-FH", "O4-T2", "O3-T4-FH"])
-def test_loopback_ranks_equal_one_context(ctx, loopback, n, mode):
+def test_loopback_ranks_equal_one_context(ctx, oracle, loopback, n, mode, overlap, monkeypatch):
+    """n ranks against the ORACLE (and the one-context aggregation), with the passes of a rank in one launch and -- the
+    overlapped schedule, MGM_MULTI_OVERLAP=1 -- one launch per pass with each round of slabs posted behind its pass."""
     import mgm_amd
     NDIR, MGM, FH, P1, P2 = mode
     nx, ny, dmin, dmax = 150, 61, -100, 27  # 128 labels; 61 rows over up to 8 ranks: uneven slabs
@@ -32,7 +48,11 @@ def test_loopback_ranks_equal_one_context(ctx, loopback, n, mode):
     du, dv = ctx.upload_image(u), ctx.upload_image(v)
     cv = ctx.costvolume_dev(du, dv, dmin, dmax, "none", "census", float("inf"), 5)
     _, o_ref, c_ref = ctx.aggregate(cv, P1, P2, NDIR, MGM, FH, 1, None, "vfit", want_S=False)
+    o_orc, c_orc = oracle_maps(oracle, u, v, dmin, dmax, mode)
+    assert ndiff(o_ref, o_orc) == 0 and ndiff(c_ref, c_orc) == 0
+    monkeypatch.setenv("MGM_MULTI_OVERLAP", str(overlap))
     m = mgm_amd.Multi([0] * n)
+    assert m.transport() == "loopback"
     try:
         cvs = []
         for k in range(n):  # every rank builds the volume itself, from the images
@@ -40,7 +60,7 @@ def test_loopback_ranks_equal_one_context(ctx, loopback, n, mode):
             cvs.append(c.costvolume_dev(c.upload_image(u), c.upload_image(v), dmin, dmax, "none", "census", float("inf"), 5))
         for rep in range(2):  # (the second call reuses the workspaces and the hand-off slots)
             o, oc = m.aggregate(cvs, P1, P2, NDIR, MGM, FH, 1, "vfit")
-            assert ndiff(o, o_ref) == 0 and ndiff(oc, c_ref) == 0, (n, mode, rep)
+            assert ndiff(o, o_orc) == 0 and ndiff(oc, c_orc) == 0, (n, mode, rep)
     finally:
         m.close()
     for h in (cv, du, dv):
@@ -76,6 +96,7 @@ def test_rccl_communicator_of_one_rank(ctx):
     cv0 = ctx.upload_volume(C, 0)
     _, o_ref, c_ref = ctx.aggregate(cv0, 8.0, 32.0, 8, 3, 0, 1, None, "vfit", want_S=False)
     m = mgm_amd.Multi([0])
+    assert m.transport() == "rccl"
     try:
         cv = m.ctx[0].upload_volume(C, 0)
         o, oc = m.aggregate([cv], 8.0, 32.0, 8, 3, 0, 1, "vfit")
@@ -91,3 +112,58 @@ def test_duplicate_devices_need_loopback_mode():
     with pytest.raises(mgm_amd.MgmError) as e:
         mgm_amd.Multi([0, 0])
     assert e.value.code == mgm_amd.MGM_ERR_INVALID
+
+
+def test_peer_transport_and_create_errors(ctx, monkeypatch):
+    """MGM_MULTI_TRANSPORT=peer: no communicator is made (the handle says so); a failed create leaves its reason behind."""
+    import mgm_amd
+    monkeypatch.delenv("MGM_MULTI_LOOPBACK", raising=False)
+    monkeypatch.setenv("MGM_MULTI_TRANSPORT", "peer")
+    C = synth.raw_volume(70, 33, 64, seed=9)
+    cv0 = ctx.upload_volume(C, 0)
+    _, o_ref, c_ref = ctx.aggregate(cv0, 8.0, 32.0, 8, 3, 0, 1, None, "vfit", want_S=False)
+    m = mgm_amd.Multi([0])
+    try:
+        assert m.transport() == "peer"
+        cv = m.ctx[0].upload_volume(C, 0)
+        o, oc = m.aggregate([cv], 8.0, 32.0, 8, 3, 0, 1, "vfit")
+        assert ndiff(o, o_ref) == 0 and ndiff(oc, c_ref) == 0
+        # an output image that does not live on device_ids[0] / a volume of another context's device is refused, not run:
+        # (one GPU here: the ownership check is exercised through its accessors)
+        lib = mgm_amd.load_library()
+        assert lib.mgm_cv_device(cv.h) == 0 and lib.mgm_img_device(ctx.new_image(4, 4).h) == 0 and lib.mgm_cv_device(None) == -1
+    finally:
+        m.close()
+    cv0.free()
+    with pytest.raises(mgm_amd.MgmError) as e:
+        mgm_amd.Multi([0, 0])
+    assert "MGM_MULTI_LOOPBACK" in str(e.value)
+    with pytest.raises(mgm_amd.MgmError) as e:
+        mgm_amd.Multi([99])
+    assert "99" in str(e.value)
+
+
+def test_workspace_limit_splits_a_batch(ctx, oracle):
+    """mgm_ctx_set_workspace_limit: a batch whose Lr volumes exceed the cap runs as several pass launches over the largest
+    sub-batches that fit -- same maps as the oracle's, more than one k_pass2 launch -- instead of MGM_ERR_NOMEM."""
+    nx, ny, L = 96, 40, 128
+    Cs = [synth.raw_volume(nx, ny, L, seed=30 + k) for k in range(6)]
+    cvs = [ctx.upload_volume(C, -5) for C in Cs]
+    per_vol = 4 * nx * ny * L * 8
+    ctx.set_workspace_limit(int(2.6 * per_vol))  # room for two volumes' Lr (and their hand-off slots)
+    try:
+        ctx.timing(True)
+        ctx.timing_reset()
+        _, outs, outcs = ctx.aggregate_batch_dev(cvs, 8.0, 32.0, 8, 3, 0, 1, None, "vfit")
+        ctx.synchronize()
+        launches = sum(1 for n, _ in ctx.timings() if n in ("k_pass2", "k_pass"))
+        ctx.timing(False)
+        assert launches == 3
+        for k in range(6):
+            S, o, c = oracle.mgm(Cs[k], -5, 8.0, 32.0, 8, 3, 0, 1)
+            ro, rc = oracle.refine(S, -5, "vfit", o, c)
+            assert ndiff(outs[k].download()[0], ro) == 0 and ndiff(outcs[k].download()[0], rc) == 0, k
+    finally:
+        ctx.set_workspace_limit(0)
+    for h in cvs + outs + outcs:
+        h.free()

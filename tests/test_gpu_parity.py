@@ -216,22 +216,34 @@ def test_both_builds_of_the_pass_kernel_agree(oracle):
     assert ndiff(res[0][0], Sa) == 0
 
 
-def test_uploaded_volume_with_nan_costs_is_refused(ctx):
-    """The scan-line kernels are compiled NaN-free; an uploaded volume is scanned once and a NaN cost refused
-    (what the reference makes of it depends on the operand order of its minima).  Both scan paths: a label count
-    with a compact copy (k_compact) and one without (k_nanscan); a refill through the device pointer is re-scanned."""
-    import mgm_amd
+def test_uploaded_volume_with_nan_costs_takes_the_exact_kernel(ctx, oracle):
+    """The fast scan-line kernels are compiled NaN-free; an uploaded volume is scanned once per filling and one that holds
+    NaN costs is aggregated by the operand-order-faithful kernel (mgm_pass_exact.hip): S, labels and costs equal the
+    oracle's -- which the NaN goldens pin on the reference -- bit for bit.  Both scan paths: a label count with a compact
+    copy (k_compact) and one without (k_nanscan); the same volume refilled clean goes back to the fast kernels."""
     for L in (64, 50):
-        C = synth.raw_volume(40, 21, L, seed=5)
+        C = synth.raw_volume(40, 21, L, seed=5, inf_frac=0.02)
         C[7, 11, 3] = np.nan
-        cv = ctx.upload_volume(C, 0)
-        with pytest.raises(mgm_amd.MgmError) as e:
-            ctx.aggregate(cv, 8.0, 32.0, 4, 2, 0, 1, None, None, want_S=False)
-        assert e.value.code == mgm_amd.MGM_ERR_UNSUPPORTED and "NaN" in str(e.value)
-        cv.free()
-        C[7, 11, 3] = 1.0
-        cv = ctx.upload_volume(C, 0)
-        ctx.aggregate(cv, 8.0, 32.0, 4, 2, 0, 1, None, None, want_S=False)  # clean: accepted
+        C[12, 5, :] = np.nan
+        for (NDIR, MGM, FH, P1, P2) in ((4, 2, 0, 8.0, 32.0), (8, 3, 1, 2.0, 20000.0), (8, 4, 0, 8.0, np.inf), (3, 2, 1, 2.0, 9.0)):
+            cv = ctx.upload_volume(C, -3)
+            ctx.timing(True)
+            ctx.timing_reset()
+            S, o, c = ctx.aggregate(cv, P1, P2, NDIR, MGM, FH, 1, None, None, want_S=True)
+            names = {n for n, _ in ctx.timings()}
+            ctx.timing(False)
+            assert "k_pass_exact" in names and "k_pass2" not in names and "k_pass" not in names
+            Sa, oa, ca = oracle.mgm(C, -3, P1, P2, NDIR, MGM, FH, 1)
+            assert ndiff(S.download(), Sa) == 0 and ndiff(c, ca) == 0 and labels_equal(o, oa, ca), (L, NDIR, MGM, FH)
+            S.free()
+            cv.free()
+        C2 = np.nan_to_num(C, nan=1.0, posinf=np.inf)
+        cv = ctx.upload_volume(C2, 0)
+        ctx.timing(True)
+        ctx.timing_reset()
+        ctx.aggregate(cv, 8.0, 32.0, 4, 2, 0, 1, None, None, want_S=False)
+        assert "k_pass_exact" not in {n for n, _ in ctx.timings()}  # clean: the fast kernels
+        ctx.timing(False)
         cv.free()
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: round-3 exploration -- single-volume / small-batch launches on pipeline-depth / band-size variants
-# built by tools/sweep_build.sh (d<N>: MGM_P2_MAXD=N, n7d<N>: 7 lines per band).
+# Runs ON THE GPU BOX: round-3 exploration of the launch heuristics (deep DMA rings, volumes per wave, bands per CU)
+# through the library's development switches.   bash tools/r3_explore.sh [list-file]
 set -u
 OUT=gpurun_out/explore; mkdir -p $OUT
 line() { python -c "
@@ -14,20 +14,15 @@ run() { # tag workload batch [env...]
   tag=$1; w=$2; b=$3; shift 3
   env "$@" timeout 300 python bench.py --workload $w --batch $b --steps ${STEPS:-20} --repeats 0 --no-cpu-baseline --no-parity 2>$OUT/err.txt | tail -1 | line "$tag"
 }
-V=$PWD/mgm_amd/lib/variants
-for wb in cfg2:1 cfg2:2 cfg3:1 cfg3:2 cfg3h:1 cfg4:1 cfg3:12 cfg2:16; do
-  w=${wb%%:*}; b=${wb##*:}
-  run base $w $b X=1
-  for v in d4 d6 d8 n7d4 n7d6; do run $v $w $b MGM_HIP_LIB=$V/$v/libmgm_hip.so; done
+for wb in cfg2:1 cfg2:2 cfg2:4 cfg2:8 cfg2:16 cfg3:1 cfg3:2 cfg3:4 cfg3:8 cfg3:12 cfg3h:1 cfg3h:2 cfg3h:12 cfg4:1 cfg4:2 cfg5:16; do
+  run auto ${wb%%:*} ${wb##*:} X=1
 done
-for wb in cfg2:1 cfg3:1 cfg3:2 cfg3h:1 cfg4:1 cfg3:12 cfg2:16; do
-  w=${wb%%:*}; b=${wb##*:}
-  for v in n7d4 n7d6; do run $v-wg2 $w $b MGM_HIP_LIB=$V/$v/libmgm_hip.so MGM_HIP_WG_PER_CU=2; done
+for wb in cfg3:4 cfg3:8 cfg3h:12 cfg2:4 cfg2:8 cfg5:16 cfg4:2; do
+  run deep0 ${wb%%:*} ${wb##*:} MGM_HIP_DEEP=0
+  run deep1 ${wb%%:*} ${wb##*:} MGM_HIP_DEEP=1
 done
-for b in 2 4; do
-  run d4-nosubv cfg2 $b MGM_HIP_LIB=$V/d4/libmgm_hip.so MGM_HIP_SUBV=0
-  run d4-subv cfg2 $b MGM_HIP_LIB=$V/d4/libmgm_hip.so
+for wb in cfg2:2 cfg2:4 cfg2:8 cfg2:16 cfg5:16; do
+  run nosubv-wg1 ${wb%%:*} ${wb##*:} MGM_HIP_SUBV=0 MGM_HIP_WG_PER_CU=1
+  run nosubv-wg2 ${wb%%:*} ${wb##*:} MGM_HIP_SUBV=0 MGM_HIP_WG_PER_CU=2
+  run nosubv-wg2-deep0 ${wb%%:*} ${wb##*:} MGM_HIP_SUBV=0 MGM_HIP_WG_PER_CU=2 MGM_HIP_DEEP=0
 done
-run base cfg5 16 X=1
-run d4 cfg5 16 MGM_HIP_LIB=$V/d4/libmgm_hip.so
-run d8 cfg5 16 MGM_HIP_LIB=$V/d8/libmgm_hip.so
