@@ -248,7 +248,8 @@ int mgm_update_ranges_dev(mgm_ctx *ctx, const mgm_img *outoff, mgm_img *dminI, m
 /* ---- what main() does to the disparity maps right after the path (device images in, device images out) ---- */
 /* median_filter (img_tools.h:203-238, called at mgm.cc:396, 419 when MEDIAN != 0): per channel, the window
  * (2*radius+1)^2 clipped at the border, NaN samples ignored, the upper median v[n/2]; an all-NaN window
- * leaves the pixel unchanged.  radius 1..7.  out must have in's size (and must not be in). */
+ * leaves the pixel unchanged.  Any radius >= 1 (beyond 7 the order statistic is found by radix selection instead of
+ * pairwise counting).  out must have in's size (and must not be in). */
 int mgm_median_dev(mgm_ctx *ctx, const mgm_img *in, int radius, mgm_img *out);
 /* leftright_test (mgm.cc:68-91, called at 420-423): out[x,y] = d[x,y] if Lx = round(x + d) lies inside `other`
  * and |Lx + other[Lx,y] - x| <= tau, NaN otherwise.  d and out have one size, `other` may have another width. */

@@ -84,7 +84,7 @@ def build_cli(force=False):
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     if force or _stale(exe, [src, LIB] + hdrs):
         rocm = os.path.dirname(os.path.dirname(hipcc()))
-        cmd = ["g++", "-O2", "-std=c++17", "-Wall", src, "-L" + LIBDIR, "-lmgm_hip", "-L" + os.path.join(rocm, "lib"),
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread", src, "-L" + LIBDIR, "-lmgm_hip", "-L" + os.path.join(rocm, "lib"),
                "-lamdhip64", "-lz", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", exe]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode:

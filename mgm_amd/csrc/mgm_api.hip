@@ -1691,7 +1691,7 @@ int mgm_median_dev(mgm_ctx *c, const mgm_img *in, int radius, mgm_img *out)
 {
     if (!c || !in || !out || in == out) return fail(c, MGM_ERR_INVALID, "mgm_median: bad arguments");
     if (out->nx != in->nx || out->ny != in->ny || out->nch != in->nch) return fail(c, MGM_ERR_INVALID, "mgm_median: image size mismatch");
-    if (radius < 1 || radius > 7) return fail(c, MGM_ERR_UNSUPPORTED, "mgm_median: radius must be 1..7");
+    if (radius < 1 || radius > 1024) return fail(c, MGM_ERR_INVALID, "mgm_median: radius must be 1..1024");
     HIPCHK(c, hipSetDevice(c->device));
     TimeScope t(c, "k_median");
     HIPCHK(c, launch_median(in->d, in->nx, in->ny, in->nch, radius, out->d, c->stream));

@@ -48,10 +48,61 @@ __global__ void __launch_bounds__(256) k_median(const float *__restrict__ u, int
     out[idx] = res;
 }
 
+// Large windows (radius > 7: the kernel above is O(w^4) per pixel): the same order statistic by RADIX SELECTION -- floats
+// mapped to keys whose unsigned order is the floats' order, the k-th smallest key found bit by bit from the top with one
+// counting sweep of the window per bit (32 w^2 instead of w^4).
+__device__ __forceinline__ unsigned order_key(float x)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ void __launch_bounds__(256) k_median_big(const float *__restrict__ u, int nx, int ny, int nch, int radius,
+                                                    float *__restrict__ out)
+{
+    const long long npix = (long long)nx * ny;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * nch) return;
+    const long long p = idx % npix;
+    const int x = (int)(p % nx), y = (int)(p / nx);
+    const float *pl = u + (idx / npix) * npix;
+    const int x0 = x - radius < 0 ? 0 : x - radius, x1 = x + radius >= nx ? nx - 1 : x + radius;
+    const int y0 = y - radius < 0 ? 0 : y - radius, y1 = y + radius >= ny ? ny - 1 : y + radius;
+    int n = 0;
+    for (int j = y0; j <= y1; j++)
+        for (int i = x0; i <= x1; i++) {
+            const float s = pl[i + (long long)j * nx];
+            n += (s == s);
+        }
+    float res = pl[p];  // an all-NaN window leaves the pixel as it is
+    if (n > 0) {
+        int k = n / 2;
+        unsigned prefix = 0;  // the bits of the answer above `b`
+        for (int b = 31; b >= 0; b--) {
+            int zeros = 0;  // samples that agree with the prefix and have bit b clear
+            for (int j = y0; j <= y1; j++)
+                for (int i = x0; i <= x1; i++) {
+                    const float s = pl[i + (long long)j * nx];
+                    const unsigned key = order_key(s);
+                    const bool match = b == 31 ? true : (key >> (b + 1)) == prefix;
+                    zeros += (s == s) && match && !((key >> b) & 1u);
+                }
+            if (k < zeros) prefix = prefix << 1;
+            else {
+                k -= zeros;
+                prefix = (prefix << 1) | 1u;
+            }
+        }
+        const unsigned ub = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+        res = __builtin_bit_cast(float, ub);
+    }
+    out[idx] = res;
+}
+
 hipError_t launch_median(const float *u, int nx, int ny, int nch, int radius, float *out, hipStream_t s)
 {
     const long long n = (long long)nx * ny * nch;
-    hipLaunchKernelGGL(k_median, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, nx, ny, nch, radius, out);
+    if (radius > 7) hipLaunchKernelGGL(k_median_big, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, nx, ny, nch, radius, out);
+    else hipLaunchKernelGGL(k_median, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, nx, ny, nch, radius, out);
     return hipGetLastError();
 }
 

@@ -187,6 +187,129 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
     }
 }
 
+// 192 and 384 labels: the same work with 16-BYTE loads.  Three labels per lane are 12-byte pieces (k_wta<3>: 5.6 TB/s of
+// reads where 16-byte pieces reach 6.4, round 2), six are a 16- and an 8-byte piece -- so here a wave takes a GROUP of
+// NPX consecutive pixels that fills three 1-KiB slabs exactly (4 x 192 or 2 x 384 labels = 768 floats) and lane l of
+// slab j holds the four floats 4*(64 j + l) .. of the group: chunk t = 64 j + l belongs to pixel t / (L/4) and starts at
+// its label 4*(t % (L/4)) (a chunk never straddles pixels: L is a multiple of four).  Every lane therefore holds three
+// chunks of up to three different pixels; the arg-min of pixel q is a wave-wide butterfly over what each lane holds OF
+// THAT PIXEL.  Plain volumes only (no padding, no windows, no ragged ranges): everything else takes k_wta.
+template <int L, int MAXD>
+__global__ void __launch_bounds__(256) k_wta_q(const WtaParams P)
+{
+    static_assert(L == 192 || L == 384, "groups of 768 floats");
+    constexpr int NPX = 768 / L;   // pixels per group
+    constexpr int CPP = L / 4;     // chunks per pixel
+    __shared__ float sS[4][768];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool c8 = P.C8 != nullptr;
+    const long long ngroup = P.npix / NPX;
+    int cpix[3], clab[3];  // per slab: this lane's chunk -> pixel of the group, first label
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int t = 64 * j + lane;
+        cpix[j] = t / CPP;
+        clab[j] = (t % CPP) * 4;
+    }
+    for (long long g = (long long)blockIdx.x * 4 + wv; g < ngroup; g += (long long)gridDim.x * 4) {
+        float c[3][4], l[MAXD][3][4];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (c8) {
+                const unsigned w = *reinterpret_cast<const unsigned *>(P.C8 + g * 768 + 256 * j + 4 * lane);
+#pragma unroll
+                for (int k = 0; k < 4; k++) c[j][k] = c8_decode((w >> (8 * k)) & 255u);
+            } else {
+                const float4 q = *reinterpret_cast<const float4 *>(P.C + g * 768 + 256 * j + 4 * lane);
+                c[j][0] = q.x; c[j][1] = q.y; c[j][2] = q.z; c[j][3] = q.w;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < MAXD; p++)
+            if (p < P.NDIR) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const float4 q = *reinterpret_cast<const float4 *>(P.Lr + (long long)p * P.nvol + g * 768 + 256 * j + 4 * lane);
+                    l[p][j][0] = q.x; l[p][j][1] = q.y; l[p][j][2] = q.z; l[p][j][3] = q.w;
+                }
+            }
+        // S = ((0 + L0) + L1) + ... in pass order, then the over-count term (mgm_core.cc:582-599)
+        float S[3][4];
+        const float f = (float)(P.NDIR - 1);
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float a = 0.0f;
+#pragma unroll
+                for (int p = 0; p < MAXD; p++)
+                    if (p < P.NDIR) a = a + l[p][j][k];
+                if (P.FIX == 1) a = a - f * c[j][k];
+                S[j][k] = a;
+            }
+        if (P.S) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) *reinterpret_cast<float4 *>(P.S + g * 768 + 256 * j + 4 * lane) = make_float4(S[j][0], S[j][1], S[j][2], S[j][3]);
+        }
+        // per chunk: first strict minimum among its finite entries, ascending label
+        float cb[3];
+        int ci[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            cb[j] = f_inf();
+            ci[j] = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (finite_bits(S[j][k]) && cb[j] > S[j][k]) {
+                    cb[j] = S[j][k];
+                    ci[j] = clab[j] + k;
+                }
+        }
+        if (P.refine == 1) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) *reinterpret_cast<float4 *>(&sS[wv][256 * j + 4 * lane]) = make_float4(S[j][0], S[j][1], S[j][2], S[j][3]);
+        }
+#pragma unroll
+        for (int q = 0; q < NPX; q++) {
+            float best = f_inf();
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < 3; j++)  // (a lane's chunks of one pixel lie in ascending label order over j)
+                if (cpix[j] == q && (cb[j] < best)) {
+                    best = cb[j];
+                    bi = ci[j];
+                }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float ov = __shfl_xor(best, d);
+                const int oi = __shfl_xor(bi, d);
+                if (ov < best || (ov == best && oi < bi)) {
+                    best = ov;
+                    bi = oi;
+                }
+            }
+            float outv, outc = best;
+            if (bi == 0x7fffffff) outv = __builtin_nanf("");  // the reference leaves minP uninitialised here
+            else outv = (float)(bi + P.dmin);
+            if (P.refine == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (bi != 0x7fffffff && bi - 1 >= 0 && bi + 2 <= L - 1) {  // mgm_refine.h:58
+                    const float *sp = sS[wv] + q * L;
+                    float vmin, dx;
+                    vfit(sp[bi - 1], sp[bi], sp[bi + 1], vmin, dx);
+                    outv = (float)(bi + P.dmin) + dx;
+                    outc = vmin;
+                }
+            }
+            if (lane == 0) {
+                P.out[g * NPX + q] = outv;
+                P.outcost[g * NPX + q] = outc;
+            }
+        }
+        if (P.refine == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next group overwrites sS
+    }
+}
+
 hipError_t launch_wta(const WtaParams &p, hipStream_t s)
 {
     long long nb = (p.npix + 3) / 4;  // (an upper bound: waves take several pixels per iteration)
@@ -212,6 +335,25 @@ hipError_t launch_wta(const WtaParams &p, hipStream_t s)
     if (wide4 < 0) {
         const char *e = getenv("MGM_HIP_WTA_WIDE4");
         wide4 = e ? atoi(e) != 0 : 1;
+    }
+    static int quad = -1;  // MGM_HIP_WTA_QUAD=0: 192 / 384 labels on k_wta<3> / <6> (A/B timing)
+    if (quad < 0) {
+        const char *e = getenv("MGM_HIP_WTA_QUAD");
+        quad = e ? atoi(e) != 0 : 1;
+    }
+    if (quad && p.Lreal == p.L && (p.L == 192 || p.L == 384) && p.npix % (768 / p.L) == 0 && !p.wlo && !p.clo && p.refine <= 1) {
+        long long nq = (p.npix / (768 / p.L) + 3) / 4;
+        const long long capq = (long long)(p.num_cu > 0 ? p.num_cu : 256) * (per_cu ? per_cu : 256);
+        if (nq > capq) nq = capq;
+        const dim3 gq((unsigned)nq);
+        if (p.L == 192) {
+            if (p.NDIR <= 4) hipLaunchKernelGGL((k_wta_q<192, 4>), gq, block, 0, s, p);
+            else hipLaunchKernelGGL((k_wta_q<192, kMaxDirs>), gq, block, 0, s, p);
+        } else {
+            if (p.NDIR <= 4) hipLaunchKernelGGL((k_wta_q<384, 4>), gq, block, 0, s, p);
+            else hipLaunchKernelGGL((k_wta_q<384, kMaxDirs>), gq, block, 0, s, p);
+        }
+        return hipGetLastError();
     }
     // 128 and 64 labels: two / four pixels per 256-float slab (16-byte loads, one butterfly for all of them)
     if (use_packed) {

@@ -8,8 +8,12 @@
 // computed on the CPU.  Image files (src/imgio.h): PNG, TIFF, PGM/PPM, PFM and .npy in -- what the
 // reference's iio decodes them to -- and float TIFF, PFM or .npy out.
 //
-// Not supported (exit code 2, message on stderr): P2 = inf together with -m/-M range files that are not constant
-// (a ragged cost volume), `-p census` with a non-census distance and a descriptor of more than 24 bits.
+// Not supported (exit code 2, message on stderr): TSGM_ITER < 1.
+//
+// Wall time (MGM_HIP_STATS=1 prints the breakdown on stderr): a 1920x1080x256 pair is ~17 ms of device work, so the
+// program is organised around its HOST costs -- both input images are decoded on their own threads while the main thread
+// brings the device context up, and the context is torn down (tens of GB of workspace handed back) on a thread of its
+// own while the outputs are encoded and written.
 //
 // WITH_MGM2=1 (mgm_naive_parallelism, mgm_core.cc:632-831): every pass on its own private Lr volume, all passes in
 // flight at once, then the volumes accumulated into S -- which is how the device path is organised anyway
@@ -17,16 +21,66 @@
 // what its default build (Makefile:1, no OpenMP) and any run with one thread compute, and one member of the outcome
 // set of a threaded run.  So the flag is accepted and changes nothing.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "../include/mgm_hip.h"
 #include "imgio.h"
+
+// ---- MGM_HIP_STATS=1: where the wall time of the run goes (stderr, one line) ------------------
+struct Stopwatch {
+    bool on = getenv("MGM_HIP_STATS") && atoi(getenv("MGM_HIP_STATS")) != 0;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    std::string line;
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[96];
+        snprintf(buf, sizeof buf, " %s %.1f", what, std::chrono::duration<double, std::milli>(now - last).count());
+        line += buf;
+        last = now;
+    }
+    // milliseconds between exec and main(): dynamic loading of the HIP runtime and its static initialisers (10 ms ticks)
+    static double premain_ms()
+    {
+        double up = 0;
+        long long start = 0;
+        if (FILE *f = fopen("/proc/uptime", "r")) {
+            if (fscanf(f, "%lf", &up) != 1) up = 0;
+            fclose(f);
+        }
+        if (FILE *f = fopen("/proc/self/stat", "r")) {
+            char buf[1024];
+            const size_t n = fread(buf, 1, sizeof buf - 1, f);
+            fclose(f);
+            buf[n] = 0;
+            if (const char *q = strrchr(buf, ')')) {  // fields after "(comm)": state is #3, starttime #22
+                int field = 2;
+                for (q++; *q && field < 22; q++)
+                    if (*q == ' ') field++;
+                start = atoll(q);
+            }
+        }
+        return (up - (double)start / 100.0) * 1e3;
+    }
+    double pre = on ? premain_ms() : 0;
+    void report()
+    {
+        if (!on) return;
+        fprintf(stderr, "[mgm stats] exec -> main() ~%.0f ms (10 ms ticks);", pre);
+        fprintf(stderr, "[mgm stats] ms since main():%s | total %.1f\n", line.c_str(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 // ---- environment "smart parameters" (smartparameter.h:26-50): double, read once --------------
 static double env_param(const char *name, double dflt)
@@ -54,31 +108,6 @@ static void remove_nonfinite(HostImg &u, float v)  // img_tools.h:37-41
 {
     for (float &x : u.data)
         if (!std::isfinite(x)) x = v;
-}
-
-// median_filter (img_tools.h:203-238): NaN-aware, window clipped at the border, upper median
-static HostImg median_filter(const HostImg &u, int radius)
-{
-    HostImg M = u;
-    std::vector<float> v;
-    for (int k = 0; k < u.nch; k++)
-        for (int y = 0; y < u.ny; y++)
-            for (int x = 0; x < u.nx; x++) {
-                v.clear();
-                for (int j = -radius; j <= radius; j++) {
-                    if (j + y < 0 || j + y >= u.ny) continue;
-                    for (int i = -radius; i <= radius; i++) {
-                        if (i + x < 0 || i + x >= u.nx) continue;
-                        const float s = u.data[(i + x) + (size_t)(j + y) * u.nx + (size_t)k * u.npix()];
-                        if (!std::isnan(s)) v.push_back(s);
-                    }
-                }
-                if (!v.empty()) {
-                    std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
-                    M.data[x + (size_t)y * u.nx + (size_t)k * u.npix()] = v[v.size() / 2];
-                }
-            }
-    return M;
 }
 
 struct Run;
@@ -205,20 +234,13 @@ static void free_run(mgm_ctx *ctx, Run &r)
     r = Run();
 }
 
-// outoff = median_filter(outoff, MEDIAN) on the device (mgm.cc:396, 419); radii beyond the kernel's range on the host
+// outoff = median_filter(outoff, MEDIAN) on the device (mgm.cc:396, 419), any radius
 static void median_run(mgm_ctx *ctx, Run &r, int radius)
 {
     mgm_img *tmp = nullptr;
     int rc = mgm_img_create(ctx, r.nx, r.ny, 1, &tmp);
     if (rc) die(ctx, rc, "mgm_img_create");
-    rc = mgm_median_dev(ctx, r.dout, radius, tmp);
-    if (rc == MGM_ERR_UNSUPPORTED) {
-        const HostImg m = median_filter(download(ctx, r.dout, r.nx, r.ny, 1), radius);
-        mgm_img_free(ctx, tmp);
-        if ((rc = mgm_img_upload(ctx, m.data.data(), r.nx, r.ny, 1, &tmp))) die(ctx, rc, "upload");
-    } else if (rc) {
-        die(ctx, rc, "mgm_median");
-    }
+    if ((rc = mgm_median_dev(ctx, r.dout, radius, tmp))) die(ctx, rc, "mgm_median");
     mgm_img_free(ctx, r.dout);
     r.dout = tmp;
 }
@@ -298,10 +320,47 @@ int main(int argc, char **argv)
     (void)env_param("WITH_MGM2", 0);  // accepted: see the header comment
     if ((int)TSGM_ITER < 1) { fprintf(stderr, "mgm: TSGM_ITER < 1 is not supported\n"); return 2; }
 
+    Stopwatch sw;
     try {
-        HostImg u = imgio::read(f_u), v = imgio::read(f_v);
-        remove_nonfinite(u, 0);
-        remove_nonfinite(v, 0);
+        // decode both inputs on their own threads while this one brings the device up (process start + HIP initialisation
+        // + context is most of a run's wall time: the device work of a full-HD pair is ~17 ms)
+        HostImg u, v;
+        std::exception_ptr eu, ev;
+        std::thread tu([&] { try { u = imgio::read(f_u); remove_nonfinite(u, 0); } catch (...) { eu = std::current_exception(); } });
+        std::thread tv([&] { try { v = imgio::read(f_v); remove_nonfinite(v, 0); } catch (...) { ev = std::current_exception(); } });
+        mgm_ctx *ctx = nullptr;
+        mgm_multi *multi = nullptr;
+        int rc;
+        std::vector<int> devs;
+        if (const char *dl = getenv("MGM_DEVICES"))  // "0,1,2,3": several GPUs of this node
+            for (const char *q = dl; *q;) {
+                char *end;
+                const long d = strtol(q, &end, 10);
+                if (end == q) break;
+                devs.push_back((int)d);
+                q = *end == ',' ? end + 1 : end;
+            }
+        if (devs.size() > 1 && ((int)TSGM_ITER > 1 || min_file[0])) {
+            fprintf(stderr, "mgm: MGM_DEVICES: TSGM_ITER > 1 and range images run on the first device only\n");
+            devs.resize(1);
+        }
+        int rc_ctx;
+        if (devs.size() > 1) {
+            if ((rc_ctx = mgm_multi_create(devs.data(), (int)devs.size(), &multi)) == 0) ctx = mgm_multi_ctx(multi, 0);
+        } else {
+            rc_ctx = mgm_ctx_create(devs.size() == 1 ? devs[0] : (int)env_param("MGM_DEVICE", 0), &ctx);
+        }
+        sw.mark("context");
+        tu.join();
+        tv.join();
+        sw.mark("decode(rest)");
+        if (eu) std::rethrow_exception(eu);
+        if (ev) std::rethrow_exception(ev);
+        if (rc_ctx && devs.size() > 1) {
+            fprintf(stderr, "mgm: MGM_DEVICES: cannot set up %d devices (mgm_multi_create = %d): %s\n", (int)devs.size(), rc_ctx, mgm_multi_last_error(nullptr));
+            return 1;
+        }
+        if (rc_ctx) { fprintf(stderr, "mgm: no usable MI355X device (mgm_ctx_create = %d); there is no CPU path\n", rc_ctx); return 1; }
         HostImg rlo, rhi;  // -m / -M range images of the left->right run (mgm.cc:342-353); the right->left run keeps -r/-R
         if (min_file[0]) {
             rlo = imgio::read(min_file);
@@ -319,32 +378,6 @@ int main(int argc, char **argv)
         o.P1 *= u.nch;  // mgm.cc:356-357
         o.P2 *= u.nch;
 
-        mgm_ctx *ctx = nullptr;
-        mgm_multi *multi = nullptr;
-        int rc;
-        std::vector<int> devs;
-        if (const char *dl = getenv("MGM_DEVICES"))  // "0,1,2,3": several GPUs of this node
-            for (const char *q = dl; *q;) {
-                char *end;
-                const long d = strtol(q, &end, 10);
-                if (end == q) break;
-                devs.push_back((int)d);
-                q = *end == ',' ? end + 1 : end;
-            }
-        if (devs.size() > 1 && ((int)TSGM_ITER > 1 || plo)) {
-            fprintf(stderr, "mgm: MGM_DEVICES: TSGM_ITER > 1 and range images run on the first device only\n");
-            devs.resize(1);
-        }
-        if (devs.size() > 1) {
-            if ((rc = mgm_multi_create(devs.data(), (int)devs.size(), &multi))) {
-                fprintf(stderr, "mgm: MGM_DEVICES: cannot set up %d devices (mgm_multi_create = %d)\n", (int)devs.size(), rc);
-                return 1;
-            }
-            ctx = mgm_multi_ctx(multi, 0);
-        } else {
-            rc = mgm_ctx_create(devs.size() == 1 ? devs[0] : (int)env_param("MGM_DEVICE", 0), &ctx);
-            if (rc) { fprintf(stderr, "mgm: no usable MI355X device (mgm_ctx_create = %d); there is no CPU path\n", rc); return 1; }
-        }
 
         HostImg outoff, outcost;
         Run L, R;
@@ -362,6 +395,7 @@ int main(int argc, char **argv)
             else if (rc != MGM_ERR_UNSUPPORTED) die(ctx, rc, "mgm_aggregate_batch");
             // (UNSUPPORTED: one image weighted, the other not -- the two runs take different update functions)
         }
+        sw.mark("upload+enqueue");
         if (multi) aggregate_run_multi(multi, u, v, o.dmin, o.dmax, o, L);
         else if (!together) aggregate_run(ctx, o, L);
         report_run(o, L);
@@ -387,7 +421,9 @@ int main(int argc, char **argv)
             L.dout = Lchk;
             R.dout = Rchk;
         }
+        sw.mark("enqueue(rest)");
         outoff = download(ctx, L.dout, L.nx, L.ny, 1);
+        sw.mark("device+download");
         outcost = download(ctx, L.dcost, L.nx, L.ny, 1);
         // back-projected image (mgm.cc:433-443)
         HostImg syn;
@@ -398,13 +434,31 @@ int main(int argc, char **argv)
             syn = download(ctx, dsyn, u.nx, u.ny, u.nch);
             mgm_img_free(ctx, dsyn);
         }
-        free_run(ctx, L);
-        free_run(ctx, R);
-        if (multi) mgm_multi_destroy(multi);
-        else mgm_ctx_destroy(ctx);
-        imgio::write(f_out, outoff);
-        if (f_cost) imgio::write(f_cost, outcost);
-        if (f_back) imgio::write(f_back, syn);
+        // the device side is torn down (volumes, tens of GB of workspace) while the outputs are encoded and written
+        std::thread teardown([&] {
+            free_run(ctx, L);
+            free_run(ctx, R);
+            if (multi) mgm_multi_destroy(multi);
+            else mgm_ctx_destroy(ctx);
+        });
+        std::exception_ptr ew;
+        try {
+            imgio::write(f_out, outoff);
+            if (f_cost) imgio::write(f_cost, outcost);
+            if (f_back) imgio::write(f_back, syn);
+        } catch (...) {
+            ew = std::current_exception();
+        }
+        sw.mark("encode+write");
+        teardown.join();
+        sw.mark("teardown(rest)");
+        sw.report();
+        if (ew) std::rethrow_exception(ew);
+        // Everything is written and the device side is down: leave without the HIP runtime's own exit handlers (unloading
+        // code objects, closing the device: tens of ms that produce nothing).  MGM_HIP_ORDERLY_EXIT=1 keeps them.
+        fflush(stdout);
+        fflush(stderr);
+        if (!(getenv("MGM_HIP_ORDERLY_EXIT") && atoi(getenv("MGM_HIP_ORDERLY_EXIT")))) _exit(0);
     } catch (const std::exception &e) {
         fprintf(stderr, "mgm: %s\n", e.what());
         return 1;
