@@ -302,6 +302,7 @@ int mgm_multi_create(const int *device_ids, int n, mgm_multi **out)
     if (r) {
         g_create_err = why;
         mgm_multi_destroy(m);
+        (void)hipGetLastError();  // (leave no stale HIP error behind for the caller's next launch to trip over)
         return r;
     }
     *out = m;
@@ -312,6 +313,7 @@ int mgm_multi_destroy(mgm_multi *m)
 {
     if (!m) return MGM_OK;
     for (int k = 0; k < m->n; k++) {
+        if (!m->ctx[k]) continue;  // (a create that failed at this rank: nothing of it exists, and its device may not either)
         (void)hipSetDevice(m->dev[k]);
         if (!m->dead) {
             if (m->ctx[k]) (void)mgm_ctx_synchronize(m->ctx[k]);

@@ -240,7 +240,7 @@ def device_view(ptr, shape):
 
 
 def aggregate_direction_sharded(ctx, cv, P1, P2, NDIR, MGM, use_fh, fix_overcount, refine, dist, group=None, w8=None,
-                                ctrl=None, timeout_s=120.0, overlap=False, stats=None):
+                                ctrl=None, timeout_s=120.0, overlap=False, stats=None, force_sharded=False):
     """The whole aggregation of ONE volume across the ranks of `group`.  Returns (out, outcost) as torch
     tensors [ny, nx] on every rank (all-gathered rows).
 
@@ -248,12 +248,12 @@ def aggregate_direction_sharded(ctx, cv, P1, P2, NDIR, MGM, use_fh, fix_overcoun
     overlap: launch this rank's passes one per launch and post each pass's slabs right behind it.
     stats: a dict that receives this rank's stage times in ms (passes / exchange / wta / gather), torch events on the
     library's stream.  Raises ExchangeError (no rank exchanged anything; the group is still usable) or ExchangeTimeout
-    (the group is wedged)."""
+    (the group is wedged).  force_sharded: take the sharded path also with ONE rank (tests: every stage but the transfers)."""
     import torch
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     nx, ny, dmin, dmax = cv.dims
     L = dmax - dmin + 1
-    if world == 1:  # nothing to shard: the plain call (which may also pad odd label counts and pick its occupancy)
+    if world == 1 and not force_sharded:  # nothing to shard: the plain call (which may also pad odd label counts and pick its occupancy)
         _, o, c = ctx.aggregate_dev(cv, P1, P2, NDIR, MGM, use_fh, fix_overcount, w8, refine)
         ctx.synchronize()
         views = [device_view(ctx.lib.mgm_img_device_ptr(im.h), (ny, nx)).clone() for im in (o, c)]
