@@ -53,8 +53,11 @@ def test_golden_aggregation(ctx, name):
     ro, rc = ctx.refine(S, "vfit", g["out"], g["outcost"])
     assert ndiff(ro, g["out_vfit"]) == 0 and ndiff(rc, g["outcost_vfit"]) == 0
     _, fo, fc = ctx.aggregate(cv, *args, "vfit", want_S=False)
+    # (a pixel without a finite S has the reference's UNINITIALISED label, mgm_core.cc:594, and what the refinement makes of
+    # it -- label and cost -- is as undefined: the fused form leaves NaN / +INF there.  Only the NaN goldens have such pixels.)
     fin = np.isfinite(g["outcost"])
-    assert ndiff(fo[fin], g["out_vfit"][fin]) == 0 and ndiff(fc, g["outcost_vfit"]) == 0
+    assert ndiff(fo[fin], g["out_vfit"][fin]) == 0 and ndiff(fc[fin], g["outcost_vfit"][fin]) == 0
+    assert not np.isfinite(fc[~fin]).any()
     assert np.nanmax(np.abs(fo[fin] - g["out_vfit"][fin]), initial=0) <= VFIT_TOL
     # the other refinements of the reference's table (refine.h; the cubic evaluates in double): as a second kernel
     # on S, both stand-alone and behind mgm_aggregate
@@ -62,7 +65,7 @@ def test_golden_aggregation(ctx, name):
         ro, rc = ctx.refine(S, meth, g["out"], g["outcost"])
         assert ndiff(ro[fin], g["out_" + meth][fin]) == 0 and ndiff(rc, g["outcost_" + meth]) == 0, meth
         _, fo, fc = ctx.aggregate(cv, *args, meth, want_S=False)
-        assert ndiff(fo[fin], g["out_" + meth][fin]) == 0 and ndiff(fc, g["outcost_" + meth]) == 0, meth
+        assert ndiff(fo[fin], g["out_" + meth][fin]) == 0 and ndiff(fc[fin], g["outcost_" + meth][fin]) == 0, meth
     S.free(), cv.free()
 
 
