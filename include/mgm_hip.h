@@ -108,9 +108,9 @@ int mgm_costvolume_build_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, i
  * int as Dvec's constructor does (mgm_costvolume.h:323).  Uniform ranges take the fast path.  RAGGED ranges
  * (-m/-M files) give a volume over the hull of all ranges in which a pixel only owns the disparities of its own
  * range -- the others read +INF, as Dvec::operator[] does (dvec.cc:129), and are exempt from the "no finite cost"
- * rule; mgm_aggregate* then searches the winner and gates the refinement inside each pixel's range.  One
- * combination returns MGM_ERR_UNSUPPORTED on a ragged volume: P2 = +INF.  The hull may span at most 2048
- * labels (up to 512 on the fast kernels); batched ragged volumes must share hull_min under FH potentials. */
+ * rule; mgm_aggregate* then searches the winner and gates the refinement inside each pixel's range.  The hull may
+ * span at most 8192 labels (up to 512 on the fast kernels, up to 2048 on the first build of the pass kernel, beyond that
+ * on the generic ones); batched ragged volumes must share hull_min under FH potentials. */
 int mgm_costvolume_build(mgm_ctx *ctx, const float *u, const float *v, int nx, int ny, int nch, int vnx, int vny,
                          const float *dminI, const float *dmaxI, const char *prefilter, const char *distance,
                          float truncDist, int census_win, mgm_cv **C);
@@ -125,9 +125,11 @@ int mgm_costvolume_build_ranged_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_im
 int mgm_weights_dev(mgm_ctx *ctx, const mgm_img *u, float aP, float aThresh, mgm_img **w8);
 
 /* ---- aggregation + WTA: mgm() ------------------------------------------ */
-/* C is not modified.  w8 may be NULL (all ones).  A volume that holds NaN costs (possible only in one uploaded with
- * mgm_cv_upload or written through mgm_cv_device_ptr; it is scanned once per filling) is refused with
- * MGM_ERR_UNSUPPORTED: what the reference's minima make of a NaN depends on operand order.  As in the reference
+/* C is not modified.  w8 may be NULL (all ones).  A volume whose aggregation can meet NaNs -- NaN costs (an uploaded
+ * volume is scanned once per filling; `-p census` with another distance from descriptors of more than 24 bits), or a ragged
+ * volume with P2 = +INF (all-INF slabs, then INF - INF) -- is aggregated by a slow kernel that keeps the OPERAND ORDER of
+ * the reference's minima (`a < b ? a : b`, mgm_core.cc:48-60; dvec.cc:81-88), which decides what a NaN does there: the
+ * results are still the reference's, at a second or so per full-HD volume instead of milliseconds.  As in the reference
  * (mgm_core.cc:420-423) a single weight != 1.0 anywhere switches the whole run
  * to the weighted update functions.  P1/P2 are used as given (the caller has
  * already multiplied by the channel count, mgm.cc:356-357).

@@ -522,8 +522,8 @@ static int cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, bool alloc_
 {
     if (!c || !out || nx <= 0 || ny <= 0 || dmax < dmin) return fail(c, MGM_ERR_INVALID, "mgm_cv_create: bad arguments");
     const long long L = (long long)dmax - dmin + 1;
-    if (L > kMaxLPL * 64)
-        return fail(c, MGM_ERR_UNSUPPORTED, "more than 2048 disparity labels per pixel are not supported");
+    if (L > kMaxLabels)
+        return fail(c, MGM_ERR_UNSUPPORTED, "more than 8192 disparity labels per pixel are not supported");
     HIPCHK(c, hipSetDevice(c->device));
     mgm_cv *cv = new mgm_cv();
     cv->d = nullptr;
@@ -1050,7 +1050,8 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     //     P2 guarantees (every term is capped at m + P2); with P2 = +INF a pixel whose neighbours' ranges miss its own gets
     //     an all-INF slab and the next one INF - INF = NaN;
     //   * (found below, by the scan of an uploaded volume) NaN costs.
-    bool exact = ragged && !(P2 < __builtin_huge_valf());
+    //   * more than 2048 labels: no fast kernel is built that wide (the reference's Dvec has no label limit, dvec.cc:60).
+    bool exact = (ragged && !(P2 < __builtin_huge_valf())) || Lreal > kMaxLPL * 64;
     for (int v = 0; v < nb; v++) exact |= Cs[v]->nan_words;
     if (exact) return run_passes_exact(c, Cs, w8s, nb, P1, P2, MGM, fh, weighted_given, first, count, slot0, nslots);
     const float *ones8 = nullptr;

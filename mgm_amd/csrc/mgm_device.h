@@ -6,7 +6,8 @@
 namespace mgm {
 
 constexpr int kMaxDirs = 8;
-constexpr int kMaxLPL = 32;          // disparities per lane -> L <= 2048 (the fast kernels stop at 8: 512 labels)
+constexpr int kMaxLPL = 32;          // disparities per lane of the fast kernels -> L <= 2048 (the fastest stop at 8: 512 labels)
+constexpr int kMaxLabels = 8192;     // beyond 2048 labels: the generic kernels (mgm_pass_exact.hip, k_wta_any); 4 x L floats of LDS
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kCensusMaxWords = 8;   // 32-bit census words per pixel
 

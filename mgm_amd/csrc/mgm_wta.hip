@@ -310,6 +310,83 @@ __global__ void __launch_bounds__(256) k_wta_q(const WtaParams P)
     }
 }
 
+// Any label count (used beyond 2048 labels, where k_wta has no instance): one wavefront per pixel, the labels strided over
+// the lanes.  Same arithmetic and the same rules as k_wta -- S = ((0 + L0) + L1) + ... in pass order, the over-count
+// term, the first strict minimum among the finite entries of the pixel's window, V-fit on the winner's neighbours --
+// with S recomputed for the three labels of the fit instead of being staged.  Nothing here is tuned: the reference's Dvec
+// has no label limit (dvec.cc:60), and this keeps the library from having one.
+__global__ void __launch_bounds__(256) k_wta_any(const WtaParams P)
+{
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int L = P.L, Lr_ = P.Lreal;
+    const float f = (float)(P.NDIR - 1);
+    float vout = 0.0f;  // what a disparity outside the volume / the pixel's own range holds in the reference's S
+    if (P.FIX == 1) vout = vout - f * f_inf();
+    for (long long pix = (long long)blockIdx.x * 4 + wv; pix < P.npix; pix += (long long)gridDim.x * 4) {
+        int cl = 0, ch = Lr_ - 1;
+        if (P.clo) {
+            cl = (int)P.clo[pix] - P.dmin;
+            ch = (int)P.chi[pix] - P.dmin;
+        }
+        const bool windowed = P.wlo != nullptr;
+        int wl = 0, wh = 0;
+        if (windowed) {
+            wl = (int)P.wlo[pix] - P.dmin;
+            wh = (int)P.whi[pix] - P.dmin;
+        }
+        auto S_at = [&](int o) {
+            float a = 0.0f;
+            for (int p = 0; p < P.NDIR; p++) a = a + P.Lr[(long long)p * P.nvol + pix * L + o];
+            if (P.FIX == 1) a = a - f * (P.C8 ? c8_decode(P.C8[pix * L + o]) : P.C[pix * L + o]);
+            if (o < cl || o > ch) a = vout;
+            return a;
+        };
+        float best = f_inf();
+        int bi = 0x7fffffff;
+        for (int o = lane; o < Lr_; o += 64) {
+            const float v = S_at(o);
+            if (P.S) P.S[pix * Lr_ + o] = v;
+            if ((!windowed || (o >= wl && o <= wh)) && finite_bits(v) && best > v) {
+                best = v;
+                bi = o;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(best, d);
+            const int oi = __shfl_xor(bi, d);
+            if (ov < best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        if (windowed && finite_bits(vout)) {  // window labels outside the volume, in scan order: below it, (the volume), above it
+            if (wl < 0 && wl <= wh && !(best < vout)) {
+                best = vout;
+                bi = wl;
+            }
+            const int hi0 = wl > Lr_ ? wl : Lr_;
+            if (wh >= Lr_ && hi0 <= wh && vout < best) {
+                best = vout;
+                bi = hi0;
+            }
+        }
+        float outv, outc = best;
+        if (bi == 0x7fffffff) outv = __builtin_nanf("");  // the reference leaves minP uninitialised here
+        else outv = (float)(bi + P.dmin);
+        if (P.refine == 1 && !windowed && bi != 0x7fffffff && bi - 1 >= 0 && bi + 2 <= Lr_ - 1) {  // mgm_refine.h:58
+            float vmin, dx;
+            vfit(S_at(bi - 1), S_at(bi), S_at(bi + 1), vmin, dx);
+            outv = (float)(bi + P.dmin) + dx;
+            outc = vmin;
+        }
+        if (lane == 0) {
+            P.out[pix] = outv;
+            P.outcost[pix] = outc;
+        }
+    }
+}
+
 hipError_t launch_wta(const WtaParams &p, hipStream_t s)
 {
     long long nb = (p.npix + 3) / 4;  // (an upper bound: waves take several pixels per iteration)
@@ -335,6 +412,10 @@ hipError_t launch_wta(const WtaParams &p, hipStream_t s)
     if (wide4 < 0) {
         const char *e = getenv("MGM_HIP_WTA_WIDE4");
         wide4 = e ? atoi(e) != 0 : 1;
+    }
+    if (p.L > kMaxLPL * 64) {  // beyond the widest k_wta instance
+        hipLaunchKernelGGL(k_wta_any, grid, block, 0, s, p);
+        return hipGetLastError();
     }
     static int quad = -1;  // MGM_HIP_WTA_QUAD=0: 192 / 384 labels on k_wta<3> / <6> (A/B timing)
     if (quad < 0) {

@@ -82,6 +82,10 @@ CASES = [
      "-P1 2 -P2 9 -r -12 -R 9 -p census -t sd -O 4", dict(TSGM="2", CENSUS_NCC_WIN="5", USE_TRUNCATED_LINEAR_POTENTIALS="1", TESTLRRL="0")),
     ("median radius 9 (beyond the pairwise-counting kernel: radix selection)", 1, "-r -16 -R 8 -t census -s vfit -O 4",
      dict(TSGM="2", MEDIAN="9", CENSUS_NCC_WIN="5")),
+    ("2500 labels (beyond every fast kernel: the generic pass and WTA kernels), census, TSGM_ITER=2", 1,
+     "-r -1250 -R 1249 -t census -O 4 -s vfit", dict(TSGM="2", TSGM_ITER="2", CENSUS_NCC_WIN="5")),
+    ("2100 labels, FH, weights, TSGM=3", 3, "-P1 2 -P2 9 -r -1050 -R 1049 -t ad -O 8 -aP2 4 -aThresh 12 -s cubic",
+     dict(TSGM="3", USE_TRUNCATED_LINEAR_POTENTIALS="1")),
     ("601 labels (the reference's Dvec has no label limit), ad, 3 channels", 3, "-r -300 -R 300 -t ad -O 4 -s vfit", dict(TSGM="2")),
     ("parabolaOCV, census, median radius 3, tight tau", 1, "-r -16 -R 8 -t census -s parabolaOCV -O 8",
      dict(TSGM="3", MEDIAN="3", TESTLRRL_TAU="0.5", CENSUS_NCC_WIN="5")),
@@ -287,10 +291,11 @@ def test_cli_random_options_match_reference(seed, tmp_path):
         np.save(tmp_path / "hi.npy", hi)
         args += ["-m", str(tmp_path / "lo.npy"), "-M", str(tmp_path / "hi.npy")]
     # `-p census` with another distance differences the descriptor words as floats: NaN costs beyond 24 bits, pixels without a
-    # finite S and with them the reference's uninitialised label, which its left-right check would spread: no check there
+    # finite S and with them the reference's uninitialised label, which its left-right check and its median filter would
+    # spread into the neighbours: neither there (seen in 18 of 1200 random command lines with them on)
     win = int(env["CENSUS_NCC_WIN"])
     if args[args.index("-p") + 1] == "census" and args[args.index("-t") + 1] != "census" and nch * (win * win - 1) > 24:
-        env["TESTLRRL"] = "0"
+        env["TESTLRRL"], env["MEDIAN"] = "0", "0"
     outs = {}
     for tag, exe in (("ref", REF), ("ours", OURS)):
         d = tmp_path / tag
