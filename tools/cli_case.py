@@ -28,7 +28,7 @@ env = dict(TSGM=str(int(rng.integers(1, 5))), TSGM_ITER=str(int(rng.choice([1, 1
            TESTLRRL_TAU=str(rng.choice([1.0, 0.5, 2.5])), CENSUS_NCC_WIN=str(int(rng.choice([3, 5, 7]))))
 win = int(env["CENSUS_NCC_WIN"])
 if args[args.index("-p") + 1] == "census" and args[args.index("-t") + 1] != "census" and nch * (win * win - 1) > 24:
-    env["TESTLRRL"], env["MEDIAN"] = "0", "0"  # (NaN costs: as tests/test_gpu_cli.py)
+    env["TESTLRRL"], env["MEDIAN"], env["TSGM_ITER"] = "0", "0", "1"  # (NaN costs: as tests/test_gpu_cli.py)
 lo = hi = None
 if rng.random() < 0.3:
     lo = np.floor(rng.integers(dmin - 3, dmax, size=(ny, nx))).astype(np.float32) + rng.random((ny, nx)).astype(np.float32)

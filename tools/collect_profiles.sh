@@ -9,8 +9,8 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-PROFILED=${PROFILED:-"cfg3:12 cfg2:16 cfg3:1 cfg4:1 cfg5:16"}
-MATRIX=${MATRIX:-"cfg3h:12 cfg2:16 cfg5:16 cfg4:1 cfg3:8 cfg3:4 cfg3:2 cfg3:1 cfg3h:1 cfg2:1"}
+PROFILED=${PROFILED:-"cfg3:12 cfg3:2 cfg3:1 cfg2:16 cfg2:2 cfg4:1 cfg4:2 cfg5:16"}
+MATRIX=${MATRIX:-"cfg3h:12 cfg2:16 cfg5:16 cfg4:1 cfg4:2 cfg3:8 cfg3:4 cfg3:2 cfg3:1 cfg3h:2 cfg3h:1 cfg2:8 cfg2:4 cfg2:2 cfg2:1"}
 : > "$OUT/bench_lines.jsonl"
 timeout 900 python bench.py 2> "$OUT/bench_default.stderr" | tail -1 >> "$OUT/bench_lines.jsonl"
 for wb in $MATRIX; do
@@ -34,6 +34,9 @@ for wb in $PROFILED; do
   fi
   rm -rf "$OUT/kt" "$OUT/fetch" "$OUT/write"
 done
+# the single-GPU ingredients of DESIGN.md section 6's direction-sharding model, and the wall time of the whole command line
+timeout 600 python tools/time_passes.py cfg4 > "$OUT/cfg4_pass_blocks.txt" 2>&1
+for i in 1 2 3; do MGM_HIP_STATS=1 bash tools/cli_fullsize.sh 2>&1 | grep -v "^disp\|^cost"; sleep 2; done > "$OUT/cli_fullsize.txt" 2>&1
 ls -la "$OUT"
 for f in "$OUT"/*_kernel_stats.csv; do echo "== $f"; head -8 "$f" | cut -c1-200; done
 cat "$OUT"/*_hbm_counters.md 2>/dev/null | grep -E "^#|Aggregation|k_pass|k_wta"
