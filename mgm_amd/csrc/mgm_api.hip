@@ -119,7 +119,6 @@ struct DevSwitches {
     bool lazy_f32;   // MGM_HIP_LAZY_F32=0: always materialise the fp32 volume next to the compact one
     bool pad;        // MGM_HIP_PAD=0: no padding of label counts to the next count of the second build
     int subv;        // MGM_HIP_SUBV=0: one volume per wave also at 128 / 64 labels; 2: volumes share waves whenever they can
-    int prio;        // MGM_HIP_PRIO=mask: passes whose workgroups run at raised wave priority; -2: the chain-critical ones
     int deep;        // MGM_HIP_DEEP=0|1: never / always the pass kernels with deep DMA rings (default: by the launch's shape)
     int wg_per_cu;   // MGM_HIP_WG_PER_CU=1|2: override the occupancy heuristic of the pass kernel (0 = heuristic)
     int xflags;      // MGM_HIP_XFLAGS: experiment bits of development builds (mgm_device.h)
@@ -131,7 +130,7 @@ static const DevSwitches &dev()
     static const DevSwitches d = [] {
         auto on = [](const char *n) { const char *e = getenv(n); return !(e && atoi(e) == 0); };
         auto num = [](const char *n, long long dflt) { const char *e = getenv(n); return e ? atoll(e) : dflt; };
-        return DevSwitches{on("MGM_HIP_C8"), on("MGM_HIP_LAZY_F32"), on("MGM_HIP_PAD"), (int)num("MGM_HIP_SUBV", 1), (int)num("MGM_HIP_PRIO", 0), (int)num("MGM_HIP_DEEP", -1),
+        return DevSwitches{on("MGM_HIP_C8"), on("MGM_HIP_LAZY_F32"), on("MGM_HIP_PAD"), (int)num("MGM_HIP_SUBV", 1), (int)num("MGM_HIP_DEEP", -1),
                            (int)num("MGM_HIP_WG_PER_CU", 0), (int)num("MGM_HIP_XFLAGS", 0), (int)num("MGM_HIP_STRIPS", -1), 64ll * num("MGM_HIP_LR_PAD", 67)};
     }();
     return d;
@@ -1203,17 +1202,6 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         p.deep = (tags && use_c8 && !(Lk <= 256 && subv > 1 && ratio > 4.5)) ? 1 : 0;
     }
     if (dev().deep >= 0) p.deep = (tags && use_c8 && dev().deep) ? 1 : 0;
-    p.prio_mask = dev().prio > 0 ? dev().prio : 0;
-    if (dev().prio == -2) {  // (experiment: the passes within 10 % of the longest chain)
-        double chains[kMaxDirs] = {}, mx = 0;
-        for (int q = first; q < PEND; q++) {
-            const PassGeom &g = p.g[q];
-            chains[q] = (double)g.slope * g.NL + (g.nstrips == 2 ? g.LL / 2 : g.LL) + 6.0 * g.nbands;
-            mx = std::max(mx, chains[q]);
-        }
-        for (int q = first; q < PEND; q++)
-            if (chains[q] >= 0.9 * mx) p.prio_mask |= 1 << q;
-    }
     if (dev().wg_per_cu) p.wg_per_cu = dev().wg_per_cu;
     // A single volume per launch (chain-bound, one band per CU) walks the lines of the passes without an in-line
     // dependency -- form 1 with 2 or 3 neighbours -- as two strips, from both image edges inwards (mgm_pass2.hip): half

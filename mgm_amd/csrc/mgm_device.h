@@ -60,7 +60,6 @@ struct PassParams {
     const int2 *tasks;  // ticket -> (volume*8 + pass, band + (strip << 16))
     int subv;                 // volumes per wave (1; 2 at 128 labels, 4 at 64: k_pass2<..., SUBV>); work items then address groups of volumes
     int wg_per_cu;            // 1 or 2 workgroups per compute unit (second build; see launch2_c8)
-    int prio_mask;            // bit p: the workgroups of pass p run at raised wave priority (chain-critical passes, two bands per CU)
     int deep;                 // 1: the build with deeper DMA rings (k_pass2, DEEP; compact unweighted kernels)
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA, 4 ignore
                               // inter-band waits, 8 skip step barriers, 16 Lr stores into a cache-resident window (-DMGM_P2_XFLAG16 builds only); all of them need a -DMGM_P2_DEV=1 build

@@ -286,9 +286,6 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     const int2 tk = P.tasks[ticket];
     const int vp = tk.x, band = tk.y & 0xffff, strip = tk.y >> 16;  // vp = volume*8 + pass
     const int pass = vp & (kMaxDirs - 1);
-    // Two bands per CU: the bands of the passes with the longest dependency chain get issue priority over their
-    // co-resident workgroup, so that sharing the CU costs the critical chain as little as possible (host: prio_mask)
-    if (P.prio_mask & (1 << pass)) __builtin_amdgcn_s_setprio(2);
     const int vgrp = (vp / kMaxDirs) * SUBV;  // first volume of this work item
     const PassVolume &V = P.vol[vgrp];
 #if MGM_P2_DEV  // in-kernel timers (MGM_HIP_DEBUG_STATS) and experiment switches (MGM_HIP_XFLAGS)
