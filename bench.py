@@ -455,19 +455,22 @@ def replicas_leg(env, name, steps, warmup):
             "k2_ms": m["avg"].get("k_cost"), "k3_ms": m["avg"][pass_name], "wta_ms": m["avg"]["k_wta"], "roofline_frac": rf["frac"]}
 
 
-def directions_legs(env, name, steps, warmup, timeout_s, transports=("single", "peer", "rccl")):
+def directions_legs(env, name, steps, warmup, timeout_s, transports=("single", "peer", "rccl"), res=None):
     """BASELINE config 4: ONE volume, its passes sharded by direction over the ranks.  Sub-legs, each guarded:
       single  the whole aggregation on rank 0's GPU (the N = 1 figure of the strong-scaling curve, and the result the
               others are compared with, bit for bit)
       peer    rank 0's process drives ALL N GPUs through mgm_multi_* with device-to-device copies for the exchange
       rccl    one process per GPU, mgm_amd/dist.py: agree, then the ordered slab exchange over RCCL, time-boxed
-    Every rank must call this (the control barriers keep the idle ranks off the GPUs while rank 0 works alone)."""
+    Every rank must call this (the control barriers keep the idle ranks off the GPUs while rank 0 works alone).  `res`: the
+    dictionary to fill -- the caller's, already hanging in the json line, so that whatever has been measured when a later
+    sub-leg hangs is what the watchdog prints."""
     from mgm_amd import dist as mdist
     w = WORKLOADS[name]
     ctx, rank, world, torch, dist = env.ctx, env.rank, env.n_ranks, env.torch, env.dist
     nx, ny, L, NDIR = w["nx"], w["ny"], labels_of(w), w["NDIR"]
-    res = {"workload": "%s: %s" % (name, w["desc"]), "ranks": world, "unit": "disparity-volumes/s", "scaling": "strong",
-           "steps": steps, "warmup": warmup}
+    res = {} if res is None else res
+    res.update({"workload": "%s: %s" % (name, w["desc"]), "ranks": world, "unit": "disparity-volumes/s", "scaling": "strong",
+                "steps": steps, "warmup": warmup})
     if env.stub:
         return stub_directions(env, res, steps)
     u, v, _ = pair_of(w, 0)  # every rank holds the SAME pair and builds the full cost volume itself
@@ -649,7 +652,7 @@ def main():
                          "leg: ONE volume per step, its passes sharded over the GPUs with the ordered slab exchange (strong)")
     ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
                     help="the cfg5-replicas and cfg4-directions legs after the headline; auto = on for the plain command line")
-    ap.add_argument("--extras-timeout", type=float, default=420.0, help="seconds the guarded extras may take altogether")
+    ap.add_argument("--extras-timeout", type=float, default=300.0, help="seconds the guarded extras may take altogether")
     ap.add_argument("--exchange-timeout", type=float, default=90.0, help="seconds one direction-sharded step may take")
     args = ap.parse_args()
     plain = args.workload is None and args.batch is None and args.mode == "pairs"
@@ -749,13 +752,13 @@ def main():
             if rank == 0:
                 res["cfg5_replicas"] = {"error": repr(e)[:300]}
         ctx.trim()
+        d = {}
+        if rank == 0:
+            res["directions"] = d  # (filled as the sub-legs finish: a later one that hangs leaves the earlier ones in the line)
         try:
-            d = directions_legs(env, "cfg4", max(2, min(args.steps, 5)), 1, args.exchange_timeout)
-            if rank == 0:
-                res["directions"] = d
+            directions_legs(env, "cfg4", max(2, min(args.steps, 5)), 1, args.exchange_timeout, res=d)
         except Exception as e:  # noqa: BLE001
-            if rank == 0:
-                res["directions"] = {"error": repr(e)[:300]}
+            d["error"] = repr(e)[:300]
     failed = line.code != 0
     if rank == 0 and failed:
         print("bench.py: PARITY GATE FAILED: %s" % json.dumps(res.get("parity")), file=sys.stderr, flush=True)
