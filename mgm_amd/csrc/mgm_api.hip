@@ -1195,11 +1195,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
             chain = std::max(chain, (double)g.slope * g.NL + g.LL + lag * g.nbands);
         }
         p.wg_per_cu = (work / (double)c->num_cu > (fh ? 1.8 : 8.0) * chain) ? 2 : 1;
-        // Deep DMA rings (k_pass2, DEEP) wherever a band's step may have to wait for its loads: everything but the
-        // launches of many 128-label volumes, which lose with them (round 3: 1920x1080x128 x 16, ratio 5.1: K3 16.2 ->
-        // 19.1 ms; 1024x1024x128 x 16, ratio 4.0, and twelve 256-label volumes, ratio 10: no change).
-        const double ratio = work / (double)c->num_cu / chain;
-        p.deep = (tags && use_c8 && !(Lk <= 256 && subv > 1 && ratio > 4.5)) ? 1 : 0;
+        // Deep DMA rings (k_pass2, DEEP) for every compact unweighted launch: same-process A/B runs of round 3
+        // (tools/ab_env.sh, shallow -> deep) give -13 % of K3 for one 128-label volume, -15 % at 4096x4096x192, -3 % for
+        // one or two 256-label FH volumes, -3 % for 8 or 16 128-label volumes, and 0..-1 % for twelve 256-label ones.
+        p.deep = (tags && use_c8) ? 1 : 0;
     }
     if (dev().deep >= 0) p.deep = (tags && use_c8 && dev().deep) ? 1 : 0;
     if (dev().wg_per_cu) p.wg_per_cu = dev().wg_per_cu;
@@ -1311,6 +1310,27 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         else HIPCHK(c, launch_pass(p, c->ntasks, R, fh, weighted ? 1 : 0, c->stream));
     }
     if (tags) c->hand_key = tag_key;  // enqueued: every slot of the region will carry this launch's tag
+    if (tags) {
+        // MGM_HIP_CHECK_TAGS=1 (debug; synchronises): the invariant the tag protocol rests on, checked after the launch --
+        // every word of the slots of this launch's passes (all bands but the last, which hands nothing over) carries the
+        // launch's tag.  A slot the kernel skipped would keep its OLD tag and validate a stale slab two launches later.
+        const char *chk = getenv("MGM_HIP_CHECK_TAGS");
+        if (chk && atoi(chk) != 0) {
+            HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
+            for (int v = 0; v < ngroups; v++)
+                for (int q = first; q < PEND; q++) {
+                    const long long nw = (long long)(p.g[q].nbands - 1) * p.g[q].LL * LPk;
+                    if (nw <= 0) continue;
+                    HIPCHK(c, launch_check_tags(hand_ptr + ((long long)v * p.hand_vstride + p.g[q].hand_base) * LPk, nw, p.hand_tag[q], words + 3, c->stream));
+                }
+            HIPCHK(c, hipMemcpyAsync(c->h_words + 3, words + 3, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->h_words[3] != 0) {
+                c->hand_key.clear();
+                return fail(c, MGM_ERR_INTERNAL, "hand-off slots: " + std::to_string(c->h_words[3]) + " words do not carry the launch's tag");
+            }
+        }
+    }
     HIPCHK(c, hipMemcpyAsync(c->h_words + 1, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     c->pending_check = true;
     if (p.dbg) {  // development aid: where does K3's time go?

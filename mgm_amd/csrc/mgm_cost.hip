@@ -670,6 +670,25 @@ __global__ void __launch_bounds__(256) k_any_not_one(const float *__restrict__ w
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
+// Debug check of the self-validating hand-off slabs (mgm_pass2.hip, TAGS): after a launch EVERY word of the slots its
+// passes own must carry the launch's tag in its sign bit -- the invariant the protocol rests on ("each slot is written
+// exactly once per launch of its pass").  Counts the words that do not.
+__global__ void __launch_bounds__(256) k_check_tags(const unsigned *__restrict__ w, long long n, unsigned tag, unsigned *count)
+{
+    unsigned bad = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        bad += ((w[i] ^ tag) >> 31);
+    if (bad) atomicAdd(count, bad);
+}
+hipError_t launch_check_tags(const float *slabs, long long nwords, unsigned tag, unsigned *count, hipStream_t s)
+{
+    long long blocks = (nwords + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_check_tags, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const unsigned *>(slabs), nwords, tag, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_any_not_one(const float *w, long long n, unsigned *flag, hipStream_t s)
 {
     long long blocks = (n + 255) / 256;

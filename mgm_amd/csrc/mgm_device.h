@@ -159,6 +159,7 @@ hipError_t launch_weights(const float *u, int nx, int ny, int nch, float aP, flo
                           hipStream_t s);
 hipError_t launch_selftest_div3(unsigned long long *nbad, hipStream_t s);
 hipError_t launch_any_not_one(const float *w, long long n, unsigned *flag, hipStream_t s);
+hipError_t launch_check_tags(const float *slabs, long long nwords, unsigned tag, unsigned *count, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // device helpers

@@ -234,8 +234,9 @@ __device__ __forceinline__ void combine_unit_E(const float (&C)[LPL], const floa
 // DEEP: the rings hold MGM_P2_DEEPD steps of DMA instead of MGM_P2_MAXD.  With two steps in flight a load has ONE step to
 // land, and a step that is shorter than the memory latency (~0.8 us under load) waits for it: measured (round 3, same
 // box, shallow -> deep) 4096x4096x192 x 1: K3 32.5 -> 27.7 ms; 1920x1080x128 x 1: 2.69 -> 2.34; 256 labels x 1: 5.71 -> 5.50
-// (Hirschmueller), 7.23 -> 7.03 (FH); x 2: 11.24 -> 10.95; twelve volumes: nothing -- and sixteen 128-label volumes LOSE
-// (16.2 -> 19.1 ms), so the host picks per launch (mgm_api.hip, run_passes).  Compact unweighted kernels only.
+// (Hirschmueller), 7.23 -> 7.03 (FH); x 2: 11.24 -> 10.95; eight / sixteen 128-label volumes 9.11 -> 8.69 / 16.6 -> 15.9;
+// twelve 256-label volumes 48.5 -> 48.2.  The default of every compact unweighted launch (mgm_api.hip, run_passes); the
+// shallow build stays for A/B runs (MGM_HIP_DEEP=0).
 template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false>
 __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, true, C8>::NL) * 64,
                                   ((C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)

@@ -283,3 +283,40 @@ def test_more_than_8192_labels_is_refused(ctx):
     with pytest.raises(mgm_amd.MgmError) as e:
         ctx.upload_volume(np.zeros((2, 2, 8193), np.float32), 0)
     assert e.value.code == mgm_amd.MGM_ERR_UNSUPPORTED
+
+
+def test_hand_off_slots_all_rewritten(ctx, oracle, monkeypatch):
+    """MGM_HIP_CHECK_TAGS=1: after every pass launch the library scans the self-validating hand-off slots of the launched
+    passes -- every word must carry the launch's tag (the invariant the protocol rests on: each slot written exactly once per
+    launch of its pass).  Shapes that take every variant: several bands per pass, ragged last bands, two strips per line
+    (one volume, passes 4-7), volumes sharing waves, padded label counts, one launch per pass into a shared region."""
+    monkeypatch.setenv("MGM_HIP_CHECK_TAGS", "1")
+    cases = [(200, 150, 256, 8, 3, 1, 2.0, 20000.0, 1), (200, 150, 128, 8, 3, 0, 8.0, 32.0, 1), (131, 77, 192, 8, 4, 0, 8.0, 32.0, 1),
+             (90, 140, 128, 4, 2, 0, 8.0, 32.0, 4), (70, 50, 64, 8, 3, 1, 2.0, 9.0, 8), (150, 61, 100, 8, 3, 0, 8.0, 32.0, 2),
+             (64, 200, 384, 5, 1, 1, 1.5, 40.0, 1)]
+    for nx, ny, L, NDIR, MGM, FH, P1, P2, nb in cases:
+        Cs = [synth.raw_volume(nx, ny, L, seed=100 + k, inf_frac=0.02) for k in range(nb)]
+        cvs = [ctx.upload_volume(C, -3) for C in Cs]
+        for rep in range(3):  # (the tag alternates: both values, and the second use of freshly cleared slots)
+            _, outs, outcs = ctx.aggregate_batch_dev(cvs, P1, P2, NDIR, MGM, FH, 1, None, "vfit")
+            ctx.synchronize()
+            if rep == 2:
+                S, o, c = oracle.mgm(Cs[-1], -3, P1, P2, NDIR, MGM, FH, 1)
+                ro, rc = oracle.refine(S, -3, "vfit", np.where(np.isfinite(c), o, -3).astype(np.float32), c)
+                fin = np.isfinite(c)
+                assert ndiff(outcs[-1].download()[0], rc) == 0 and ndiff(outs[-1].download()[0][fin], ro[fin]) == 0
+            for h in outs + outcs:
+                h.free()
+        for h in cvs:
+            h.free()
+    # one launch per pass, all passes' slots in one region (the overlapped multi-GPU schedule)
+    C = synth.raw_volume(160, 130, 128, seed=7)
+    cv = ctx.upload_volume(C, 0)
+    for rep in range(3):
+        for k in range(8):
+            ctx.aggregate_passes_at_dev(cv, 8.0, 32.0, 3, 0, k, 1, k, 8, 8)
+        ctx.synchronize()
+    _, _, _, lr = oracle.mgm(C, 0, 8.0, 32.0, 8, 3, 0, 1, None, dump_lr=True)
+    for k in range(8):
+        assert ndiff(ctx.debug_lr(cv, k), lr[k]) == 0, k
+    cv.free()
