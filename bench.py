@@ -302,6 +302,9 @@ class Env:
         self.dist, self.ctrl, self.torch = None, None, None
 
     def setup(self):
+        # dmabuf IPC: RCCL between processes (and any device-memory sharing) needs it on this driver; the launcher exports it
+        # already, a rank started some other way gets it here, before the HIP runtime comes up
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         self.torch = torch
         args = self.args

@@ -4,6 +4,8 @@ an n-GPU split runs (n = 1, 2, 4, 8) -- in one launch, and one launch per pass (
 WTA on ny/n rows.  Only the xGMI rate of the table is an assumption."""
 import os, sys, time
 import numpy as np
+import torch
+torch.cuda.init()  # (torch's HIP runtime first: the library then shares it -- the other order leaves torch without devices)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import mgm_amd
 from mgm_amd import synth, dist as mdist
@@ -39,7 +41,6 @@ for n in (1, 2, 4, 8):
     print("n=%d  K3 per rank, one launch: max %.2f ms (%s) | one launch per pass: max %.2f ms (%s)" % (
         n, max(one), " ".join("%.1f" % t for t in one), max(per), " ".join("%.1f" % t for t in per)), flush=True)
 # row-slab WTA: all passes of ny/n rows (the slabs are read from the workspace of an 8-pass run: same traffic)
-import torch
 ctx.aggregate_passes_dev(cv, w["P1"], w["P2"], w["MGM"], w["FH"], 0, NDIR)
 ctx.synchronize()
 for n in (1, 2, 4, 8):
