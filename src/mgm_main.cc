@@ -8,8 +8,6 @@
 // computed on the CPU.  Image files (src/imgio.h): PNG, TIFF, PGM/PPM, PFM and .npy in -- what the
 // reference's iio decodes them to -- and float TIFF, PFM or .npy out.
 //
-// Not supported (exit code 2, message on stderr): TSGM_ITER < 1.
-//
 // Wall time (MGM_HIP_STATS=1 prints the breakdown on stderr): a 1920x1080x256 pair is ~17 ms of device work, so the
 // program is organised around its HOST costs -- both input images are decoded on their own threads while the main thread
 // brings the device context up, and the context is torn down (tens of GB of workspace handed back) on a thread of its
@@ -318,7 +316,9 @@ int main(int argc, char **argv)
     const double TSGM_ITER = env_param("TSGM_ITER", 1), TESTLRRL = env_param("TESTLRRL", 1);
     const double TAU = env_param("TESTLRRL_TAU", 1.0), MEDIAN = env_param("MEDIAN", 0);
     (void)env_param("WITH_MGM2", 0);  // accepted: see the header comment
-    if ((int)TSGM_ITER < 1) { fprintf(stderr, "mgm: TSGM_ITER < 1 is not supported\n"); return 2; }
+    // main()'s loops are `for (int i = 0; i < TSGM_ITER(); i++)` on a DOUBLE (mgm.cc:377, 406): ceil() iterations; none at
+    // all for TSGM_ITER <= 0 -- the maps then stay the zero images they were allocated as (mgm.cc:360-365)
+    const int ITER = TSGM_ITER > 0 ? (int)std::ceil(TSGM_ITER) : 0;
 
     Stopwatch sw;
     try {
@@ -340,7 +340,7 @@ int main(int argc, char **argv)
                 devs.push_back((int)d);
                 q = *end == ',' ? end + 1 : end;
             }
-        if (devs.size() > 1 && ((int)TSGM_ITER > 1 || min_file[0])) {
+        if (devs.size() > 1 && (ITER > 1 || min_file[0])) {
             fprintf(stderr, "mgm: MGM_DEVICES: TSGM_ITER > 1 and range images run on the first device only\n");
             devs.resize(1);
         }
@@ -383,7 +383,19 @@ int main(int argc, char **argv)
         Run L, R;
         prepare_run(ctx, u, v, o.dmin, o.dmax, o, L, plo, phi);
         bool together = false;
-        if (!multi && TESTLRRL != 0 && !plo && u.nx == v.nx && u.ny == v.ny && env_param("MGM_BATCH_LR", 1) != 0) {
+        auto zero_run = [&](Run &r) {  // no iteration: mgm() is never called, outoff / outcost keep their zeros
+            const std::vector<float> z((size_t)r.nx * r.ny, 0.0f);
+            for (mgm_img **im : {&r.dout, &r.dcost}) {
+                mgm_img_free(ctx, *im);
+                *im = nullptr;
+                if ((rc = mgm_img_upload(ctx, z.data(), r.nx, r.ny, 1, im))) die(ctx, rc, "upload");
+            }
+        };
+        if (ITER == 0) {
+            zero_run(L);
+            together = true;  // (nothing to aggregate)
+        }
+        if (ITER > 0 && !multi && TESTLRRL != 0 && !plo && u.nx == v.nx && u.ny == v.ny && env_param("MGM_BATCH_LR", 1) != 0) {
             // both runs of the pair (mgm.cc:376-385 and 405-414) through ONE launch of the pass kernel
             prepare_run(ctx, v, u, -o.dmax, -o.dmin, o, R);  // mgm.cc:366, 405
             const mgm_cv *Cs[2] = {L.C, R.C};
@@ -396,18 +408,24 @@ int main(int argc, char **argv)
             // (UNSUPPORTED: one image weighted, the other not -- the two runs take different update functions)
         }
         sw.mark("upload+enqueue");
-        if (multi) aggregate_run_multi(multi, u, v, o.dmin, o.dmax, o, L);
-        else if (!together) aggregate_run(ctx, o, L);
-        report_run(o, L);
-        iterate_run(ctx, o, L, (int)TSGM_ITER, o.dmin, o.dmax, plo, phi);
+        if (ITER > 0) {
+            if (multi) aggregate_run_multi(multi, u, v, o.dmin, o.dmax, o, L);
+            else if (!together) aggregate_run(ctx, o, L);
+            report_run(o, L);
+            iterate_run(ctx, o, L, ITER, o.dmin, o.dmax, plo, phi);
+        }
         if (MEDIAN != 0) median_run(ctx, L, (int)MEDIAN);
         if (nolr_file[0]) imgio::write(nolr_file, download(ctx, L.dout, L.nx, L.ny, 1));
         if (TESTLRRL != 0) {
             if (!R.C) prepare_run(ctx, v, u, -o.dmax, -o.dmin, o, R);  // mgm.cc:366, 405
-            if (multi) aggregate_run_multi(multi, v, u, -o.dmax, -o.dmin, o, R);
-            else if (!together) aggregate_run(ctx, o, R);
-            report_run(o, R);
-            iterate_run(ctx, o, R, (int)TSGM_ITER, -o.dmax, -o.dmin);
+            if (ITER == 0) {
+                zero_run(R);
+            } else {
+                if (multi) aggregate_run_multi(multi, v, u, -o.dmax, -o.dmin, o, R);
+                else if (!together) aggregate_run(ctx, o, R);
+                report_run(o, R);
+                iterate_run(ctx, o, R, ITER, -o.dmax, -o.dmin);
+            }
             if (MEDIAN != 0) median_run(ctx, R, (int)MEDIAN);
             // leftright_test both ways on copies of the unchecked maps (mgm.cc:420-423)
             mgm_img *Lchk = nullptr, *Rchk = nullptr;
