@@ -1209,7 +1209,11 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // is bound by the stalls of the min-convolution's repair path, and -5 % with two volumes).  A throughput-bound launch
     // has nothing to gain from it (1-2 % of the pixels of such a pass are computed twice).
     bool any_strips = false;
-    if (tags && (dev().strips == 1 || (dev().strips < 0 && p.wg_per_cu == 1 && ngroups == 1)))
+    // Round 3: with the deep DMA rings the strips LOSE (same-box A/B, strips -> none: 256 labels x 1 K3 7.60 -> 7.21 ms FH,
+    // 5.42 -> 5.15 Hirschmueller; 4096x4096x192 27.5 -> 26.2; two or three volumes -2..-5 % too) -- twice the work items,
+    // each with its own pipeline ramp and hand-off lag, for half a line of critical path -- so they are an option now
+    // (MGM_HIP_STRIPS=1), no longer the default of single-volume launches.
+    if (tags && dev().strips == 1)
         for (int q = first; q < PEND; q++)
             if (p.g[q].form == 1 && (MGM == 2 || MGM == 3) && p.g[q].LL >= 8 * R) {
                 p.g[q].nstrips = 2;
