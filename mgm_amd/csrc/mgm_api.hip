@@ -1212,8 +1212,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // Round 3: with the deep DMA rings the strips LOSE (same-box A/B, strips -> none: 256 labels x 1 K3 7.60 -> 7.21 ms FH,
     // 5.42 -> 5.15 Hirschmueller; 4096x4096x192 27.5 -> 26.2; two or three volumes -2..-5 % too) -- twice the work items,
     // each with its own pipeline ramp and hand-off lag, for half a line of critical path -- so they are an option now
-    // (MGM_HIP_STRIPS=1), no longer the default of single-volume launches.
-    if (tags && dev().strips == 1)
+    // (MGM_HIP_STRIPS=1), no longer the default of single-volume launches -- except where a launch runs only a FEW passes of
+    // one volume (a rank of a direction-sharded run): there the chain is all there is and the CUs idle anyway (4096x4096x192,
+    // tools/time_passes.py, none -> strips: one pass 8.8 -> 7.8-8.0 ms, two 10.7 -> 9.7, four 15.5 -> 14.9-15.2).
+    if (tags && (dev().strips == 1 || (dev().strips < 0 && ngroups == 1 && count <= 4 && p.wg_per_cu == 1)))
         for (int q = first; q < PEND; q++)
             if (p.g[q].form == 1 && (MGM == 2 || MGM == 3) && p.g[q].LL >= 8 * R) {
                 p.g[q].nstrips = 2;
