@@ -102,6 +102,7 @@ struct mgm_ctx {
     std::string hand_key;
     unsigned hand_tags[kMaxDirs] = {};  // per pass: the tag its slots carry after its last launch
     int num_cu = 256;  // hipDeviceProp_t::multiProcessorCount
+    int xcc_mask = -1;  // XCC ids the workgroups of a launch see (k_xcc_census; -1: not looked yet)
     // timing
     bool timing = false;
     std::vector<Timing> tim;
@@ -123,6 +124,8 @@ struct DevSwitches {
     int wg_per_cu;   // MGM_HIP_WG_PER_CU=1|2: override the occupancy heuristic of the pass kernel (0 = heuristic)
     int xflags;      // MGM_HIP_XFLAGS: experiment bits of development builds (mgm_device.h)
     int strips;      // MGM_HIP_STRIPS=0|1: never / always walk the lines of passes 4-7 as two strips (default: chain-bound launches only)
+    int xcdq;        // MGM_HIP_XCDQ=0|1: never / whenever possible the per-XCD work queues of k_pass2 (default: chain-bound launches)
+    int xcdq_k;      // MGM_HIP_XCDQ_K: consecutive bands of a pass per queue block (0: a pass stays on one XCD; default: by the launch's shape)
     long long lr_pad;  // MGM_HIP_LR_PAD: floats between consecutive Lr volumes beyond their size, in 256-byte blocks (67)
 };
 static const DevSwitches &dev()
@@ -131,7 +134,7 @@ static const DevSwitches &dev()
         auto on = [](const char *n) { const char *e = getenv(n); return !(e && atoi(e) == 0); };
         auto num = [](const char *n, long long dflt) { const char *e = getenv(n); return e ? atoll(e) : dflt; };
         return DevSwitches{on("MGM_HIP_C8"), on("MGM_HIP_LAZY_F32"), on("MGM_HIP_PAD"), (int)num("MGM_HIP_SUBV", 1), (int)num("MGM_HIP_DEEP", -1),
-                           (int)num("MGM_HIP_WG_PER_CU", 0), (int)num("MGM_HIP_XFLAGS", 0), (int)num("MGM_HIP_STRIPS", -1), 64ll * num("MGM_HIP_LR_PAD", 67)};
+                           (int)num("MGM_HIP_WG_PER_CU", 0), (int)num("MGM_HIP_XFLAGS", 0), (int)num("MGM_HIP_STRIPS", -1), (int)num("MGM_HIP_XCDQ", -1), (int)num("MGM_HIP_XCDQ_K", -1), 64ll * num("MGM_HIP_LR_PAD", 67)};
     }();
     return d;
 }
@@ -1179,6 +1182,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     }
     if ((r = reserve(c, c->handm, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL))) return r;
 
+    double load_ratio = 0;  // band-steps per CU over the longest chain of the launch
     {
         // Two bands per CU pay when the launch is bound by throughput, not by the longest chain of bands: compare the
         // band-steps one CU has to run with the critical path of the slowest pass (steps of slope*lines + line length
@@ -1195,6 +1199,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
             chain = std::max(chain, (double)g.slope * g.NL + g.LL + lag * g.nbands);
         }
         p.wg_per_cu = (work / (double)c->num_cu > (fh ? 1.8 : 8.0) * chain) ? 2 : 1;
+        load_ratio = work / (double)c->num_cu / chain;
         // Deep DMA rings (k_pass2, DEEP) for every compact unweighted launch: same-process A/B runs of round 3
         // (tools/ab_env.sh, shallow -> deep) give -13 % of K3 for one 128-label volume, -15 % at 4096x4096x192, -3 % for
         // one or two 256-label FH volumes, -3 % for 8 or 16 128-label volumes, and 0..-1 % for twelve 256-label ones.
@@ -1223,8 +1228,33 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
                 any_strips = true;
             }
 
+    // Per-XCD work queues (k_pass2, XCDQ): launches in which the chains of bands matter -- the hand-off lag of every band is
+    // in the critical path of its pass.  Same-box A/B runs (round 3, 1920x1080, K3 without -> with): 256 labels FH x 1
+    // 6.8 -> 6.4 ms, x 2 10.95 -> 10.33, x 3 14.6 -> 13.9, x 4 18.6 -> 17.8, x 6 and x 12 (load/chain 5 and 10) 0 .. +1 %;
+    // Hirschmueller x 1 5.2 -> 4.75, x 2 8.6 -> 8.15; 128 labels x 1 2.38 -> 2.07, x 3 4.40 -> 4.24; 4096x4096x192 x 1
+    // +-0, x 2 (load/chain 5.4) +1 %.  Needs all eight XCC ids to show up in a launch (a partitioned device shows fewer).
+    bool xcdq = false;
+    if (tags && p.deep && subv == 1 && !any_strips && R2 && !pass2_devtools() && (dev().xcdq == 1 || (dev().xcdq < 0 && load_ratio < 4.0))) {
+        if (c->xcc_mask < 0) {
+            HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
+            HIPCHK(c, launch_xcc_census(words + 3, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_words + 3, words + 3, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->xcc_mask = (int)c->h_words[3];
+        }
+        xcdq = c->xcc_mask == 0xff;
+    }
+    // bands per queue block: a pass stays on one XCD when the passes of the launch fill the eight queues evenly; otherwise
+    // blocks of two bands, which spread four or twelve passes over all XCDs at the price of every second hand-off
+    // crossing (measured, round 3: see DESIGN.md section 4)
+    int QK = (ngroups * count) % 8 == 0 ? 0 : 2;
+    if (dev().xcdq_k >= 0) QK = dev().xcdq_k;
+    if (QK <= 0) QK = 1 << 20;
+    if (getenv("MGM_HIP_SHOW_PLAN"))  // development aid: what the launch heuristics decided
+        fprintf(stderr, "[mgm plan] %dx%dx%d passes %d..%d x %d volumes: load/chain %.2f, %d wg/cu, deep %d, subv %d, strips %d, xcd queues %d (block %d)\n", nx, ny, L,
+                first, PEND - 1, nb, load_ratio, p.wg_per_cu, p.deep, subv, any_strips ? 1 : 0, xcdq ? 1 : 0, QK >= (1 << 20) ? 0 : QK);
     // task table: ticket -> (pass, band [, strip]); item (p, b, .) always follows the items (p, b-1, .)
-    const int tk_key = (((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv) * 2 + (any_strips ? 1 : 0);
+    const int tk_key = ((((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv) * 2 + (any_strips ? 1 : 0)) * 2 + (xcdq ? 1 : 0);
     if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != tk_key || c->tk_r != R)
         for (auto &t : c->ttabs)
             if (t.nx == nx && t.ny == ny && t.key == tk_key && t.R == R) {  // a shape seen before: its table is still on the device
@@ -1251,10 +1281,31 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
             if (c->ttabs.front().buf.p) (void)hipFree(c->ttabs.front().buf.p);
             c->ttabs.erase(c->ttabs.begin());
         }
+        // The table's header: the eight XCD queues (first ticket, count).  xcdq: the sorted items are dealt to the queues
+        // in blocks of QK consecutive bands of a pass, consecutive blocks to consecutive queues, the passes staggered;
+        // every queue keeps the global order (what the progress argument of k_pass2 rests on), and an item whose
+        // successor band sits in the same queue is marked for a plain hand-off (bit 24).
+        std::vector<int2> table(8, make_int2(0, 0));
+        if (xcdq) {
+            std::vector<int2> qs[8];
+            for (const int2 &t : tasks) {
+                const int v = t.x / kMaxDirs, q = t.x % kMaxDirs, b = t.y & 0xffff;
+                const int chain = v * count + (q - first);
+                const bool same = b + 1 < p.g[q].nbands && (b + 1) / QK == b / QK;
+                qs[(b / QK + chain) % 8].push_back(make_int2(t.x, t.y | (same ? 1 << 24 : 0)));
+            }
+            int at = 0;
+            for (int k = 0; k < 8; k++) {
+                table[k] = make_int2(at, (int)qs[k].size());
+                at += (int)qs[k].size();
+                table.insert(table.end(), qs[k].begin(), qs[k].end());
+            }
+        } else
+            table.insert(table.end(), tasks.begin(), tasks.end());
         c->tasks = Buf{};
-        if ((r = reserve(c, c->tasks, sizeof(int2) * tasks.size()))) return r;
+        if ((r = reserve(c, c->tasks, sizeof(int2) * table.size()))) return r;
         c->ttabs.push_back(mgm_ctx::TaskTab{nx, ny, tk_key, R, (int)tasks.size(), c->tasks});
-        HIPCHK(c, hipMemcpyAsync(c->tasks.p, tasks.data(), sizeof(int2) * tasks.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->tasks.p, table.data(), sizeof(int2) * table.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->ntasks = (int)tasks.size();
         c->tk_nx = nx;
@@ -1277,7 +1328,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.ticket = words + 0;
     p.err = words + 1;
     p.prog = words + 4;
-    p.tasks = (const int2 *)c->tasks.p;
+    p.tasks = (const int2 *)c->tasks.p + 8;  // (behind the header)
+    p.xcdq = xcdq ? 1 : 0;
+    p.qticket = words + 4;  // (the progress words of the other protocol: the kernels with tags do not use them)
+    if (xcdq) HIPCHK(c, hipMemsetAsync(words + 4, 0, 9 * sizeof(unsigned), c->stream));
     p.npix = npix;
     p.nvol = lr_stride;
     p.L = L;
@@ -1343,7 +1397,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         std::vector<unsigned long long> d((size_t)c->ntasks * 16);
         std::vector<int2> tk(c->ntasks);
         HIPCHK(c, hipMemcpyAsync(d.data(), p.dbg, d.size() * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(tk.data(), c->tasks.p, tk.size() * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(tk.data(), (const int2 *)c->tasks.p + 8, tk.size() * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         unsigned long long t0 = ~0ull, t1 = 0;
         for (int i = 0; i < c->ntasks; i++) {
@@ -1354,7 +1408,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         fprintf(stderr, "[mgm stats] %d workgroups, kernel span %.1f us\n", c->ntasks, (t1 - t0) * tick);
         if (c->debug_stats >= 2)  // one line per work item: pass, band, strip, ticket, start / first step / end (us), time in the slow path
             for (int i = 0; i < c->ntasks; i++)
-                fprintf(stderr, "[mgm item] %d %d %d %d %.1f %.1f %.1f %.1f\n", tk[i].x % kMaxDirs, tk[i].y & 0xffff, tk[i].y >> 16, i,
+                fprintf(stderr, "[mgm item] %d %d %d %d %.1f %.1f %.1f %.1f\n", tk[i].x % kMaxDirs, tk[i].y & 0xffff, (tk[i].y >> 16) & 0xff, i,
                         (d[i * 16 + 0] - t0) * tick, (d[i * 16 + 1] - t0) * tick, (d[i * 16 + 2] - t0) * tick, d[i * 16 + 6] * tick);
         for (int q = first; q < PEND; q++) {
             double run = 0, slow = 0, pro = 0, nslow = 0, nspin = 0, steps = 0, first = 1e30, last = 0;

@@ -680,6 +680,19 @@ __global__ void __launch_bounds__(256) k_check_tags(const unsigned *__restrict__
         bad += ((w[i] ^ tag) >> 31);
     if (bad) atomicAdd(count, bad);
 }
+// which XCC ids the workgroups of a launch see (bit i: some workgroup ran on XCD i)
+__global__ void k_xcc_census(unsigned *mask)
+{
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    if (threadIdx.x == 0) atomicOr(mask, 1u << (xcc & 31u));
+}
+hipError_t launch_xcc_census(unsigned *mask, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_xcc_census, dim3(2048), dim3(64), 0, s, mask);
+    return hipGetLastError();
+}
+
 hipError_t launch_check_tags(const float *slabs, long long nwords, unsigned tag, unsigned *count, hipStream_t s)
 {
     long long blocks = (nwords + 255) / 256;

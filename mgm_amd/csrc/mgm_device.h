@@ -57,7 +57,10 @@ struct PassParams {
     unsigned *prog;     // progress words  [volume*8 + pass][maxbands]
     unsigned *ticket;   // work-item ticket counter
     unsigned *err;      // watchdog word
-    const int2 *tasks;  // ticket -> (volume*8 + pass, band + (strip << 16))
+    const int2 *tasks;  // ticket -> (volume*8 + pass, band + (strip << 16) + (plain hand-off << 24)); tasks[-8 .. -1]: the
+                        // XCD queues (first ticket, count) of an xcdq launch
+    unsigned *qticket;  // xcdq: the eight queues' ticket counters + the count of workgroups that have left
+    int xcdq;                 // 1: per-XCD work queues (k_pass2, XCDQ)
     int subv;                 // volumes per wave (1; 2 at 128 labels, 4 at 64: k_pass2<..., SUBV>); work items then address groups of volumes
     int wg_per_cu;            // 1 or 2 workgroups per compute unit (second build; see launch2_c8)
     int deep;                 // 1: the build with deeper DMA rings (k_pass2, DEEP; compact unweighted kernels)
@@ -160,6 +163,7 @@ hipError_t launch_weights(const float *u, int nx, int ny, int nch, float aP, flo
 hipError_t launch_selftest_div3(unsigned long long *nbad, hipStream_t s);
 hipError_t launch_any_not_one(const float *w, long long n, unsigned *flag, hipStream_t s);
 hipError_t launch_check_tags(const float *slabs, long long nwords, unsigned tag, unsigned *count, hipStream_t s);
+hipError_t launch_xcc_census(unsigned *mask, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // device helpers

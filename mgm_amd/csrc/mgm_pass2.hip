@@ -112,6 +112,22 @@ __device__ __forceinline__ void store_slab_sc1_wide(float *slab, int lane, const
     else if constexpr (LPL == 6) { st_sc1_x4(p, v[0], v[1], v[2], v[3]); st_sc1_x2(p + 4, v[4], v[5]); }
     else { st_sc1_x4(p, v[0], v[1], v[2], v[3]); st_sc1_x4(p + 4, v[4], v[5], v[6], v[7]); }
 }
+// the same slab with plain stores (XCDQ: the reader is on this XCD)
+template <int LPL>
+__device__ __forceinline__ void store_slab_plain(float *slab, int lane, const float (&v)[LPL])
+{
+    float *p = slab + lane * LPL;
+    if constexpr (LPL % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < LPL; k += 4) {
+            const f32x4 q = {v[k], v[k + 1], v[k + 2], v[k + 3]};
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p + k), "v"(q) : "memory");
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < LPL; k++) asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" ::"v"(p + k), "v"(v[k]) : "memory");
+    }
+}
 template <int LPL>
 constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 1; }
 
@@ -237,9 +253,18 @@ __device__ __forceinline__ void combine_unit_E(const float (&C)[LPL], const floa
 // (Hirschmueller), 7.23 -> 7.03 (FH); x 2: 11.24 -> 10.95; eight / sixteen 128-label volumes 9.11 -> 8.69 / 16.6 -> 15.9;
 // twelve 256-label volumes 48.5 -> 48.2.  The default of every compact unweighted launch (mgm_api.hip, run_passes); the
 // shallow build stays for A/B runs (MGM_HIP_DEEP=0).
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false>
-__global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, true, C8>::NL) * 64,
-                                  ((C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
+// where the work-item word lives in the workgroup's LDS (the layout of pass2_item, below)
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, bool DEEP>
+struct P2Lds {
+    static constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
+    static constexpr bool pubE = !WEIGHTED && !(FH && MGM == 2);
+    using PL = Plan<LPL, NS, !pubE, C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD>;
+    static constexpr int RD = PL::rd(PL::D);
+    static constexpr int task_off = PL::NC * PL::RT * NS * PL::LP + RD * NS * PL::LP + PL::cring_floats(RD) + PL::NC * PL::RT + RD + RD;  // floats
+};
+
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV, bool DEEP, bool XCDQ>
+__device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket)
 {
     static_assert(!DEEP || (C8 && !WEIGHTED && !(FH && MGM == 2)), "the deep rings exist for the compact kernels that publish E");
     static_assert(SUBV == 1 || (LPL == 4 && C8 && !WEIGHTED && !(FH && MGM == 2)), "volumes share a wave only in the compact unweighted kernels that publish E");
@@ -276,16 +301,14 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     float *Tm = Cring + PL::cring_floats(RD);     // [NC][RT]
     float *Hm = Tm + NC * RT;                     // [RD]
     unsigned *Hprog = reinterpret_cast<unsigned *>(Hm + RD);  // [RD]
-    int *s_task = reinterpret_cast<int *>(Hprog + RD);
+    int *s_task = reinterpret_cast<int *>(smem + P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP>::task_off);  // (= Hprog + RD; the kernel's ticket word)
     unsigned *Cflag = reinterpret_cast<unsigned *>(s_task + 40);  // [RD][16] (compact costs; behind the spare words)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) *s_task = (int)atomicAdd(P.ticket, 1u);
-    __syncthreads();
-    const int ticket = *s_task;
     const int2 tk = P.tasks[ticket];
-    const int vp = tk.x, band = tk.y & 0xffff, strip = tk.y >> 16;  // vp = volume*8 + pass
+    const int vp = tk.x, band = tk.y & 0xffff, strip = (tk.y >> 16) & 0xff;  // vp = volume*8 + pass
+    const bool plain_out = XCDQ && ((tk.y >> 24) & 1) != 0;  // the next band of the chain runs on this XCD (see k_pass2)
     const int pass = vp & (kMaxDirs - 1);
     const int vgrp = (vp / kMaxDirs) * SUBV;  // first volume of this work item
     const PassVolume &V = P.vol[vgrp];
@@ -805,7 +828,12 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 #pragma unroll
                         for (int k = 0; k < LPL; k++)
                             tagged[k] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, nb_i.w[0][k]) & 0x7fffffffu) | tag_out);  // (a NaN -- INF costs with P2 = INF -- may carry a sign of its own)
-                        store_slab_sc1_wide<LPL>(hand_out + (long long)(mirror ? LL - 1 - i : i) * LP, lane, tagged);
+                        float *hs = hand_out + (long long)(mirror ? LL - 1 - i : i) * LP;
+                        if constexpr (XCDQ) {
+                            if (plain_out) store_slab_plain<LPL>(hs, lane, tagged);
+                            else store_slab_sc1_wide<LPL>(hs, lane, tagged);
+                        } else
+                            store_slab_sc1_wide<LPL>(hs, lane, tagged);
                     }
                 } else if (to_global) {
 #pragma unroll
@@ -860,8 +888,55 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     else if constexpr (MGM <= 3) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
 }
 
+// The kernel: one work item per workgroup, taken by ticket -- or, XCDQ, the work items of the XCD the workgroup finds
+// itself on.  XCDQ (single-volume launches, one workgroup per CU; mgm_api.hip, run_passes): the host deals the bands of
+// every pass in blocks of consecutive bands to eight queues, one per XCD; a workgroup reads its XCC id at run time and
+// works through THAT queue, one item after the other, until it is empty.  A band whose successor sits in the same queue
+// hands its slabs over with PLAIN stores: they stay in the XCD's L2, where the successor's L2-served (sc1) loads find
+// them after an L2 round trip instead of a trip through the fabric (write-through stores drop the line from the L2 --
+// MI355X_MICROARCH, "stores of each flavour") -- the hand-off lag of a band shrinks, and with it the chain of a pass.
+// The last band of a block hands over write-through as before.  Nothing depends on WHERE a workgroup runs except
+// through the id it reads itself; progress needs one resident workgroup per XCD (every queue is in global ticket
+// order, so the earliest unfinished item of the launch is always at the head of its queue with all it needs finished),
+// and the last workgroup to leave checks that every queue was worked off -- a queue without workgroups raises the
+// watchdog word instead of leaving lines unwritten.
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false>
+__global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, true, C8>::NL) * 64,
+                                  ((C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int *s_ticket = reinterpret_cast<int *>(smem + P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP>::task_off);
+    if constexpr (!XCDQ) {
+        if (threadIdx.x == 0) *s_ticket = (int)atomicAdd(P.ticket, 1u);
+        __syncthreads();
+        pass2_item<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, false>(P, *s_ticket);
+    } else {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        const int xq = (int)(xcc & 7u);
+        const int2 qi = P.tasks[xq - 8];  // (first ticket, count) of this XCD's queue: the table's header
+        for (;;) {
+            if (threadIdx.x == 0) *s_ticket = (int)atomicAdd(P.qticket + xq, 1u);
+            __syncthreads();
+            const int t = *s_ticket;
+            if (t >= qi.y) break;
+            pass2_item<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, true>(P, qi.x + t);
+            wait_vmcnt<0>();   // (the loader's DMAs beyond the last step)
+            __syncthreads();   // LDS and s_ticket are free again
+        }
+        if (threadIdx.x == 0) {
+            const unsigned left = atomicAdd(P.qticket + 8, 1u) + 1u;
+            if (left == gridDim.x) {
+                bool all = true;
+                for (int q = 0; q < 8; q++) all = all && __hip_atomic_load(P.qticket + q, RLX_AGENT) >= (unsigned)P.tasks[q - 8].y;
+                if (!all) __hip_atomic_store(P.err, 1u, RLX_AGENT);
+            }
+        }
+    }
+}
+
 // ---- launcher (one translation unit per LPL: -DMGM_P2_LPL=n) -----------------------
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false>
 static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 {
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
@@ -872,7 +947,7 @@ static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
     // right when the launch is throughput-bound (a batch of volumes); a single volume is bound by the chain of
     // bands, where the doubled step latency costs more than it gives, so it asks for > half the LDS and runs alone.
     if (p.wg_per_cu < 2 && shmem < 81 * 1024) shmem = 81 * 1024;
-    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP>;
+    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, XCDQ>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
@@ -883,15 +958,26 @@ static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 template <int LPL, bool FH, bool WEIGHTED, int MGM>
 static hipError_t launch2_one(const PassParams &p, int ntasks, hipStream_t s)
 {
+    // (The kernels with per-XCD queues do not exist in development builds: with the timers compiled in, this compiler
+    // fails on some of their instances -- "Illegal instruction detected: Operand has incorrect register class",
+    // V_CMP_NE_U32 on src_shared_base.  The host does not ask for them there, mgm_api.hip.)
     if constexpr (LPL == 4 && !WEIGHTED && !(FH && MGM == 2)) {  // several volumes per wave (128 / 64 labels)
-        if (p.subv == 2 && p.vol[0].C8)
+        if (p.subv > 1 && p.xcdq) return hipErrorInvalidValue;  // (no gain measured there: cfg2 x 4..16, cfg5 x 4..16 within noise)
+        if (p.subv == 2 && p.vol[0].C8) {
             return p.deep ? launch2_c8<LPL, FH, WEIGHTED, MGM, true, 2, true>(p, ntasks, s) : launch2_c8<LPL, FH, WEIGHTED, MGM, true, 2>(p, ntasks, s);
-        if (p.subv == 4 && p.vol[0].C8)
+        }
+        if (p.subv == 4 && p.vol[0].C8) {
             return p.deep ? launch2_c8<LPL, FH, WEIGHTED, MGM, true, 4, true>(p, ntasks, s) : launch2_c8<LPL, FH, WEIGHTED, MGM, true, 4>(p, ntasks, s);
+        }
     }
     if (p.subv > 1) return hipErrorInvalidValue;
     if constexpr (!WEIGHTED && !(FH && MGM == 2))
-        if (p.vol[0].C8 && p.deep) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 1, true>(p, ntasks, s);
+        if (p.vol[0].C8 && p.deep) {
+            if constexpr (!MGM_P2_DEV)
+                if (p.xcdq) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 1, true, true>(p, ntasks, s);
+            if (p.xcdq) return hipErrorInvalidValue;
+            return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 1, true>(p, ntasks, s);
+        }
     if (p.vol[0].C8) return launch2_c8<LPL, FH, WEIGHTED, MGM, true>(p, ntasks, s);
     return launch2_c8<LPL, FH, WEIGHTED, MGM, false>(p, ntasks, s);
 }
