@@ -42,6 +42,14 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
@@ -53,8 +61,10 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJDIR, src.replace(".hip", suffix + ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            jobs.append([cc] + COMMON + extra + ["-c", s, "-o", o])
+        cmd = [cc] + COMMON + extra + ["-c", s, "-o", o]
+        # an object built with other flags (MGM_P2_DEFINES of a tuning or development build) is stale too
+        if force or _stale(o, [s] + headers) or _read(o + ".cmd") != " ".join(cmd):
+            jobs.append(cmd)
 
     def run(cmd):
         if verbose:
@@ -62,6 +72,9 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode:
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stdout))
+        if "-c" in cmd:
+            with open(cmd[-1] + ".cmd", "w") as f:
+                f.write(" ".join(cmd))
         return r.stdout
 
     if jobs:

@@ -1234,7 +1234,11 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // Hirschmueller x 1 5.2 -> 4.75, x 2 8.6 -> 8.15; 128 labels x 1 2.38 -> 2.07, x 3 4.40 -> 4.24; 4096x4096x192 x 1
     // +-0, x 2 (load/chain 5.4) +1 %.  Needs all eight XCC ids to show up in a launch (a partitioned device shows fewer).
     bool xcdq = false;
-    if (tags && p.deep && subv == 1 && !any_strips && R2 && !pass2_devtools() && (dev().xcdq == 1 || (dev().xcdq < 0 && load_ratio < 4.0))) {
+    int nitems = 0;  // work items of the launch = its workgroups
+    for (int q = first; q < PEND; q++) nitems += ngroups * p.g[q].nbands * p.g[q].nstrips;
+    // (a queue is only worked off by workgroups that find themselves on its XCD: the launch must be large enough for the
+    // dispatcher's round robin to have put several on each -- a small launch keeps the single ticket counter)
+    if (tags && p.deep && subv == 1 && !any_strips && R2 && nitems >= 32 && !pass2_devtools() && (dev().xcdq == 1 || (dev().xcdq < 0 && load_ratio < 4.0))) {
         if (c->xcc_mask < 0) {
             HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
             HIPCHK(c, launch_xcc_census(words + 3, c->stream));
@@ -1251,8 +1255,8 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     if (dev().xcdq_k >= 0) QK = dev().xcdq_k;
     if (QK <= 0) QK = 1 << 20;
     if (getenv("MGM_HIP_SHOW_PLAN"))  // development aid: what the launch heuristics decided
-        fprintf(stderr, "[mgm plan] %dx%dx%d passes %d..%d x %d volumes: load/chain %.2f, %d wg/cu, deep %d, subv %d, strips %d, xcd queues %d (block %d)\n", nx, ny, L,
-                first, PEND - 1, nb, load_ratio, p.wg_per_cu, p.deep, subv, any_strips ? 1 : 0, xcdq ? 1 : 0, QK >= (1 << 20) ? 0 : QK);
+        fprintf(stderr, "[mgm plan] %dx%dx%d passes %d..%d x %d volumes: load/chain %.2f, %d wg/cu, deep %d, subv %d, strips %d, xcd queues %d (block %d; xcc ids seen 0x%x)\n", nx, ny, L,
+                first, PEND - 1, nb, load_ratio, p.wg_per_cu, p.deep, subv, any_strips ? 1 : 0, xcdq ? 1 : 0, QK >= (1 << 20) ? 0 : QK, (unsigned)c->xcc_mask);
     // task table: ticket -> (pass, band [, strip]); item (p, b, .) always follows the items (p, b-1, .)
     const int tk_key = ((((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv) * 2 + (any_strips ? 1 : 0)) * 2 + (xcdq ? 1 : 0);
     if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != tk_key || c->tk_r != R)
