@@ -1207,38 +1207,20 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     }
     if (dev().deep >= 0) p.deep = (tags && use_c8 && dev().deep) ? 1 : 0;
     if (dev().wg_per_cu) p.wg_per_cu = dev().wg_per_cu;
-    // A single volume per launch (chain-bound, one band per CU) walks the lines of the passes without an in-line
-    // dependency -- form 1 with 2 or 3 neighbours -- as two strips, from both image edges inwards (mgm_pass2.hip): half
-    // the line length in the critical path of a pass, and bands that live half as long (measured, 1920x1080: K3 -5 % at
-    // 256 labels with Hirschmueller potentials and at 128 labels; nothing with FH potentials, whose single-volume launch
-    // is bound by the stalls of the min-convolution's repair path, and -5 % with two volumes).  A throughput-bound launch
-    // has nothing to gain from it (1-2 % of the pixels of such a pass are computed twice).
-    bool any_strips = false;
-    // Round 3: with the deep DMA rings the strips LOSE (same-box A/B, strips -> none: 256 labels x 1 K3 7.60 -> 7.21 ms FH,
-    // 5.42 -> 5.15 Hirschmueller; 4096x4096x192 27.5 -> 26.2; two or three volumes -2..-5 % too) -- twice the work items,
-    // each with its own pipeline ramp and hand-off lag, for half a line of critical path -- so they are an option now
-    // (MGM_HIP_STRIPS=1), no longer the default of single-volume launches -- except where a launch runs only a FEW passes of
-    // one volume (a rank of a direction-sharded run): there the chain is all there is and the CUs idle anyway (4096x4096x192,
-    // tools/time_passes.py, none -> strips: one pass 8.8 -> 7.8-8.0 ms, two 10.7 -> 9.7, four 15.5 -> 14.9-15.2).
-    if (tags && (dev().strips == 1 || (dev().strips < 0 && ngroups == 1 && count <= 4 && p.wg_per_cu == 1)))
-        for (int q = first; q < PEND; q++)
-            if (p.g[q].form == 1 && (MGM == 2 || MGM == 3) && p.g[q].LL >= 8 * R) {
-                p.g[q].nstrips = 2;
-                p.g[q].split = p.g[q].LL / 2;
-                any_strips = true;
-            }
-
-    // Per-XCD work queues (k_pass2, XCDQ): launches in which the chains of bands matter -- the hand-off lag of every band is
-    // in the critical path of its pass.  Same-box A/B runs (round 3, 1920x1080, K3 without -> with): 256 labels FH x 1
-    // 6.8 -> 6.4 ms, x 2 10.95 -> 10.33, x 3 14.6 -> 13.9, x 4 18.6 -> 17.8, x 6 and x 12 (load/chain 5 and 10) 0 .. +1 %;
-    // Hirschmueller x 1 5.2 -> 4.75, x 2 8.6 -> 8.15; 128 labels x 1 2.38 -> 2.07, x 3 4.40 -> 4.24; 4096x4096x192 x 1
-    // +-0, x 2 (load/chain 5.4) +1 %.  Needs all eight XCC ids to show up in a launch (a partitioned device shows fewer).
+    // Per-XCD work queues (k_pass2, XCDQ): launches in which the chains of bands matter.  The workgroups stay and work a
+    // queue off (a band that follows another on a CU starts at once instead of waiting for a workgroup to be dispatched),
+    // and most hand-offs stay inside an XCD's L2.  Same-box A/B runs (round 3, 1920x1080, K3 without -> with queues):
+    // 256 labels FH x 1 6.9 -> 6.4 ms, x 2 11.0 -> 10.3, x 3 14.6 -> 13.9, x 4 18.6 -> 17.8, x 6 and x 12 (load/chain 5
+    // and 10) 0 .. +1 %; Hirschmueller x 1 5.4 -> 4.85, x 2 8.6 -> 8.15; 128 labels x 1 2.38 -> 2.07, x 3 4.40 -> 4.24;
+    // 4096x4096x192 x 1 +-0, x 2 (load/chain 5.4) +1 %.  One queue for all XCDs (MGM_HIP_XCDQ=2: the staying workgroups
+    // alone) gives 6.5, 5.2 and 2.08 ms for the three single volumes, 16.3 instead of 15.3 for three 256-label ones.
+    // Needs all eight XCC ids to show up in a launch (a partitioned device shows fewer), and a launch large enough for
+    // the dispatcher's round robin to have put several workgroups on every XCD: a queue is only worked off by
+    // workgroups that find themselves on its XCD -- a small launch keeps the single ticket counter.
     bool xcdq = false;
-    int nitems = 0;  // work items of the launch = its workgroups
-    for (int q = first; q < PEND; q++) nitems += ngroups * p.g[q].nbands * p.g[q].nstrips;
-    // (a queue is only worked off by workgroups that find themselves on its XCD: the launch must be large enough for the
-    // dispatcher's round robin to have put several on each -- a small launch keeps the single ticket counter)
-    if (tags && p.deep && subv == 1 && !any_strips && R2 && nitems >= 32 && !pass2_devtools() && (dev().xcdq == 1 || (dev().xcdq < 0 && load_ratio < 4.0))) {
+    int nitems = 0;  // work items of the launch (before strips) = its workgroups
+    for (int q = first; q < PEND; q++) nitems += ngroups * p.g[q].nbands;
+    if (tags && p.deep && subv == 1 && R2 && nitems >= 32 && !pass2_devtools() && (dev().xcdq >= 1 || (dev().xcdq < 0 && load_ratio < 4.0))) {
         if (c->xcc_mask < 0) {
             HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
             HIPCHK(c, launch_xcc_census(words + 3, c->stream));
@@ -1248,10 +1230,34 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         }
         xcdq = c->xcc_mask == 0xff;
     }
+    // Two strips per line: the passes without an in-line dependency -- form 1 with 2 or 3 neighbours -- walk their lines
+    // from both image edges inwards (mgm_pass2.hip): half the line length in the critical path of a pass, bands that
+    // live half as long, for twice the work items, each with its own pipeline ramp and hand-off lag (and 1-2 % of the
+    // pixels of such a pass computed twice).  Round 3, same-box A/B runs:
+    //   * with the deep rings alone the strips LOSE on whole volumes (strips -> none, 1920x1080: 256 labels x 1 K3 7.60 ->
+    //     7.21 ms FH, 5.42 -> 5.15 Hirschmueller; 4096x4096x192 27.5 -> 26.2; two or three volumes -2..-5 % too) and win
+    //     where a launch runs only a FEW passes of one volume (a rank of a direction-sharded run; 4096x4096x192,
+    //     tools/time_passes.py, none -> strips: one pass 8.8 -> 7.8-8.0 ms, two 10.7 -> 9.7, four 15.5 -> 14.9-15.2);
+    //   * with the XCD queues -- a finished strip's successor starts at once -- they win wherever the chains dominate
+    //     (none -> strips, 1920x1080x256: FH x 1 6.47 -> 6.18, x 2 10.25 -> 10.0, x 3 14.0 -> 13.5 but x 4 17.7 -> 18.1;
+    //     Hirschmueller x 1 4.85 -> 4.70, x 2 and x 3 +-0; 4096x4096x192 x 1 (load/chain 2.7) 26.5 -> 27.0, x 2 50.9 -> 52.6;
+    //     a rank's four passes of 4096x4096x192 9.6 -> 8.4 with queues and strips together): on below a load/chain of 2.
+    bool any_strips = false;
+    if (tags && (dev().strips == 1 || (dev().strips < 0 && ((ngroups == 1 && count <= 4 && p.wg_per_cu == 1) || (xcdq && load_ratio < 2.0)))))
+        for (int q = first; q < PEND; q++)
+            if (p.g[q].form == 1 && (MGM == 2 || MGM == 3) && p.g[q].LL >= 8 * R) {
+                p.g[q].nstrips = 2;
+                p.g[q].split = p.g[q].LL / 2;
+                any_strips = true;
+            }
     // bands per queue block: a pass stays on one XCD when the passes of the launch fill the eight queues evenly; otherwise
     // blocks of two bands, which spread four or twelve passes over all XCDs at the price of every second hand-off
-    // crossing (measured, round 3: see DESIGN.md section 4)
-    int QK = (ngroups * count) % 8 == 0 ? 0 : 2;
+    // crossing.
+    // Measured (K3, block 0 / 1 / 2, no queues): 1920x1080x256 FH x 2 10.2 / 10.9 / 11.3 (11.4), x 3 14.2 / 15.5 / 15.5 (16.5),
+    // x 4 17.7 / 18.4 / 17.9 (19.1); Hirschmueller x 3 13.0 / 13.35 / 13.4 (13.5); 128 labels x 1 (four passes) 2.85 / 2.08 /
+    // 2.07 (2.35); 4096x4096x192 x 1 27.2 / 27.5 / 26.4 (27.65) -- lines that long keep far more bands in flight than an
+    // XCD has CUs, and a pinned pass that takes longer than the others leaves the other XCDs idle at the end.
+    int QK = ((ngroups * count) % 8 == 0 && maxLL <= 3000) ? 0 : 2;
     if (dev().xcdq_k >= 0) QK = dev().xcdq_k;
     if (QK <= 0) QK = 1 << 20;
     if (getenv("MGM_HIP_SHOW_PLAN"))  // development aid: what the launch heuristics decided
@@ -1296,7 +1302,8 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
                 const int v = t.x / kMaxDirs, q = t.x % kMaxDirs, b = t.y & 0xffff;
                 const int chain = v * count + (q - first);
                 const bool same = b + 1 < p.g[q].nbands && (b + 1) / QK == b / QK;
-                qs[(b / QK + chain) % 8].push_back(make_int2(t.x, t.y | (same ? 1 << 24 : 0)));
+                if (dev().xcdq == 2) qs[0].push_back(t);  // (A/B setting: one queue, write-through hand-offs)
+                else qs[(b / QK + chain) % 8].push_back(make_int2(t.x, t.y | (same ? 1 << 24 : 0)));
             }
             int at = 0;
             for (int k = 0; k < 8; k++) {
@@ -1333,7 +1340,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.err = words + 1;
     p.prog = words + 4;
     p.tasks = (const int2 *)c->tasks.p + 8;  // (behind the header)
-    p.xcdq = xcdq ? 1 : 0;
+    p.xcdq = xcdq ? (dev().xcdq == 2 ? 2 : 1) : 0;
     p.qticket = words + 4;  // (the progress words of the other protocol: the kernels with tags do not use them)
     if (xcdq) HIPCHK(c, hipMemsetAsync(words + 4, 0, 9 * sizeof(unsigned), c->stream));
     p.npix = npix;

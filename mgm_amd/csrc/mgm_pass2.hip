@@ -913,7 +913,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
     } else {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-        const int xq = (int)(xcc & 7u);
+        const int xq = P.xcdq == 2 ? 0 : (int)(xcc & 7u);  // (2: one queue for all -- the persistent loop alone, an A/B setting)
         const int2 qi = P.tasks[xq - 8];  // (first ticket, count) of this XCD's queue: the table's header
         for (;;) {
             if (threadIdx.x == 0) *s_ticket = (int)atomicAdd(P.qticket + xq, 1u);
