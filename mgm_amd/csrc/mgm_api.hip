@@ -1198,7 +1198,9 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
             work += (double)ngroups * g.nbands * (g.LL + g.slope * R);
             chain = std::max(chain, (double)g.slope * g.NL + g.LL + lag * g.nbands);
         }
-        p.wg_per_cu = (work / (double)c->num_cu > (fh ? 1.8 : 8.0) * chain) ? 2 : 1;
+        // (round 3, with the XCD queues: two 256-label FH volumes, ratio 1.66, K3 10.29 -> 9.93 ms with the second band; one
+        // volume -- 0.83 -- loses 20 % with it: the FH threshold moved from 1.8 to 1.5)
+        p.wg_per_cu = (work / (double)c->num_cu > (fh ? 1.5 : 8.0) * chain) ? 2 : 1;
         load_ratio = work / (double)c->num_cu / chain;
         // Deep DMA rings (k_pass2, DEEP) for every compact unweighted launch: same-process A/B runs of round 3
         // (tools/ab_env.sh, shallow -> deep) give -13 % of K3 for one 128-label volume, -15 % at 4096x4096x192, -3 % for
