@@ -81,13 +81,39 @@ def pair_of(w, seed_offset=0):
     return synth.stereo_pair(w["nx"], w["ny"], w["dmin"] * 3 // 4, max(0, w["dmax"] * 3 // 4), seed=synth.SEED + seed_offset)
 
 
-def kernel_source_hash():
-    """Identity of the kernels a committed PMC summary was measured on (profiles/*_traffic.json)."""
+def strip_comments(src):
+    """C / C++ source without its comments and with every run of white space as one blank (string and character
+    literals kept as they are): what a compiler sees of it, give or take line numbers."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c in "\"'":  # a literal: copy up to its closing quote
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+            out.append(src[i:j + 1])
+            i = j + 1
+        elif src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
+def kernel_source_hash(csrc=None):
+    """Identity of the kernels a committed PMC summary was measured on (profiles/*_traffic.json): the sources under
+    mgm_amd/csrc without their comments and line breaks, so that rewording a comment does not orphan a measurement."""
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "mgm_amd", "csrc")
+    d = csrc or os.path.join(ROOT, "mgm_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
+            h.update(f.encode() + b"\0" + strip_comments(open(os.path.join(d, f), encoding="utf-8").read()).encode() + b"\0")
     return h.hexdigest()[:16]
 
 

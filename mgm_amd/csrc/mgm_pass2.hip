@@ -18,9 +18,10 @@
 //     launch's tag in the sign bit of every word, one slot per band: see TAGS in
 //     k_pass2) -- no progress words, no publication lag; the weighted kernels
 //     keep the first build's progress-word protocol;
-//   * single-volume launches walk the lines of passes 4-7 (2 or 3 neighbours: no
+//   * chain-bound launches walk the lines of passes 4-7 (2 or 3 neighbours: no
 //     in-line dependency) as TWO strips from the image edges inwards (see
-//     `strips` in k_pass2).
+//     `strips` in pass2_item), and their workgroups stay and work per-XCD queues
+//     of work items off (see k_pass2, XCDQ).
 //
 // Used when every slab is a whole number of 16-byte DMA pieces (L == 64*LPL,
 // LPL in {1,2,3,4,6,8}); other label counts run padded to the next such count,
@@ -889,12 +890,14 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
 }
 
 // The kernel: one work item per workgroup, taken by ticket -- or, XCDQ, the work items of the XCD the workgroup finds
-// itself on.  XCDQ (single-volume launches, one workgroup per CU; mgm_api.hip, run_passes): the host deals the bands of
-// every pass in blocks of consecutive bands to eight queues, one per XCD; a workgroup reads its XCC id at run time and
+// itself on.  XCDQ (launches in which the chains of bands matter; mgm_api.hip, run_passes): the host deals the bands of
+// every pass in blocks of consecutive bands -- or whole passes -- to eight queues, one per XCD; a workgroup reads its XCC id at run time and
 // works through THAT queue, one item after the other, until it is empty.  A band whose successor sits in the same queue
 // hands its slabs over with PLAIN stores: they stay in the XCD's L2, where the successor's L2-served (sc1) loads find
 // them after an L2 round trip instead of a trip through the fabric (write-through stores drop the line from the L2 --
-// MI355X_MICROARCH, "stores of each flavour") -- the hand-off lag of a band shrinks, and with it the chain of a pass.
+// MI355X_MICROARCH, "stores of each flavour") -- the hand-off lag of a band shrinks, and with it the chain of a pass;
+// and a band that follows another on a CU starts without a workgroup having to be dispatched first, which measured
+// as the larger half of the gain.
 // The last band of a block hands over write-through as before.  Nothing depends on WHERE a workgroup runs except
 // through the id it reads itself; progress needs one resident workgroup per XCD (every queue is in global ticket
 // order, so the earliest unfinished item of the launch is always at the head of its queue with all it needs finished),

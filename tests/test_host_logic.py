@@ -49,3 +49,22 @@ def test_multi_plan_partitions_passes_and_rows():
                 assert max(c for _, c, _, _ in plan) - min(c for _, c, _, _ in plan) <= 1
                 assert [(f, c) for f, c, _, _ in plan] == [mdist.passes_of_rank(NDIR, n, k) for k in range(n)]
                 assert [(r0, nr) for _, _, r0, nr in plan] == mdist.row_slabs(ny, n)
+
+
+def test_kernel_hash_ignores_comments_only(tmp_path):
+    """bench.kernel_source_hash (the guard of profiles/*_traffic.json): comments and line breaks do not count, code does."""
+    import bench
+    assert bench.strip_comments('a = "x//y"; // c\n/* k */ b = \'"\';\n\n  f(1 /* one */, 2);') == 'a = "x//y"; b = \'"\'; f(1 , 2);'
+    d = tmp_path / "csrc"
+    d.mkdir()
+    (d / "k.hip").write_text("// one\n__global__ void k(int *p) { *p = 1; }  /* tail */\n")
+    (d / "notes.txt").write_text("not a source")
+    h0 = bench.kernel_source_hash(str(d))
+    (d / "k.hip").write_text("// another comment\n\n__global__ void k(int *p)\n{\n    *p = 1;  // set\n}\n")
+    assert bench.kernel_source_hash(str(d)) == h0
+    (d / "k.hip").write_text("__global__ void k(int *p) { *p = 2; }\n")
+    assert bench.kernel_source_hash(str(d)) != h0
+    # the committed counter summaries of this round belong to the kernels in the tree
+    import json, glob, os
+    files = glob.glob(os.path.join(bench.ROOT, "profiles", "r03_*_traffic.json"))
+    assert files and all(json.load(open(f))["kernel_source_sha"] == bench.kernel_source_hash() for f in files)
