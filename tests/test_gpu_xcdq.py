@@ -50,6 +50,9 @@ SHAPES = [
     (260, 190, 128, 4, 2, 0, 8.0, 32.0, 1),     # four passes: blocks of two bands by default
     (200, 170, 256, 8, 4, 1, 2.0, 9.0, 3),      # three volumes: 24 chains
     (180, 140, 192, 8, 3, 0, 8.0, 32.0, 1),     # three labels per lane
+    (170, 150, 384, 8, 1, 0, 8.0, 32.0, 1),     # six labels per lane, one neighbour
+    (150, 130, 512, 8, 3, 1, 2.0, 30.0, 1),     # eight labels per lane, FH with a finite cap
+    (230, 170, 64, 8, 4, 0, 8.0, 32.0, 1),      # one label per lane, four neighbours
 ]
 
 
