@@ -1222,7 +1222,13 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     bool xcdq = false;
     int nitems = 0;  // work items of the launch (before strips) = its workgroups
     for (int q = first; q < PEND; q++) nitems += ngroups * p.g[q].nbands;
-    if (tags && p.deep && subv == 1 && R2 && nitems >= 32 && !pass2_devtools() && (dev().xcdq >= 1 || (dev().xcdq < 0 && load_ratio < 4.0))) {
+    // Hirschmueller potentials (short steps: the second band per CU never gave them more than 3 %): with the queues, ONE band per
+    // CU is the better schedule at every batch size -- same-box A/B runs of 256-label volumes, two bands per CU without
+    // queues -> one with: x 8 0.964 -> 0.985 of the roofline, x 12 0.957 -> 0.981 (K3 46.9 -> 44.9 ms); 4096x4096x192 x 2 +-0 --,
+    // so they take the queues whatever the load; the FH kernels, which need the second band from a load/chain of 1.5 on,
+    // below a load/chain of 4.
+    const bool always_q = !fh;
+    if (tags && p.deep && subv == 1 && R2 && nitems >= 32 && !pass2_devtools() && (dev().xcdq >= 1 || (dev().xcdq < 0 && (always_q || load_ratio < 4.0)))) {
         if (c->xcc_mask < 0) {
             HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
             HIPCHK(c, launch_xcc_census(words + 3, c->stream));
@@ -1232,6 +1238,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         }
         xcdq = c->xcc_mask == 0xff;
     }
+    if (xcdq && always_q && !dev().wg_per_cu) p.wg_per_cu = 1;
     // Two strips per line: the passes without an in-line dependency -- form 1 with 2 or 3 neighbours -- walk their lines
     // from both image edges inwards (mgm_pass2.hip): half the line length in the critical path of a pass, bands that
     // live half as long, for twice the work items, each with its own pipeline ramp and hand-off lag (and 1-2 % of the
