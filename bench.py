@@ -38,7 +38,6 @@ torch is used for the process group, the barrier and the max-reduction only.
 """
 import argparse
 import hashlib
-import importlib.util
 import json
 import os
 import signal
@@ -67,6 +66,10 @@ WORKLOADS = {
     "cfg5": dict(nx=1024, ny=1024, dmin=-127, dmax=0, win=3, NDIR=4, MGM=2, FH=0, P1=8.0, P2=32.0,
                  desc="1024x1024 synthetic pair, 128 disparities, CENSUS 3x3, -O 4 TSGM=2 (throughput mode)"),
 }
+# Set ONLY by a test driver that imports this module (tests/run_bench_stub.py) to drive the launcher, the rendezvous and the
+# JSON contract on CPU ranks; nothing in the environment or on the command line can set it, and the line such a run prints
+# says `"data": "stub (no device work)"`.
+TEST_CONTEXT_FACTORY = None
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PARITY_MAX_CELLS = 1.2e9  # the in-run oracle takes whole volumes up to this size (cfg4: see tests/test_gpu_fullsize.py)
 
@@ -251,9 +254,10 @@ def free_port():
 
 
 def relaunch_under_torchrun(args):
-    """`python bench.py --gpus N` without a rendezvous environment: become the launcher of N ranks of this same file."""
+    """`python bench.py --gpus N` without a rendezvous environment: become the launcher of N ranks of the script that was
+    started (this file -- or the test driver that imported it, tests/run_bench_stub.py)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(free_port()), os.path.abspath(sys.argv[0])] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
@@ -355,10 +359,7 @@ class Env:
             self.dist = dist
         self.n_ranks = self.dist.get_world_size() if self.dist is not None else 1  # the world RCCL actually initialised
         if self.stub:
-            spec = importlib.util.spec_from_file_location("bench_stub", os.environ["MGM_BENCH_STUB"])
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
-            self.ctx = mod.StubContext(self.local)
+            self.ctx = TEST_CONTEXT_FACTORY(self.local)
         else:
             import mgm_amd
             self.ctx = mgm_amd.Context(self.local)
@@ -632,7 +633,7 @@ def directions_legs(env, name, steps, warmup, timeout_s, transports=("single", "
 
 
 def stub_directions(env, res, steps):
-    """MGM_BENCH_STUB: the control flow of the direction-sharded leg on CPU ranks -- agreement and the ordered slab
+    """Test driver only (TEST_CONTEXT_FACTORY): the control flow of the direction-sharded leg on CPU ranks -- agreement and the ordered slab
     exchange over gloo on small host tensors (mgm_amd/dist.py, the code the RCCL leg runs), no device work."""
     from mgm_amd import dist as mdist
     torch, dist = env.torch, env.dist
@@ -688,7 +689,7 @@ def main():
     extras = args.extras == "on" or (args.extras == "auto" and plain)
     wname = args.workload or ("cfg4" if args.mode == "directions" else "cfg3")
     w = WORKLOADS[wname]
-    stub = bool(os.environ.get("MGM_BENCH_STUB"))  # tests/test_dist_cpu.py: gloo ranks on CPU, a context that computes nothing
+    stub = TEST_CONTEXT_FACTORY is not None  # (tests/run_bench_stub.py: gloo ranks on CPU, a context that computes nothing)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args)

@@ -65,6 +65,9 @@ int mgm_ctx_trim(mgm_ctx *ctx);
  * hand-off slots; 0 = no cap, the default).  mgm_aggregate_batch_dev runs a batch that exceeds it -- or that the
  * device cannot hold -- as several launches over the largest sub-batches that fit instead of returning MGM_ERR_NOMEM. */
 int mgm_ctx_set_workspace_limit(mgm_ctx *ctx, unsigned long long bytes);
+/* Free and total device memory in bytes as the runtime sees them now (hipMemGetInfo on the context's device): what a
+ * caller sizes its batches -- or mgm_ctx_set_workspace_limit -- with.  Either pointer may be NULL. */
+int mgm_ctx_mem_info(mgm_ctx *ctx, unsigned long long *free_bytes, unsigned long long *total_bytes);
 void *mgm_ctx_stream(mgm_ctx *ctx); /* the hipStream_t everything is enqueued on */
 const char *mgm_version(void);
 
@@ -251,7 +254,9 @@ int mgm_update_ranges_dev(mgm_ctx *ctx, const mgm_img *outoff, mgm_img *dminI, m
 /* median_filter (img_tools.h:203-238, called at mgm.cc:396, 419 when MEDIAN != 0): per channel, the window
  * (2*radius+1)^2 clipped at the border, NaN samples ignored, the upper median v[n/2]; an all-NaN window
  * leaves the pixel unchanged.  Any radius >= 1 (beyond 7 the order statistic is found by radix selection instead of
- * pairwise counting).  out must have in's size (and must not be in). */
+ * pairwise counting: 33 sweeps of the window per pixel, so the call is bounded -- MGM_ERR_UNSUPPORTED when
+ * 33 * (2*radius+1)^2 * nx*ny*nch exceeds 1e13 window reads, i.e. beyond radius ~190 at 1920x1080; up to that it
+ * takes at most about a minute).  out must have in's size (and must not be in). */
 int mgm_median_dev(mgm_ctx *ctx, const mgm_img *in, int radius, mgm_img *out);
 /* leftright_test (mgm.cc:68-91, called at 420-423): out[x,y] = d[x,y] if Lx = round(x + d) lies inside `other`
  * and |Lx + other[Lx,y] - x| <= tau, NaN otherwise.  d and out have one size, `other` may have another width. */

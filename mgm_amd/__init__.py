@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "mgm_wta_windowed_dev", "mgm_update_ranges_dev", "mgm_costvolume_build_ranged_dev",
     "mgm_multi_create", "mgm_multi_destroy", "mgm_multi_size", "mgm_multi_ctx", "mgm_multi_last_error", "mgm_multi_plan",
     "mgm_multi_aggregate", "mgm_multi_transport", "mgm_img_device", "mgm_cv_device", "mgm_aggregate_passes_at_dev",
-    "mgm_ctx_set_workspace_limit",
+    "mgm_ctx_set_workspace_limit", "mgm_ctx_mem_info",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -118,6 +118,7 @@ def load_library():
     L.mgm_cv_device.argtypes = [vp]
     L.mgm_aggregate_passes_at_dev.argtypes = [vp, vp, vp, f, f, i, i, i, i, i, i, i]
     L.mgm_ctx_set_workspace_limit.argtypes = [vp, C.c_ulonglong]
+    L.mgm_ctx_mem_info.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
 
@@ -217,6 +218,12 @@ class Context:
     def set_workspace_limit(self, nbytes):
         """Cap on the workspace of one pass launch; larger batches run as several launches (mgm_ctx_set_workspace_limit)."""
         self._chk(self.lib.mgm_ctx_set_workspace_limit(self.h, int(nbytes)))
+
+    def mem_info(self):
+        """(free, total) bytes of the context's device right now."""
+        f, t = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._chk(self.lib.mgm_ctx_mem_info(self.h, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
 
     def stream_ptr(self):
         """The hipStream_t everything is enqueued on (for torch.cuda.ExternalStream)."""

@@ -126,6 +126,7 @@ struct DevSwitches {
     int strips;      // MGM_HIP_STRIPS=0|1: never / always walk the lines of passes 4-7 as two strips (default: chain-bound launches only)
     int xcdq;        // MGM_HIP_XCDQ=0|1: never / whenever possible the per-XCD work queues of k_pass2 (default: chain-bound launches)
     int xcdq_k;      // MGM_HIP_XCDQ_K: consecutive bands of a pass per queue block (0: a pass stays on one XCD; default: by the launch's shape)
+    bool oneb;       // MGM_HIP_ONEB=0: launches that run one band per CU keep the queue kernels capped at 64 VGPRs (A/B)
     long long lr_pad;  // MGM_HIP_LR_PAD: floats between consecutive Lr volumes beyond their size, in 256-byte blocks (67)
 };
 static const DevSwitches &dev()
@@ -134,7 +135,7 @@ static const DevSwitches &dev()
         auto on = [](const char *n) { const char *e = getenv(n); return !(e && atoi(e) == 0); };
         auto num = [](const char *n, long long dflt) { const char *e = getenv(n); return e ? atoll(e) : dflt; };
         return DevSwitches{on("MGM_HIP_C8"), on("MGM_HIP_LAZY_F32"), on("MGM_HIP_PAD"), (int)num("MGM_HIP_SUBV", 1), (int)num("MGM_HIP_DEEP", -1),
-                           (int)num("MGM_HIP_WG_PER_CU", 0), (int)num("MGM_HIP_XFLAGS", 0), (int)num("MGM_HIP_STRIPS", -1), (int)num("MGM_HIP_XCDQ", -1), (int)num("MGM_HIP_XCDQ_K", -1), 64ll * num("MGM_HIP_LR_PAD", 67)};
+                           (int)num("MGM_HIP_WG_PER_CU", 0), (int)num("MGM_HIP_XFLAGS", 0), (int)num("MGM_HIP_STRIPS", -1), (int)num("MGM_HIP_XCDQ", -1), (int)num("MGM_HIP_XCDQ_K", -1), on("MGM_HIP_ONEB"), 64ll * num("MGM_HIP_LR_PAD", 67)};
     }();
     return d;
 }
@@ -155,6 +156,20 @@ int hipfail(mgm_ctx *c, hipError_t e, const char *what)
         if (e__ != hipSuccess) return hipfail((c), e__, #call);  \
     } while (0)
 
+// hipMalloc whose failure does not outlive the call: the runtime keeps the last error until somebody reads it, and every
+// launch wrapper here ends with `return hipGetLastError()` -- without this, the first kernel launched after an
+// MGM_ERR_NOMEM return (the smaller chunk mgm_aggregate_batch_dev retries with, or simply the caller's next call) would
+// report the stale hipErrorOutOfMemory as its own.
+hipError_t dev_malloc(void **p, size_t bytes)
+{
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        (void)hipGetLastError();
+    }
+    return e;
+}
+
 int reserve(mgm_ctx *c, Buf &b, size_t bytes)
 {
     if (bytes <= b.cap) return MGM_OK;
@@ -164,9 +179,8 @@ int reserve(mgm_ctx *c, Buf &b, size_t bytes)
         b.p = nullptr;
         b.cap = 0;
     }
-    hipError_t e = hipMalloc(&b.p, bytes);
+    hipError_t e = dev_malloc(&b.p, bytes);
     if (e != hipSuccess) {
-        b.p = nullptr;
         return fail(c, MGM_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
     }
     b.cap = bytes;
@@ -407,6 +421,17 @@ int mgm_ctx_set_workspace_limit(mgm_ctx *c, unsigned long long bytes)
     return MGM_OK;
 }
 
+int mgm_ctx_mem_info(mgm_ctx *c, unsigned long long *free_bytes, unsigned long long *total_bytes)
+{
+    if (!c) return MGM_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIPCHK(c, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return MGM_OK;
+}
+
 const char *mgm_last_error(const mgm_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 void *mgm_ctx_stream(mgm_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -454,7 +479,7 @@ int mgm_img_create(mgm_ctx *c, int nx, int ny, int nch, mgm_img **out)
     if (!c || !out || nx <= 0 || ny <= 0 || nch <= 0) return fail(c, MGM_ERR_INVALID, "mgm_img_create: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     mgm_img *im = new mgm_img{nullptr, nx, ny, nch, c->device};
-    hipError_t e = hipMalloc((void **)&im->d, sizeof(float) * (size_t)nx * ny * nch);
+    hipError_t e = dev_malloc((void **)&im->d, sizeof(float) * (size_t)nx * ny * nch);
     if (e != hipSuccess) {
         delete im;
         return fail(c, MGM_ERR_NOMEM, std::string("mgm_img_create: ") + hipGetErrorString(e));
@@ -514,7 +539,7 @@ static int cv_alloc_f32(mgm_ctx *c, mgm_cv *cv)
 {
     if (cv->d) return MGM_OK;
     const size_t n = (size_t)cv->nx * cv->ny * (size_t)(cv->dmax - cv->dmin + 1);
-    hipError_t e = hipMalloc((void **)&cv->d, sizeof(float) * n);
+    hipError_t e = dev_malloc((void **)&cv->d, sizeof(float) * n);
     if (e != hipSuccess) {
         cv->d = nullptr;
         return fail(c, MGM_ERR_NOMEM, std::string("cost volume (fp32): ") + hipGetErrorString(e));
@@ -540,7 +565,7 @@ static int cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, bool alloc_
             delete cv;
             return r;
         }
-    if (hipMalloc((void **)&cv->bad8, 64) != hipSuccess) {
+    if (dev_malloc((void **)&cv->bad8, 64) != hipSuccess) {
         if (cv->d) (void)hipFree(cv->d);
         delete cv;
         return fail(c, MGM_ERR_NOMEM, "mgm_cv_create: flag word");
@@ -632,7 +657,7 @@ int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
 static int c8_alloc(mgm_ctx *c, mgm_cv *cv)
 {
     const size_t n = (size_t)cv->nx * cv->ny * (size_t)(cv->dmax - cv->dmin + 1);
-    if (!cv->d8 && hipMalloc((void **)&cv->d8, n + 64) != hipSuccess) {
+    if (!cv->d8 && dev_malloc((void **)&cv->d8, n + 64) != hipSuccess) {
         cv->d8 = nullptr;
         return fail(c, MGM_ERR_NOMEM, "hipMalloc of the compact cost volume failed");
     }
@@ -752,7 +777,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     if (rloI) {  // the volume keeps its own copy of the range images: K4-K6 need them again
         const size_t nb = sizeof(float) * (size_t)u->nx * u->ny;
         for (float **q : {&(*out)->rlo, &(*out)->rhi})
-            if (!*q && hipMalloc((void **)q, nb) != hipSuccess) {
+            if (!*q && dev_malloc((void **)q, nb) != hipSuccess) {
                 *q = nullptr;
                 return fail(c, MGM_ERR_NOMEM, "mgm_costvolume_build: range images");
             }
@@ -1297,6 +1322,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         });
         if (c->ttabs.size() >= 24) {  // (bounded: drop the oldest; the stream is synchronised below before anything is reused)
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->ttabs.front().buf.p == c->tasks.p) {  // (the table the cached key still names)
+                c->tasks = Buf{};
+                c->tk_nx = c->tk_ny = c->tk_ndir = c->tk_r = -1;
+            }
             if (c->ttabs.front().buf.p) (void)hipFree(c->ttabs.front().buf.p);
             c->ttabs.erase(c->ttabs.begin());
         }
@@ -1322,11 +1351,18 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
             }
         } else
             table.insert(table.end(), tasks.begin(), tasks.end());
-        c->tasks = Buf{};
-        if ((r = reserve(c, c->tasks, sizeof(int2) * table.size()))) return r;
-        c->ttabs.push_back(mgm_ctx::TaskTab{nx, ny, tk_key, R, (int)tasks.size(), c->tasks});
-        HIPCHK(c, hipMemcpyAsync(c->tasks.p, table.data(), sizeof(int2) * table.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // (the table in use and its key change together, and only once the new table is on the device: a failure on the
+        // way leaves the context with the table -- and the key -- it had)
+        Buf fresh{};
+        if ((r = reserve(c, fresh, sizeof(int2) * table.size()))) return r;
+        hipError_t ce = hipMemcpyAsync(fresh.p, table.data(), sizeof(int2) * table.size(), hipMemcpyHostToDevice, c->stream);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
+        if (ce != hipSuccess) {
+            (void)hipFree(fresh.p);
+            return hipfail(c, ce, "task table upload");
+        }
+        c->ttabs.push_back(mgm_ctx::TaskTab{nx, ny, tk_key, R, (int)tasks.size(), fresh});
+        c->tasks = fresh;
         c->ntasks = (int)tasks.size();
         c->tk_nx = nx;
         c->tk_ny = ny;
@@ -1350,6 +1386,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.prog = words + 4;
     p.tasks = (const int2 *)c->tasks.p + 8;  // (behind the header)
     p.xcdq = xcdq ? (dev().xcdq == 2 ? 2 : 1) : 0;
+    p.oneb = (xcdq && p.wg_per_cu < 2 && dev().oneb) ? 1 : 0;
     p.qticket = words + 4;  // (the progress words of the other protocol: the kernels with tags do not use them)
     if (xcdq) HIPCHK(c, hipMemsetAsync(words + 4, 0, 9 * sizeof(unsigned), c->stream));
     p.npix = npix;
@@ -1793,6 +1830,12 @@ int mgm_median_dev(mgm_ctx *c, const mgm_img *in, int radius, mgm_img *out)
     if (!c || !in || !out || in == out) return fail(c, MGM_ERR_INVALID, "mgm_median: bad arguments");
     if (out->nx != in->nx || out->ny != in->ny || out->nch != in->nch) return fail(c, MGM_ERR_INVALID, "mgm_median: image size mismatch");
     if (radius < 1 || radius > 1024) return fail(c, MGM_ERR_INVALID, "mgm_median: radius must be 1..1024");
+    // Beyond radius 7 the order statistic costs 33 sweeps of the (2r+1)^2 window per pixel, read straight from memory
+    // (no tiling): bounded here so that the call finishes in about a minute at most -- 1920x1080 up to radius ~190;
+    // the launches themselves are cut into pieces of bounded work (mgm_post.hip).
+    constexpr double kMedianMaxReads = 1.0e13;
+    if (radius > 7 && 33.0 * (2.0 * radius + 1.0) * (2.0 * radius + 1.0) * (double)in->nx * in->ny * in->nch > kMedianMaxReads)
+        return fail(c, MGM_ERR_UNSUPPORTED, "mgm_median: window too large for this image (33 * (2r+1)^2 * pixels must stay below 1e13)");
     HIPCHK(c, hipSetDevice(c->device));
     TimeScope t(c, "k_median");
     HIPCHK(c, launch_median(in->d, in->nx, in->ny, in->nch, radius, out->d, c->stream));

@@ -64,6 +64,7 @@ struct PassParams {
     int subv;                 // volumes per wave (1; 2 at 128 labels, 4 at 64: k_pass2<..., SUBV>); work items then address groups of volumes
     int wg_per_cu;            // 1 or 2 workgroups per compute unit (second build; see launch2_c8)
     int deep;                 // 1: the build with deeper DMA rings (k_pass2, DEEP; compact unweighted kernels)
+    int oneb;                 // 1: the queue kernels built for one band per CU (k_pass2, ONEB: no 64-VGPR cap)
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA, 4 ignore
                               // inter-band waits, 8 skip step barriers, 16 Lr stores into a cache-resident window (-DMGM_P2_XFLAG16 builds only); all of them need a -DMGM_P2_DEV=1 build
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)

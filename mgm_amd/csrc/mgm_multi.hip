@@ -134,6 +134,7 @@ int reserve(mgm_multi *m, int k, Grow &b, size_t bytes)
     }
     if (hipMalloc(&b.p, bytes) != hipSuccess) {
         b.p = nullptr;
+        (void)hipGetLastError();  // (the runtime keeps the error until it is read: the next launch wrapper would report it)
         return fail(m, MGM_ERR_NOMEM, "mgm_multi: hipMalloc(" + std::to_string(bytes) + ") on device " + std::to_string(m->dev[k]));
     }
     b.cap = bytes;

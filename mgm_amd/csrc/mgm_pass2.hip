@@ -135,6 +135,9 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 
 #ifndef MGM_P2_WAVES_PER_EU
 #define MGM_P2_WAVES_PER_EU 8   // (compact unweighted kernels only; every other kernel is built for 4)
 #endif
+#ifndef MGM_P2_ONEB_WPE
+#define MGM_P2_ONEB_WPE 4       // ... the queue kernels of launches that run ONE band per CU (k_pass2, ONEB)
+#endif
 #ifndef MGM_P2_NC
 #define MGM_P2_NC 14
 #endif
@@ -903,9 +906,13 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
 // order, so the earliest unfinished item of the launch is always at the head of its queue with all it needs finished),
 // and the last workgroup to leave checks that every queue was worked off -- a queue without workgroups raises the
 // watchdog word instead of leaving lines unwritten.
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false>
+// ONEB: the build for launches that run ONE band per CU (chain-bound: mgm_api.hip, wg_per_cu == 1).  The compact
+// unweighted kernels are otherwise capped at 64 VGPRs so that two bands fit a CU, and under that cap every FH instance
+// with the queue loop spilled 9-14 VGPRs (40-52 bytes of scratch per lane) and ~50 SGPRs -- scratch traffic and
+// v_readlane restores on the critical chain of exactly the launches that are bound by the length of a step.
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false, bool ONEB = false>
 __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, true, C8>::NL) * 64,
-                                  ((C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
+                                  (ONEB ? MGM_P2_ONEB_WPE : (C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *s_ticket = reinterpret_cast<int *>(smem + P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP>::task_off);
@@ -939,7 +946,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 }
 
 // ---- launcher (one translation unit per LPL: -DMGM_P2_LPL=n) -----------------------
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false, bool ONEB = false>
 static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 {
     constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
@@ -950,7 +957,7 @@ static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
     // right when the launch is throughput-bound (a batch of volumes); a single volume is bound by the chain of
     // bands, where the doubled step latency costs more than it gives, so it asks for > half the LDS and runs alone.
     if (p.wg_per_cu < 2 && shmem < 81 * 1024) shmem = 81 * 1024;
-    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, XCDQ>;
+    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, XCDQ, ONEB>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
@@ -976,8 +983,12 @@ static hipError_t launch2_one(const PassParams &p, int ntasks, hipStream_t s)
     if (p.subv > 1) return hipErrorInvalidValue;
     if constexpr (!WEIGHTED && !(FH && MGM == 2))
         if (p.vol[0].C8 && p.deep) {
-            if constexpr (!MGM_P2_DEV)
-                if (p.xcdq) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 1, true, true>(p, ntasks, s);
+            if constexpr (!MGM_P2_DEV) {
+                // (the Hirschmueller launches with queues run one band per CU unless told otherwise, the FH ones up to a
+                // load/chain of 1.5: mgm_api.hip)
+                if (p.xcdq && p.oneb) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 1, true, true, true>(p, ntasks, s);
+                if (p.xcdq) return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 1, true, true, false>(p, ntasks, s);
+            }
             if (p.xcdq) return hipErrorInvalidValue;
             return launch2_c8<LPL, FH, WEIGHTED, MGM, true, 1, true>(p, ntasks, s);
         }

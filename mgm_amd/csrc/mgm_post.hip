@@ -57,11 +57,11 @@ __device__ __forceinline__ unsigned order_key(float x)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __global__ void __launch_bounds__(256) k_median_big(const float *__restrict__ u, int nx, int ny, int nch, int radius,
-                                                    float *__restrict__ out)
+                                                    float *__restrict__ out, long long first, long long last)
 {
     const long long npix = (long long)nx * ny;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= npix * nch) return;
+    const long long idx = first + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= last) return;
     const long long p = idx % npix;
     const int x = (int)(p % nx), y = (int)(p / nx);
     const float *pl = u + (idx / npix) * npix;
@@ -101,8 +101,18 @@ __global__ void __launch_bounds__(256) k_median_big(const float *__restrict__ u,
 hipError_t launch_median(const float *u, int nx, int ny, int nch, int radius, float *out, hipStream_t s)
 {
     const long long n = (long long)nx * ny * nch;
-    if (radius > 7) hipLaunchKernelGGL(k_median_big, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, nx, ny, nch, radius, out);
-    else hipLaunchKernelGGL(k_median, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, nx, ny, nch, radius, out);
+    if (radius > 7) {
+        // 33 sweeps of a (2r+1)^2 window per pixel, one thread per pixel: cut into launches of bounded work (~1.5e11 window
+        // reads each, a fraction of a second) so that no single kernel runs long enough to look hung; the total is
+        // capped by the caller (mgm_median_dev, kMedianMaxReads)
+        const double per_pixel = 33.0 * (2.0 * radius + 1.0) * (2.0 * radius + 1.0);
+        long long chunk = (long long)(1.5e11 / per_pixel);
+        chunk = chunk < 256 ? 256 : (chunk / 256) * 256;
+        for (long long a = 0; a < n; a += chunk) {
+            const long long b = a + chunk < n ? a + chunk : n;
+            hipLaunchKernelGGL(k_median_big, dim3((unsigned)((b - a + 255) / 256)), dim3(256), 0, s, u, nx, ny, nch, radius, out, a, b);
+        }
+    } else hipLaunchKernelGGL(k_median, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u, nx, ny, nch, radius, out);
     return hipGetLastError();
 }
 

@@ -75,9 +75,29 @@ def n_rounds(NDIR, world):
     return max(passes_of_rank(NDIR, world, g)[1] for g in range(world))
 
 
+_auto_ctrl = {}
+
+
+def control_group(dist, group=None):
+    """A CPU (gloo) group over the ranks of the DEFAULT group, made once per process, for agree().  Only for
+    group=None: new_group is a collective of the whole default group, which the ranks of a sub-group cannot call alone."""
+    if group is not None:
+        return None
+    if "g" not in _auto_ctrl:
+        from datetime import timedelta
+        _auto_ctrl["g"] = dist.new_group(backend="gloo", timeout=timedelta(seconds=900))
+    return _auto_ctrl["g"]
+
+
 def agree(ok, dist, group=None, ctrl=None, device=None):
     """True iff `ok` on EVERY rank.  Every rank must call it (it is a collective): the point is that a rank whose
-    own work failed still gets here, so the others learn of it instead of waiting for its slabs."""
+    own work failed still gets here, so the others learn of it instead of waiting for its slabs.
+
+    With a CPU control group (`ctrl`, gloo) nothing touches the device.  WITHOUT one the flag is a device tensor reduced on
+    `group` (RCCL) and read back with .item(): the collective is ordered behind whatever the current stream holds -- the
+    pass kernel just launched -- so the host blocks until that pass has finished.  That is harmless when all passes are
+    launched before the exchange, and it costs the pass-by-pass schedule (overlap=True) most of its overlap:
+    aggregate_direction_sharded therefore makes itself a control group in that case (control_group)."""
     import torch
     g = ctrl if ctrl is not None else group
     on_cpu = ctrl is not None or device is None or torch.device(device).type == "cpu"
@@ -244,7 +264,8 @@ def aggregate_direction_sharded(ctx, cv, P1, P2, NDIR, MGM, use_fh, fix_overcoun
     """The whole aggregation of ONE volume across the ranks of `group`.  Returns (out, outcost) as torch
     tensors [ny, nx] on every rank (all-gathered rows).
 
-    ctrl: a CPU (gloo) group of the same ranks for the agreement step (default: `group` itself, device tensors).
+    ctrl: a CPU (gloo) group of the same ranks for the agreement step (default: `group` itself, device tensors -- the host
+    then waits for the launched passes in agree(); with overlap=True and the default group a gloo group is made once).
     overlap: launch this rank's passes one per launch and post each pass's slabs right behind it.
     stats: a dict that receives this rank's stage times in ms (passes / exchange / wta / gather), torch events on the
     library's stream.  Raises ExchangeError (no rank exchanged anything; the group is still usable) or ExchangeTimeout
@@ -259,6 +280,10 @@ def aggregate_direction_sharded(ctx, cv, P1, P2, NDIR, MGM, use_fh, fix_overcoun
         views = [device_view(ctx.lib.mgm_img_device_ptr(im.h), (ny, nx)).clone() for im in (o, c)]
         o.free(), c.free()
         return views[0], views[1]
+    if overlap and ctrl is None:
+        # the per-round agreement must not wait for the pass it follows (agree): CPU control group, made once.  A caller
+        # on a sub-group has to bring its own; without one the schedule still works, pass k+1 just starts after pass k.
+        ctrl = control_group(dist, group)
     deadline = (time.monotonic() + timeout_s) if timeout_s else None
     first, count = passes_of_rank(NDIR, world, rank)
     rounds = n_rounds(NDIR, world)

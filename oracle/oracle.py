@@ -23,6 +23,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libmgm_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libmgm_ref.so")
+REFPOST_SO = os.path.join(HERE, "_ref", "libmgm_refpost.so")
 REF_MGM = os.path.join(HERE, "_ref", "mgm")
 REF_MGM_O = os.path.join(HERE, "_ref", "mgm_o")
 
@@ -221,6 +222,39 @@ class Reference:
         outcost = np.array(outcost, np.float32, copy=True)
         self.lib.ref_refine(S, nx, ny, dmin, dmin + L - 1, method.encode(), out, outcost)
         return out, outcost
+
+
+class RefPost:
+    """median_filter / leftright_test / update_dmin_dmax of the compiled reference (oracle/ref_post_harness.cc), where built."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(REFPOST_SO)
+
+    def __init__(self):
+        L = self.lib = C.CDLL(REFPOST_SO)
+        L.refpost_median.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        L.refpost_leftright.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_float]
+        L.refpost_update_ranges.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int]
+
+    def median(self, u, radius):
+        u = _img(u)
+        nch, ny, nx = u.shape
+        out = np.empty_like(u)
+        self.lib.refpost_median(u, nx, ny, nch, radius, out)
+        return out
+
+    def leftright(self, d, other, tau):
+        d = np.array(d, np.float32, copy=True).reshape(d.shape[-2], d.shape[-1])
+        other = np.ascontiguousarray(other, np.float32).reshape(other.shape[-2], other.shape[-1])
+        self.lib.refpost_leftright(d, d.shape[1], d.shape[0], other, other.shape[1], other.shape[0], tau)
+        return d
+
+    def update_ranges(self, outoff, lo, hi, slack=3, radius=2):
+        o = np.ascontiguousarray(outoff, np.float32).reshape(outoff.shape[-2], outoff.shape[-1])
+        lo, hi = np.array(lo, np.float32, copy=True).reshape(o.shape), np.array(hi, np.float32, copy=True).reshape(o.shape)
+        self.lib.refpost_update_ranges(o, o.shape[1], o.shape[0], lo, hi, slack, radius)
+        return lo, hi
 
 
 class _quiet_stdout:

@@ -1,7 +1,7 @@
 """A stand-in for mgm_amd.Context that computes NOTHING: bench.py's launcher, rendezvous, barrier / max-over-ranks timing,
 extra legs and JSON contract can then be driven on CPU ranks (gloo) by tests/test_dist_cpu.py.  It is a test double, not a
-CPU path of the product: bench.py does not know this file -- the test INJECTS it (MGM_BENCH_STUB=<path of this file>) -- and
-labels the line `"data": "stub (no device work)"`."""
+CPU path of the product: bench.py does not know this file -- tests/run_bench_stub.py imports bench and hands it this class --
+and bench.py labels the line `"data": "stub (no device work)"`."""
 import os
 import time
 

@@ -114,10 +114,10 @@ def test_bench_launches_its_own_ranks():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MGM_BENCH_STUB=os.path.join(root, "tests", "bench_stub.py"))  # the stub is injected by path
+    env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "cfg5",
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "run_bench_stub.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "cfg5",
                         "--batch", "2", "--repeats", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = r.stdout.strip().splitlines()[-1]
@@ -135,10 +135,10 @@ def _run_bench(args, extra_env=None, timeout=600):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MGM_BENCH_STUB=os.path.join(root, "tests", "bench_stub.py"), **(extra_env or {}))
+    env = dict(os.environ, **(extra_env or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "run_bench_stub.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
     return r, (json.loads(lines[-1]) if lines else None), lines
 

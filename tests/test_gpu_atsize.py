@@ -94,9 +94,10 @@ def test_cfg5_sixteen_pairs(bigctx, oracle, mode):
     batch_against_oracle(bigctx, oracle, 1024, 1024, -127, 0, 3, NDIR, MGM, FH, P1, P2, 16, seed0=6000)
 
 
-def test_cfg3_twelve_volumes_per_launch_first_and_last(bigctx, oracle):
+def test_cfg3_twelve_volumes_per_launch_all_of_them(bigctx, oracle):
     ctx = bigctx
-    """bench.py's default line: 12 pairs of cfg3 per launch (204 GB of Lr volumes); first and last volume vs the oracle."""
+    """bench.py's default line: 12 pairs of cfg3 per launch (204 GB of Lr volumes); EVERY volume of the launch vs the oracle
+    (~5 s of oracle per volume on 16 threads)."""
     nx, ny, dmin, dmax, win, NDIR, MGM, FH, P1, P2 = 1920, 1080, -255, 0, 5, 8, 3, 1, 2.0, 20000.0
     dus, dvs, cvs = [], [], []
     for b in range(12):
@@ -107,7 +108,7 @@ def test_cfg3_twelve_volumes_per_launch_first_and_last(bigctx, oracle):
     _, outs, outcs = ctx.aggregate_batch_dev(cvs, P1, P2, NDIR, MGM, FH, 1, None, "vfit")
     oracle.set_threads(oracle_threads())
     try:
-        for b in (0, 11):
+        for b in range(12):
             C = cvs[b].download()
             Sa, oa, ca = oracle.mgm(C, dmin, P1, P2, NDIR, MGM, FH, 1)
             ra, rca = oracle.refine(Sa, dmin, "vfit", oa, ca)

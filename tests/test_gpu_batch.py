@@ -71,3 +71,50 @@ def test_batch_rejects_mismatched_geometry(ctx):
     assert e.value.code == mgm_amd.MGM_ERR_INVALID
     a.free()
     b.free()
+
+
+def test_batch_survives_a_real_out_of_memory(oracle):
+    """The device-OOM fallback of mgm_aggregate_batch_dev with a REAL hipMalloc failure: ballast images leave room
+    for about five volumes' workspace, a batch of eight is asked for -- the full reservation fails inside the runtime, the call
+    must go on with half the batch (a stale hipErrorOutOfMemory must not surface from the retry's first launch as
+    MGM_ERR_HIP) and give the same bits as the oracle; and the context stays usable afterwards."""
+    import mgm_amd
+    nx, ny, dmin, dmax, NDIR, MGM = 960, 540, -255, 0, 8, 3
+    L = dmax - dmin + 1
+    nb = 8
+    per_vol = 4.0 * nx * ny * L * NDIR * 1.08
+    c = mgm_amd.Context(0)
+    ballast = []
+    try:
+        dus, dvs, cvs = [], [], []
+        for b in range(nb):
+            u, v, _ = synth.stereo_pair(nx, ny, -190, 0, seed=777 + b)
+            dus.append(c.upload_image(u))
+            dvs.append(c.upload_image(v))
+            cvs.append(c.costvolume_dev(dus[-1], dvs[-1], dmin, dmax, "none", "census", float("inf"), 5))
+        c.synchronize()
+        free = c.mem_info()[0]
+        want_free = 5.2 * per_vol
+        assert free > want_free + (1 << 30), "device too full for this test"
+        left = free - want_free
+        while left > (64 << 20):  # ballast in pieces of at most 16 GiB
+            piece = int(min(left, 16 << 30))
+            ballast.append(c.new_image(1 << 14, piece // 4 // (1 << 14), 1))
+            left -= piece
+        _, outs, outcs = c.aggregate_batch_dev(cvs, 2.0, 20000.0, NDIR, MGM, 1, 1, None, "vfit")
+        c.synchronize()
+        from oracle.oracle import usable_cpus
+        oracle.set_threads(min(32, usable_cpus()))
+        try:
+            for b in (0, 3, 4, 7):  # (both halves of the batch)
+                Ca = cvs[b].download()
+                Sa, oa, ca = oracle.mgm(Ca, dmin, 2.0, 20000.0, NDIR, MGM, 1, 1)
+                ra, rca = oracle.refine(Sa, dmin, "vfit", oa, ca)
+                assert ndiff(rca, outcs[b].download()[0]) == 0 and ndiff(ra, outs[b].download()[0]) == 0, b
+        finally:
+            oracle.set_threads(1)
+        # and the next call -- a plain one that fits -- must not inherit an error either
+        _, o1, c1 = c.aggregate_dev(cvs[0], 2.0, 20000.0, NDIR, MGM, 1, 1, None, "vfit")
+        assert ndiff(o1.download(), outs[0].download()) == 0
+    finally:
+        c.close()

@@ -55,3 +55,47 @@ def test_costvolume_sweep(oracle, reference):
         assert ndiff(oracle.weights(u, 4.0, 5.0), reference.weights(u, 4.0, 5.0)) == 0
         if (nch * (win * win - 1)) % 8 == 0:
             assert np.array_equal(oracle.census(u, win // 2), reference.census(u, win // 2))
+
+
+# ---- the steps main() applies right after the path, on maps with NaN labels and +INF costs ---------------------------------
+from oracle import oracle as orc_mod  # noqa: E402
+
+
+def nan_label_map(ny, nx, seed, frac_nan=0.15, frac_inf=0.03, lo=-20.0, hi=8.0, subpixel=True):
+    """A disparity map as the NaN-faithful path leaves it: labels in [lo, hi] (sub-pixel where refined), NaN where a pixel
+    had no finite S, in patches and isolated; optionally +-INF samples (cost maps)."""
+    rng = np.random.default_rng(seed)
+    m = rng.uniform(lo, hi, (ny, nx)).astype(np.float32)
+    if not subpixel:
+        m = np.rint(m).astype(np.float32)
+    m[rng.random((ny, nx)) < frac_nan] = np.nan
+    y0, x0 = rng.integers(0, ny - 4), rng.integers(0, nx - 6)
+    m[y0:y0 + 4, x0:x0 + 6] = np.nan  # a patch wider than the small windows: all-NaN windows occur
+    m[rng.random((ny, nx)) < frac_inf] = np.inf
+    m[rng.random((ny, nx)) < frac_inf / 2] = -np.inf
+    return m
+
+
+@pytest.mark.skipif(not orc_mod.RefPost.available(), reason="oracle/_ref/libmgm_refpost.so was not built here")
+@pytest.mark.parametrize("radius", [1, 2, 3, 9])
+def test_median_restatement_vs_reference_with_nan_labels(radius):
+    """oracle/post.py::median against the reference's median_filter (img_tools.h:203-238) on maps holding NaN and +-INF."""
+    from oracle import post
+    rp = orc_mod.RefPost()
+    for seed in range(4):
+        m = np.stack([nan_label_map(23, 31, 100 * radius + seed, frac_inf=0.03 if seed % 2 else 0.0) for _ in range(1 + seed % 2)])
+        assert orc_mod.bits_equal(rp.median(m, radius), post.median(m, radius)), (radius, seed)
+
+
+@pytest.mark.skipif(not orc_mod.RefPost.available(), reason="oracle/_ref/libmgm_refpost.so was not built here")
+def test_leftright_restatement_vs_reference_with_nan_labels():
+    """oracle/post.py::leftright against the reference's leftright_test (mgm.cc:68-91): NaN / infinite labels in either map,
+    a right map of another width, several thresholds."""
+    from oracle import post
+    rp = orc_mod.RefPost()
+    for seed, (tau, rnx) in enumerate([(1.0, 31), (0.5, 31), (2.0, 27), (1.0, 40), (0.0, 31)]):
+        d = nan_label_map(19, 31, 7000 + seed, frac_inf=0.02)
+        o = -nan_label_map(19, rnx, 7100 + seed, frac_inf=0.02, lo=-20.0, hi=8.0)
+        assert orc_mod.bits_equal(rp.leftright(d, o, tau), post.leftright(d, o, tau)), (seed, tau, rnx)
+        di = nan_label_map(19, 31, 7200 + seed, frac_inf=0.0, subpixel=False)  # integer labels: exact ties at the threshold
+        assert orc_mod.bits_equal(rp.leftright(di, np.rint(o), tau), post.leftright(di, np.rint(o), tau)), (seed, "int")
