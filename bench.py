@@ -32,8 +32,9 @@ Workload matrix (BASELINE.json configs; cfg1 is the reference's CPU-runnable cas
     --workload cfg5   1024x1024x128, census 3x3, -O 4, TSGM 2, 16 pairs per step and GPU (throughput mode)
 
 Rank 0 prints ONE JSON line, the last thing on stdout; fields `roofline`, `cpu_baseline` and `parity` are described
-in DESIGN.md.  PARITY GATE: the disparity and cost maps of pair 0 computed by the LAST timed step are compared, bit for
-bit, with the CPU oracle run on the same seeded pair in the same process; a mismatch fails the run (exit code 3).
+in DESIGN.md.  PARITY GATE: the disparity and cost maps of ONE pair of the batch -- its index drawn from the step count --
+computed by the LAST timed step are compared, bit for bit, with the CPU oracle run on the same seeded pair in the same
+process (and with the reference's own maps where oracle/_ref travelled); a mismatch fails the run (exit code 3).
 torch is used for the process group, the barrier and the max-reduction only.
 """
 import argparse
@@ -65,6 +66,24 @@ WORKLOADS = {
                  desc="4096x4096 satellite-style synthetic pair, 192 disparities, CENSUS 5x5, -O 8 TSGM=3"),
     "cfg5": dict(nx=1024, ny=1024, dmin=-127, dmax=0, win=3, NDIR=4, MGM=2, FH=0, P1=8.0, P2=32.0,
                  desc="1024x1024 synthetic pair, 128 disparities, CENSUS 3x3, -O 4 TSGM=2 (throughput mode)"),
+    # ---- the variants north_star names beside the headline combination (round 4): per-edge weights, AD, NCC, a label
+    # count that runs padded, and one beyond the 512 labels of the second pass-kernel build.  Optional keys: cost
+    # (default census), nch (1), aP2 / aThresh (the reference's -aP2 / -aThresh: image-driven weights w_pq), trunc.
+    # main() scales P1 and P2 by the channel count (mgm.cc:356-357): the values here are the scaled ones.
+    "cfg3w": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, aP2=4.0, aThresh=12.0,
+                  desc="cfg3 with per-edge weights: -aP2 4 -aThresh 12 (update_costW_trunclinear with w_pq)"),
+    "cfg3hw": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0, aP2=4.0, aThresh=12.0,
+                   desc="cfg3h with per-edge weights: -aP2 4 -aThresh 12 (update_costW with w_pq)"),
+    "cfg3ad": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=6.0, P2=60000.0, cost="ad", nch=3,
+                   desc="1920x1080 synthetic RGB pair, 256 disparities, -t ad (costs up to 765), -O 8 TSGM=3, FH"),
+    "cfg3ad1": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, cost="ad", nch=1,
+                    desc="1920x1080 synthetic grey pair, 256 disparities, -t ad (costs 0..255), -O 8 TSGM=3, FH"),
+    "cfg3ncc": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, cost="ncc",
+                    desc="1920x1080 synthetic pair, 256 disparities, -t ncc (CENSUS_NCC_WIN=5), -O 8 TSGM=3, FH"),
+    "cfg1s": dict(nx=700, ny=500, dmin=-120, dmax=30, win=3, NDIR=4, MGM=2, FH=0, P1=24.0, P2=96.0, cost="ad", nch=3,
+                  desc="BASELINE config 1's shape on a synthetic RGB pair: 700x500, -r -120 -R 30 (151 labels, padded to 192), -t ad, -O 4 TSGM=2"),
+    "cfg3L768": dict(nx=1920, ny=1080, dmin=-767, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0,
+                     desc="1920x1080 synthetic pair, 768 disparities (beyond the second build's 512), CENSUS 5x5, -O 8 TSGM=3"),
 }
 # Set ONLY by a test driver that imports this module (tests/run_bench_stub.py) to drive the launcher, the rendezvous and the
 # JSON contract on CPU ranks; nothing in the environment or on the command line can set it, and the line such a run prints
@@ -81,7 +100,20 @@ def labels_of(w):
 def pair_of(w, seed_offset=0):
     """The synthetic pair every leg of the run uses for a given index (GPU steps, parity oracle, CPU baseline)."""
     from mgm_amd import synth
-    return synth.stereo_pair(w["nx"], w["ny"], w["dmin"] * 3 // 4, max(0, w["dmax"] * 3 // 4), seed=synth.SEED + seed_offset)
+    return synth.stereo_pair(w["nx"], w["ny"], w["dmin"] * 3 // 4, max(0, w["dmax"] * 3 // 4), seed=synth.SEED + seed_offset,
+                             nch=w.get("nch", 1))
+
+
+def cost_of(w):
+    return w.get("cost", "census")
+
+
+def trunc_of(w):
+    return float(w.get("trunc", float("inf")))
+
+
+def weighted(w):
+    return float(w.get("aP2", 1.0)) != 1.0  # (mgm.cc:372: the weights are computed -- and used -- only when -aP2 != 1)
 
 
 def strip_comments(src):
@@ -133,24 +165,25 @@ def cpu_model():
 def compact_costs(w):
     """Do this workload's costs travel as one byte per label?  (single-word census costs at a label count the compact
     kernels take: mgm_api.hip, costvolume_fill / c8_supported)"""
-    return labels_of(w) in (64, 128, 192, 256, 384, 512) and os.environ.get("MGM_HIP_C8", "1") != "0"
+    return cost_of(w) == "census" and labels_of(w) in (64, 128, 192, 256, 384, 512) and os.environ.get("MGM_HIP_C8", "1") != "0"
 
 
 # ---- the CPU legs (rank 0 only; never inside a timed GPU region) --------------------------------------------------------
-def oracle_whole_volume(w, threads):
-    """Pair 0 through the CPU oracle (oracle/mgm_oracle.c), whole volume, `threads` OpenMP threads (the reference
+def oracle_whole_volume(w, threads, pair=0):
+    """Pair `pair` through the CPU oracle (oracle/mgm_oracle.c), whole volume, `threads` OpenMP threads (the reference
     parallelises each diagonal of a pass the same way, mgm_core.cc:505-579).  Returns (disp, cost, seconds)."""
     from oracle.oracle import Oracle
     orc = Oracle(threads=threads)
-    u, v, _ = pair_of(w)
+    u, v, _ = pair_of(w, pair)
     t0 = time.perf_counter()
-    C = orc.costvolume(u, v, w["dmin"], w["dmax"], "none", "census", np.inf, w["win"])
-    S, o, c = orc.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1)
+    C = orc.costvolume(u, v, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w), w["win"])
+    w8 = orc.weights(u, w["aP2"], w["aThresh"]) if weighted(w) else None
+    S, o, c = orc.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, w8)
     ro, rc = orc.refine(S, w["dmin"], "vfit", o, c)
     return ro, rc, time.perf_counter() - t0
 
 
-def reference_whole_volume(w, threads, want=None):
+def reference_whole_volume(w, threads, want=None, pair=0):
     """The REAL reference (oracle/_ref/libmgm_ref.so: gfacciol/mgm compiled from its own sources behind
     oracle/ref_harness.cc) on pair 0: allocate_and_fill_sgm_costvolume + mgm() + subpixel_refinement_sgm, timed INSIDE
     the harness around those three calls (the dense <-> Dvec container copies of the harness are not the reference's
@@ -163,11 +196,12 @@ def reference_whole_volume(w, threads, want=None):
     if ref.census_win() != w["win"] or not hasattr(ref.lib, "ref_seconds"):
         return None
     Oracle(threads=threads)  # (sets the OpenMP thread count of the process: both libraries share libgomp)
-    u, v, _ = pair_of(w)
+    u, v, _ = pair_of(w, pair)
     os.environ["USE_TRUNCATED_LINEAR_POTENTIALS"] = "1" if w["FH"] else "0"
-    C = ref.costvolume(u, v, w["dmin"], w["dmax"], "none", "census", np.inf)
+    C = ref.costvolume(u, v, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w))
     t = ref.seconds()
-    S, o, c = ref.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1)
+    w8 = ref.weights(u, w["aP2"], w["aThresh"]) if weighted(w) else None  # (compute_mgm_weights: negligible, not timed)
+    S, o, c = ref.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, w8)
     t += ref.seconds()
     ro, rc = ref.refine(S, w["dmin"], "vfit", o, c)
     t += ref.seconds()
@@ -176,7 +210,7 @@ def reference_whole_volume(w, threads, want=None):
     return t
 
 
-def cpu_baseline(w, whole_first, threads, seconds_target=12.0):
+def cpu_baseline(w, whole_first, threads, seconds_target=12.0, pair=0):
     """The CPU path timed on the GPU box's host cores (rank 0, N = 1): bounded samples of the same workload.
       reference  the REAL reference's three calls on the whole pair, `threads` OpenMP threads, median of 3 (where
                  oracle/_ref/libmgm_ref.so travelled to this box)
@@ -191,7 +225,7 @@ def cpu_baseline(w, whole_first, threads, seconds_target=12.0):
     # -- port, all threads: median of 3 whole volumes
     runs = [whole_first] if whole_first is not None else []
     while len(runs) < 3:
-        runs.append(oracle_whole_volume(w, threads)[2])
+        runs.append(oracle_whole_volume(w, threads, pair)[2])
     med = float(np.median(runs))
     port = {"value": 1.0 / med, "cores": threads, "kind": "port", "runs_s": [round(t, 3) for t in runs],
             "sample": "one whole %dx%dx%d volume (cost volume + %d-direction mgm + vfit), oracle/mgm_oracle.c on %d OpenMP threads, "
@@ -201,10 +235,11 @@ def cpu_baseline(w, whole_first, threads, seconds_target=12.0):
     orc = Oracle(threads=1)
 
     def band(rows):
-        u, v, _ = synth.stereo_pair(nx, rows, w["dmin"] * 3 // 4, max(0, w["dmax"] * 3 // 4))
+        u, v, _ = synth.stereo_pair(nx, rows, w["dmin"] * 3 // 4, max(0, w["dmax"] * 3 // 4), nch=w.get("nch", 1))
         t0 = time.perf_counter()
-        C = orc.costvolume(u, v, w["dmin"], w["dmax"], "none", "census", np.inf, w["win"])
-        S, o, c = orc.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1)
+        C = orc.costvolume(u, v, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w), w["win"])
+        w8 = orc.weights(u, w["aP2"], w["aThresh"]) if weighted(w) else None
+        S, o, c = orc.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, w8)
         orc.refine(S, w["dmin"], "vfit", o, c)
         return time.perf_counter() - t0
 
@@ -219,7 +254,7 @@ def cpu_baseline(w, whole_first, threads, seconds_target=12.0):
     ref_runs, ref_out = [], {}
     try:
         for _ in range(3):
-            t = reference_whole_volume(w, threads, ref_out if not ref_runs else None)
+            t = reference_whole_volume(w, threads, ref_out if not ref_runs else None, pair)
             if t is None:
                 break
             ref_runs.append(t)
@@ -382,39 +417,51 @@ class Env:
             self.dist.barrier(group=self.ctrl)  # (stub: the default group is gloo)
 
 
-def pairs_leg(env, w, B, steps, warmup, repeats, keep=False):
+def pairs_leg(env, w, B, steps, warmup, repeats, keep=False, pipeline=1):
     """Independent pairs, B per step and GPU: W warm-up steps, then EXACTLY K timed steps between barrier + synchronize
-    brackets, MAX over ranks.  Returns the measurement (and, with `keep`, the device outputs of the last step)."""
+    brackets, MAX over ranks.  Returns the measurement (and, with `keep`, the device outputs of the last step).
+    pipeline = D >= 2: the context gathers the aggregation calls of D consecutive steps into one batched launch
+    (mgm_ctx_set_pipeline); the steps then use D sets of volumes and output images in turn -- what a caller with a stream of
+    pairs would do -- and all work of the K steps still happens inside the timed region (the closing synchronisation runs
+    whatever is still deferred)."""
     ctx, rank = env.ctx, env.rank
     nx, ny = w["nx"], w["ny"]
-    dus, dvs, outs, outcs = [], [], [], []
+    D = max(1, pipeline)
+    if D > 1:
+        ctx.set_pipeline(D)
+    dus, dvs = [], []
     for b in range(B):
         u, v, _ = pair_of(w, rank * B + b)  # every rank gets its own pairs (different seeds): independent units, no exchange
         dus.append(ctx.upload_image(u))
         dvs.append(ctx.upload_image(v))
-        outs.append(ctx.new_image(nx, ny))
-        outcs.append(ctx.new_image(nx, ny))
+    sets = [{"cv": [None] * B, "w8": [None] * B, "o": [ctx.new_image(nx, ny) for _ in range(B)], "c": [ctx.new_image(nx, ny) for _ in range(B)]}
+            for _ in range(D)]  # (the W*H*L volumes and the weight planes are allocated by a set's first step and refilled after)
+    count = [0]
 
-    def step(cvs):
-        # one step = one batch: the cost volume of every pair, ONE pass launch over the batch, WTA + vfit per volume
-        cvs = cvs or [None] * B
-        cvs = [ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", "census", float("inf"), w["win"], into=cv)
-               for du, dv, cv in zip(dus, dvs, cvs)]
-        ctx.aggregate_batch_dev(cvs, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, None, "vfit", outs, outcs, want_S=False)
-        return cvs
-
-    cv = None  # the W*H*L volumes are allocated once and refilled every step
+    def step():
+        # one step = one batch: the cost volume (and, weighted workloads, the edge weights) of every pair, ONE pass launch
+        # over the batch, WTA + vfit per volume
+        st = sets[count[0] % D]
+        count[0] += 1
+        st["cv"] = [ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w), w["win"], into=cv)
+                    for du, dv, cv in zip(dus, dvs, st["cv"])]
+        if weighted(w):
+            for b in range(B):
+                st["w8"][b] = ctx.weights_dev(dus[b], w["aP2"], w["aThresh"], into=st["w8"][b])
+        ctx.aggregate_batch_dev(st["cv"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, st["w8"] if weighted(w) else None, "vfit",
+                                st["o"], st["c"], want_S=False)
+        return st
 
     def timed_block():
         env.sync_all()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(cv)  # enqueue only: nothing synchronises inside the timed region
+            step()  # enqueue only: nothing synchronises inside the timed region
         env.sync_all()
         return env.max_over_ranks(time.perf_counter() - t0)
 
-    for _ in range(max(1, warmup)):
-        cv = step(cv)
+    for _ in range(max(1, warmup, D)):
+        step()
     env.sync_all()
     ctx.timing(True)
     ctx.timing_reset()
@@ -428,17 +475,23 @@ def pairs_leg(env, w, B, steps, warmup, repeats, keep=False):
     reps = repeats if repeats is not None else int(min(8, max(0, np.ceil(10.0 / max(dt, 1e-3)) - 1)))
     rep_dt = [timed_block() for _ in range(reps)]
     m = {"dt": dt, "rep_dt": rep_dt, "avg": {k: float(np.mean(vs)) for k, vs in kern.items()},
-         "per_step": {k: float(np.sum(vs)) / steps for k, vs in kern.items()}, "B": B, "steps": steps}
+         "per_step": {k: float(np.sum(vs)) / steps for k, vs in kern.items()}, "B": B, "steps": steps, "pipeline": D}
+    last = sets[(count[0] - 1) % D]  # the set the LAST step wrote
+    ctx.synchronize()
+    if D > 1:
+        ctx.set_pipeline(1)
     if keep:
-        m["outs"], m["outcs"] = outs, outcs
-    for x in cv:
-        x.free()
-    for h in dus + dvs + ([] if keep else outs + outcs):
+        m["outs"], m["outcs"] = last["o"], last["c"]
+    for st in sets:
+        for h in st["cv"] + st["w8"] + ([] if (keep and st is last) else st["o"] + st["c"]):
+            if h is not None:
+                h.free()
+    for h in dus + dvs:
         h.free()
     return m
 
 
-def roofline_of(w, B, avg, workload):
+def roofline_of(w, B, avg, workload, step_ms=None):
     """SURVEY.md 8(d): the aggregation = K3 (pass kernel, one launch per batch) + K4-K6 (k_wta, one launch per volume);
     ALGORITHMIC bytes = 12 B per cell per direction (read C, read S, write S in fp32).  `frac` is that figure over the
     measured launch times; `frac_counter` prices the same time against the HBM bytes the PMC counters saw (committed summary
@@ -448,6 +501,10 @@ def roofline_of(w, B, avg, workload):
     cells = float(nx) * ny * L
     pass_name = "k_pass2" if "k_pass2" in avg else "k_pass"
     agg_ms = avg[pass_name] + B * avg["k_wta"]
+    if step_ms is not None:
+        # pipelined steps: one pass launch serves D steps, so per-launch durations are not per-step figures; the aggregation
+        # is priced against the WHOLE step's wall time instead -- an upper bound of its time (the step also holds K1 / K2)
+        agg_ms = step_ms
     alg_bytes = 12.0 * w["NDIR"] * cells * B
     achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
     cbytes = 1.0 if compact_costs(w) else 4.0
@@ -463,6 +520,8 @@ def roofline_of(w, B, avg, workload):
     per_kernel = {k: {"format_bytes": b, "GBps": b / (avg[k] * 1e-3) / 1e9, "frac": b / (avg[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                   for k, b in fmt.items() if k in avg}
     return {"bound": "hbm", "kernel": "%s (one launch per batch of %d volumes) + k_wta (one launch per volume): the %d-direction aggregation" % (pass_name, B, w["NDIR"]),
+            "time_basis": "sum of the average launch durations (HIP events on the kernels' streams)" if step_ms is None else
+                          "wall time per step (pipelined: one pass launch serves several steps)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
             "achieved_counter": (traffic / (agg_ms * 1e-3) / 1e9) if traffic else None,
@@ -677,6 +736,9 @@ def main():
                     help="pairs per step and GPU: their volumes share ONE launch of the pass kernel.  Default: "
                          "12 (204 GB of Lr volumes at 1920x1080x256 x 8 directions), 16 for workloads of at most 128 labels "
                          "(two / four of those volumes share every wave), 1 for cfg4")
+    ap.add_argument("--pipeline", type=int, default=1, choices=list(range(1, 17)),
+                    help="D >= 2: the context gathers the aggregation calls of D consecutive steps into one batched launch "
+                         "(mgm_ctx_set_pipeline) -- a caller with a stream of single pairs or small batches")
     ap.add_argument("--mode", default="pairs", choices=["pairs", "directions"],
                     help="'pairs' = independent pairs (weak scaling, the headline); 'directions' = only the direction-sharded "
                          "leg: ONE volume per step, its passes sharded over the GPUs with the ordered slab exchange (strong)")
@@ -685,7 +747,7 @@ def main():
     ap.add_argument("--extras-timeout", type=float, default=300.0, help="seconds the guarded extras may take altogether")
     ap.add_argument("--exchange-timeout", type=float, default=90.0, help="seconds one direction-sharded step may take")
     args = ap.parse_args()
-    plain = args.workload is None and args.batch is None and args.mode == "pairs"
+    plain = args.workload is None and args.batch is None and args.mode == "pairs" and args.pipeline == 1
     extras = args.extras == "on" or (args.extras == "auto" and plain)
     wname = args.workload or ("cfg4" if args.mode == "directions" else "cfg3")
     w = WORKLOADS[wname]
@@ -720,7 +782,7 @@ def main():
     if args.batch is None:
         args.batch = 1 if wname == "cfg4" else (16 if L <= 128 else 12)
     B = args.batch
-    m = pairs_leg(env, w, B, args.steps, args.warmup, args.repeats, keep=True)
+    m = pairs_leg(env, w, B, args.steps, args.warmup, args.repeats, keep=True, pipeline=args.pipeline)
     dt = m["dt"]
     if rank == 0:
         from mgm_amd import shard
@@ -733,9 +795,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not stub else "stub (no device work)",
             "config": {"workload": "%s: %s" % (wname, w["desc"]), "W": nx, "H": ny, "L": L, "pairs_per_step": B,
                        "NDIR": w["NDIR"], "TSGM": w["MGM"], "potential": "FH" if w["FH"] else "Hirschmueller",
-                       "P1": w["P1"], "P2": w["P2"], "census_win": w["win"], "refine": "vfit",
+                       "P1": w["P1"], "P2": w["P2"], "cost": cost_of(w), "channels": w.get("nch", 1), "census_win": w["win"], "refine": "vfit",
+                       "edge_weights": ("-aP2 %g -aThresh %g" % (w["aP2"], w["aThresh"])) if weighted(w) else None,
+                       "pipeline_depth": args.pipeline,
                        "parallelism": ("independent pairs, %d per step and GPU, no data-path collective" % B) if n_ranks > 1 else "1 GPU"},
-            "roofline": roofline_of(w, B, m["avg"], wname),
+            "roofline": roofline_of(w, B, m["avg"], wname, step_ms=(dt / args.steps * 1e3) if args.pipeline > 1 else None),
             "kernel_ms_per_step": m["per_step"],
             "repeat_values": [vols_per_block / t for t in m["rep_dt"]],
             "parity": None,
@@ -743,6 +807,7 @@ def main():
 
     # ---- parity gate: pair 0 of the last timed step against the CPU oracle; CPU baseline --------------------------------
     parity, whole_s, T = None, None, 1
+    gate = (args.steps + args.warmup) % B  # which pair of the batch is gated: not always the first
     if rank == 0 and not stub:
         from oracle.oracle import usable_cpus
         T = min(32, usable_cpus())
@@ -750,19 +815,19 @@ def main():
             if cells > PARITY_MAX_CELLS:
                 parity = {"status": "skipped", "why": "%.1f G cells: beyond the in-run oracle (covered by tests/test_gpu_fullsize.py)" % (cells / 1e9)}
             else:
-                got_o, got_c = m["outs"][0].download()[0], m["outcs"][0].download()[0]
-                ref_o, ref_c, whole_s = oracle_whole_volume(w, T)
+                got_o, got_c = m["outs"][gate].download()[0], m["outcs"][gate].download()[0]
+                ref_o, ref_c, whole_s = oracle_whole_volume(w, T, gate)
                 bad = nd(ref_o, got_o.reshape(ref_o.shape)) + nd(ref_c, got_c.reshape(ref_c.shape))
-                parity = {"status": "bit-exact" if bad == 0 else "FAILED", "differing_words": bad,
-                          "what": "refined disparity and cost maps (2 x %dx%d float32) of pair 0 from the last timed step vs oracle/mgm_oracle.c "
-                                  "on the same pair (%d threads, %.1f s)" % (nx, ny, T, whole_s)}
+                parity = {"status": "bit-exact" if bad == 0 else "FAILED", "differing_words": bad, "pair": gate,
+                          "what": "refined disparity and cost maps (2 x %dx%d float32) of pair %d of %d (drawn from the step count) from the last "
+                                  "timed step vs oracle/mgm_oracle.c on the same pair (%d threads, %.1f s)" % (nx, ny, gate, B, T, whole_s)}
                 if bad:
                     line.code = 3
             res["parity"] = parity
         if n_ranks == 1 and not args.no_cpu_baseline and cells <= PARITY_MAX_CELLS:
-            res["cpu_baseline"], ref_out = cpu_baseline(w, whole_s, T)
+            res["cpu_baseline"], ref_out = cpu_baseline(w, whole_s, T, pair=gate)
             if ref_out and parity is not None and parity.get("status") != "skipped":  # the reference's own maps, while we have them
-                got_o, got_c = m["outs"][0].download()[0], m["outcs"][0].download()[0]
+                got_o, got_c = m["outs"][gate].download()[0], m["outcs"][gate].download()[0]
                 parity["vs_reference_differing_words"] = nd(ref_out["o"], got_o.reshape(ref_out["o"].shape)) + nd(ref_out["c"], got_c.reshape(ref_out["c"].shape))
                 if parity["vs_reference_differing_words"]:
                     parity["status"], line.code = "FAILED", 3

@@ -65,6 +65,21 @@ int mgm_ctx_trim(mgm_ctx *ctx);
  * hand-off slots; 0 = no cap, the default).  mgm_aggregate_batch_dev runs a batch that exceeds it -- or that the
  * device cannot hold -- as several launches over the largest sub-batches that fit instead of returning MGM_ERR_NOMEM. */
 int mgm_ctx_set_workspace_limit(mgm_ctx *ctx, unsigned long long bytes);
+/* PIPELINED CONTEXT for a caller that has ONE volume (or one small batch) at a time -- a stream of stereo pairs.
+ * depth 1 (the default): every call runs when it is made.  depth D = 2..16: mgm_aggregate[_batch]_dev calls are DEFERRED --
+ * checked, remembered, MGM_OK returned -- until D of them have been gathered, and those then run as ONE batch: one launch
+ * of the pass kernel over all their volumes (what mgm_aggregate_batch_dev does for a caller that has the volumes
+ * together: a single volume's launch is bound by its chains of bands, and the other volumes' bands fill its gaps; round
+ * 4, 1920x1080x256, 8 directions, FH: 0.70 of the roofline one volume at a time, 0.82 with D = 2, 0.87 with D = 4).  Every
+ * volume gets exactly the result of an unpipelined call.  The workspace holds the Lr volumes of D calls.
+ * What the caller must know: (1) results exist once the D-th call of a group, mgm_ctx_synchronize or any other entry point
+ * of the context that is not part of gathering a step has returned (downloads, post-processing, frees and the rest first
+ * run what has been deferred); (2) consecutive calls need DIFFERENT cost volumes, weight images and output images (D sets,
+ * used in turn) -- refilling a volume or weights that a deferred call still needs, or naming an output image twice, is
+ * still correct (the deferred calls then run first) but defeats the gathering; (3) an error of the deferred work is
+ * returned by the call that made it run.  A call that does not fit the waiting ones (other geometry or settings, S
+ * wanted) makes them run first.  Synchronises; MGM_ERR_INVALID for a depth outside 1..16. */
+int mgm_ctx_set_pipeline(mgm_ctx *ctx, int depth);
 /* Free and total device memory in bytes as the runtime sees them now (hipMemGetInfo on the context's device): what a
  * caller sizes its batches -- or mgm_ctx_set_workspace_limit -- with.  Either pointer may be NULL. */
 int mgm_ctx_mem_info(mgm_ctx *ctx, unsigned long long *free_bytes, unsigned long long *total_bytes);
@@ -125,6 +140,8 @@ int mgm_costvolume_build_ranged_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_im
                                     const char *distance, float truncDist, int census_win, mgm_cv **C);
 
 /* ---- edge weights: compute_mgm_weights --------------------------------- */
+/* compute_mgm_weights (mgm_weights.h:63-85; called at mgm.cc:372 when -aP2 != 1): 8 planes of nx*ny weights.  *w8 == NULL
+ * on entry: a new image is created; non-NULL: that nx*ny*8 image is refilled (like *C of mgm_costvolume_build_dev). */
 int mgm_weights_dev(mgm_ctx *ctx, const mgm_img *u, float aP, float aThresh, mgm_img **w8);
 
 /* ---- aggregation + WTA: mgm() ------------------------------------------ */

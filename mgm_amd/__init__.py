@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "mgm_wta_windowed_dev", "mgm_update_ranges_dev", "mgm_costvolume_build_ranged_dev",
     "mgm_multi_create", "mgm_multi_destroy", "mgm_multi_size", "mgm_multi_ctx", "mgm_multi_last_error", "mgm_multi_plan",
     "mgm_multi_aggregate", "mgm_multi_transport", "mgm_img_device", "mgm_cv_device", "mgm_aggregate_passes_at_dev",
-    "mgm_ctx_set_workspace_limit", "mgm_ctx_mem_info",
+    "mgm_ctx_set_workspace_limit", "mgm_ctx_mem_info", "mgm_ctx_set_pipeline",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -118,6 +118,7 @@ def load_library():
     L.mgm_cv_device.argtypes = [vp]
     L.mgm_aggregate_passes_at_dev.argtypes = [vp, vp, vp, f, f, i, i, i, i, i, i, i]
     L.mgm_ctx_set_workspace_limit.argtypes = [vp, C.c_ulonglong]
+    L.mgm_ctx_set_pipeline.argtypes = [vp, i]
     L.mgm_ctx_mem_info.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     _lib = L
     return L
@@ -219,6 +220,11 @@ class Context:
         """Cap on the workspace of one pass launch; larger batches run as several launches (mgm_ctx_set_workspace_limit)."""
         self._chk(self.lib.mgm_ctx_set_workspace_limit(self.h, int(nbytes)))
 
+    def set_pipeline(self, depth):
+        """depth >= 2: aggregate calls are deferred and gathered, `depth` of them run as one batched launch (results after the
+        last call of a group, synchronize() or any download); see mgm_ctx_set_pipeline in mgm_hip.h."""
+        self._chk(self.lib.mgm_ctx_set_pipeline(self.h, int(depth)))
+
     def mem_info(self):
         """(free, total) bytes of the context's device right now."""
         f, t = C.c_ulonglong(0), C.c_ulonglong(0)
@@ -273,10 +279,10 @@ class Context:
                                                 census_win, C.byref(h)))
         return CostVolume(self, h)
 
-    def weights_dev(self, u, aP, aThresh):
-        h = C.c_void_p()
+    def weights_dev(self, u, aP, aThresh, into=None):
+        h = C.c_void_p(into.h.value) if into is not None else C.c_void_p()
         self._chk(self.lib.mgm_weights_dev(self.h, u.h, aP, aThresh, C.byref(h)))
-        return Image(self, h)
+        return into if into is not None else Image(self, h)
 
     def aggregate_dev(self, Cv, P1, P2, NDIR, MGM, use_fh=0, fix_overcount=1, w8=None, refine=None, out=None,
                       outcost=None, want_S=False):

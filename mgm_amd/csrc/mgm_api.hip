@@ -73,6 +73,19 @@ struct mgm_ctx {
     // workspace
     Buf exact_mins;  // slab minima of the operand-order-faithful pass kernel (mgm_pass_exact.hip)
     Buf lr, hand, hand2, handm, words, tasks, census_u, census_v, dbg, stmp, ones8;  // hand: self-validating slabs (TAGS); hand2: the other kernels' slots
+    // Pipelined contexts (mgm_ctx_set_pipeline, depth >= 2): aggregation calls are DEFERRED and gathered -- up to `depth`
+    // calls of the same geometry and settings become ONE launch of the pass kernel (see PendingAgg, pipe_flush)
+    struct PendingAgg {
+        std::vector<const mgm_cv *> C;
+        std::vector<const mgm_img *> w8;  // empty: unweighted
+        std::vector<mgm_img *> out, outcost;
+        float P1, P2;
+        int NDIR, MGM, use_fh, fix_overcount;
+        std::string refine;
+        bool has_refine;
+    };
+    int pipe_depth = 1;
+    std::vector<PendingAgg> pend;
     size_t ws_limit = 0;  // mgm_ctx_set_workspace_limit: cap on the Lr + hand-off workspace of one pass launch (0 = none)
     int debug_stats = 0;  // MGM_HIP_DEBUG_STATS=1: per-workgroup timing summary of K3 on stderr
     unsigned *h_words = nullptr;  // pinned mirror of the control words
@@ -326,6 +339,24 @@ static int check_watchdog(mgm_ctx *c, bool block = true)
     return MGM_OK;
 }
 
+// ---- pipelined contexts -------------------------------------------------------------------------------------------------
+// Every entry point that is not part of gathering a step (cost volume build into a volume no pending call uses, weights,
+// the aggregation calls themselves) first runs what has been deferred: downloads, post-processing, frees, synchronisation,
+// the direction-sharded building blocks.  A no-op for plain contexts.
+static int pipe_flush(mgm_ctx *c);
+static int pipe_join(mgm_ctx *c) { return (c && !c->pend.empty()) ? pipe_flush(c) : MGM_OK; }
+static bool pipe_uses(const mgm_ctx *c, const void *obj)  // is `obj` (a volume or an image) an operand of a deferred call?
+{
+    if (!c || !obj) return false;
+    for (const auto &q : c->pend) {
+        for (const mgm_cv *x : q.C) if (x == obj) return true;
+        for (const mgm_img *x : q.w8) if (x == obj) return true;
+        for (const mgm_img *x : q.out) if (x == obj) return true;
+        for (const mgm_img *x : q.outcost) if (x == obj) return true;
+    }
+    return false;
+}
+
 // ---------------------------------------------------------------------------
 extern "C" {
 
@@ -364,6 +395,7 @@ int mgm_ctx_destroy(mgm_ctx *c)
 {
     if (!c) return MGM_OK;
     (void)hipSetDevice(c->device);
+    (void)pipe_join(c);  // (deferred calls of a pipelined context still write the caller's images)
     (void)hipStreamSynchronize(c->stream);
     std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->words, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
     for (int v = 0; v < kMaxBatch; v++) {
@@ -384,11 +416,22 @@ int mgm_ctx_destroy(mgm_ctx *c)
     return MGM_OK;
 }
 
+// Pipelined context: see mgm_hip.h.  depth 1 switches it off (after running whatever was deferred).
+int mgm_ctx_set_pipeline(mgm_ctx *c, int depth)
+{
+    if (!c) return MGM_ERR_INVALID;
+    if (depth < 1 || depth > kMaxBatch) return fail(c, MGM_ERR_INVALID, "mgm_ctx_set_pipeline: depth must be 1..16");
+    if (int r = mgm_ctx_synchronize(c)) return r;
+    c->pipe_depth = depth;
+    return MGM_OK;
+}
+
 // The workspace (Lr volumes, hand-off slots, census images, ...) only ever grows with the largest call seen; this hands
 // it back to the device.  The next call allocates what it needs again; mgm_wta_windowed_dev / mgm_debug_download_lr /
 // mgm_lr_device_ptr have nothing to work on until the next aggregation.
 int mgm_ctx_trim(mgm_ctx *c)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c) return MGM_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     if (int r = mgm_ctx_synchronize(c)) return r;
@@ -440,6 +483,7 @@ int mgm_ctx_synchronize(mgm_ctx *c)
 {
     if (!c) return MGM_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
+    if (int r = pipe_join(c)) return r;  // (pipelined context: run what has been deferred)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_watchdog(c);
 }
@@ -452,6 +496,7 @@ int mgm_timing_enable(mgm_ctx *c, int enable)
 }
 int mgm_timing_reset(mgm_ctx *c)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c) return MGM_ERR_INVALID;
     (void)hipStreamSynchronize(c->stream);
     for (auto &t : c->tim) {
@@ -504,6 +549,7 @@ int mgm_img_upload(mgm_ctx *c, const float *host, int nx, int ny, int nch, mgm_i
 }
 int mgm_img_download(mgm_ctx *c, const mgm_img *im, float *host)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !im || !host) return fail(c, MGM_ERR_INVALID, "mgm_img_download: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(host, im->d, sizeof(float) * (size_t)im->nx * im->ny * im->nch, hipMemcpyDeviceToHost,
@@ -522,6 +568,7 @@ void *mgm_img_device_ptr(mgm_img *im) { return im ? im->d : nullptr; }
 int mgm_img_device(const mgm_img *im) { return im ? im->device : -1; }
 int mgm_img_free(mgm_ctx *c, mgm_img *im)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!im) return MGM_OK;
     if (c) {
         (void)hipSetDevice(c->device);
@@ -607,6 +654,7 @@ static int ensure_f32(mgm_ctx *c, const mgm_cv *ccv)
 }
 int mgm_cv_download(mgm_ctx *c, const mgm_cv *cv, float *dense)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !cv || !dense) return fail(c, MGM_ERR_INVALID, "mgm_cv_download: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     if (int r = ensure_f32(c, cv)) return r;
@@ -626,6 +674,7 @@ int mgm_cv_dims(const mgm_cv *cv, int *nx, int *ny, int *dmin, int *dmax)
 int mgm_cv_device(const mgm_cv *cv) { return (cv && cv->owner) ? cv->owner->device : -1; }
 void *mgm_cv_device_ptr(mgm_cv *cv)
 {
+    if (cv) (void)pipe_join(cv->owner);
     if (!cv) return nullptr;
     if (cv->owner && ensure_f32(cv->owner, cv)) return nullptr;
     cv->c8_state = 0;  // the caller may write through the pointer: re-derive the compact copy at the next use
@@ -635,6 +684,7 @@ void *mgm_cv_device_ptr(mgm_cv *cv)
 }
 int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!cv) return MGM_OK;
     if (c) {
         (void)hipSetDevice(c->device);
@@ -762,6 +812,8 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     if (*out) {  // caller-provided volume to refill (must have the right geometry)
         if ((*out)->nx != u->nx || (*out)->ny != u->ny || (*out)->dmin != dmin || (*out)->dmax != dmax)
             return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: *C is non-NULL but has a different geometry");
+        // (pipelined context: a deferred aggregation still wants the costs this volume holds now)
+        if (pipe_uses(c, *out) && (r = pipe_flush(c))) return r;
     } else if ((r = cv_create(c, u->nx, u->ny, dmin, dmax, false, out))) {
         return r;
     }
@@ -790,10 +842,16 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     }
     p.rlo = (*out)->rlo;
     p.rhi = (*out)->rhi;
+    // (NCC costs are (nch - clipped NCC) * 64 and Birchfield-Tomasi costs are built on half-way interpolants: practically
+    // never whole numbers, so no compact copy is attempted -- one byte store per label of K2, for nothing)
+    const bool may_be_integer = costfn <= 2;
     if (c8_supported(dmax - dmin + 1) && dev().c8) {
-        if ((r = c8_alloc(c, *out))) return r;
-        p.C8 = (*out)->d8;
-        (*out)->c8_state = 1;
+        if (may_be_integer) {
+            if ((r = c8_alloc(c, *out))) return r;
+            p.C8 = (*out)->d8;
+            (*out)->c8_state = 1;
+        } else
+            (*out)->c8_state = -1;
     }
     (*out)->f32_state = 1;
     p.nx = u->nx;
@@ -865,6 +923,14 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         p.u = (const float *)c->census_u.p;
         p.v = (const float *)c->census_v.p;
     }
+    if (costfn == 3 && pre == 0 && !rloI && u->nch <= 4) {
+        // clipped NCC on the plain images: the per-pixel window statistics are computed once (k_ncc_stats), in the census
+        // buffers, which this combination leaves free
+        if ((r = reserve(c, c->census_u, sizeof(float) * (size_t)u->nx * u->ny * (2 * u->nch + 1)))) return r;
+        if ((r = reserve(c, c->census_v, sizeof(float) * (size_t)v->nx * v->ny * (2 * v->nch + 1)))) return r;
+        p.ncc_u = (float *)c->census_u.p;
+        p.ncc_v = (float *)c->census_v.p;
+    }
     p.trunc = truncDist * (float)p.nch;  // mgm_costvolume.h:401,405
     // A census cost over one descriptor word is a bit count 0..32, clipped to `trunc`: with trunc = +INF
     // or an integer up to 254 every cost fits the compact form, and the fp32 volume -- which neither K3
@@ -925,14 +991,24 @@ int mgm_costvolume_build(mgm_ctx *c, const float *u, const float *v, int nx, int
 int mgm_weights_dev(mgm_ctx *c, const mgm_img *u, float aP, float aThresh, mgm_img **w8)
 {
     if (!c || !u || !w8) return fail(c, MGM_ERR_INVALID, "mgm_weights: null argument");
-    int r = mgm_img_create(c, u->nx, u->ny, 8, w8);
-    if (r) return r;
+    const bool provided = *w8 != nullptr;  // (a caller that computes weights pair after pair refills its image)
+    int r = MGM_OK;
+    if (provided) {
+        if ((*w8)->nx != u->nx || (*w8)->ny != u->ny || (*w8)->nch != 8)
+            return fail(c, MGM_ERR_INVALID, "mgm_weights: *w8 is non-NULL but is not an nx*ny*8 image");
+        if (pipe_uses(c, *w8))  // (pipelined context: a deferred aggregation still wants the weights it holds now)
+            if ((r = pipe_flush(c))) return r;
+    } else if ((r = mgm_img_create(c, u->nx, u->ny, 8, w8)))
+        return r;
+    HIPCHK(c, hipSetDevice(c->device));
     TimeScope t(c, "k_weights");
     const hipError_t e = launch_weights(u->d, u->nx, u->ny, u->nch, aP, aThresh, (*w8)->d, c->stream);
     if (e != hipSuccess) {
         r = hipfail(c, e, "k_weights");
-        mgm_img_free(c, *w8);
-        *w8 = nullptr;
+        if (!provided) {
+            mgm_img_free(c, *w8);
+            *w8 = nullptr;
+        }
         return r;
     }
     return MGM_OK;
@@ -1601,9 +1677,9 @@ static int run_wta_refine(mgm_ctx *c, const mgm_cv *C, long long pix0, long long
     return MGM_OK;
 }
 
-int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm_img *const *w8, float P1, float P2, int NDIR,
-                            int MGM, int use_fh, int fix_overcount, const char *refine, mgm_img *const *out,
-                            mgm_img *const *outcost, mgm_cv **S)
+// Arguments of an aggregation call, checked (shared by the immediate and the deferred path)
+static int check_aggregate_args(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm_img *const *w8, int NDIR, int MGM, mgm_img *const *out,
+                                mgm_img *const *outcost)
 {
     if (!c || !C || !out || !outcost || n < 1) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: null argument");
     if (n > kMaxBatch) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: at most 16 volumes per call");
@@ -1623,6 +1699,15 @@ int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm
         if (w8 && (w8[v] == nullptr) != (w8[0] == nullptr))
             return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: weights for all volumes or for none");
     }
+    return MGM_OK;
+}
+
+// The aggregation itself, now: one pass launch over the batch (several if it does not fit), then the winner search per volume.
+static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm_img *const *w8, float P1, float P2, int NDIR,
+                               int MGM, int use_fh, int fix_overcount, const char *refine, mgm_img *const *out,
+                               mgm_img *const *outcost, mgm_cv **S)
+{
+    const int nx = C[0]->nx, ny = C[0]->ny, L = C[0]->dmax - C[0]->dmin + 1;
     const int ridx = refinement_index(refine);
     HIPCHK(c, hipSetDevice(c->device));
     int r = MGM_OK;
@@ -1673,6 +1758,69 @@ int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm
     return r;
 }
 
+// Pipelined context: everything that has been deferred, as ONE batch (the calls were checked to fit together when they
+// were queued).  An error is the error of the call that made the flush happen.
+static int pipe_flush(mgm_ctx *c)
+{
+    if (c->pend.empty()) return MGM_OK;
+    std::vector<mgm_ctx::PendingAgg> q;
+    q.swap(c->pend);  // (nothing below may see them as pending any more)
+    std::vector<const mgm_cv *> Cs;
+    std::vector<const mgm_img *> Ws;
+    std::vector<mgm_img *> Os, Ks;
+    for (const auto &a : q) {
+        Cs.insert(Cs.end(), a.C.begin(), a.C.end());
+        Ws.insert(Ws.end(), a.w8.begin(), a.w8.end());
+        Os.insert(Os.end(), a.out.begin(), a.out.end());
+        Ks.insert(Ks.end(), a.outcost.begin(), a.outcost.end());
+    }
+    const auto &a = q[0];
+    return aggregate_batch_now(c, (int)Cs.size(), Cs.data(), Ws.empty() ? nullptr : Ws.data(), a.P1, a.P2, a.NDIR, a.MGM, a.use_fh,
+                               a.fix_overcount, a.has_refine ? a.refine.c_str() : nullptr, Os.data(), Ks.data(), nullptr);
+}
+
+int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm_img *const *w8, float P1, float P2, int NDIR,
+                            int MGM, int use_fh, int fix_overcount, const char *refine, mgm_img *const *out,
+                            mgm_img *const *outcost, mgm_cv **S)
+{
+    if (int r = check_aggregate_args(c, n, C, w8, NDIR, MGM, out, outcost)) return r;
+    if (c->pipe_depth < 2) return aggregate_batch_now(c, n, C, w8, P1, P2, NDIR, MGM, use_fh, fix_overcount, refine, out, outcost, S);
+    // Pipelined context (mgm_ctx_set_pipeline): the call is DEFERRED -- remembered, not run -- until `depth` calls have been
+    // gathered, and those then run as one batch: ONE launch of the pass kernel over all their volumes, where the chains of
+    // bands of one volume fill the gaps of the others'.  A call that does not fit what is waiting (other geometry or
+    // settings, weighted against unweighted, S wanted, an operand that a waiting call already uses as an output, more than
+    // 16 volumes together) makes the waiting ones run first.
+    const bool weighted_call = w8 && w8[0];
+    bool fits = !S;
+    int waiting = 0;
+    if (!c->pend.empty()) {
+        const auto &a = c->pend[0];
+        for (const auto &q : c->pend) waiting += (int)q.C.size();
+        const mgm_cv *A = a.C[0];
+        fits = fits && A->nx == C[0]->nx && A->ny == C[0]->ny && A->dmax - A->dmin == C[0]->dmax - C[0]->dmin && a.P1 == P1 && a.P2 == P2 &&
+               a.NDIR == NDIR && a.MGM == MGM && a.use_fh == use_fh && a.fix_overcount == fix_overcount && a.has_refine == (refine != nullptr) &&
+               (!refine || a.refine == refine) && !a.w8.empty() == weighted_call && waiting + n <= kMaxBatch;
+        for (int v = 0; v < n && fits; v++) fits = !pipe_uses(c, out[v]) && !pipe_uses(c, outcost[v]);
+    }
+    for (int v = 0; v < n && fits; v++)  // (within the call: an image cannot be two outputs)
+        for (int u = 0; u < n; u++) fits = fits && out[v] != outcost[u] && (u == v || (out[v] != out[u] && outcost[v] != outcost[u]));
+    if (!fits) {
+        if (int r = pipe_flush(c)) return r;
+        if (S) return aggregate_batch_now(c, n, C, w8, P1, P2, NDIR, MGM, use_fh, fix_overcount, refine, out, outcost, S);
+    }
+    mgm_ctx::PendingAgg a;
+    a.C.assign(C, C + n);
+    if (weighted_call) a.w8.assign(w8, w8 + n);
+    a.out.assign(out, out + n);
+    a.outcost.assign(outcost, outcost + n);
+    a.P1 = P1, a.P2 = P2, a.NDIR = NDIR, a.MGM = MGM, a.use_fh = use_fh, a.fix_overcount = fix_overcount;
+    a.has_refine = refine != nullptr;
+    a.refine = refine ? refine : "";
+    c->pend.push_back(std::move(a));
+    if ((int)c->pend.size() >= c->pipe_depth) return pipe_flush(c);
+    return MGM_OK;
+}
+
 int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int NDIR, int MGM, int use_fh,
                       int fix_overcount, const char *refine, mgm_img *out, mgm_img *outcost, mgm_cv **S)
 {
@@ -1684,6 +1832,7 @@ int mgm_aggregate_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, 
 int mgm_aggregate_passes_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int MGM, int use_fh,
                              int first_pass, int n_passes)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !C) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes: null argument");
     if (first_pass < 0 || n_passes < 1 || first_pass + n_passes > kMaxDirs)
         return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes: passes must lie in 0..7");
@@ -1700,6 +1849,7 @@ int mgm_aggregate_passes_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, flo
 int mgm_aggregate_passes_at_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, float P1, float P2, int MGM, int use_fh,
                                 int first_pass, int n_passes, int slot0, int n_slots, int NDIR_total)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !C) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes_at: null argument");
     if (first_pass < 0 || n_passes < 1 || first_pass + n_passes > kMaxDirs || NDIR_total > kMaxDirs)
         return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes_at: passes must lie in 0..7");
@@ -1714,6 +1864,7 @@ int mgm_aggregate_passes_at_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, 
 
 void *mgm_lr_device_ptr(mgm_ctx *c, int slot)
 {
+    (void)pipe_join(c);
     if (!c || !c->lr.p || slot < 0 || slot >= c->last_ndir || c->last_Lk != c->last_L) return nullptr;
     return (float *)c->lr.p + (size_t)slot * c->last_stride;
 }
@@ -1721,6 +1872,7 @@ void *mgm_lr_device_ptr(mgm_ctx *c, int slot)
 int mgm_wta_rows_dev(mgm_ctx *c, const mgm_cv *C, int row0, int nrows, const void *lr_slabs, int NDIR, int fix_overcount,
                      const char *refine, void *out_rows, void *outcost_rows)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !C || !lr_slabs || !out_rows || !outcost_rows) return fail(c, MGM_ERR_INVALID, "mgm_wta_rows: null argument");
     if (row0 < 0 || nrows < 1 || row0 + nrows > C->ny || NDIR < 1 || NDIR > kMaxDirs)
         return fail(c, MGM_ERR_INVALID, "mgm_wta_rows: bad row range or NDIR");
@@ -1751,6 +1903,7 @@ int mgm_aggregate(mgm_ctx *c, const mgm_cv *C, const float *w8, float P1, float 
 
 int mgm_debug_download_lr(mgm_ctx *c, int pass, float *dense)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !dense || pass < 0 || pass >= c->last_ndir || !c->lr.p)
         return fail(c, MGM_ERR_INVALID, "mgm_debug_download_lr: nothing to download");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1764,6 +1917,7 @@ int mgm_debug_download_lr(mgm_ctx *c, int pass, float *dense)
 // ---- self-tests -------------------------------------------------------------------
 int mgm_selftest_div3(mgm_ctx *c, unsigned long long *nbad)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !nbad) return fail(c, MGM_ERR_INVALID, "mgm_selftest_div3: null argument");
     HIPCHK(c, hipSetDevice(c->device));
     int r;
@@ -1779,6 +1933,7 @@ int mgm_selftest_div3(mgm_ctx *c, unsigned long long *nbad)
 // ---- refinement -----------------------------------------------------------------
 int mgm_refine_dev(mgm_ctx *c, const mgm_cv *S, const char *method, mgm_img *out, mgm_img *outcost)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !S || !out || !outcost) return fail(c, MGM_ERR_INVALID, "mgm_refine: null argument");
     if (out->nx != S->nx || out->ny != S->ny || outcost->nx != S->nx || outcost->ny != S->ny)
         return fail(c, MGM_ERR_INVALID, "mgm_refine: image size mismatch");
@@ -1794,6 +1949,7 @@ int mgm_refine_dev(mgm_ctx *c, const mgm_cv *S, const char *method, mgm_img *out
 int mgm_wta_windowed_dev(mgm_ctx *c, const mgm_cv *C, int NDIR, int fix_overcount, const char *refine, const mgm_img *dminI,
                          const mgm_img *dmaxI, mgm_img *out, mgm_img *outcost)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !C || !dminI || !dmaxI || !out || !outcost) return fail(c, MGM_ERR_INVALID, "mgm_wta_windowed: null argument");
     const int nx = C->nx, ny = C->ny, L = C->dmax - C->dmin + 1;
     for (const mgm_img *im : {dminI, dmaxI, (const mgm_img *)out, (const mgm_img *)outcost})
@@ -1810,6 +1966,7 @@ int mgm_wta_windowed_dev(mgm_ctx *c, const mgm_cv *C, int NDIR, int fix_overcoun
 
 int mgm_update_ranges_dev(mgm_ctx *c, const mgm_img *outoff, mgm_img *dminI, mgm_img *dmaxI, int slack, int radius)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !outoff || !dminI || !dmaxI) return fail(c, MGM_ERR_INVALID, "mgm_update_ranges: null argument");
     for (const mgm_img *im : {(const mgm_img *)dminI, (const mgm_img *)dmaxI})
         if (im->nx != outoff->nx || im->ny != outoff->ny || im->nch != 1 || outoff->nch != 1)
@@ -1827,6 +1984,7 @@ int mgm_update_ranges_dev(mgm_ctx *c, const mgm_img *outoff, mgm_img *dminI, mgm
 
 int mgm_median_dev(mgm_ctx *c, const mgm_img *in, int radius, mgm_img *out)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !in || !out || in == out) return fail(c, MGM_ERR_INVALID, "mgm_median: bad arguments");
     if (out->nx != in->nx || out->ny != in->ny || out->nch != in->nch) return fail(c, MGM_ERR_INVALID, "mgm_median: image size mismatch");
     if (radius < 1 || radius > 1024) return fail(c, MGM_ERR_INVALID, "mgm_median: radius must be 1..1024");
@@ -1844,6 +2002,7 @@ int mgm_median_dev(mgm_ctx *c, const mgm_img *in, int radius, mgm_img *out)
 
 int mgm_leftright_dev(mgm_ctx *c, const mgm_img *d, const mgm_img *other, float tau, mgm_img *out)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !d || !other || !out || out == other) return fail(c, MGM_ERR_INVALID, "mgm_leftright: bad arguments");
     if (d->nch != 1 || other->nch != 1 || out->nch != 1 || out->nx != d->nx || out->ny != d->ny || other->ny < d->ny)
         return fail(c, MGM_ERR_INVALID, "mgm_leftright: image size mismatch");
@@ -1855,6 +2014,7 @@ int mgm_leftright_dev(mgm_ctx *c, const mgm_img *d, const mgm_img *other, float 
 
 int mgm_backproject_dev(mgm_ctx *c, const mgm_img *u, const mgm_img *v, const mgm_img *disp, mgm_img *out)
 {
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !u || !v || !disp || !out) return fail(c, MGM_ERR_INVALID, "mgm_backproject: null argument");
     if (u->nch != v->nch || disp->nx != u->nx || disp->ny != u->ny || disp->nch != 1 || out->nx != u->nx || out->ny != u->ny ||
         out->nch != u->nch)

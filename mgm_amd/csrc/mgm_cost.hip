@@ -181,6 +181,14 @@ __device__ __forceinline__ float cost_ncc(const CostParams &P, int px, int py, i
     return clipped * 64;
 }
 
+// Raise a bit of a flag word that many waves may want to raise: look first -- an atomic per wave on ONE address serialises
+// (round 4: RGB absolute differences exceed 254 at nearly every pixel, and 2 M atomicOr on the "no compact form" word made
+// K2 take 21.8 ms at 1920x1080x256 where the grey-level volume took 1.55).
+__device__ __forceinline__ void flag_once(unsigned *word, unsigned bit)
+{
+    if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0u) atomicOr(word, bit);
+}
+
 // ---- K2 -----------------------------------------------------------------------
 // One wavefront per pixel; lane l fills labels o = l, l+64, ... so that every
 // store instruction writes 64 consecutive floats of the pixel's slab.
@@ -257,8 +265,8 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
             if (Cp8) Cp8[o] = 0;
         }
     else if (Cp8 && __builtin_amdgcn_ballot_w64(bad8) != 0ull && lane == 0)
-        atomicOr(P.bad8, 1u);
-    if (P.bad8 && __builtin_amdgcn_ballot_w64(nanv) != 0ull && lane == 0) atomicOr(P.bad8, 2u);
+        flag_once(P.bad8, 1u);
+    if (P.bad8 && __builtin_amdgcn_ballot_w64(nanv) != 0ull && lane == 0) flag_once(P.bad8, 2u);
 }
 
 // compact copy of an existing fp32 volume (uploaded by the caller); flag bit 0: some cost has no compact form,
@@ -281,8 +289,8 @@ __global__ void __launch_bounds__(256) k_compact(const float *__restrict__ C, lo
         else
             for (int k = 0; k < 4 && i + k < n; k++) C8[i + k] = (uint8_t)(w >> (8 * k));
     }
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(bad8, 1u);
-    if (__builtin_amdgcn_ballot_w64(nanv) != 0ull && (threadIdx.x & 63) == 0) atomicOr(bad8, 2u);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) flag_once(bad8, 1u);
+    if (__builtin_amdgcn_ballot_w64(nanv) != 0ull && (threadIdx.x & 63) == 0) flag_once(bad8, 2u);
 }
 
 // NaN scan alone, for volumes that get no compact copy (flag bit 1)
@@ -295,7 +303,7 @@ __global__ void __launch_bounds__(256) k_nanscan(const float *__restrict__ C, lo
         nanv |= f.x != f.x || f.y != f.y || f.z != f.z || f.w != f.w;
     }
     for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) nanv |= C[i] != C[i];
-    if (__builtin_amdgcn_ballot_w64(nanv) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 2u);
+    if (__builtin_amdgcn_ballot_w64(nanv) != 0ull && (threadIdx.x & 63) == 0) flag_once(flag, 2u);
 }
 hipError_t launch_nanscan(const float *C, long long n, unsigned *flag, hipStream_t s)
 {
@@ -344,7 +352,7 @@ __global__ void __launch_bounds__(256) k_pad(const float *__restrict__ C, long l
                 C8p[pix * LP + o] = (uint8_t)b;
             }
         }
-    if (C8p && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicOr(bad8, 1u);
+    if (C8p && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) flag_once(bad8, 1u);
 }
 
 hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, unsigned *bad8, hipStream_t s)
@@ -577,9 +585,149 @@ __global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restric
     }
 }
 
+// ---- clipped NCC, restructured (round 4) ---------------------------------------------------------------------------
+// computeC_clippedNCC (mgm_costvolume.h:137-165) accumulates five window sums per (pixel, label, channel) -- but mu1 and s1
+// depend on the left pixel alone and mu2, s2 on the right pixel alone: only the cross term is per cell.  Each sum is a
+// sequential fp32 accumulation over the window in the reference's (i outer, j inner) order, so computing it ONCE per pixel
+// in that order gives the same bits as computing it per label; likewise s - mu*mu (one rounded product, one rounded
+// difference).  k_ncc_stats does that for both images (and notes whether the window lies inside the image and is NaN-free:
+// otherwise the reference returns INFINITY whatever the other window holds); k_cost_ncc then needs 25 products per cell
+// instead of 125 operations and 50 loads, with the rows of both images staged in LDS.
+__global__ void __launch_bounds__(256) k_ncc_stats(const float *__restrict__ u, int nx, int ny, int nch, int hw, float *__restrict__ st)
+{
+    const long long npix = (long long)nx * ny;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const int x = (int)(idx % nx), y = (int)(idx / nx);
+    bool ok = x - hw >= 0 && y - hw >= 0 && x + hw < nx && y + hw < ny;
+    for (int t = 0; t < nch; t++) {
+        float mu = 0, s2 = 0;
+        int n = 0;
+        if (ok)
+            for (int i = -hw; i <= hw; i++)
+                for (int j = -hw; j <= hw; j++) {
+                    const float v = u[(x + i) + (long long)(y + j) * nx + t * npix];
+                    ok = ok && (v == v);
+                    mu += v;
+                    s2 += v * v;
+                    n++;
+                }
+        n = n ? n : 1;
+        mu /= n;
+        s2 /= n;
+        st[idx + (long long)t * npix] = mu;
+        st[idx + (long long)(nch + t) * npix] = s2 - mu * mu;
+    }
+    st[idx + (long long)(2 * nch) * npix] = ok ? 1.0f : 0.0f;
+}
+
+// One wavefront per pixel, lane l takes the labels l, l+64, ...; a workgroup of four waves walks PXB consecutive pixels of
+// one image row with the 2*hw+1 rows of both images around it in LDS (conflict-free: consecutive lanes read consecutive
+// words; the left window is a broadcast read).
+constexpr int kNccPxb = 32;       // pixels of a row per workgroup
+constexpr int kNccMaxHw = 3;      // windows up to 7x7 (CENSUS_NCC_WIN <= 7); wider ones take the general kernel
+constexpr int kNccMaxL = 1024;    // LDS: (PXB + L + 2*hw) floats per row and channel
+template <int HW>
+__global__ void __launch_bounds__(256) k_cost_ncc(const CostParams P)
+{
+    constexpr int WIN = 2 * HW + 1;
+    extern __shared__ float ncc_lds[];
+    const int nch = P.nch, L = P.L;
+    const int ntx = (P.nx + kNccPxb - 1) / kNccPxb;
+    const int y = blockIdx.x / ntx, x0 = (blockIdx.x % ntx) * kNccPxb;
+    const int uw = kNccPxb + 2 * HW;           // staged columns of the left image: x0-HW ..
+    const int vw = kNccPxb + L - 1 + 2 * HW;   // ... of the right image: x0+dmin-HW ..
+    float *Lu = ncc_lds;                       // [nch][WIN][uw]
+    float *Lv = Lu + nch * WIN * uw;           // [nch][WIN][vw]
+    const long long npix = (long long)P.nx * P.ny, vpix = (long long)P.vnx * P.vny;
+    for (int k = threadIdx.x; k < nch * WIN * uw; k += blockDim.x) {
+        const int c = k % uw, r = (k / uw) % WIN, t = k / (uw * WIN);
+        const int xx = x0 - HW + c, yy = y - HW + r;
+        Lu[k] = (xx >= 0 && xx < P.nx && yy >= 0 && yy < P.ny) ? P.u[xx + (long long)yy * P.nx + t * npix] : 0.0f;
+    }
+    for (int k = threadIdx.x; k < nch * WIN * vw; k += blockDim.x) {
+        const int c = k % vw, r = (k / vw) % WIN, t = k / (vw * WIN);
+        const int xx = x0 + P.dmin - HW + c, yy = y - HW + r;
+        Lv[k] = (xx >= 0 && xx < P.vnx && yy >= 0 && yy < P.vny) ? P.v[xx + (long long)yy * P.vnx + t * vpix] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool yin = y < P.vny;
+    for (int xl = wave; xl < kNccPxb; xl += 4) {
+        const int x = x0 + xl;
+        if (x >= P.nx) break;
+        const long long pix = (long long)y * P.nx + x;
+        float *Cp = P.C + pix * L;
+        const bool ok1 = P.ncc_u[pix + (long long)(2 * nch) * npix] != 0.0f;
+        bool anyfinite = false, nanv = false;
+        for (int o = lane; o < L; o += 64) {
+            const int qx = x + o + P.dmin;
+            float e = P.trunc;
+            if (yin && qx >= 0 && qx < P.vnx) {
+                const long long q = (long long)y * P.vnx + qx;
+                if (!ok1 || P.ncc_v[q + (long long)(2 * nch) * vpix] == 0.0f) {
+                    e = __builtin_huge_valf();
+                } else {
+                    float NCC = 0;
+                    for (int t = 0; t < nch; t++) {
+                        const float *a = Lu + (t * WIN) * uw + xl;            // left window: column xl + (i + HW), row j + HW
+                        const float *b = Lv + (t * WIN) * vw + xl + o;        // right window: column xl + o + (i + HW)
+                        float prod = 0;
+#pragma unroll
+                        for (int i = 0; i < WIN; i++)
+#pragma unroll
+                            for (int j = 0; j < WIN; j++) prod += a[j * uw + i] * b[j * vw + i];
+                        prod /= (WIN * WIN);
+                        const float mu1 = P.ncc_u[pix + (long long)t * npix], mu2 = P.ncc_v[q + (long long)t * vpix];
+                        const float var = P.ncc_u[pix + (long long)(nch + t) * npix] * P.ncc_v[q + (long long)(nch + t) * vpix];
+                        const double den = (0.0000001 > var) ? 0.0000001 : (double)var;
+                        NCC = (float)(NCC + (prod - mu1 * mu2) / __builtin_sqrt(den));
+                    }
+                    const float m = (NCC < nch) ? NCC : (float)nch;
+                    const float c = (0 > m) ? 0 : m;
+                    const float clipped = nch - c;
+                    e = clipped * 64;
+                }
+            }
+            e = (e < P.trunc) ? e : P.trunc;
+            Cp[o] = e;
+            anyfinite |= finite_bits(e);
+            nanv |= e != e;
+        }
+        // no valid hypothesis for this pixel => all labels cost 0 (mgm_costvolume.h:414-421)
+        if (__builtin_amdgcn_ballot_w64(anyfinite) == 0ull)
+            for (int o = lane; o < L; o += 64) Cp[o] = 0.0f;
+        if (P.bad8 && __builtin_amdgcn_ballot_w64(nanv) != 0ull && lane == 0) flag_once(P.bad8, 2u);
+    }
+}
+
 hipError_t launch_cost(const CostParams &p, hipStream_t s)
 {
     const long long npix = (long long)p.nx * p.ny;
+    if (p.costfn == 3 && p.ncc_u && p.ncc_v && p.C && !p.C8 && !p.rlo && p.hwin >= 1 && p.hwin <= kNccMaxHw && p.L <= kNccMaxL && p.nch <= 4) {
+        const long long vpix = (long long)p.vnx * p.vny;
+        hipLaunchKernelGGL(k_ncc_stats, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, p.u, p.nx, p.ny, p.nch, p.hwin, p.ncc_u);
+        hipLaunchKernelGGL(k_ncc_stats, dim3((unsigned)((vpix + 255) / 256)), dim3(256), 0, s, p.v, p.vnx, p.vny, p.nch, p.hwin, p.ncc_v);
+        const int win = 2 * p.hwin + 1;
+        const size_t lds = sizeof(float) * (size_t)p.nch * win * ((kNccPxb + 2 * p.hwin) + (kNccPxb + p.L - 1 + 2 * p.hwin));
+        const dim3 grid((unsigned)(((p.nx + kNccPxb - 1) / kNccPxb) * (long long)p.ny));
+        hipError_t e = hipSuccess;
+        switch (p.hwin) {
+            case 1:
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cost_ncc<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e == hipSuccess) hipLaunchKernelGGL(k_cost_ncc<1>, grid, dim3(256), lds, s, p);
+                break;
+            case 2:
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cost_ncc<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e == hipSuccess) hipLaunchKernelGGL(k_cost_ncc<2>, grid, dim3(256), lds, s, p);
+                break;
+            default:
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cost_ncc<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e == hipSuccess) hipLaunchKernelGGL(k_cost_ncc<3>, grid, dim3(256), lds, s, p);
+                break;
+        }
+        return e != hipSuccess ? e : hipGetLastError();
+    }
     if (!p.C && p.C8 && p.costfn == 2 && p.nch == 1 && c8_supported(p.L)) {
         const unsigned tb = p.trunc == __builtin_huge_valf() ? 255u : (unsigned)p.trunc;
         long long nb = (npix + 3) / 4;
@@ -667,7 +815,7 @@ __global__ void __launch_bounds__(256) k_any_not_one(const float *__restrict__ w
     bool bad = false;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         bad |= (w[i] != 1.0f);
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) flag_once(flag, 1u);
 }
 
 // Debug check of the self-validating hand-off slabs (mgm_pass2.hip, TAGS): after a launch EVERY word of the slots its

@@ -155,6 +155,10 @@ struct CostParams {
     // disparities [(int)rlo(p), (int)rhi(p)]; the others are +INF in the dense layout and exempt from the
     // "no finite cost => zeros" rule.  nullptr: every pixel has the whole range.
     const float *rlo, *rhi;
+    // ncc: scratch for the per-pixel window statistics of the two images (k_ncc_stats): (2*nch + 1) planes of nx*ny /
+    // vnx*vny floats each -- mean and variance term per channel, then the "window inside the image and NaN-free" flag --
+    // or nullptr (the general kernel recomputes every window for every label)
+    float *ncc_u, *ncc_v;
 };
 hipError_t launch_cost(const CostParams &p, hipStream_t s);
 hipError_t launch_filter2d(const float *u, int nx, int ny, int nch, const float *taps, int fnx, int fny, float *out,

@@ -29,6 +29,9 @@ class StubContext:
             self._t += [("k_census", 0.01), ("k_census", 0.01), ("k_cost", 0.1)]
         return into if into is not None else _Handle()
 
+    def weights_dev(self, u, aP, aThresh, into=None):
+        return into if into is not None else _Handle()
+
     def aggregate_batch_dev(self, Cvs, P1, P2, NDIR, MGM, use_fh=0, fix_overcount=1, w8s=None, refine=None, outs=None, outcosts=None,
                             want_S=False):
         time.sleep(0.002 * (1 + self.device))  # rank 1 is the slow one
@@ -37,6 +40,9 @@ class StubContext:
         if self._timing:
             self._t += [("k_pass2", 1.0 * len(Cvs))] + [("k_wta", 0.5)] * len(Cvs)
         return None, outs, outcosts
+
+    def set_pipeline(self, depth):
+        pass
 
     def synchronize(self):
         pass
