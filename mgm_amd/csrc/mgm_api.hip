@@ -107,6 +107,7 @@ struct mgm_ctx {
     int last_batch = 0;
     int last_L = 0, last_Lk = 0;          // labels of the last aggregation, and the label stride its kernels ran with (>= last_L)
     Buf padf[kMaxBatch], pad8[kMaxBatch];  // padded copies of the cost volumes of a launch whose label count was padded
+    Buf wsel[kMaxBatch], wvals;            // two-valued weights (k_pass2, W2): selector words per volume; the value scan's words
     bool last_pad_c8 = false;
     const mgm_cv *last_cvs[kMaxBatch] = {};  // the volumes of the last aggregation (identity only, never dereferenced) ...
     unsigned long long last_gens[kMaxBatch] = {};  // ... and their generations at that time
@@ -139,6 +140,7 @@ struct DevSwitches {
     int strips;      // MGM_HIP_STRIPS=0|1: never / always walk the lines of passes 4-7 as two strips (default: chain-bound launches only)
     int xcdq;        // MGM_HIP_XCDQ=0|1: never / whenever possible the per-XCD work queues of k_pass2 (default: chain-bound launches)
     int xcdq_k;      // MGM_HIP_XCDQ_K: consecutive bands of a pass per queue block (0: a pass stays on one XCD; default: by the launch's shape)
+    bool w2;         // MGM_HIP_W2=0: two-valued weights take the general weighted kernels too (A/B)
     bool oneb;       // MGM_HIP_ONEB=0: launches that run one band per CU keep the queue kernels capped at 64 VGPRs (A/B)
     long long lr_pad;  // MGM_HIP_LR_PAD: floats between consecutive Lr volumes beyond their size, in 256-byte blocks (67)
 };
@@ -148,7 +150,7 @@ static const DevSwitches &dev()
         auto on = [](const char *n) { const char *e = getenv(n); return !(e && atoi(e) == 0); };
         auto num = [](const char *n, long long dflt) { const char *e = getenv(n); return e ? atoll(e) : dflt; };
         return DevSwitches{on("MGM_HIP_C8"), on("MGM_HIP_LAZY_F32"), on("MGM_HIP_PAD"), (int)num("MGM_HIP_SUBV", 1), (int)num("MGM_HIP_DEEP", -1),
-                           (int)num("MGM_HIP_WG_PER_CU", 0), (int)num("MGM_HIP_XFLAGS", 0), (int)num("MGM_HIP_STRIPS", -1), (int)num("MGM_HIP_XCDQ", -1), (int)num("MGM_HIP_XCDQ_K", -1), on("MGM_HIP_ONEB"), 64ll * num("MGM_HIP_LR_PAD", 67)};
+                           (int)num("MGM_HIP_WG_PER_CU", 0), (int)num("MGM_HIP_XFLAGS", 0), (int)num("MGM_HIP_STRIPS", -1), (int)num("MGM_HIP_XCDQ", -1), (int)num("MGM_HIP_XCDQ_K", -1), on("MGM_HIP_W2"), on("MGM_HIP_ONEB"), 64ll * num("MGM_HIP_LR_PAD", 67)};
     }();
     return d;
 }
@@ -401,7 +403,9 @@ int mgm_ctx_destroy(mgm_ctx *c)
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);
         bufs.push_back(&c->pad8[v]);
+        bufs.push_back(&c->wsel[v]);
     }
+    bufs.push_back(&c->wvals);
     for (auto &t : c->ttabs)
         if (t.buf.p) (void)hipFree(t.buf.p);
     for (Buf *b : bufs)
@@ -439,7 +443,9 @@ int mgm_ctx_trim(mgm_ctx *c)
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);
         bufs.push_back(&c->pad8[v]);
+        bufs.push_back(&c->wsel[v]);
     }
+    bufs.push_back(&c->wvals);
     for (Buf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;
@@ -1022,7 +1028,7 @@ int mgm_weights_dev(mgm_ctx *c, const mgm_img *u, float aP, float aThresh, mgm_i
 // smallest label count the second K3 build takes that holds L labels (0: none)
 static int padded_labels(int L)
 {
-    for (int lp : {64, 128, 192, 256, 384, 512})
+    for (int lp : {64, 128, 192, 256, 384, 512, 768, 1024})
         if (lp >= L) return lp;
     return 0;
 }
@@ -1109,7 +1115,8 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // uniform range has a finite minimum, so the added term is finite.
     int L = Lreal;
     bool padded = false;
-    if (allow_pad && !first_build && pass2_lines(Lreal, false) == 0 && dev().pad) {
+    // (weights with more than 512 labels run on the first build, which takes any label count as it is: no padding then)
+    if (allow_pad && !first_build && pass2_lines(Lreal, false) == 0 && dev().pad && !(w8s && w8s[0] && Lreal > 512)) {
         const int lp = padded_labels(Lreal);
         if (lp) {
             L = lp;
@@ -1123,20 +1130,29 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     unsigned *words = (unsigned *)c->words.p;
     HIPCHK(c, hipMemsetAsync(words, 0, sizeof(unsigned), c->stream));  // the ticket (the progress words: below, where they are used)
 
-    // weighted? (mgm_core.cc:420-423: any value != 1.0 switches every update)
-    bool weighted = false;
-    for (int v = 0; v < nb; v++) {
-        bool wv = false;
-        if (w8s && w8s[v]) {
-            HIPCHK(c, hipMemsetAsync(words + 2, 0, sizeof(unsigned), c->stream));
-            HIPCHK(c, launch_any_not_one(w8s[v]->d, npix * 8, words + 2, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_words + 2, words + 2, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            wv = c->h_words[2] != 0;
+    // weighted? (mgm_core.cc:420-423: any value != 1.0 switches every update) -- and what values do the weights take: the
+    // planes compute_mgm_weights makes hold 1 and ONE other value, which the pass kernel exploits (k_pass2, W2)
+    bool weighted = false, w2cand = false;
+    float w2a[kMaxBatch] = {};
+    if (w8s && w8s[0]) {
+        if ((r = reserve(c, c->wvals, sizeof(unsigned) * 4 * kMaxBatch))) return r;
+        unsigned init[4 * kMaxBatch], got[4 * kMaxBatch];
+        for (int v = 0; v < nb; v++) init[4 * v] = 0u, init[4 * v + 1] = 0xffffffffu, init[4 * v + 2] = 0u, init[4 * v + 3] = 0u;
+        HIPCHK(c, hipMemcpyAsync(c->wvals.p, init, sizeof(unsigned) * 4 * nb, hipMemcpyHostToDevice, c->stream));
+        for (int v = 0; v < nb; v++)
+            if (w8s[v]) HIPCHK(c, launch_weight_values(w8s[v]->d, npix * 8, (unsigned *)c->wvals.p + 4 * v, c->stream));
+        HIPCHK(c, hipMemcpyAsync(got, c->wvals.p, sizeof(unsigned) * 4 * nb, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        w2cand = true;
+        for (int v = 0; v < nb; v++) {
+            const bool wv = w8s[v] && got[4 * v] != 0;
+            if (v && wv != weighted)
+                return fail(c, MGM_ERR_UNSUPPORTED, "batched volumes must be all weighted or all unweighted");
+            weighted = wv;
+            w2cand = w2cand && wv && got[4 * v + 3] == 0 && got[4 * v + 1] == got[4 * v + 2];
+            memcpy(&w2a[v], &got[4 * v + 1], 4);
         }
-        if (v && wv != weighted)
-            return fail(c, MGM_ERR_UNSUPPORTED, "batched volumes must be all weighted or all unweighted");
-        weighted = wv;
+        w2cand = w2cand && weighted;
     }
     const bool fh = use_fh > 0;
     const bool weighted_given = weighted;  // (before the ragged FH path borrows the weighted kernels below)
@@ -1176,7 +1192,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         ones8 = (const float *)c->ones8.p;
         weighted = true;
     }
-    const int NS = pass_ns(fh, weighted);
+    int NS = pass_ns(fh, weighted);  // (two slabs per slot also for two-valued weights: decided below)
 
     // compact costs (one byte per label) when the volume allows it
     bool use_c8 = true;
@@ -1209,7 +1225,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     } else {
         for (int v = 0; v < nb; v++) use_c8 = use_c8 && c8ok[v];
     }
-    if (first_build) use_c8 = false;
+    // (768 / 1024 labels with weights that are not two-valued-and-narrow: the weighted kernels of the second build stop at
+    // 512 labels -- two slabs per slot do not fit the LDS beyond -- so those take the first build, which has no compact costs)
+    const bool wide_weighted = weighted && lpl > 8;
+    if (first_build || wide_weighted) use_c8 = false;
     // second build (LDS-DMA loaders) whenever the slabs are whole DMA pieces
     // 128 / 64 labels: 2 / 4 volumes of the launch share every wave of the 256-label kernels (k_pass2<..., SUBV>) -- a
     // step is mostly fixed cost, so it may as well serve several volumes.  Compact costs, no weights, not FH with
@@ -1223,7 +1242,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         subv = 256 / L;
     const int ngroups = nb / subv;  // work items address groups of `subv` volumes
     const int Lk = L * subv;        // label slots of a wave
-    const int R2 = first_build ? 0 : pass2_lines(Lk, use_c8);
+    const int R2 = (first_build || wide_weighted) ? 0 : pass2_lines(Lk, use_c8);
     const int R = R2 ? R2 : (lpl > 8 ? 4 : kR);  // (more than 512 labels: the first build with bands of four lines)
     PassParams p{};
     int maxLL = 0, maxbands = 0;
@@ -1233,19 +1252,39 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         maxbands = std::max(maxbands, p.g[q].nbands);
     }
     if (maxbands > kMaxBands) return fail(c, MGM_ERR_UNSUPPORTED, "image side exceeds 65536 pixels");
+    // Two-valued weights (k_pass2, W2): the compact kernels with deep rings and per-XCD queues, every volume's weights 1 and
+    // one other positive value.  Anything they do not cover -- fp32 costs, more than 256 labels, launches too small for the
+    // queues, a partitioned device, FH on ragged volumes (which borrows the weighted kernels above) -- keeps the general
+    // weighted kernels.
+    bool w2 = w2cand && dev().w2 && R2 && use_c8 && lpl <= 4 && !ones8 && !pass2_devtools() && dev().xcdq != 0 && dev().deep != 0;
+    if (w2) {
+        int items = 0;
+        for (int q = first; q < PEND; q++) items += nb * p.g[q].nbands;
+        w2 = items >= 32;
+    }
+    if (w2 && c->xcc_mask < 0) {
+        HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
+        HIPCHK(c, launch_xcc_census(words + 3, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_words + 3, words + 3, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->xcc_mask = (int)c->h_words[3];
+    }
+    w2 = w2 && c->xcc_mask == 0xff;
+    const bool wk = weighted && !w2;  // the general weighted kernels (consumer-side transforms, progress words)
 
     // Consecutive passes' volumes are staggered by an odd number of 256-byte blocks so that the
     // NDIR slabs of one pixel (read together by k_wta) do not fall on the same HBM channel.
     const long long lr_stride = nvol + lr_pad_floats();
     if ((r = reserve(c, c->lr, sizeof(float) * (size_t)lr_stride * nslots * nb))) return r;
-    const int LPk = subv > 1 ? Lk : LP;  // floats per hand-off slab
+    if (w2) NS = 2;
+    const int LPk = (subv > 1 ? Lk : LP) * (w2 ? 2 : 1);  // floats per hand-off slot of the self-validating protocol
     // The second build's unweighted kernels hand slabs from band to band that validate themselves (mgm_pass2.hip, TAGS):
     // one slot per (volume, pass, band, pixel), written once per launch OF THAT PASS with the tag in the sign bits.  A
     // pass's tag alternates between its consecutive launches over the same slots; a different geometry clears the region
     // first (all-ones words) and starts every pass again with tag 0.  The region is laid out for the passes
     // [0, layout_ndir) and is this protocol's alone (the other kernels' slots live in `hand2`), so neither a caller that
     // launches the passes one by one nor one that alternates weighted and unweighted runs makes it be cleared again.
-    const bool tags = R2 && !weighted && !(fh && MGM == 2);
+    const bool tags = R2 && !wk && (w2 || !(fh && MGM == 2));
     std::string tag_key;
     float *hand_ptr = nullptr;
     if (tags) {
@@ -1259,7 +1298,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         const void *before = c->hand.p;
         if ((r = reserve(c, c->hand, bytes))) return r;
         char key[160];
-        snprintf(key, sizeof key, "%d %d %d %d %d %d %d", nx, ny, LPk, ngroups, layout_ndir, R, MGM <= 3 ? 1 : 0);
+        snprintf(key, sizeof key, "%d %d %d %d %d %d %d", nx, ny, LPk, ngroups, layout_ndir, R, MGM <= 3 ? 1 : 0);  // (LPk tells the W2 layout apart)
         if (c->hand.p != before || c->hand_key != key) {
             HIPCHK(c, hipMemsetAsync(c->hand.p, 0xff, bytes, c->stream));
             c->hand_key = key;
@@ -1276,7 +1315,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         c->hand_key.clear();
         hand_ptr = (float *)c->hand.p;
     } else {
-        if ((r = reserve(c, c->hand2, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * LPk))) return r;
+        if ((r = reserve(c, c->hand2, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * (subv > 1 ? Lk : LP)))) return r;
         hand_ptr = (float *)c->hand2.p;
         // progress words of this protocol: [volume*8 + pass][band]
         HIPCHK(c, hipMemsetAsync(words + 4, 0, sizeof(unsigned) * (size_t)nb * kMaxDirs * kMaxBands, c->stream));
@@ -1329,7 +1368,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // so they take the queues whatever the load; the FH kernels, which need the second band from a load/chain of 1.5 on,
     // below a load/chain of 4.
     const bool always_q = !fh;
-    if (tags && p.deep && subv == 1 && R2 && nitems >= 32 && !pass2_devtools() && (dev().xcdq >= 1 || (dev().xcdq < 0 && (always_q || load_ratio < 4.0)))) {
+    if (tags && p.deep && subv == 1 && R2 && nitems >= 32 && !pass2_devtools() && (w2 || dev().xcdq >= 1 || (dev().xcdq < 0 && (always_q || load_ratio < 4.0)))) {
         if (c->xcc_mask < 0) {
             HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
             HIPCHK(c, launch_xcc_census(words + 3, c->stream));
@@ -1340,6 +1379,10 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         xcdq = c->xcc_mask == 0xff;
     }
     if (xcdq && always_q && !dev().wg_per_cu) p.wg_per_cu = 1;
+    if (w2) {
+        if (!xcdq || !p.deep) return fail(c, MGM_ERR_INTERNAL, "two-valued weights: the launch plan lost its queues");
+        p.wg_per_cu = 1;  // (two slabs per slot: one band per CU)
+    }
     // Two strips per line: the passes without an in-line dependency -- form 1 with 2 or 3 neighbours -- walk their lines
     // from both image edges inwards (mgm_pass2.hip): half the line length in the critical path of a pass, bands that
     // live half as long, for twice the work items, each with its own pipeline ramp and hand-off lag (and 1-2 % of the
@@ -1353,7 +1396,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     //     Hirschmueller x 1 4.85 -> 4.70, x 2 and x 3 +-0; 4096x4096x192 x 1 (load/chain 2.7) 26.5 -> 27.0, x 2 50.9 -> 52.6;
     //     a rank's four passes of 4096x4096x192 9.6 -> 8.4 with queues and strips together): on below a load/chain of 2.
     bool any_strips = false;
-    if (tags && (dev().strips == 1 || (dev().strips < 0 && ((ngroups == 1 && count <= 4 && p.wg_per_cu == 1) || (xcdq && load_ratio < 2.0)))))
+    if (tags && !w2 && (dev().strips == 1 || (dev().strips < 0 && ((ngroups == 1 && count <= 4 && p.wg_per_cu == 1) || (xcdq && load_ratio < 2.0)))))
         for (int q = first; q < PEND; q++)
             if (p.g[q].form == 1 && (MGM == 2 || MGM == 3) && p.g[q].LL >= 8 * R) {
                 p.g[q].nstrips = 2;
@@ -1454,6 +1497,15 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         p.vol[v].w8 = ones8 ? ones8 : (weighted ? w8s[v]->d : nullptr);
         p.vol[v].rlo = (fh && ragged) ? Cs[v]->rlo : nullptr;
         p.vol[v].rhi = (fh && ragged) ? Cs[v]->rhi : nullptr;
+        if (w2) {
+            if ((r = reserve(c, c->wsel[v], sizeof(unsigned) * (size_t)npix))) return r;
+            HIPCHK(c, launch_wsel(w8s[v]->d, npix, (unsigned *)c->wsel[v].p, c->stream));
+            p.vol[v].wsel = (const unsigned *)c->wsel[v].p;
+            p.vol[v].p1a = P1 * w2a[v];  // (fp32 products, rounded once: what update_costW computes for D = a)
+            p.vol[v].p2a = P2 * w2a[v];
+            // (FH: the cap min(., m + P2*a) is skipped where it cannot bind, as for the unit penalties below)
+            if (fh && p.vol[v].p1a >= 0.0f && p.vol[v].p2a >= 4.0f * (float)Lk * p.vol[v].p1a + 4096.0f) p.vol[v].p2a = __builtin_huge_valf();
+        }
     }
     p.hand = hand_ptr;
     p.handm = (float *)c->handm.p;
@@ -1499,7 +1551,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     }
     {
         TimeScope t(c, R2 ? "k_pass2" : "k_pass");
-        if (R2) HIPCHK(c, launch_pass2(p, c->ntasks, fh, weighted ? 1 : 0, c->stream));
+        if (R2) HIPCHK(c, launch_pass2(p, c->ntasks, fh, w2 ? 2 : (wk ? 1 : 0), c->stream));
         else HIPCHK(c, launch_pass(p, c->ntasks, R, fh, weighted ? 1 : 0, c->stream));
     }
     if (tags) c->hand_key = tag_key;  // enqueued: every slot of the region will carry this launch's tag

@@ -743,7 +743,9 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
                 case 192: hipLaunchKernelGGL(k_cost_census8x<192>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
                 case 256: hipLaunchKernelGGL(k_cost_census8x<256>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
                 case 384: hipLaunchKernelGGL(k_cost_census8x<384>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-                default: hipLaunchKernelGGL(k_cost_census8x<512>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                case 512: hipLaunchKernelGGL(k_cost_census8x<512>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                case 768: hipLaunchKernelGGL(k_cost_census8x<768>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                default: hipLaunchKernelGGL(k_cost_census8x<1024>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
             }
             return hipGetLastError();
         }
@@ -766,7 +768,9 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
             case 3: hipLaunchKernelGGL(k_cost_census8<3>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
             case 4: hipLaunchKernelGGL(k_cost_census8<4>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
             case 6: hipLaunchKernelGGL(k_cost_census8<6>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-            default: hipLaunchKernelGGL(k_cost_census8<8>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+            case 8: hipLaunchKernelGGL(k_cost_census8<8>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+            case 12: hipLaunchKernelGGL(k_cost_census8<12>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+            default: hipLaunchKernelGGL(k_cost_census8<16>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
         }
         return hipGetLastError();
     }
@@ -816,6 +820,52 @@ __global__ void __launch_bounds__(256) k_any_not_one(const float *__restrict__ w
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         bad |= (w[i] != 1.0f);
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) flag_once(flag, 1u);
+}
+
+// What values do the weights take (see launch_weight_values)?  out[1] must start as 0xffffffff, the others as 0.
+__global__ void __launch_bounds__(256) k_weight_values(const float *__restrict__ w, long long n, unsigned *out)
+{
+    bool any = false, odd = false;
+    unsigned lo = 0xffffffffu, hi = 0u;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = w[i];
+        if (x == 1.0f) continue;
+        any = true;
+        const unsigned b = __builtin_bit_cast(unsigned, x);
+        if (x > 0.0f && x < __builtin_huge_valf()) {  // positive finite: the bit patterns order like the values
+            lo = b < lo ? b : lo;
+            hi = b > hi ? b : hi;
+        } else
+            odd = true;
+    }
+    if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
+    if (any) {
+        if (lo != 0xffffffffu) {
+            atomicMin(out + 1, lo);
+            atomicMax(out + 2, hi);
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull && (threadIdx.x & 63) == 0) flag_once(out + 3, 1u);
+    if ((threadIdx.x & 63) == 0) flag_once(out + 0, 1u);
+}
+hipError_t launch_weight_values(const float *w, long long n, unsigned *out4, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_weight_values, dim3(256 * 8), dim3(256), 0, s, w, n, out4);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) k_wsel(const float *__restrict__ w8, long long npix, unsigned *__restrict__ sel)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) m |= (w8[k * npix + p] != 1.0f ? 1u : 0u) << k;
+    sel[p] = m;
+}
+hipError_t launch_wsel(const float *w8, long long npix, unsigned *sel, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_wsel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, w8, npix, sel);
+    return hipGetLastError();
 }
 
 // Debug check of the self-validating hand-off slabs (mgm_pass2.hip, TAGS): after a launch EVERY word of the slots its

@@ -44,6 +44,10 @@ struct PassVolume {
     float *Lr;          // NDIR volumes, pass p at Lr + (p - pass0)*nvol
     const float *w8;    // 8 planes [npix] or nullptr (all volumes alike)
     const float *rlo, *rhi;  // ragged volume: per-pixel range images (only the weighted FH kernels read them), or nullptr
+    // two-valued weights (k_pass2, W2): one selector word per pixel, bit p = "the weight of plane p is not 1" (k_wsel), and
+    // the penalties scaled by the other value a: P1*a, P2*a (P2*a = +INF where the cap cannot bind, like PassParams::P2)
+    const unsigned *wsel;
+    float p1a, p2a;
 };
 struct PassParams {
     PassVolume vol[kMaxBatch];
@@ -124,7 +128,7 @@ hipError_t launch_pass2(const PassParams &p, int ntasks, bool fh, int wmode, hip
 template <int LPL>
 hipError_t launch_pass2_lpl(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s);
 // compact-cost support: labels per lane for which the C8 forms of K3 / k_wta exist
-inline bool c8_supported(int L) { return L == 64 || L == 128 || L == 192 || L == 256 || L == 384 || L == 512; }
+inline bool c8_supported(int L) { return L == 64 || L == 128 || L == 192 || L == 256 || L == 384 || L == 512 || L == 768 || L == 1024; }
 hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s);
 hipError_t launch_nanscan(const float *C, long long n, unsigned *flag, hipStream_t s);
 hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, unsigned *bad8, hipStream_t s);
@@ -167,6 +171,11 @@ hipError_t launch_weights(const float *u, int nx, int ny, int nch, float aP, flo
                           hipStream_t s);
 hipError_t launch_selftest_div3(unsigned long long *nbad, hipStream_t s);
 hipError_t launch_any_not_one(const float *w, long long n, unsigned *flag, hipStream_t s);
+// what values do the weights take?  out[0] = 1 if some weight is not 1.0; out[1], out[2] = smallest and largest bit pattern
+// among the weights that are not 1.0 and are positive finite floats; out[3] = 1 if some weight is neither (negative, 0, NaN, INF)
+hipError_t launch_weight_values(const float *w, long long n, unsigned *out4, hipStream_t s);
+// selector words of two-valued weights: sel[p] bit k = (w[k*npix + p] != 1.0f), k = 0..7
+hipError_t launch_wsel(const float *w8, long long npix, unsigned *sel, hipStream_t s);
 hipError_t launch_check_tags(const float *slabs, long long nwords, unsigned tag, unsigned *count, hipStream_t s);
 hipError_t launch_xcc_census(unsigned *mask, hipStream_t s);
 

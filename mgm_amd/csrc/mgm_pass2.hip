@@ -111,7 +111,11 @@ __device__ __forceinline__ void store_slab_sc1_wide(float *slab, int lane, const
     else if constexpr (LPL == 3) { st_sc1_x2(p, v[0], v[1]); st_sc1_x1(p + 2, v[2]); }
     else if constexpr (LPL == 4) st_sc1_x4(p, v[0], v[1], v[2], v[3]);
     else if constexpr (LPL == 6) { st_sc1_x4(p, v[0], v[1], v[2], v[3]); st_sc1_x2(p + 4, v[4], v[5]); }
-    else { st_sc1_x4(p, v[0], v[1], v[2], v[3]); st_sc1_x4(p + 4, v[4], v[5], v[6], v[7]); }
+    else {
+        static_assert(LPL % 4 == 0, "whole 16-byte pieces");
+#pragma unroll
+        for (int k = 0; k < LPL; k += 4) st_sc1_x4(p + k, v[k], v[k + 1], v[k + 2], v[k + 3]);
+    }
 }
 // the same slab with plain stores (XCDQ: the reader is on this XCD)
 template <int LPL>
@@ -130,7 +134,7 @@ __device__ __forceinline__ void store_slab_plain(float *slab, int lane, const fl
     }
 }
 template <int LPL>
-constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 1; }
+constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 ? 2 : (LPL + 3) / 4; }
 
 #ifndef MGM_P2_WAVES_PER_EU
 #define MGM_P2_WAVES_PER_EU 8   // (compact unweighted kernels only; every other kernel is built for 4)
@@ -170,7 +174,7 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 || LPL == 8 ? 2 : 
 #define MGM_P2_LEAD 2
 #endif
 // ---- geometry of the build --------------------------------------------------------
-template <int LPL, int NS, bool HASM, bool C8, int MAXD = MGM_P2_MAXD>
+template <int LPL, int NS, bool HASM, bool C8, int MAXD = MGM_P2_MAXD, int EXTRA = 0>
 struct Plan {
     static constexpr int LP = LPL * 64;
     static constexpr int IPS = (LPL * 16 + 63) / 64;  // DMA pieces per fp32 slab
@@ -185,7 +189,8 @@ struct Plan {
     // DMA instructions per step: loader A = its C pieces + hand-off slabs [+ minimum + progress word: the kernels whose
     // hand-off slabs are not self-validating, see TAGS in k_pass2]
     // compact costs with two loaders: A = hand-off only, B = all C pieces
-    static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + NS * IPS + (HASM ? 2 : 0);
+    // (EXTRA: one more 4-byte piece per step -- the weight-selector words of the lines, k_pass2 W2)
+    static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + NS * IPS + (HASM ? 2 : 0) + EXTRA;
     static constexpr int nB = (C8 && NL == 2) ? NDMA : (NC - NCA) * IPS;
     // Ring geometry: RT = T-ring slots per line (2 with barriers), RDEPTH = steps of C / hand-off data the rings
     // hold, D = steps of DMA kept in flight (D <= RDEPTH-1).  The largest of a few candidates that fits in LDS.
@@ -197,7 +202,8 @@ struct Plan {
                + rdepth * NS * LP      // hand-off ring
                + 2 * rdepth + 8 + 32   // hand-off minima, progress words, task word (+ spare)
                + cring_floats(rdepth)  // C ring
-               + (C8 ? rdepth * 16 : 0);  // per line and ring slot: does the compact slab hold a +INF code?
+               + (C8 ? rdepth * 16 : 0)   // per line and ring slot: does the compact slab hold a +INF code?
+               + EXTRA * rdepth * 64;     // per line and ring slot: the pixel's weight-selector word (W2)
     }
     static constexpr bool fits(int rt, int rdepth, int d)
     {
@@ -245,6 +251,29 @@ __device__ __forceinline__ void combine_unit_E(const float (&C)[LPL], const floa
     }
 }
 
+// TWO-VALUED WEIGHTS (k_pass2, W2).  update_costW / update_costW_trunclinear (mgm_core.cc:95-144, 229-281) scale the penalties of
+// neighbour k by the weight D_k of the RECEIVING pixel's edge, so the transform of a slab depends on its reader -- the general
+// weighted kernels therefore hand over L (and N) and transform on the consumer side, three or four times per pixel.  But the
+// weights the reference itself makes (compute_mgm_weights, mgm_weights.h:63-85: aP2 where the image is flat, 1 elsewhere)
+// take TWO values, 1 and a: the producer can publish both transforms, E_1 = T(L; P1, P2) - m and E_a = T(L; P1*a, P2*a) - m
+// (P1*a and P2*a rounded once, as the reference's products are), and every reader picks one per neighbour by a bit of its
+// own pixel's selector word.  What is handed over is E >= +0 again: self-validating slabs, deep rings, per-XCD queues and
+// compact costs all apply, and the consumer's update is the unweighted one.  The association is update_costW's for every
+// TSGM, 2 included: e = ((0 + e_1) + e_2) + ..., Lp = C + e / TSGM.
+template <int LPL, int MGM>
+__device__ __forceinline__ void combine_w2(const float (&C)[LPL], const Nb<LPL, 2> &n1, const Nb<LPL, 2> &n2, const Nb<LPL, 2> &n3,
+                                           const Nb<LPL, 2> &n4, bool a1, bool a2, bool a3, bool a4, float (&out)[LPL])
+{
+#pragma unroll
+    for (int k = 0; k < LPL; k++) {
+        float e = a1 ? n1.w[1][k] : n1.w[0][k];
+        if constexpr (MGM >= 2) e += a2 ? n2.w[1][k] : n2.w[0][k];
+        if constexpr (MGM >= 3) e += a3 ? n3.w[1][k] : n3.w[0][k];
+        if constexpr (MGM >= 4) e += a4 ? n4.w[1][k] : n4.w[0][k];
+        out[k] = C[k] + div_small<MGM>(e);
+    }
+}
+
 // SUBV > 1: the wave's 256 label slots hold the slabs of SUBV different VOLUMES of the launch (128 labels: 2, 64: 4),
 // same pass, same line, same pixel -- every lane group walks its own volume, nothing crosses between them, and a step
 // that is mostly fixed cost (barrier, LDS round trips, DMA issue) serves SUBV volumes.  The LDS rings, the hand-off
@@ -258,23 +287,24 @@ __device__ __forceinline__ void combine_unit_E(const float (&C)[LPL], const floa
 // twelve 256-label volumes 48.5 -> 48.2.  The default of every compact unweighted launch (mgm_api.hip, run_passes); the
 // shallow build stays for A/B runs (MGM_HIP_DEEP=0).
 // where the work-item word lives in the workgroup's LDS (the layout of pass2_item, below)
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, bool DEEP>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, bool DEEP, bool W2 = false>
 struct P2Lds {
-    static constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
-    static constexpr bool pubE = !WEIGHTED && !(FH && MGM == 2);
-    using PL = Plan<LPL, NS, !pubE, C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD>;
+    static constexpr int NS = (W2 || (WEIGHTED && !FH)) ? 2 : 1;
+    static constexpr bool pubE = W2 || (!WEIGHTED && !(FH && MGM == 2));
+    using PL = Plan<LPL, NS, !pubE, C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD, W2 ? 1 : 0>;
     static constexpr int RD = PL::rd(PL::D);
     static constexpr int task_off = PL::NC * PL::RT * NS * PL::LP + RD * NS * PL::LP + PL::cring_floats(RD) + PL::NC * PL::RT + RD + RD;  // floats
 };
 
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV, bool DEEP, bool XCDQ>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV, bool DEEP, bool XCDQ, bool W2 = false>
 __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket)
 {
-    static_assert(!DEEP || (C8 && !WEIGHTED && !(FH && MGM == 2)), "the deep rings exist for the compact kernels that publish E");
+    static_assert(!W2 || (!WEIGHTED && C8 && DEEP && SUBV == 1 && LPL <= 4), "two-valued weights: the compact kernels with deep rings");
+    static_assert(!DEEP || (C8 && !WEIGHTED && (W2 || !(FH && MGM == 2))), "the deep rings exist for the compact kernels that publish E");
     static_assert(SUBV == 1 || (LPL == 4 && C8 && !WEIGHTED && !(FH && MGM == 2)), "volumes share a wave only in the compact unweighted kernels that publish E");
     constexpr int LANES = 64 / SUBV;  // lanes per volume
-    constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
-    constexpr bool pubE = !WEIGHTED && !(FH && MGM == 2);  // slabs carry E = T - m; minima not needed
+    constexpr int NS = (W2 || (WEIGHTED && !FH)) ? 2 : 1;
+    constexpr bool pubE = W2 || (!WEIGHTED && !(FH && MGM == 2));  // slabs carry E = T - m; minima not needed
     // Inter-band hand-off of the kernels that publish E.  E >= +0 always (T >= m; the host sends negative penalties to
     // the first build), so the sign bit of every word is free: the last line of a band stores its slabs with the sign
     // bits set to the LAUNCH's tag bit.  Every band has its own hand-off slots, written exactly once per launch, and
@@ -290,7 +320,8 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
     // have the time -- the FH kernels (cfg3 x 12: K3 50.1 -> 48.9 ms); the Hirschmueller kernels, whose loader is on the
     // critical path of a short step, lose 8-25 % with it (cfg2 x 16, cfg4) and keep decoding every byte.
     constexpr bool CFLAG = C8 && FH;
-    using PL = Plan<LPL, NS, !pubE, C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD>;
+    using PL = Plan<LPL, NS, !pubE, C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD, W2 ? 1 : 0>;
+    static_assert(!W2 || PL::NL == 1, "two-valued weights: one loader wave");
     constexpr int LP = PL::LP, NC = PL::NC, NCA = PL::NCA, D = PL::D, IPS = PL::IPS;
     constexpr int LPS = PL::LPS, LPD = PL::LPD, NDMA = PL::NDMA;
     constexpr int LPW = NCA;   // C lines per loader wave (NC - NCA == NCA when there are two loaders)
@@ -305,8 +336,9 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
     float *Tm = Cring + PL::cring_floats(RD);     // [NC][RT]
     float *Hm = Tm + NC * RT;                     // [RD]
     unsigned *Hprog = reinterpret_cast<unsigned *>(Hm + RD);  // [RD]
-    int *s_task = reinterpret_cast<int *>(smem + P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP>::task_off);  // (= Hprog + RD; the kernel's ticket word)
+    int *s_task = reinterpret_cast<int *>(smem + P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP, W2>::task_off);  // (= Hprog + RD; the kernel's ticket word)
     unsigned *Cflag = reinterpret_cast<unsigned *>(s_task + 40);  // [RD][16] (compact costs; behind the spare words)
+    unsigned *Wring = Cflag + RD * 16;                             // [RD][64] (W2: lane r = line r's weight-selector word)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -395,6 +427,17 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                 cptr[q] = V.C + (gbase + (long long)j * g.jstep) * L + lane * 4;
             ci[q] = -1 - SL * r;
         }
+        // W2: the weight-selector word of every line's pixel travels like the costs -- lane r fetches line r's word of the
+        // target step (4 bytes per lane, one DMA instruction per step)
+        const unsigned *wptr = nullptr;
+        int wi = 0;
+        if constexpr (W2) {
+            const int r = lane < NC ? lane : NC - 1;
+            int j = band * NC + r;
+            j = j < NLn ? j : NLn - 1;
+            wptr = V.wsel + (gbase + (long long)j * g.jstep);
+            wi = -1 - SL * r;
+        }
         // hand-off slab wanted by wave 0 at step t: pixel t (its fwd neighbour) with slope 2, pixel t-1
         // (its same neighbour) with slope 1; clamped to [0, LL-1]
         const int Hmax = W < LL ? W : LL - 1;  // last pixel of the previous band's last line this tile reads
@@ -419,6 +462,12 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                 const bool adv = (ci[q] >= 0) && (ci[q] < W - 1);
                 cptr[q] += adv ? cstride : 0;
                 ci[q]++;
+            }
+            if constexpr (W2) {
+                dma4<0>(wptr, Wring + slot * 64);
+                const bool wadv = (wi >= 0) && (wi < W - 1);
+                wptr += wadv ? istep : 0;
+                wi++;
             }
             if (wl == 0) {
                 const int h = ht < 0 ? 0 : (ht <= Hmax ? ht : Hmax);
@@ -484,20 +533,25 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                 for (;;) {
                     bool ok = true;
 #pragma unroll
-                    for (int c = 0; c < IPS; c++)
-                        if (c * 64 + lane < LPL * 16) {
-                            const u32x4 v = lds_read_b128_opaque(Hring + vslot * NSLP + c * 256 + lane * 4);
-                            // all four sign bits must equal the expected tag
-                            ok = ok && (tag_in ? ((v.x & v.y & v.z & v.w) >> 31) != 0u : ((v.x | v.y | v.z | v.w) >> 31) == 0u);
-                        }
+                    for (int q = 0; q < NS; q++)
+#pragma unroll
+                        for (int c = 0; c < IPS; c++)
+                            if (c * 64 + lane < LPL * 16) {
+                                const u32x4 v = lds_read_b128_opaque(Hring + vslot * NSLP + q * LP + c * 256 + lane * 4);
+                                // all four sign bits must equal the expected tag
+                                ok = ok && (tag_in ? ((v.x & v.y & v.z & v.w) >> 31) != 0u : ((v.x | v.y | v.z | v.w) >> 31) == 0u);
+                            }
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                     if (spins == 0) n_slow++;
                     n_spin++;
                     __builtin_amdgcn_s_sleep(4);
 #pragma unroll
-                    for (int c = 0; c < IPS; c++)
-                        if (c * 64 + lane < LPL * 16)
-                            dma16<AUX_SC1>(hand_in + (long long)(mirror ? LL - 1 - h : h) * NSLP + c * 256 + lane * 4, Hring + vslot * NSLP + c * 256);
+                    for (int q = 0; q < NS; q++)
+#pragma unroll
+                        for (int c = 0; c < IPS; c++)
+                            if (c * 64 + lane < LPL * 16)
+                                dma16<AUX_SC1>(hand_in + (long long)(mirror ? LL - 1 - h : h) * NSLP + q * LP + c * 256 + lane * 4,
+                                               Hring + vslot * NSLP + q * LP + c * 256);
                     wait_vmcnt<0>();
                     if (((++spins) & 255u) == 0) {
                         if (lane == 0) dma4<AUX_SC1>(P.err, Hprog);
@@ -528,7 +582,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                     const unsigned long long bal = __builtin_amdgcn_ballot_w64((ff(v.x) | ff(v.y) | ff(v.z) | ff(v.w)) != 0u);
                     const int line = q * LPD + lane;
                     if (lane < LPD && line < NC)
-                        Cflag[vslot * 16 + line] = ((bal >> (lane * LPS)) & ((1ull << LPS) - 1ull)) != 0ull ? 1u : 0u;
+                        Cflag[vslot * 16 + line] = ((bal >> ((lane * LPS) & 63)) & (LPS >= 64 ? ~0ull : ((1ull << (LPS & 63)) - 1ull))) != 0ull ? 1u : 0u;
                 }
             }
         };
@@ -615,6 +669,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
         // where this lane's part of the Lr slab of step s goes: a running pointer (one 64-bit add per step instead of
         // rebuilding pixel index * label stride from half a dozen scalars that would otherwise have to stay live -- the FH
         // kernels spill SGPRs, and every restore is a VALU slot)
+        const int wb[4] = {g.wplane[0], g.wplane[1], g.wplane[2], g.wplane[3]};  // (W2) weight plane of neighbour k
         float *qs = Lrb + (pix0 + (long long)(-1 - SLOPE * r) * istep) * L + (lane % LANES) * LPL;
         const long long dq = istep * L;
         auto step = [&](int s, int cslot, NbT &X, const NbT &Y, const NbT &Z) {
@@ -632,7 +687,9 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                 if constexpr (TAGS)
                     if (r == 0) {  // (wave-uniform) the slab came from the previous band: E >= +0, drop the hand-off tag
 #pragma unroll
-                        for (int k = 0; k < LPL; k++) X.w[0][k] = __builtin_fabsf(X.w[0][k]);
+                        for (int q = 0; q < NS; q++)
+#pragma unroll
+                            for (int k = 0; k < LPL; k++) X.w[q][k] = __builtin_fabsf(X.w[q][k]);
                     }
                 if constexpr (!pubE) X.m = fwd_m0[sl];
             }
@@ -712,7 +769,13 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                 const NbT &nb_back = SLOPE == 2 ? Y : Z;
                 const NbT &nb_fwd = X;  // only read with SLOPE == 2
                 if (interior) {
-                    if constexpr (!WEIGHTED) {
+                    if constexpr (W2) {
+                        // the selector word of THIS pixel: bit p = "the weight of plane p is not 1" (k_wsel)
+                        const unsigned wm = (unsigned)__builtin_amdgcn_readfirstlane((int)Wring[cslot * 64 + r]);
+                        const bool a0 = (wm >> wb[0]) & 1u, a1 = (wm >> wb[1]) & 1u, a2 = (wm >> wb[2]) & 1u, a3 = (wm >> wb[3]) & 1u;
+                        if constexpr (FORM == 0) combine_w2<LPL, MGM>(Cv, nb_i, nb_same, nb_back, nb_fwd, a0, a1, a2, a3, Lv);
+                        else combine_w2<LPL, MGM>(Cv, nb_fwd, nb_back, nb_same, nb_i, a0, a1, a2, a3, Lv);
+                    } else if constexpr (!WEIGHTED) {
                         if constexpr (pubE) {
                             if constexpr (FORM == 0)
                                 combine_unit_E<LPL, MGM, FH>(Cv, nb_i.w[0], nb_same.w[0], nb_back.w[0], nb_fwd.w[0], Lv);
@@ -785,7 +848,30 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                     ph[2] += clock64() - c2;  // store issue + wave min
                 }
                 const unsigned long long c3 = prof ? clock64() : 0;
-                if constexpr (!WEIGHTED) {
+                if constexpr (W2) {
+                    const float P1a = V.p1a, P2a = V.p2a;  // P1 * a, P2 * a: rounded once, as the reference's products are
+                    if constexpr (!FH) {
+                        float N[LPL];
+                        neighbour_min<LPL>(Lv, N);
+                        const float cap = m + P2, capa = m + P2a;
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) {
+                            nb_i.w[0][k] = fminf(fminf(Lv[k], N[k] + P1), cap) - m;
+                            nb_i.w[1][k] = fminf(fminf(Lv[k], N[k] + P1a), capa) - m;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) nb_i.w[0][k] = nb_i.w[1][k] = Lv[k];
+                        unsigned sw = 0;
+                        fh_minconv<LPL, false, 1>(nb_i.w[0], m, P1, P2, lane, P.Lreal, sw);
+                        fh_minconv<LPL, false, 1>(nb_i.w[1], m, P1a, P2a, lane, P.Lreal, sw);
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) {
+                            nb_i.w[0][k] -= m;
+                            nb_i.w[1][k] -= m;
+                        }
+                    }
+                } else if constexpr (!WEIGHTED) {
                     if constexpr (!FH) {
                         float N[LPL];
                         neighbour_min<LPL>(Lv, N, SUBV > 1 && lane % LANES == 0, SUBV > 1 && lane % LANES == LANES - 1);
@@ -828,16 +914,19 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                 }
                 if constexpr (TAGS) {
                     if (to_global) {
-                        float tagged[LPL];
 #pragma unroll
-                        for (int k = 0; k < LPL; k++)
-                            tagged[k] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, nb_i.w[0][k]) & 0x7fffffffu) | tag_out);  // (a NaN -- INF costs with P2 = INF -- may carry a sign of its own)
-                        float *hs = hand_out + (long long)(mirror ? LL - 1 - i : i) * LP;
-                        if constexpr (XCDQ) {
-                            if (plain_out) store_slab_plain<LPL>(hs, lane, tagged);
-                            else store_slab_sc1_wide<LPL>(hs, lane, tagged);
-                        } else
-                            store_slab_sc1_wide<LPL>(hs, lane, tagged);
+                        for (int q = 0; q < NS; q++) {
+                            float tagged[LPL];
+#pragma unroll
+                            for (int k = 0; k < LPL; k++)
+                                tagged[k] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, nb_i.w[q][k]) & 0x7fffffffu) | tag_out);  // (a NaN -- INF costs with P2 = INF -- may carry a sign of its own)
+                            float *hs = hand_out + ((long long)(mirror ? LL - 1 - i : i) * NS + q) * LP;
+                            if constexpr (XCDQ) {
+                                if (plain_out) store_slab_plain<LPL>(hs, lane, tagged);
+                                else store_slab_sc1_wide<LPL>(hs, lane, tagged);
+                            } else
+                                store_slab_sc1_wide<LPL>(hs, lane, tagged);
+                        }
                     }
                 } else if (to_global) {
 #pragma unroll
@@ -910,16 +999,16 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
 // unweighted kernels are otherwise capped at 64 VGPRs so that two bands fit a CU, and under that cap every FH instance
 // with the queue loop spilled 9-14 VGPRs (40-52 bytes of scratch per lane) and ~50 SGPRs -- scratch traffic and
 // v_readlane restores on the critical chain of exactly the launches that are bound by the length of a step.
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false, bool ONEB = false>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false, bool ONEB = false, bool W2 = false>
 __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, true, C8>::NL) * 64,
-                                  (ONEB ? MGM_P2_ONEB_WPE : (C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
+                                  (LPL >= 12 ? 2 : ONEB ? MGM_P2_ONEB_WPE : (C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int *s_ticket = reinterpret_cast<int *>(smem + P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP>::task_off);
+    int *s_ticket = reinterpret_cast<int *>(smem + P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP, W2>::task_off);
     if constexpr (!XCDQ) {
         if (threadIdx.x == 0) *s_ticket = (int)atomicAdd(P.ticket, 1u);
         __syncthreads();
-        pass2_item<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, false>(P, *s_ticket);
+        pass2_item<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, false, W2>(P, *s_ticket);
     } else {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
@@ -930,7 +1019,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             __syncthreads();
             const int t = *s_ticket;
             if (t >= qi.y) break;
-            pass2_item<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, true>(P, qi.x + t);
+            pass2_item<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, true, W2>(P, qi.x + t);
             wait_vmcnt<0>();   // (the loader's DMAs beyond the last step)
             __syncthreads();   // LDS and s_ticket are free again
         }
@@ -946,18 +1035,17 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 }
 
 // ---- launcher (one translation unit per LPL: -DMGM_P2_LPL=n) -----------------------
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false, bool ONEB = false>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false, bool ONEB = false, bool W2 = false>
 static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 {
-    constexpr int NS = (WEIGHTED && !FH) ? 2 : 1;
-    using PL = Plan<LPL, NS, WEIGHTED || (FH && MGM == 2), C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD>;
+    using PL = typename P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP, W2>::PL;
     size_t shmem = sizeof(float) * (size_t)PL::lds_floats(PL::D);
     // Occupancy is chosen per launch through the LDS request: the compact unweighted kernels are built for two
     // workgroups per CU (<= 64 VGPRs, < 80 KB of LDS).  Two bands per CU hide each other's barrier and LDS stalls --
     // right when the launch is throughput-bound (a batch of volumes); a single volume is bound by the chain of
     // bands, where the doubled step latency costs more than it gives, so it asks for > half the LDS and runs alone.
     if (p.wg_per_cu < 2 && shmem < 81 * 1024) shmem = 81 * 1024;
-    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, XCDQ, ONEB>;
+    auto kern = k_pass2<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, XCDQ, ONEB, W2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
@@ -1009,14 +1097,33 @@ static hipError_t launch2_mgm(const PassParams &p, int ntasks, hipStream_t s)
 }
 
 #ifndef MGM_P2_LPL
-#error "compile with -DMGM_P2_LPL=<1|2|3|4|6|8>"
+#error "compile with -DMGM_P2_LPL=<1|2|3|4|6|8|12|16>"
 #endif
+// two-valued weights (wmode 2): the compact kernels with deep rings and per-XCD queues, one band per CU
+template <int LPL, bool FH>
+static hipError_t launch2_w2(const PassParams &p, int ntasks, hipStream_t s)
+{
+    if constexpr (LPL <= 4 && !MGM_P2_DEV) {
+        if (!p.vol[0].C8 || !p.deep || !p.xcdq || p.subv > 1 || !p.vol[0].wsel) return hipErrorInvalidValue;
+        switch (p.MGM) {
+            case 1: return launch2_c8<LPL, FH, false, 1, true, 1, true, true, true, true>(p, ntasks, s);
+            case 2: return launch2_c8<LPL, FH, false, 2, true, 1, true, true, true, true>(p, ntasks, s);
+            case 3: return launch2_c8<LPL, FH, false, 3, true, 1, true, true, true, true>(p, ntasks, s);
+            case 4: return launch2_c8<LPL, FH, false, 4, true, 1, true, true, true, true>(p, ntasks, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
 template <>
 hipError_t launch_pass2_lpl<MGM_P2_LPL>(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s)
 {
     constexpr int LPL = MGM_P2_LPL;
+    if (wmode == 2) return fh ? launch2_w2<LPL, true>(p, ntasks, s) : launch2_w2<LPL, false>(p, ntasks, s);
     if (!wmode) return fh ? launch2_mgm<LPL, true, false>(p, ntasks, s) : launch2_mgm<LPL, false, false>(p, ntasks, s);
-    return fh ? launch2_mgm<LPL, true, true>(p, ntasks, s) : launch2_mgm<LPL, false, true>(p, ntasks, s);
+    if constexpr (LPL >= 12) return hipErrorInvalidValue;  // (768 / 1024 labels: the weighted kernels' rings do not fit the LDS; first build)
+    else return fh ? launch2_mgm<LPL, true, true>(p, ntasks, s) : launch2_mgm<LPL, false, true>(p, ntasks, s);
 }
 
 }  // namespace mgm

@@ -24,7 +24,7 @@ int pass2_lines(int L, bool c8)
     const int lpl = L / 64;
     if (c8 && c8_supported(L)) return lpl <= 4 ? MGM_P2_C8_NC : 7;  // compact costs need fewer loader waves
     if (lpl == 1 || lpl == 2 || lpl == 3 || lpl == 4) return 14;
-    if (lpl == 6 || lpl == 8) return 7;
+    if (lpl == 6 || lpl == 8 || lpl == 12 || lpl == 16) return 7;  // (768 / 1024 labels: round 4)
     return 0;
 }
 
@@ -37,6 +37,8 @@ hipError_t launch_pass2(const PassParams &p, int ntasks, bool fh, int wmode, hip
         case 4: return launch_pass2_lpl<4>(p, ntasks, fh, wmode, s);
         case 6: return launch_pass2_lpl<6>(p, ntasks, fh, wmode, s);
         case 8: return launch_pass2_lpl<8>(p, ntasks, fh, wmode, s);
+        case 12: return launch_pass2_lpl<12>(p, ntasks, fh, wmode, s);
+        case 16: return launch_pass2_lpl<16>(p, ntasks, fh, wmode, s);
         default: return hipErrorInvalidValue;
     }
 }

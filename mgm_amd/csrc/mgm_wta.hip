@@ -462,8 +462,15 @@ hipError_t launch_wta(const WtaParams &p, hipStream_t s)
         WTA_CASE(8, 1)
 #undef WTA_CASE
         // 513..2048 labels: one pixel per wave and iteration, guarded loads
-        case 12: hipLaunchKernelGGL((k_wta<12, 1, false>), grid, block, 0, s, p); break;
-        case 16: hipLaunchKernelGGL((k_wta<16, 1, false>), grid, block, 0, s, p); break;
+        // (768 and 1024 labels exactly: the second pass-kernel build takes them since round 4, with compact costs)
+        case 12:
+            if (p.L == 768) hipLaunchKernelGGL((k_wta<12, 1, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((k_wta<12, 1, false>), grid, block, 0, s, p);
+            break;
+        case 16:
+            if (p.L == 1024) hipLaunchKernelGGL((k_wta<16, 1, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((k_wta<16, 1, false>), grid, block, 0, s, p);
+            break;
         case 24: hipLaunchKernelGGL((k_wta<24, 1, false>), grid, block, 0, s, p); break;
         case 32: hipLaunchKernelGGL((k_wta<32, 1, false>), grid, block, 0, s, p); break;
         default: return hipErrorInvalidValue;

@@ -258,9 +258,9 @@ def test_uploaded_volume_with_nan_costs_takes_the_exact_kernel(ctx, oracle):
                                   (8, 4, 0, 8.0, 32.0, True), (5, 1, 1, 1.5, 40.0, True)],
                          ids=["O8-T3", "O8-T3-FH", "O4-T2-FH", "O8-T4-w", "O5-T1-FH-w"])
 def test_more_than_512_labels(ctx, oracle, L, mode):
-    """The reference's Dvec has no label limit (dvec.cc:55-64); 513..2048 labels take the first pass-kernel build with
-    bands of four lines (12 / 16 / 24 / 32 labels per lane) and the generic WTA instance, 2049..8192 the generic kernels
-    (mgm_pass_exact.hip, k_wta_any)."""
+    """The reference's Dvec has no label limit (dvec.cc:55-64); 513..1024 labels take the second pass-kernel build (round 4;
+    weighted ones and 1025..2048 labels the first build with bands of four lines: 12 / 16 / 24 / 32 labels per lane) and the
+    generic WTA instance, 2049..8192 the generic kernels (mgm_pass_exact.hip, k_wta_any)."""
     NDIR, MGM, FH, P1, P2, weighted = mode
     nx, ny, dmin = (23, 19, -L // 3) if L <= 2048 else (13, 11, -L // 3)
     C = synth.raw_volume(nx, ny, L, seed=L, inf_frac=0.04)
@@ -278,6 +278,36 @@ def test_more_than_512_labels(ctx, oracle, L, mode):
     assert ndiff(c, rc) == 0
     fin = np.isfinite(co)
     assert ndiff(o[fin], ro[fin]) == 0
+    S.free(), cv.free()
+
+
+@pytest.mark.parametrize("L", [768, 1024, 900])
+@pytest.mark.parametrize("mode", [(8, 3, 0, 8.0, 32.0), (8, 3, 1, 2.0, 20000.0), (4, 2, 1, 2.0, 9.0), (8, 4, 0, 8.0, 32.0)],
+                         ids=["O8-T3", "O8-T3-FH", "O4-T2-FH", "O8-T4"])
+def test_768_and_1024_labels_on_the_second_build(ctx, oracle, L, mode):
+    """Round 4: 768 and 1024 labels (12 / 16 labels per lane; 513..1024 run padded to them) take the second pass-kernel build
+    -- compact costs, deep rings, queues -- instead of the first build's bands of four lines.  Images with several bands per
+    pass (7 lines per band) and enough work items for the queues; integer costs (compact) and, for the padded count, fp32."""
+    from oracle.oracle import usable_cpus
+    NDIR, MGM, FH, P1, P2 = mode
+    nx, ny, dmin = 150, 101, -L // 2
+    C = synth.raw_volume(nx, ny, L, seed=L + MGM, maxcost=40, inf_frac=0.03)
+    if L == 900:
+        C = (C * np.float32(0.5)).astype(np.float32)  # half-integers: no compact form
+    oracle.set_threads(min(16, usable_cpus()))
+    try:
+        So, oo, co = oracle.mgm(C, dmin, P1, P2, NDIR, MGM, FH, 1)
+        ro, rc = oracle.refine(So, dmin, "vfit", oo, co)
+    finally:
+        oracle.set_threads(1)
+    cv = ctx.upload_volume(C, dmin)
+    ctx.timing(True)
+    ctx.timing_reset()
+    S, o, c = ctx.aggregate(cv, P1, P2, NDIR, MGM, FH, 1, None, "vfit", want_S=True)
+    names = {n for n, _ in ctx.timings()}
+    ctx.timing(False)
+    assert "k_pass2" in names and "k_pass" not in names
+    assert ndiff(S.download(), So) == 0 and ndiff(c, rc) == 0 and ndiff(o, ro) == 0
     S.free(), cv.free()
 
 
