@@ -162,10 +162,19 @@ def cpu_model():
     return "unknown"
 
 
-def compact_costs(w):
-    """Do this workload's costs travel as one byte per label?  (single-word census costs at a label count the compact
-    kernels take: mgm_api.hip, costvolume_fill / c8_supported)"""
-    return cost_of(w) == "census" and labels_of(w) in (64, 128, 192, 256, 384, 512) and os.environ.get("MGM_HIP_C8", "1") != "0"
+def cost_bytes(w):
+    """Bytes per label the costs of this workload travel as between K2, K3 and k_wta (mgm_api.hip, costvolume_fill): one for
+    single-word census costs and grey-level absolute differences, two for absolute differences of colour pairs and squared
+    differences (round 4), four (fp32) for everything else; weighted launches other than the two-valued compact ones read fp32."""
+    L = labels_of(w)
+    if os.environ.get("MGM_HIP_C8", "1") == "0":
+        return 4.0
+    if L in (64, 128, 192, 256, 384, 512, 768, 1024) or L < 1024:  # (other label counts run padded to the next of these)
+        if cost_of(w) == "census" or (cost_of(w) == "ad" and w.get("nch", 1) == 1):
+            return 1.0
+        if cost_of(w) in ("ad", "sd") and L <= 512 and not weighted(w):
+            return 2.0
+    return 4.0
 
 
 # ---- the CPU legs (rank 0 only; never inside a timed GPU region) --------------------------------------------------------
@@ -507,7 +516,7 @@ def roofline_of(w, B, avg, workload, step_ms=None):
         agg_ms = step_ms
     alg_bytes = 12.0 * w["NDIR"] * cells * B
     achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
-    cbytes = 1.0 if compact_costs(w) else 4.0
+    cbytes = cost_bytes(w)
     traffic, traffic_src = None, None
     for prof in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
         tj = json.load(open(os.path.join(ROOT, "profiles", prof)))

@@ -24,6 +24,10 @@ struct mgm_cv {
     int nx, ny, dmin, dmax;
     // compact (one byte per cost) copy used by K3 / k_wta when every cost is an integer 0..254 or +INF
     uint8_t *d8 = nullptr;
+    int cbytes = 1;            // bytes per cost of the compact copy: 1 (0..254, 255 = +INF) or 2 (0..65534, 65535 = +INF; round 4:
+                               // absolute differences of colour pairs, squared differences)
+    size_t d8_cap = 0;         // bytes allocated at d8
+    mutable int pad_hint = 1;  // a label count that runs padded: the compact form its padded copy took last time (0: none did)
     unsigned *bad8 = nullptr;  // device word: 1 = not representable
     int c8_state = 0;          // 0 none, 1 written (validity not read back yet), 2 valid, -1 invalid
     // K2 skips the fp32 write when its costs are known to fit the compact form (single-word census):
@@ -109,6 +113,7 @@ struct mgm_ctx {
     Buf padf[kMaxBatch], pad8[kMaxBatch];  // padded copies of the cost volumes of a launch whose label count was padded
     Buf wsel[kMaxBatch], wvals;            // two-valued weights (k_pass2, W2): selector words per volume; the value scan's words
     bool last_pad_c8 = false;
+    int last_pad_cb = 1;  // ... bytes per compact cost of those padded copies
     const mgm_cv *last_cvs[kMaxBatch] = {};  // the volumes of the last aggregation (identity only, never dereferenced) ...
     unsigned long long last_gens[kMaxBatch] = {};  // ... and their generations at that time
     bool pending_check = false;
@@ -710,13 +715,23 @@ int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
 }
 
 // ---- compact costs -----------------------------------------------------------
-static int c8_alloc(mgm_ctx *c, mgm_cv *cv)
+static int c8_alloc(mgm_ctx *c, mgm_cv *cv, int cb = 1)
 {
-    const size_t n = (size_t)cv->nx * cv->ny * (size_t)(cv->dmax - cv->dmin + 1);
-    if (!cv->d8 && dev_malloc((void **)&cv->d8, n + 64) != hipSuccess) {
+    const size_t n = (size_t)cv->nx * cv->ny * (size_t)(cv->dmax - cv->dmin + 1) * cb + 64;
+    if (cv->d8 && cv->d8_cap < n) {  // (refilled with a cost that takes the wider form)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(cv->d8);
         cv->d8 = nullptr;
-        return fail(c, MGM_ERR_NOMEM, "hipMalloc of the compact cost volume failed");
     }
+    if (!cv->d8) {
+        if (dev_malloc((void **)&cv->d8, n) != hipSuccess) {
+            cv->d8 = nullptr;
+            cv->d8_cap = 0;
+            return fail(c, MGM_ERR_NOMEM, "hipMalloc of the compact cost volume failed");
+        }
+        cv->d8_cap = n;
+    }
+    cv->cbytes = cb;
     return MGM_OK;
 }
 // Decide (once per filling of the volume) whether the compact copy can stand in for C, and whether the volume
@@ -730,8 +745,8 @@ static int c8_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *use)
     const bool enabled = dev().c8 && c8_supported(L);
     const long long n = (long long)cv->nx * cv->ny * L;
     bool launched = false;
-    if (enabled && cv->c8_state == 0) {  // uploaded / externally written volume: make the compact copy now
-        int r = c8_alloc(c, cv);
+    if (enabled && cv->c8_state == 0) {  // uploaded / externally written volume: make the compact copy now (one byte per cost)
+        int r = c8_alloc(c, cv, 1);
         if (r) return r;
         HIPCHK(c, hipMemsetAsync(cv->bad8, 0, 4, c->stream));
         TimeScope t(c, "k_compact");
@@ -851,10 +866,15 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     // (NCC costs are (nch - clipped NCC) * 64 and Birchfield-Tomasi costs are built on half-way interpolants: practically
     // never whole numbers, so no compact copy is attempted -- one byte store per label of K2, for nothing)
     const bool may_be_integer = costfn <= 2;
+    // Which compact form: census costs are bit counts (one byte); absolute differences of a one-channel 8-bit pair stay below
+    // 256, of a colour pair below 766, squared differences below 65026 per channel: two bytes (up to 512 labels: the pass
+    // kernels that read them).  The flag word tells afterwards whether every cost really had the form.
+    const int cb = (costfn == 2 || (costfn == 0 && u->nch == 1) || dmax - dmin + 1 > 512) ? 1 : 2;
     if (c8_supported(dmax - dmin + 1) && dev().c8) {
         if (may_be_integer) {
-            if ((r = c8_alloc(c, *out))) return r;
+            if ((r = c8_alloc(c, *out, cb))) return r;
             p.C8 = (*out)->d8;
+            p.cbytes = cb;
             (*out)->c8_state = 1;
         } else
             (*out)->c8_state = -1;
@@ -1204,26 +1224,52 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
         exact |= Cs[v]->nan_state < 0;
     }
     if (exact) return run_passes_exact(c, Cs, w8s, nb, P1, P2, MGM, fh, weighted_given, first, count, slot0, nslots);
+    int cb = 1;  // bytes per compact cost of this launch
     if (padded) {
-        // padded copies of the costs: the compact form if every volume allows it, else fp32
-        HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
-        for (int v = 0; v < nb; v++) {
-            if ((r = ensure_f32(c, Cs[v]))) return r;
-            if ((r = reserve(c, c->pad8[v], (size_t)npix * L))) return r;
-            TimeScope t(c, "k_pad");
-            HIPCHK(c, launch_pad(Cs[v]->d, npix, Lreal, L, nullptr, (uint8_t *)c->pad8[v].p, words + 3, c->stream));
+        // padded copies of the costs: a compact form if every volume allows it -- the one that worked for the first volume
+        // last time first (mgm_cv::pad_hint), then the other --, else fp32
+        int tries[3] = {Cs[0]->pad_hint == 2 ? 2 : 1, Cs[0]->pad_hint == 2 ? 1 : 2, 0};
+        if (Cs[0]->pad_hint == 0) tries[0] = 0;
+        use_c8 = false;
+        for (int t = 0; t < 3 && dev().c8 && !use_c8; t++) {
+            const int tb = tries[t];
+            if (tb == 0 || (tb == 2 && L > 512)) break;
+            HIPCHK(c, hipMemsetAsync(words + 3, 0, sizeof(unsigned), c->stream));
+            for (int v = 0; v < nb; v++) {
+                if ((r = ensure_f32(c, Cs[v]))) return r;
+                if ((r = reserve(c, c->pad8[v], (size_t)npix * L * tb))) return r;
+                TimeScope ts(c, "k_pad");
+                HIPCHK(c, launch_pad(Cs[v]->d, npix, Lreal, L, nullptr, (uint8_t *)c->pad8[v].p, tb, words + 3, c->stream));
+            }
+            HIPCHK(c, hipMemcpyAsync(c->h_words + 3, words + 3, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->h_words[3] == 0) {
+                use_c8 = true;
+                cb = tb;
+            }
         }
-        HIPCHK(c, hipMemcpyAsync(c->h_words + 3, words + 3, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        use_c8 = c->h_words[3] == 0 && dev().c8;
+        for (int v = 0; v < nb; v++) Cs[v]->pad_hint = use_c8 ? cb : 0;
         if (!use_c8)
+            for (int v = 0; v < nb; v++) {
+                if ((r = ensure_f32(c, Cs[v]))) return r;
+                if ((r = reserve(c, c->padf[v], sizeof(float) * (size_t)npix * L))) return r;
+                TimeScope t(c, "k_pad");
+                HIPCHK(c, launch_pad(Cs[v]->d, npix, Lreal, L, (float *)c->padf[v].p, nullptr, 1, nullptr, c->stream));
+            }
+    } else {
+        for (int v = 0; v < nb; v++) use_c8 = use_c8 && c8ok[v] && Cs[v]->cbytes == Cs[0]->cbytes;
+        cb = use_c8 ? Cs[0]->cbytes : 1;
+    }
+    // Two bytes per cost: read by the unweighted kernels with deep rings that publish E, up to 512 labels (k_pass2, C8 == 2);
+    // everything else reads the fp32 volume (which K2 always writes next to a two-byte copy).
+    if (use_c8 && cb == 2 && (weighted || (fh && MGM == 2) || pass_lpl(L) > 8 || dev().deep == 0)) {
+        if (padded)
             for (int v = 0; v < nb; v++) {
                 if ((r = reserve(c, c->padf[v], sizeof(float) * (size_t)npix * L))) return r;
                 TimeScope t(c, "k_pad");
-                HIPCHK(c, launch_pad(Cs[v]->d, npix, Lreal, L, (float *)c->padf[v].p, nullptr, nullptr, c->stream));
+                HIPCHK(c, launch_pad(Cs[v]->d, npix, Lreal, L, (float *)c->padf[v].p, nullptr, 1, nullptr, c->stream));
             }
-    } else {
-        for (int v = 0; v < nb; v++) use_c8 = use_c8 && c8ok[v];
+        use_c8 = false;
     }
     // (768 / 1024 labels with weights that are not two-valued-and-narrow: the weighted kernels of the second build stop at
     // 512 labels -- two slabs per slot do not fit the LDS beyond -- so those take the first build, which has no compact costs)
@@ -1237,7 +1283,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // the 256-label kernels, and a launch of one group is bound by its chain of bands, i.e. by the step (round 3,
     // 1920x1080x128 x 2: K3 3.74 ms sharing, 3.11 ms as two plain work items; x 4: the same either way).
     int subv = 1;
-    if (!first_build && use_c8 && !weighted && !(fh && MGM == 2) && (L == 128 || L == 64) && nb % (256 / L) == 0 &&
+    if (!first_build && use_c8 && cb == 1 && !weighted && !(fh && MGM == 2) && (L == 128 || L == 64) && nb % (256 / L) == 0 &&
         (dev().subv == 2 || (dev().subv == 1 && nb / (256 / L) >= 2)))
         subv = 256 / L;
     const int ngroups = nb / subv;  // work items address groups of `subv` volumes
@@ -1256,7 +1302,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     // one other positive value.  Anything they do not cover -- fp32 costs, more than 256 labels, launches too small for the
     // queues, a partitioned device, FH on ragged volumes (which borrows the weighted kernels above) -- keeps the general
     // weighted kernels.
-    bool w2 = w2cand && dev().w2 && R2 && use_c8 && lpl <= 4 && !ones8 && !pass2_devtools() && dev().xcdq != 0 && dev().deep != 0;
+    bool w2 = w2cand && dev().w2 && R2 && use_c8 && cb == 1 && lpl <= 4 && !ones8 && !pass2_devtools() && dev().xcdq != 0 && dev().deep != 0;
     if (w2) {
         int items = 0;
         for (int q = first; q < PEND; q++) items += nb * p.g[q].nbands;
@@ -1515,6 +1561,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     p.tasks = (const int2 *)c->tasks.p + 8;  // (behind the header)
     p.xcdq = xcdq ? (dev().xcdq == 2 ? 2 : 1) : 0;
     p.oneb = (xcdq && p.wg_per_cu < 2 && dev().oneb) ? 1 : 0;
+    p.cbytes = use_c8 ? cb : 1;
     p.qticket = words + 4;  // (the progress words of the other protocol: the kernels with tags do not use them)
     if (xcdq) HIPCHK(c, hipMemsetAsync(words + 4, 0, 9 * sizeof(unsigned), c->stream));
     p.npix = npix;
@@ -1650,6 +1697,7 @@ static int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const 
     c->last_L = Lreal;
     c->last_Lk = L;
     c->last_pad_c8 = padded && use_c8;
+    c->last_pad_cb = cb;
     for (int v = 0; v < kMaxBatch; v++) {
         c->last_cvs[v] = v < nb ? Cs[v] : nullptr;
         c->last_gens[v] = v < nb ? Cs[v]->gen : 0;
@@ -1671,9 +1719,12 @@ static int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
     WtaParams w{};
     if (padded) {
         w.C = c->last_pad_c8 ? nullptr : (const float *)c->padf[slot].p + pix0 * L;
-        w.C8 = c->last_pad_c8 ? (const uint8_t *)c->pad8[slot].p + pix0 * L : nullptr;
+        w.cbytes = c->last_pad_c8 ? c->last_pad_cb : 1;
+        w.C8 = c->last_pad_c8 ? (const uint8_t *)c->pad8[slot].p + pix0 * L * w.cbytes : nullptr;
     } else {
-        w.C8 = (C->c8_state == 2 && c->force_build != 1) ? C->d8 + pix0 * L : nullptr;
+        // (two-byte costs: the exact k_wta instances and k_wta_q read them -- label counts of the compact pass kernels)
+        w.cbytes = C->cbytes;
+        w.C8 = (C->c8_state == 2 && c->force_build != 1) ? C->d8 + pix0 * L * w.cbytes : nullptr;
         if (!w.C8)
             if (int r = ensure_f32(c, C)) return r;
         w.C = C->d ? C->d + pix0 * L : nullptr;

@@ -201,7 +201,8 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
     const int x = (int)(pix % P.nx), y = (int)(pix / P.nx);
     const long long vpix = (long long)P.vnx * P.vny;
     float *Cp = P.C ? P.C + pix * P.L : nullptr;  // nullptr: only the compact copy is wanted
-    uint8_t *Cp8 = P.C8 ? P.C8 + pix * P.L : nullptr;
+    uint8_t *Cp8 = P.C8 ? P.C8 + pix * P.L * P.cbytes : nullptr;
+    const bool two = P.cbytes == 2;  // (the compact copy holds two bytes per cost)
     const bool yin = (y < P.vny);  // q.y = p.y >= 0 always
     bool anyfinite = false, bad8 = false, nanv = false;
     int rl = 0, rh = P.L - 1;  // the pixel's own label range (ragged volumes)
@@ -214,7 +215,10 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
         float e = P.trunc;
         if (o < rl || o > rh) {  // not a label of this pixel
             if (Cp) Cp[o] = __builtin_huge_valf();
-            if (Cp8) Cp8[o] = 255;
+            if (Cp8) {
+                if (two) reinterpret_cast<unsigned short *>(Cp8)[o] = 65535;
+                else Cp8[o] = 255;
+            }
             continue;
         }
         if (yin && qx >= 0 && qx < P.vnx) {
@@ -252,9 +256,15 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
         anyfinite |= finite_bits(e);
         nanv |= e != e;  // (only a NaN truncDist gets here: a NaN cost loses the comparison above)
         if (Cp8) {
-            const unsigned b = c8_encode(e);
-            bad8 |= b > 255u;
-            Cp8[o] = (uint8_t)b;
+            if (two) {
+                const unsigned b = c16_encode(e);
+                bad8 |= b > 65535u;
+                reinterpret_cast<unsigned short *>(Cp8)[o] = (unsigned short)b;
+            } else {
+                const unsigned b = c8_encode(e);
+                bad8 |= b > 255u;
+                Cp8[o] = (uint8_t)b;
+            }
         }
     }
     // no valid hypothesis for this pixel => all labels cost 0 (mgm_costvolume.h:414-421)
@@ -262,7 +272,10 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
         for (int o = lane; o < P.L; o += 64) {
             if (o < rl || o > rh) continue;
             if (Cp) Cp[o] = 0.0f;
-            if (Cp8) Cp8[o] = 0;
+            if (Cp8) {
+                if (two) reinterpret_cast<unsigned short *>(Cp8)[o] = 0;
+                else Cp8[o] = 0;
+            }
         }
     else if (Cp8 && __builtin_amdgcn_ballot_w64(bad8) != 0ull && lane == 0)
         flag_once(P.bad8, 1u);
@@ -338,7 +351,7 @@ hipError_t launch_expand(const uint8_t *C8, long long n, float *C, hipStream_t s
 // [pix][L] -> [pix][LP] (LP > L, a multiple of 64): the label slots L..LP-1 get +INF, i.e. "no such label" (dvec.cc:129).
 // Writes the fp32 copy and/or the compact copy (with its "not representable" flag).  One wave per pixel.
 __global__ void __launch_bounds__(256) k_pad(const float *__restrict__ C, long long npix, int L, int LP, float *__restrict__ Cp,
-                                             uint8_t *__restrict__ C8p, unsigned *bad8)
+                                             uint8_t *__restrict__ C8p, int cbytes, unsigned *bad8)
 {
     const int lane = threadIdx.x & 63;
     bool bad = false;
@@ -347,19 +360,25 @@ __global__ void __launch_bounds__(256) k_pad(const float *__restrict__ C, long l
             const float x = o < L ? C[pix * L + o] : __builtin_huge_valf();
             if (Cp) Cp[pix * LP + o] = x;
             if (C8p) {
-                const unsigned b = c8_encode(x);
-                bad |= b > 255u;
-                C8p[pix * LP + o] = (uint8_t)b;
+                if (cbytes == 2) {
+                    const unsigned b = c16_encode(x);
+                    bad |= b > 65535u;
+                    reinterpret_cast<unsigned short *>(C8p)[pix * LP + o] = (unsigned short)b;
+                } else {
+                    const unsigned b = c8_encode(x);
+                    bad |= b > 255u;
+                    C8p[pix * LP + o] = (uint8_t)b;
+                }
             }
         }
     if (C8p && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) flag_once(bad8, 1u);
 }
 
-hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, unsigned *bad8, hipStream_t s)
+hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, int cbytes, unsigned *bad8, hipStream_t s)
 {
     long long nb = (npix + 3) / 4;
     if (nb > 256 * 32) nb = 256 * 32;
-    hipLaunchKernelGGL(k_pad, dim3((unsigned)nb), dim3(256), 0, s, C, npix, L, LP, Cp, C8p, bad8);
+    hipLaunchKernelGGL(k_pad, dim3((unsigned)nb), dim3(256), 0, s, C, npix, L, LP, Cp, C8p, cbytes, bad8);
     return hipGetLastError();
 }
 

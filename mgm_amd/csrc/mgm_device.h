@@ -40,7 +40,8 @@ struct PassGeom {
 constexpr int kMaxBatch = 16;
 struct PassVolume {
     const float *C;     // [npix][L]
-    const uint8_t *C8;  // [npix][L] compact costs (integers 0..254, 255 = +INF) or nullptr (all volumes alike)
+    const uint8_t *C8;  // [npix][L] compact costs, PassParams::cbytes bytes each (integers, all-ones = +INF: c8_encode /
+                        // c16_encode) or nullptr (all volumes alike)
     float *Lr;          // NDIR volumes, pass p at Lr + (p - pass0)*nvol
     const float *w8;    // 8 planes [npix] or nullptr (all volumes alike)
     const float *rlo, *rhi;  // ragged volume: per-pixel range images (only the weighted FH kernels read them), or nullptr
@@ -69,6 +70,7 @@ struct PassParams {
     int wg_per_cu;            // 1 or 2 workgroups per compute unit (second build; see launch2_c8)
     int deep;                 // 1: the build with deeper DMA rings (k_pass2, DEEP; compact unweighted kernels)
     int oneb;                 // 1: the queue kernels built for one band per CU (k_pass2, ONEB: no 64-VGPR cap)
+    int cbytes;               // bytes per compact cost of PassVolume::C8 (1 or 2)
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA, 4 ignore
                               // inter-band waits, 8 skip step barriers, 16 Lr stores into a cache-resident window (-DMGM_P2_XFLAG16 builds only); all of them need a -DMGM_P2_DEV=1 build
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
@@ -85,6 +87,7 @@ struct PassParams {
 struct WtaParams {
     const float *C;
     const uint8_t *C8;  // compact copy of C (see PassParams) or nullptr
+    int cbytes;         // bytes per compact cost (1 or 2)
     const float *Lr;    // NDIR volumes
     float *S;           // nullptr or corrected volume out
     float *out, *outcost;
@@ -131,7 +134,7 @@ hipError_t launch_pass2_lpl(const PassParams &p, int ntasks, bool fh, int wmode,
 inline bool c8_supported(int L) { return L == 64 || L == 128 || L == 192 || L == 256 || L == 384 || L == 512 || L == 768 || L == 1024; }
 hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s);
 hipError_t launch_nanscan(const float *C, long long n, unsigned *flag, hipStream_t s);
-hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, unsigned *bad8, hipStream_t s);
+hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, int cbytes, unsigned *bad8, hipStream_t s);
 hipError_t launch_expand(const uint8_t *C8, long long n, float *C, hipStream_t s);
 hipError_t launch_wta(const WtaParams &p, hipStream_t s);
 hipError_t launch_median(const float *u, int nx, int ny, int nch, int radius, float *out, hipStream_t s);
@@ -149,6 +152,7 @@ struct CostParams {
     const uint32_t *cu, *cv;     // census words (planar) when prefiltered
     float *C;
     uint8_t *C8;                 // compact copy, written alongside C
+    int cbytes;                  // its bytes per cost (1 or 2)
     unsigned *bad8;              // set to 1 if some cost is not representable in the compact form
     int nx, ny, vnx, vny, nch;   // nch = channels of the (prefiltered) images
     int dmin, L;
@@ -196,6 +200,17 @@ __device__ __forceinline__ unsigned c8_encode(float x)
     return (x >= 0.0f && x <= 254.0f && r == x && !neg0) ? (unsigned)r : 256u;
 }
 __device__ __forceinline__ float c8_decode(unsigned b) { return b == 255u ? __builtin_huge_valf() : (float)b; }
+// The same with TWO bytes per cost (round 4): integers in [0, 65534] or +INF (65535) -- absolute differences summed over
+// the channels of a colour pair (up to 765), squared differences of one channel (up to 65025).  Returns 65536 if x is not
+// representable.  cb = bytes per compact cost (1 or 2) picks between the two forms.
+__device__ __forceinline__ unsigned c16_encode(float x)
+{
+    if (x == __builtin_huge_valf()) return 65535u;
+    const float r = __builtin_rintf(x);
+    const bool neg0 = __builtin_bit_cast(unsigned, x) == 0x80000000u;
+    return (x >= 0.0f && x <= 65534.0f && r == x && !neg0) ? (unsigned)r : 65536u;
+}
+__device__ __forceinline__ float c16_decode(unsigned h) { return h == 65535u ? __builtin_huge_valf() : (float)h; }
 
 // DPP lane shifts over the whole wave (gfx9 wave_shr / wave_shl).
 // shr1: lane l receives lane l-1 (lane 0 gets `fill`).

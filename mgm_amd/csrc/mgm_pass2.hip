@@ -174,13 +174,14 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 ? 2 : (LPL + 3) / 
 #define MGM_P2_LEAD 2
 #endif
 // ---- geometry of the build --------------------------------------------------------
-template <int LPL, int NS, bool HASM, bool C8, int MAXD = MGM_P2_MAXD, int EXTRA = 0>
+template <int LPL, int NS, bool HASM, int C8, int MAXD = MGM_P2_MAXD, int EXTRA = 0>
 struct Plan {
     static constexpr int LP = LPL * 64;
     static constexpr int IPS = (LPL * 16 + 63) / 64;  // DMA pieces per fp32 slab
     // compact costs: a slab is LP bytes = LPS lanes of one DMA piece, so one 64-lane piece carries the
     // slabs of LPD different lines (every lane has its own source address)
-    static constexpr int LPS = LPL * 4;
+    // (C8 = bytes per compact cost: 1, or 2 since round 4 -- 0: fp32 costs)
+    static constexpr int LPS = LPL * 4 * (C8 ? C8 : 1);
     static constexpr int LPD = C8 ? 64 / LPS : 1;
     static constexpr int NL = (LPL <= 4 && MGM_P2_NC > 7) ? (C8 ? MGM_P2_C8_NL : 2) : 1;  // loader waves
     static constexpr int NC = (LPL <= 4) ? (C8 ? MGM_P2_C8_NC : MGM_P2_NC) : 7;   // compute waves = lines per band
@@ -287,7 +288,7 @@ __device__ __forceinline__ void combine_w2(const float (&C)[LPL], const Nb<LPL, 
 // twelve 256-label volumes 48.5 -> 48.2.  The default of every compact unweighted launch (mgm_api.hip, run_passes); the
 // shallow build stays for A/B runs (MGM_HIP_DEEP=0).
 // where the work-item word lives in the workgroup's LDS (the layout of pass2_item, below)
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, bool DEEP, bool W2 = false>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, int C8, bool DEEP, bool W2 = false>
 struct P2Lds {
     static constexpr int NS = (W2 || (WEIGHTED && !FH)) ? 2 : 1;
     static constexpr bool pubE = W2 || (!WEIGHTED && !(FH && MGM == 2));
@@ -296,12 +297,13 @@ struct P2Lds {
     static constexpr int task_off = PL::NC * PL::RT * NS * PL::LP + RD * NS * PL::LP + PL::cring_floats(RD) + PL::NC * PL::RT + RD + RD;  // floats
 };
 
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV, bool DEEP, bool XCDQ, bool W2 = false>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, int C8, int SUBV, bool DEEP, bool XCDQ, bool W2 = false>
 __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket)
 {
     static_assert(!W2 || (!WEIGHTED && C8 && DEEP && SUBV == 1 && LPL <= 4), "two-valued weights: the compact kernels with deep rings");
     static_assert(!DEEP || (C8 && !WEIGHTED && (W2 || !(FH && MGM == 2))), "the deep rings exist for the compact kernels that publish E");
-    static_assert(SUBV == 1 || (LPL == 4 && C8 && !WEIGHTED && !(FH && MGM == 2)), "volumes share a wave only in the compact unweighted kernels that publish E");
+    static_assert(SUBV == 1 || (LPL == 4 && C8 == 1 && !WEIGHTED && !(FH && MGM == 2)), "volumes share a wave only in the compact unweighted kernels that publish E");
+    static_assert(!W2 || C8 == 1, "two-valued weights: one byte per cost");
     constexpr int LANES = 64 / SUBV;  // lanes per volume
     constexpr int NS = (W2 || (WEIGHTED && !FH)) ? 2 : 1;
     constexpr bool pubE = W2 || (!WEIGHTED && !(FH && MGM == 2));  // slabs carry E = T - m; minima not needed
@@ -409,7 +411,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
         constexpr int NPIECE = C8 ? NDMA : LPW;
         const float *cptr[NPIECE];
         int ci[NPIECE];
-        const long long cstride = C8 ? (istep * L) / 4 : istep * L;  // in floats (compact: L bytes per pixel)
+        const long long cstride = C8 ? (istep * L * C8) / 4 : istep * L;  // in floats (compact: L * C8 bytes per pixel)
 #pragma unroll
         for (int q = 0; q < NPIECE; q++) {
             int r = C8 ? q * LPD + lane / LPS : r0 + q;
@@ -421,8 +423,8 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                 const int chunk = lane % LPS;
                 const uint8_t *c8 = P.vol[vgrp + chunk / CPV].C8;
                 cptr[q] = reinterpret_cast<const float *>(c8 + (gbase + (long long)j * g.jstep) * L + (chunk % CPV) * 16);
-            } else if constexpr (C8)
-                cptr[q] = reinterpret_cast<const float *>(V.C8 + (gbase + (long long)j * g.jstep) * L + (lane % LPS) * 16);
+            } else if constexpr (C8 != 0)
+                cptr[q] = reinterpret_cast<const float *>(V.C8 + (gbase + (long long)j * g.jstep) * L * C8 + (lane % LPS) * 16);
             else
                 cptr[q] = V.C + (gbase + (long long)j * g.jstep) * L + lane * 4;
             ci[q] = -1 - SL * r;
@@ -578,7 +580,8 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
 #pragma unroll
                 for (int q = 0; q < NDMA; q++) {
                     const u32x4 v = lds_read_b128_opaque(Cring + (vslot * NDMA + q) * 256 + lane * 4);
-                    auto ff = [](unsigned w) { return ((~w) - 0x01010101u) & w & 0x80808080u; };  // != 0 iff a byte of w is 0xFF
+                    // != 0 iff a byte (two-byte costs: an aligned halfword) of w is all ones, the +INF code
+                    auto ff = [](unsigned w) { return C8 == 2 ? (((~w) - 0x00010001u) & w & 0x80008000u) : (((~w) - 0x01010101u) & w & 0x80808080u); };
                     const unsigned long long bal = __builtin_amdgcn_ballot_w64((ff(v.x) | ff(v.y) | ff(v.z) | ff(v.w)) != 0u);
                     const int line = q * LPD + lane;
                     if (lane < LPD && line < NC)
@@ -650,7 +653,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
     const float *fwd_m0 = r > 0 ? Tm + (r - 1) * RT : Hm;
     // fp32: own ring [RD][LP]; compact: byte (r%LPD)*LPS*16 + lane*LPL of piece r/LPD of the step's slot
     const float *c_src0 = C8 ? Cring + (r / LPD) * 256 : Cring + r * RD * LP + lane * LPL;
-    const int c8_byte = (r % LPD) * LPS * 16 + lane * LPL;
+    const int c8_byte = (r % LPD) * LPS * 16 + lane * LPL * (C8 ? C8 : 1);
     float *t_dst0 = Tring + r * RT * NSLP + lane * LPL;
 
     // The whole line walk, specialised on the neighbour order of the pass (FORM).
@@ -697,7 +700,37 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                 long long pix = 0;
                 if constexpr (WEIGHTED || MGM_P2_DEV) pix = pix0 + (long long)i * istep;
                 float Cv[LPL], Lv[LPL];
-                if constexpr (C8) {
+                if constexpr (C8 == 2) {
+                    // two bytes per cost: convert the halfwords; the +INF code (all ones) is patched in only where the slab
+                    // holds one -- flagged by the loader (FH kernels) or found by the wave itself
+                    const unsigned char *src = reinterpret_cast<const unsigned char *>(c_src0 + cslot * NDMA * 256) + c8_byte;
+                    unsigned hv[LPL];
+                    if constexpr (LPL % 2 == 0) {
+#pragma unroll
+                        for (int h = 0; h < LPL / 2; h++) {
+                            const unsigned w = reinterpret_cast<const unsigned *>(src)[h];
+                            hv[2 * h] = w & 65535u;
+                            hv[2 * h + 1] = w >> 16;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) hv[k] = reinterpret_cast<const unsigned short *>(src)[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < LPL; k++) Cv[k] = (float)hv[k];
+                    bool patch;
+                    if constexpr (CFLAG) patch = __builtin_amdgcn_readfirstlane((int)Cflag[cslot * 16 + r]) != 0;
+                    else {
+                        bool any = false;
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) any |= hv[k] == 65535u;
+                        patch = __builtin_amdgcn_ballot_w64(any) != 0ull;
+                    }
+                    if (patch) {
+#pragma unroll
+                        for (int k = 0; k < LPL; k++) Cv[k] = hv[k] == 65535u ? f_inf() : Cv[k];
+                    }
+                } else if constexpr (C8 == 1) {
                     const unsigned char *src = reinterpret_cast<const unsigned char *>(c_src0 + cslot * NDMA * 256) + c8_byte;
                     // (wave-uniform) no +INF code in this slab: the bytes are the costs
                     const bool plain = CFLAG && __builtin_amdgcn_readfirstlane((int)Cflag[cslot * 16 + r]) == 0;
@@ -999,7 +1032,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
 // unweighted kernels are otherwise capped at 64 VGPRs so that two bands fit a CU, and under that cap every FH instance
 // with the queue loop spilled 9-14 VGPRs (40-52 bytes of scratch per lane) and ~50 SGPRs -- scratch traffic and
 // v_readlane restores on the critical chain of exactly the launches that are bound by the length of a step.
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false, bool ONEB = false, bool W2 = false>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, int C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false, bool ONEB = false, bool W2 = false>
 __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, true, C8>::NL) * 64,
                                   (LPL >= 12 ? 2 : ONEB ? MGM_P2_ONEB_WPE : (C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
 {
@@ -1035,7 +1068,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 }
 
 // ---- launcher (one translation unit per LPL: -DMGM_P2_LPL=n) -----------------------
-template <int LPL, bool FH, bool WEIGHTED, int MGM, bool C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false, bool ONEB = false, bool W2 = false>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, int C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false, bool ONEB = false, bool W2 = false>
 static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 {
     using PL = typename P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP, W2>::PL;
@@ -1069,6 +1102,17 @@ static hipError_t launch2_one(const PassParams &p, int ntasks, hipStream_t s)
         }
     }
     if (p.subv > 1) return hipErrorInvalidValue;
+    if constexpr (!WEIGHTED && !(FH && MGM == 2) && LPL <= 8)
+        if (p.vol[0].C8 && p.cbytes == 2) {  // two bytes per cost (round 4): the kernels with deep rings only
+            if (!p.deep) return hipErrorInvalidValue;
+            if constexpr (!MGM_P2_DEV) {
+                if (p.xcdq && p.oneb) return launch2_c8<LPL, FH, WEIGHTED, MGM, 2, 1, true, true, true>(p, ntasks, s);
+                if (p.xcdq) return launch2_c8<LPL, FH, WEIGHTED, MGM, 2, 1, true, true, false>(p, ntasks, s);
+            }
+            if (p.xcdq) return hipErrorInvalidValue;
+            return launch2_c8<LPL, FH, WEIGHTED, MGM, 2, 1, true>(p, ntasks, s);
+        }
+    if (p.vol[0].C8 && p.cbytes == 2) return hipErrorInvalidValue;
     if constexpr (!WEIGHTED && !(FH && MGM == 2))
         if (p.vol[0].C8 && p.deep) {
             if constexpr (!MGM_P2_DEV) {

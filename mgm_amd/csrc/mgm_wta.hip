@@ -64,7 +64,11 @@ __global__ void __launch_bounds__(256) k_wta(const WtaParams P)
 #pragma unroll
         for (int u = 0; u < PPW; u++) {
             const long long g = g0 + u < nslab ? g0 + u : nslab - 1;
-            if (c8) {
+            if (c8 && P.cbytes == 2) {  // (two bytes per cost: absolute differences of colour pairs, ...)
+                const unsigned short *q = reinterpret_cast<const unsigned short *>(P.C8) + g * Ls + m0;
+#pragma unroll
+                for (int k = 0; k < LPL; k++) c[u][k] = c16_decode(q[k]);
+            } else if (c8) {
                 const uint8_t *q = P.C8 + g * Ls + m0;
 #pragma unroll
                 for (int k = 0; k < LPL; k++) c[u][k] = c8_decode(q[k]);
@@ -215,7 +219,11 @@ __global__ void __launch_bounds__(256) k_wta_q(const WtaParams P)
         float c[3][4], l[MAXD][3][4];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            if (c8) {
+            if (c8 && P.cbytes == 2) {
+                const uint2 w = *reinterpret_cast<const uint2 *>(P.C8 + (g * 768 + 256 * j + 4 * lane) * 2);
+                c[j][0] = c16_decode(w.x & 65535u); c[j][1] = c16_decode(w.x >> 16);
+                c[j][2] = c16_decode(w.y & 65535u); c[j][3] = c16_decode(w.y >> 16);
+            } else if (c8) {
                 const unsigned w = *reinterpret_cast<const unsigned *>(P.C8 + g * 768 + 256 * j + 4 * lane);
 #pragma unroll
                 for (int k = 0; k < 4; k++) c[j][k] = c8_decode((w >> (8 * k)) & 255u);
@@ -337,7 +345,9 @@ __global__ void __launch_bounds__(256) k_wta_any(const WtaParams P)
         auto S_at = [&](int o) {
             float a = 0.0f;
             for (int p = 0; p < P.NDIR; p++) a = a + P.Lr[(long long)p * P.nvol + pix * L + o];
-            if (P.FIX == 1) a = a - f * (P.C8 ? c8_decode(P.C8[pix * L + o]) : P.C[pix * L + o]);
+            if (P.FIX == 1)
+                a = a - f * (!P.C8 ? P.C[pix * L + o]
+                                   : (P.cbytes == 2 ? c16_decode(reinterpret_cast<const unsigned short *>(P.C8)[pix * L + o]) : c8_decode(P.C8[pix * L + o])));
             if (o < cl || o > ch) a = vout;
             return a;
         };

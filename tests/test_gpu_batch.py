@@ -84,9 +84,8 @@ def test_batch_survives_a_real_out_of_memory(oracle):
     nb = 8
     per_vol = 4.0 * nx * ny * L * NDIR * 1.08
     c = mgm_amd.Context(0)
-    ballast = []
+    ballast, dus, dvs, cvs = [], [], [], []
     try:
-        dus, dvs, cvs = [], [], []
         for b in range(nb):
             u, v, _ = synth.stereo_pair(nx, ny, -190, 0, seed=777 + b)
             dus.append(c.upload_image(u))
@@ -116,5 +115,8 @@ def test_batch_survives_a_real_out_of_memory(oracle):
         # and the next call -- a plain one that fits -- must not inherit an error either
         _, o1, c1 = c.aggregate_dev(cvs[0], 2.0, 20000.0, NDIR, MGM, 1, 1, None, "vfit")
         assert ndiff(o1.download(), outs[0].download()) == 0
+        ballast += [o1, c1] + list(outs) + list(outcs)
     finally:
+        for h in ballast + dus + dvs + cvs:  # (images and volumes are the caller's: closing the context does not free them)
+            h.free()
         c.close()

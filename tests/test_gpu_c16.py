@@ -1,0 +1,88 @@
+"""Two-byte compact costs (round 4): absolute differences of colour pairs (up to 765) and squared differences (up to 65025) are
+integers that do not fit the one-byte form; K2 writes them as 16-bit words next to the fp32 volume, the unweighted pass kernels
+with deep rings and k_wta read those (half the cost traffic of fp32).  Everything against the oracle, bit for bit: the cost
+volume, S, labels and refined maps -- at label counts of every kernel width, a count that runs padded (BASELINE config 1's 151),
+with the combinations that must fall back to the fp32 volume (weights, FH with TSGM 2) and with costs that overflow the form."""
+import numpy as np
+import pytest
+
+from helpers import ndiff
+from mgm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def threads(oracle, n=16):
+    from oracle.oracle import usable_cpus
+    oracle.set_threads(min(n, usable_cpus()))
+
+
+def run_case(ctx, oracle, nx, ny, dmin, dmax, cost, nch, NDIR, MGM, FH, P1, P2, w=None, scale=1.0, trunc=np.inf):
+    u, v, _ = synth.stereo_pair(nx, ny, dmin * 3 // 4, max(0, dmax * 3 // 4), seed=dmax - dmin + MGM, nch=nch)
+    u, v = (u * np.float32(scale)).astype(np.float32), (v * np.float32(scale)).astype(np.float32)
+    du, dv = ctx.upload_image(u), ctx.upload_image(v)
+    cv = ctx.costvolume_dev(du, dv, dmin, dmax, "none", cost, float(trunc), 3)
+    dw = ctx.upload_image(w) if w is not None else None
+    S, o, k = ctx.aggregate_dev(cv, P1, P2, NDIR, MGM, FH, 1, dw, "vfit", want_S=True)
+    threads(oracle)
+    try:
+        Ca = oracle.costvolume(u, v, dmin, dmax, "none", cost, trunc, 3)
+        Sa, oa, ca = oracle.mgm(Ca, dmin, P1, P2, NDIR, MGM, FH, 1, w)
+        ra, rca = oracle.refine(Sa, dmin, "vfit", oa, ca)
+    finally:
+        oracle.set_threads(1)
+    bad = (ndiff(cv.download(), Ca), ndiff(S.download(), Sa), ndiff(k.download()[0], rca), ndiff(o.download()[0], ra))
+    for h in (du, dv, cv, S, o, k) + ((dw,) if dw is not None else ()):
+        h.free()
+    return bad
+
+
+@pytest.mark.parametrize("L", [64, 128, 192, 256, 384, 512])
+@pytest.mark.parametrize("mode", [(8, 3, 0, 24.0, 96.0), (8, 3, 1, 6.0, 60000.0), (4, 2, 0, 24.0, 96.0), (8, 4, 1, 4.5, 40.0), (8, 1, 1, 6.0, 300.0)],
+                         ids=["O8-T3", "O8-T3-FH", "O4-T2", "O8-T4-FH", "O8-T1-FH"])
+def test_colour_absolute_differences(ctx, oracle, L, mode):
+    NDIR, MGM, FH, P1, P2 = mode
+    assert run_case(ctx, oracle, 333, 241, -(L - 1) + L // 4, L // 4, "ad", 3, NDIR, MGM, FH, P1, P2) == (0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("cost,nch,scale", [("sd", 1, 1.0), ("sd", 3, 0.5), ("ad", 3, 100.0), ("sd", 1, 2.0)],
+                         ids=["sd-grey", "sd-colour-small", "ad-overflows-two-bytes", "sd-overflows"])
+def test_squared_differences_and_overflow(ctx, oracle, cost, nch, scale):
+    """Squared differences of one channel fit two bytes; costs that do not (values beyond 65534: the flag word says so) are
+    aggregated from the fp32 volume."""
+    assert run_case(ctx, oracle, 300, 200, -100, 27, cost, nch, 8, 3, 1, 6.0, 60000.0, scale=scale) == (0, 0, 0, 0)
+
+
+def test_config1_shape_runs_padded_with_two_byte_costs(ctx, oracle):
+    """BASELINE config 1's shape: 700x500 RGB, -r -120 -R 30 (151 labels -> 192), -t ad, -O 4, TSGM 2; also truncated costs."""
+    assert run_case(ctx, oracle, 700, 500, -120, 30, "ad", 3, 4, 2, 0, 24.0, 96.0) == (0, 0, 0, 0)
+    assert run_case(ctx, oracle, 350, 250, -120, 30, "ad", 3, 8, 3, 1, 6.0, 60000.0, trunc=40.0) == (0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("kind", ["weights", "FH-TSGM2"])
+def test_combinations_that_read_the_fp32_volume(ctx, oracle, kind):
+    nx, ny = 333, 241
+    if kind == "weights":
+        rng = np.random.default_rng(3)
+        w = np.where(rng.random((8, ny, nx)) < 0.4, np.float32(4.0), np.float32(1.0)).astype(np.float32)
+        assert run_case(ctx, oracle, nx, ny, -100, 27, "ad", 3, 8, 3, 1, 6.0, 60000.0, w=w) == (0, 0, 0, 0)
+    else:
+        assert run_case(ctx, oracle, nx, ny, -100, 27, "ad", 3, 4, 2, 1, 6.0, 60.0) == (0, 0, 0, 0)
+
+
+def test_batch_of_colour_pairs(ctx, oracle):
+    nx, ny, dmin, dmax = 320, 200, -127, 0
+    cvs, Cas = [], []
+    for b in range(4):
+        u, v, _ = synth.stereo_pair(nx, ny, -90, 0, seed=60 + b, nch=3)
+        du, dv = ctx.upload_image(u), ctx.upload_image(v)
+        cvs.append(ctx.costvolume_dev(du, dv, dmin, dmax, "none", "ad", float("inf"), 3))
+        Cas.append(oracle.costvolume(u, v, dmin, dmax, "none", "ad", np.inf, 3))
+    _, outs, outcs = ctx.aggregate_batch_dev(cvs, 24.0, 96.0, 8, 3, 0, 1, None, None)
+    threads(oracle)
+    try:
+        for b in range(4):
+            Sa, oa, ca = oracle.mgm(Cas[b], dmin, 24.0, 96.0, 8, 3, 0, 1)
+            assert ndiff(outcs[b].download()[0], ca) == 0 and ndiff(outs[b].download()[0], oa) == 0, b
+    finally:
+        oracle.set_threads(1)
