@@ -268,7 +268,77 @@ static void iterate_run(mgm_ctx *ctx, const Opts &o, Run &r, int iterations, int
     mgm_img_free(ctx, dhi);
 }
 
+// The device side of the process: created for the first pair, kept for the following ones (resident mode).
+struct Session {
+    mgm_ctx *ctx = nullptr;
+    mgm_multi *multi = nullptr;
+    std::vector<int> devs;
+    bool tried = false;
+    int rc_ctx = 0;
+};
+
+static int run_pair(Session &S, int argc, char **argv, bool last);
+
+// RESIDENT MODE (round 4): `mgm --batch FILE` (FILE = - : stdin).  Every non-empty line of FILE is one command line of this
+// program without its name -- options, u, v, out [cost [backflow]] -- and all of them run in THIS process, on one device
+// context: HIP start-up (~0.1 s) and the allocation of the tens of GB of workspace are paid once, a further pair costs its
+// decoding, ~10-20 ms of device work and its encoding.  Per pair, stdout and every output file are what the one-shot
+// command writes (the environment parameters are the process's, the same for all lines); `#` starts a comment.  Exit code:
+// 0 if every line succeeded, else 1 (the remaining lines still run).
+static int run_batch(const char *file)
+{
+    FILE *f = strcmp(file, "-") ? fopen(file, "r") : stdin;
+    if (!f) {
+        fprintf(stderr, "mgm: --batch: cannot open %s\n", file);
+        return 1;
+    }
+    std::vector<std::string> lines;
+    char buf[16384];
+    while (fgets(buf, sizeof buf, f)) {
+        std::string l(buf);
+        const size_t h = l.find('#');
+        if (h != std::string::npos) l.resize(h);
+        if (l.find_first_not_of(" \t\r\n") != std::string::npos) lines.push_back(l);
+    }
+    if (f != stdin) fclose(f);
+    Session S;
+    int bad = 0;
+    for (size_t k = 0; k < lines.size(); k++) {
+        std::vector<std::string> tok{"mgm"};
+        size_t i = 0;
+        const std::string &l = lines[k];
+        while (i < l.size()) {
+            while (i < l.size() && strchr(" \t\r\n", l[i])) i++;
+            size_t j = i;
+            while (j < l.size() && !strchr(" \t\r\n", l[j])) j++;
+            if (j > i) tok.push_back(l.substr(i, j - i));
+            i = j;
+        }
+        std::vector<char *> av;
+        for (auto &t : tok) av.push_back(&t[0]);
+        av.push_back(nullptr);
+        if (run_pair(S, (int)tok.size(), av.data(), /*last=*/false) != 0) {  // (the process leaves through _exit: no teardown)
+            fprintf(stderr, "mgm: --batch: line %zu failed\n", k + 1);
+            bad = 1;
+        }
+        fflush(stdout);
+    }
+    return bad;
+}
+
 int main(int argc, char **argv)
+{
+    if (argc >= 3 && !strcmp(argv[1], "--batch")) {
+        const int r = run_batch(argv[2]);
+        fflush(stdout);
+        fflush(stderr);
+        _exit(r);  // (as the one-shot run: without the HIP runtime's exit handlers)
+    }
+    Session S;
+    return run_pair(S, argc, argv, true);
+}
+
+static int run_pair(Session &S, int argc, char **argv, bool last)
 {
     if (argc < 2 || !strcmp(argv[1], "-h")) return 0 * puts("usage:\n\tmgm [-options] u v out [cost [backflow]]");
     if (!strcmp(argv[1], "-?")) return 0 * puts("Compute stereo disparities by the MGM algorithm.");
@@ -278,7 +348,8 @@ int main(int argc, char **argv)
                         "options: -r dmin(-30) -R dmax(30) -O NDIR(4) -P1 (8) -P2 (32) -p prefilter(none) -t distance(ad)\n"
                         "         -truncDist (inf) -s subpix(none) -aP1 (1) -aP2 (1) -aThresh (5) -m FILE -M FILE -l FILE\n"
                         "environment: CENSUS_NCC_WIN=3 TESTLRRL=1 TESTLRRL_TAU=1.0 MEDIAN=0 TSGM=4 TSGM_ITER=1\n"
-                        "             TSGM_FIX_OVERCOUNT=1 USE_TRUNCATED_LINEAR_POTENTIALS=0 MGM_DEVICE=0 MGM_DEVICES=0,1,...");
+                        "             TSGM_FIX_OVERCOUNT=1 USE_TRUNCATED_LINEAR_POTENTIALS=0 MGM_DEVICE=0 MGM_DEVICES=0,1,...\n"
+                        "resident mode: mgm --batch FILE|-   (one such command line per line of FILE, one device context for all)");
     if (argc < 4) {
         fprintf(stderr, "too few parameters\n   usage: %s  [-r dmin -R dmax] [-m dminImg -M dmaxImg] [-O NDIR: 2, (4), 8] u v out "
                         "[cost [backflow]]\n", argv[0]);
@@ -328,28 +399,37 @@ int main(int argc, char **argv)
         std::exception_ptr eu, ev;
         std::thread tu([&] { try { u = imgio::read(f_u); remove_nonfinite(u, 0); } catch (...) { eu = std::current_exception(); } });
         std::thread tv([&] { try { v = imgio::read(f_v); remove_nonfinite(v, 0); } catch (...) { ev = std::current_exception(); } });
-        mgm_ctx *ctx = nullptr;
-        mgm_multi *multi = nullptr;
         int rc;
-        std::vector<int> devs;
-        if (const char *dl = getenv("MGM_DEVICES"))  // "0,1,2,3": several GPUs of this node
-            for (const char *q = dl; *q;) {
-                char *end;
-                const long d = strtol(q, &end, 10);
-                if (end == q) break;
-                devs.push_back((int)d);
-                q = *end == ',' ? end + 1 : end;
+        if (!S.tried) {  // (resident mode: the first pair brings the device side up, the others find it there)
+            S.tried = true;
+            if (const char *dl = getenv("MGM_DEVICES"))  // "0,1,2,3": several GPUs of this node
+                for (const char *q = dl; *q;) {
+                    char *end;
+                    const long d = strtol(q, &end, 10);
+                    if (end == q) break;
+                    S.devs.push_back((int)d);
+                    q = *end == ',' ? end + 1 : end;
+                }
+            if (S.devs.size() > 1 && (ITER > 1 || min_file[0])) {
+                fprintf(stderr, "mgm: MGM_DEVICES: TSGM_ITER > 1 and range images run on the first device only\n");
+                S.devs.resize(1);
             }
-        if (devs.size() > 1 && (ITER > 1 || min_file[0])) {
-            fprintf(stderr, "mgm: MGM_DEVICES: TSGM_ITER > 1 and range images run on the first device only\n");
-            devs.resize(1);
+            if (S.devs.size() > 1) {
+                if ((S.rc_ctx = mgm_multi_create(S.devs.data(), (int)S.devs.size(), &S.multi)) == 0) S.ctx = mgm_multi_ctx(S.multi, 0);
+            } else {
+                S.rc_ctx = mgm_ctx_create(S.devs.size() == 1 ? S.devs[0] : (int)env_param("MGM_DEVICE", 0), &S.ctx);
+            }
         }
-        int rc_ctx;
-        if (devs.size() > 1) {
-            if ((rc_ctx = mgm_multi_create(devs.data(), (int)devs.size(), &multi)) == 0) ctx = mgm_multi_ctx(multi, 0);
-        } else {
-            rc_ctx = mgm_ctx_create(devs.size() == 1 ? devs[0] : (int)env_param("MGM_DEVICE", 0), &ctx);
+        mgm_ctx *ctx = S.ctx;
+        mgm_multi *multi = S.multi;
+        if (multi && min_file[0]) {
+            fprintf(stderr, "mgm: --batch with MGM_DEVICES: range images are not supported on several devices\n");
+            tu.join();
+            tv.join();
+            return 1;
         }
+        const std::vector<int> &devs = S.devs;
+        const int rc_ctx = S.rc_ctx;
         sw.mark("context");
         tu.join();
         tv.join();
@@ -456,8 +536,11 @@ int main(int argc, char **argv)
         std::thread teardown([&] {
             free_run(ctx, L);
             free_run(ctx, R);
+            if (!last) return;  // (resident mode: the context and its workspace stay for the next pair)
             if (multi) mgm_multi_destroy(multi);
             else mgm_ctx_destroy(ctx);
+            S.ctx = nullptr;
+            S.multi = nullptr;
         });
         std::exception_ptr ew;
         try {
@@ -476,7 +559,7 @@ int main(int argc, char **argv)
         // code objects, closing the device: tens of ms that produce nothing).  MGM_HIP_ORDERLY_EXIT=1 keeps them.
         fflush(stdout);
         fflush(stderr);
-        if (!(getenv("MGM_HIP_ORDERLY_EXIT") && atoi(getenv("MGM_HIP_ORDERLY_EXIT")))) _exit(0);
+        if (last && !(getenv("MGM_HIP_ORDERLY_EXIT") && atoi(getenv("MGM_HIP_ORDERLY_EXIT")))) _exit(0);
     } catch (const std::exception &e) {
         fprintf(stderr, "mgm: %s\n", e.what());
         return 1;

@@ -311,3 +311,40 @@ def test_cli_random_options_match_reference(seed, tmp_path):
     if FUZZ_N:  # long campaigns: do not let thousands of test directories pile up on the box
         import shutil
         shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference CLI (oracle/_ref/mgm) was not built")
+def test_resident_batch_mode_matches_reference_pair_by_pair(tmp_path):
+    """`mgm --batch FILE`: several command lines in ONE process on one device context (round 4).  Per pair, stdout and every
+    output file must be what the reference binary gives for that command line run on its own -- different sizes, costs,
+    potentials and weights in turn, so that the context's workspace, task tables and hand-off slots are reused across
+    geometries."""
+    env = dict(MEDIAN="1", CENSUS_NCC_WIN="3", USE_TRUNCATED_LINEAR_POTENTIALS="1", TSGM="3")
+    jobs = [("a", 112, 72, 1, "-P2 20000 -P1 2 -r -20 -R 12 -t census -s vfit -O 8"),
+            ("b", 96, 80, 3, "-r -16 -R 8 -t ad -O 4 -s parabola"),
+            ("c", 112, 72, 1, "-P2 20000 -P1 2 -r -20 -R 12 -t census -s vfit -O 8 -aP2 4 -aThresh 12"),
+            ("d", 64, 48, 1, "-r -12 -R 9 -t ncc -O 8 -s cubic"),
+            ("e", 112, 72, 1, "-P2 20000 -P1 2 -r -20 -R 12 -t census -s vfit -O 8")]
+    lines, ref_stdout = [], ""
+    for tag, nx, ny, nch, args in jobs:
+        u, v, _ = synth.stereo_pair(nx, ny, -16, 8, seed=50 + len(lines), nch=nch)
+        np.save(tmp_path / (tag + "_u.npy"), np.ascontiguousarray(u.transpose(1, 2, 0)) if nch > 1 else u[0])
+        np.save(tmp_path / (tag + "_v.npy"), np.ascontiguousarray(v.transpose(1, 2, 0)) if nch > 1 else v[0])
+        files = lambda who: [str(tmp_path / (tag + "_u.npy")), str(tmp_path / (tag + "_v.npy"))] + [str(tmp_path / ("%s_%s_%s.npy" % (who, tag, k))) for k in ("disp", "cost", "back")]
+        r = subprocess.run([REF] + args.split() + files("ref"), env=dict(os.environ, OMP_NUM_THREADS="4", **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        ref_stdout += r.stdout
+        lines.append(" ".join(args.split() + files("ours")) + ("   # pair %s" % tag))
+    (tmp_path / "list.txt").write_text("# five pairs, one process\n\n" + "\n".join(lines) + "\n")
+    r = subprocess.run([OURS, "--batch", str(tmp_path / "list.txt")], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == ref_stdout, "stdout differs"
+    for tag, nx, ny, nch, args in jobs:
+        for k in ("disp", "cost", "back"):
+            a, b = np.load(tmp_path / ("ref_%s_%s.npy" % (tag, k))), np.load(tmp_path / ("ours_%s_%s.npy" % (tag, k)))
+            assert a.shape == b.shape and ndiff(a, b) == 0, (tag, k)
+    # a line that fails (missing file) does not stop the others, and the exit code says so
+    (tmp_path / "list2.txt").write_text(lines[0] + "\n-r -4 -R 4 /nonexistent/u.npy /nonexistent/v.npy " + str(tmp_path / "x.npy") + "\n" + lines[4] + "\n")
+    r = subprocess.run([OURS, "--batch", str(tmp_path / "list2.txt")], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1 and "line 2 failed" in r.stderr
+    assert ndiff(np.load(tmp_path / "ours_e_disp.npy"), np.load(tmp_path / "ref_e_disp.npy")) == 0
