@@ -388,7 +388,7 @@ class Env:
             if not torch.cuda.is_available():
                 sys.exit("bench.py needs an MI355X: there is no CPU path in mgm_amd")
             torch.cuda.set_device(self.local)
-        if self.world > 1 or args.mode == "directions":
+        if self.world > 1 or args.mode in ("directions", "pairs2"):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
@@ -644,6 +644,10 @@ def directions_legs(env, name, steps, warmup, timeout_s, transports=("single", "
                         res["peer"]["differs_from_single"] = nd(po, ref["o"]) + nd(pc, ref["c"])
                     else:
                         ref["o"], ref["c"] = po, pc
+                    try:  # what the links of this node carry, device to device (DESIGN.md section 6 assumes 153 GB/s)
+                        res["peer"]["link_probe"] = mdist.peer_copy_probe(world)
+                    except Exception as e:  # noqa: BLE001
+                        res["peer"]["link_probe"] = {"error": repr(e)[:200]}
                 finally:
                     m.close()
             except Exception as e:  # noqa: BLE001
@@ -653,6 +657,16 @@ def directions_legs(env, name, steps, warmup, timeout_s, transports=("single", "
     if "rccl" in transports and world > 1:
         variants = [("rccl", False)] + ([("rccl_overlap", True)] if mdist.n_rounds(NDIR, world) > 1 else [])
         cv = None
+        try:  # the links as the exchange will use them: every rank to rank+d at once (guarded by the leg's own time-out)
+            lp = mdist.link_probe(dist, None, "cuda", 256, 3, min(60.0, timeout_s))
+            if rank == 0:
+                res["rccl_link_probe"] = lp
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                res["rccl_link_probe"] = {"error": repr(e)[:200]}
+            if isinstance(e, mdist.ExchangeTimeout):
+                res["rccl"] = {"error": "link probe timed out: " + repr(e)[:200], "fatal": True}
+                variants = []
         for key, overlap in variants:
             stats, err, got = {}, None, None
             try:
@@ -683,6 +697,7 @@ def directions_legs(env, name, steps, warmup, timeout_s, transports=("single", "
             pn = "k_pass2" if "k_pass2" in a else "k_pass"
             res[key] = {"value": steps / dt, "ms_per_volume": dt / steps * 1e3, "rccl_ranks": world, "overlap": overlap, "k2_ms": a.get("k_cost"),
                         "k3_ms": a.get(pn), "passes_ms": stats.get("passes_ms", 0.0) / n, "exchange_ms": stats.get("exchange_ms", 0.0) / n,
+                        "exchange_rounds": mdist.n_rounds(NDIR, world), "exchange_ms_per_round": stats.get("exchange_ms", 0.0) / n / max(1, mdist.n_rounds(NDIR, world)),
                         "wta_ms": stats.get("wta_ms", 0.0) / n, "gather_ms": stats.get("gather_ms", 0.0) / n,
                         "what": "one process per GPU; rank 0's stage times (torch events on the library's stream): its passes, the wait for the "
                                 "slabs after them, its rows' ordered sum + WTA + vfit, the all-gather of the rows"}
@@ -691,12 +706,86 @@ def directions_legs(env, name, steps, warmup, timeout_s, transports=("single", "
         if cv is not None:
             cv.free()
     du.free(), dv.free()
+    if rank == 0:
+        # DESIGN.md section 6's model next to what was measured: its single-GPU terms from THIS run's `single` leg where they
+        # exist, its link rate from the probes (the assumed 153 GB/s otherwise)
+        sg = res.get("single", {}) if isinstance(res.get("single"), dict) else {}
+        lp = res.get("rccl_link_probe", {}) if isinstance(res.get("rccl_link_probe"), dict) else {}
+        link = lp.get("min") or ((res.get("peer", {}).get("link_probe", {}) or {}).get("min") if isinstance(res.get("peer"), dict) else None) or 153.0
+        k3_one = {1: 7.8, 2: 8.5, 4: 14.0, 8: sg.get("k3_ms") or 26.5}  # ms, measured on one GPU (profiles/r03_cfg4_pass_blocks.txt)
+        res["model"] = {"what": "DESIGN.md section 6: K2 + K3(passes per rank) + exchange over one link + k_wta on 1/n of the rows",
+                        "link_gbps_used": link, "link_rate_source": "measured (probe)" if (lp.get("min") or link != 153.0) else "assumed",
+                        "prediction": mdist.sharding_model(world, NDIR, 4.0 * nx * ny * L / 1e9, k3_one, sg.get("wta_ms") or 17.3, sg.get("k2_ms") or 1.25, link)}
+        for k in ("rccl", "rccl_overlap", "peer"):
+            if isinstance(res.get(k), dict) and "ms_per_volume" in res[k] and res["model"]["prediction"].get("total_ms"):
+                res[k]["vs_model"] = res[k]["ms_per_volume"] / res["model"]["prediction"]["total_ms"]
     best = [(res[k]["value"], k) for k in ("rccl", "rccl_overlap", "peer", "single") if isinstance(res.get(k), dict) and "value" in res[k]
             and (world == 1 or k != "single")]
     if best:
         res["value"], res["transport"] = max(best)
         if "single" in res and "value" in res["single"]:
             res["speedup_vs_single"] = res["value"] / res["single"]["value"]
+    return res
+
+
+def pairs2_leg(env, name, steps, warmup):
+    """ONE stereo pair per step split over TWO GPUs by run: the left->right mgm() on the even rank, the right->left one on
+    the odd rank (no data-path exchange during the aggregation at all), then the odd rank's disparity map travels to the even
+    one (W*H floats, one point-to-point transfer) for the left-right check -- what main() does with a pair (mgm.cc:376-423).
+    With N ranks N/2 pairs run side by side.  The split DESIGN.md section 6's model prefers below 8 GPUs.  On one rank both
+    runs share one launch (the N = 1 point)."""
+    from mgm_amd import dist as mdist
+    w = WORKLOADS[name]
+    ctx, rank, world, torch, dist = env.ctx, env.rank, env.n_ranks, env.torch, env.dist
+    nx, ny, L = w["nx"], w["ny"], labels_of(w)
+    res = {"workload": "%s: %s" % (name, w["desc"]), "ranks": world, "unit": "disparity-volumes/s", "scaling": "strong",
+           "steps": steps, "warmup": warmup, "what": "one pair per step and pair of ranks: left->right run on the even rank, right->left on the odd "
+                                                      "one, disparity map sent over for the left-right check"}
+    if env.stub:
+        res["value"], res["stub"] = 1.0, True
+        return res
+    if world > 1 and world % 2:
+        res["error"] = "needs an even number of ranks"
+        return res
+    u, v, _ = pair_of(w, rank // 2 if world > 1 else 0)
+    lr = world == 1 or rank % 2 == 0
+    du, dv = ctx.upload_image(u), ctx.upload_image(v)
+    cvs, outs, outcs = [None, None], [ctx.new_image(nx, ny) for _ in range(2)], [ctx.new_image(nx, ny) for _ in range(2)]
+    chk = [ctx.new_image(nx, ny) for _ in range(2)]
+    other = ctx.new_image(nx, ny)  # (the partner rank's map)
+
+    def one_step():
+        if world == 1:
+            cvs[0] = ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", "census", float("inf"), w["win"], into=cvs[0])
+            cvs[1] = ctx.costvolume_dev(dv, du, -w["dmax"], -w["dmin"], "none", "census", float("inf"), w["win"], into=cvs[1])
+            ctx.aggregate_batch_dev(cvs, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, None, "vfit", outs, outcs)
+            ctx.leftright_dev(outs[0], outs[1], 1.0, out=chk[0])
+            return
+        a, b, lo, hi = (du, dv, w["dmin"], w["dmax"]) if lr else (dv, du, -w["dmax"], -w["dmin"])
+        cvs[0] = ctx.costvolume_dev(a, b, lo, hi, "none", "census", float("inf"), w["win"], into=cvs[0])
+        ctx.aggregate_dev(cvs[0], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, None, "vfit", out=outs[0], outcost=outcs[0])
+        ctx.synchronize()  # (the transfer below runs on torch's stream)
+        mine = mdist.device_view(ctx.lib.mgm_img_device_ptr(outs[0].h), (ny, nx))
+        if lr:
+            dist.recv(mdist.device_view(ctx.lib.mgm_img_device_ptr(other.h), (ny, nx)), src=rank + 1)
+            torch.cuda.synchronize()
+            ctx.leftright_dev(outs[0], other, 1.0, out=chk[0])
+        else:
+            dist.send(mine, dst=rank - 1)
+            torch.cuda.synchronize()
+
+    for _ in range(max(1, warmup)):
+        one_step()
+    env.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    env.sync_all()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    npairs = max(1, world // 2)
+    res.update({"value": 2.0 * npairs * steps / dt, "pairs_per_s": npairs * steps / dt, "ms_per_pair": dt / steps * 1e3})
+    for h in [du, dv, other] + [x for x in cvs if x is not None] + outs + outcs + chk:
+        h.free()
     return res
 
 
@@ -724,7 +813,11 @@ def stub_directions(env, res, steps):
         bad += int((recv != vols[:, r0:r0 + nr]).sum())
     dt = env.max_over_ranks(time.perf_counter() - t0)
     res["rccl"] = {"value": steps / dt, "ms_per_volume": dt / steps * 1e3, "rccl_ranks": world, "overlap": False, "stub": True,
-                   "differs_from_single": bad}
+                   "differs_from_single": bad, "exchange_rounds": mdist.n_rounds(NDIR, world)}
+    res["rccl_link_probe"] = mdist.link_probe(dist, None, "cpu", 1, 1, 30.0)  # (the probe's own code, over gloo, 1 MB)
+    if rank == 0:
+        res["model"] = {"prediction": mdist.sharding_model(world, NDIR, 4.0 * nx * ny * L / 1e9, {1: 1.0, 2: 1.0, 4: 1.0, 8: 1.0}, 1.0, 0.1,
+                                                           res["rccl_link_probe"]["min"] or 1.0)}
     res["value"], res["transport"] = res["rccl"]["value"], "rccl"
     return res
 
@@ -748,9 +841,10 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, choices=list(range(1, 17)),
                     help="D >= 2: the context gathers the aggregation calls of D consecutive steps into one batched launch "
                          "(mgm_ctx_set_pipeline) -- a caller with a stream of single pairs or small batches")
-    ap.add_argument("--mode", default="pairs", choices=["pairs", "directions"],
+    ap.add_argument("--mode", default="pairs", choices=["pairs", "directions", "pairs2"],
                     help="'pairs' = independent pairs (weak scaling, the headline); 'directions' = only the direction-sharded "
-                         "leg: ONE volume per step, its passes sharded over the GPUs with the ordered slab exchange (strong)")
+                         "leg: ONE volume per step, its passes sharded over the GPUs with the ordered slab exchange (strong); "
+                         "'pairs2' = one stereo pair per step and pair of GPUs, its two mgm() runs on one GPU each (strong)")
     ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
                     help="the cfg5-replicas and cfg4-directions legs after the headline; auto = on for the plain command line")
     ap.add_argument("--extras-timeout", type=float, default=300.0, help="seconds the guarded extras may take altogether")
@@ -758,7 +852,7 @@ def main():
     args = ap.parse_args()
     plain = args.workload is None and args.batch is None and args.mode == "pairs" and args.pipeline == 1
     extras = args.extras == "on" or (args.extras == "auto" and plain)
-    wname = args.workload or ("cfg4" if args.mode == "directions" else "cfg3")
+    wname = args.workload or ("cfg4" if args.mode in ("directions", "pairs2") else "cfg3")
     w = WORKLOADS[wname]
     stub = TEST_CONTEXT_FACTORY is not None  # (tests/run_bench_stub.py: gloo ranks on CPU, a context that computes nothing)
 
@@ -771,6 +865,20 @@ def main():
     nx, ny, L = w["nx"], w["ny"], labels_of(w)
     cells = float(nx) * ny * L
 
+    if args.mode == "pairs2":  # one pair split by run over two GPUs, as the headline
+        line.guard(args.extras_timeout)
+        d = pairs2_leg(env, wname, args.steps, args.warmup)
+        if rank == 0:
+            line.res = {"metric": "disparity-volumes/sec (W*H*L cost volume -> 8-dir MGM -> WTA+vfit)", "value": d.get("value"),
+                        "unit": "disparity-volumes/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
+                        "ms_per_step": d.get("ms_per_pair"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                        "data": "synthetic" if not stub else "stub (no device work)",
+                        "config": {"workload": "%s: %s" % (wname, w["desc"]), "W": nx, "H": ny, "L": L, "pairs_per_step": max(1, n_ranks // 2),
+                                   "parallelism": "one pair per two GPUs: its left->right and right->left runs on one GPU each"},
+                        "pairs2": d}
+        line.emit(env.dist is not None)
+        ctx.close()
+        return 0
     if args.mode == "directions":  # the direction-sharded leg alone, as the headline
         line.guard(args.extras_timeout)
         d = directions_legs(env, wname, args.steps, args.warmup, args.exchange_timeout, ("single", "rccl") if n_ranks > 1 else ("single",))
@@ -863,6 +971,14 @@ def main():
             directions_legs(env, "cfg4", max(2, min(args.steps, 5)), 1, args.exchange_timeout, res=d)
         except Exception as e:  # noqa: BLE001
             d["error"] = repr(e)[:300]
+        if n_ranks >= 2 and n_ranks % 2 == 0 and not d.get("rccl", {}).get("fatal") and not d.get("rccl_overlap", {}).get("fatal"):
+            ctx.trim()
+            try:  # (the split the model prefers below 8 GPUs: one run of the pair per GPU)
+                p2 = pairs2_leg(env, "cfg4", max(2, min(args.steps, 5)), 1)
+            except Exception as e:  # noqa: BLE001
+                p2 = {"error": repr(e)[:300]}
+            if rank == 0:
+                res["cfg4_pairs2"] = p2
     failed = line.code != 0
     if rank == 0 and failed:
         print("bench.py: PARITY GATE FAILED: %s" % json.dumps(res.get("parity")), file=sys.stderr, flush=True)

@@ -359,3 +359,101 @@ def aggregate_direction_sharded(ctx, cv, P1, P2, NDIR, MGM, use_fh, fix_overcoun
             stats[n] = stats.get(n, 0.0) + marks[i].elapsed_time(marks[i + 1])
         stats["steps"] = stats.get("steps", 0) + 1
     return full_o, full_c
+
+
+# ---- self-diagnosis of the first run on a real node (round 4) ----------------------------------------------------------------
+def link_probe(dist, group=None, device="cuda", mbytes=256, reps=3, timeout_s=60.0):
+    """Point-to-point rates of the exchange's own transport (batch_isend_irecv: grouped ncclSend/ncclRecv on RCCL, TCP on
+    gloo), in the exchange's own pattern: for every distance d = 1 .. world-1 ALL ranks send `mbytes` MB to rank+d and receive
+    from rank-d at the same time -- every link busy, one peer per link, as in a round of the slab exchange.
+    Returns {"gbps": [[rate of rank r at distance d for d in 1..world-1] for r in ranks], "min", "max", "mbytes"} on every
+    rank (the rates are all-gathered); DESIGN.md section 6 ASSUMES 153 GB/s per xGMI link -- this measures it."""
+    import torch
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world < 2:
+        return {"gbps": [], "min": None, "max": None, "mbytes": mbytes}
+    n = mbytes * (1 << 20) // 4
+    src = torch.ones(n, dtype=torch.float32, device=device)
+    dst = torch.empty(n, dtype=torch.float32, device=device)
+    on_gpu = torch.device(device).type == "cuda"
+    mine = []
+    deadline = time.monotonic() + timeout_s
+    for d in range(1, world):
+        to, frm = (rank + d) % world, (rank - d) % world
+        to_g = dist.get_global_rank(group, to) if group is not None else to
+        frm_g = dist.get_global_rank(group, frm) if group is not None else frm
+        best = 0.0
+        for it in range(reps + 1):  # (the first repetition sets the connection up)
+            ops = [dist.P2POp(dist.isend, src, to_g, group), dist.P2POp(dist.irecv, dst, frm_g, group)]
+            if on_gpu:
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            works = dist.batch_isend_irecv(ops)
+            if on_gpu:
+                done = torch.cuda.Event()
+                done.record()
+                poll_event(done, deadline, "link probe, distance %d" % d)
+            else:
+                for w in works:
+                    w.wait(timedelta(seconds=max(1.0, deadline - time.monotonic())))
+            dt = time.perf_counter() - t0
+            if it:
+                best = max(best, mbytes * (1 << 20) / dt / 1e9)
+        mine.append(best)
+    t = torch.tensor(mine, dtype=torch.float64, device=device)
+    allr = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(allr, t, group)
+    rates = [[float(x) for x in a.cpu()] for a in allr]
+    flat = [x for a in rates for x in a]
+    return {"gbps": rates, "min": min(flat), "max": max(flat), "mbytes": mbytes,
+            "what": "GB/s per direction and rank; all ranks send to rank+d and receive from rank-d at once (d = 1 .. world-1)"}
+
+
+def peer_copy_probe(n_devices, mbytes=256):
+    """The same question for the one-process transport (hipMemcpyPeerAsync behind mgm_multi): device-to-device copy rates
+    i -> j for all ordered pairs, one copy at a time, and with all devices copying to their neighbour at distance d at once.
+    Needs a process that sees all `n_devices` GPUs.  Returns {"pairs_gbps": [[...]], "all_at_once_gbps": [per d], ...}."""
+    import torch
+    n = mbytes * (1 << 20) // 4
+    bufs = [(torch.ones(n, dtype=torch.float32, device="cuda:%d" % i), torch.empty(n, dtype=torch.float32, device="cuda:%d" % i))
+            for i in range(n_devices)]
+    pairs = [[0.0] * n_devices for _ in range(n_devices)]
+    for i in range(n_devices):
+        for j in range(n_devices):
+            if i == j:
+                continue
+            for it in range(2):
+                torch.cuda.synchronize(i), torch.cuda.synchronize(j)
+                t0 = time.perf_counter()
+                bufs[j][1].copy_(bufs[i][0], non_blocking=True)
+                torch.cuda.synchronize(i), torch.cuda.synchronize(j)
+                dt = time.perf_counter() - t0
+            pairs[i][j] = mbytes * (1 << 20) / dt / 1e9
+    at_once = []
+    for d in range(1, n_devices):
+        for i in range(n_devices):
+            torch.cuda.synchronize(i)
+        t0 = time.perf_counter()
+        for i in range(n_devices):
+            bufs[(i + d) % n_devices][1].copy_(bufs[i][0], non_blocking=True)
+        for i in range(n_devices):
+            torch.cuda.synchronize(i)
+        at_once.append(mbytes * (1 << 20) / (time.perf_counter() - t0) / 1e9)
+    off = [pairs[i][j] for i in range(n_devices) for j in range(n_devices) if i != j]
+    return {"pairs_gbps": pairs, "all_at_once_gbps_per_link": at_once, "min": min(off) if off else None, "max": max(off) if off else None,
+            "mbytes": mbytes, "what": "device-to-device copies i -> j one at a time (pairs_gbps[i][j]), and every device to its neighbour at "
+                                      "distance d at once (rate of each link)"}
+
+
+def sharding_model(world, NDIR, lr_volume_gb, k3_ms_of_passes, wta_ms_full, k2_ms, link_gbps):
+    """DESIGN.md section 6's model of one direction-sharded step, with whatever has been MEASURED put in: k3_ms_of_passes[c] =
+    pass-kernel time of a rank that runs c passes in one launch (single-GPU measurements), wta_ms_full = ordered sum + WTA
+    over all rows on one GPU, k2_ms = the cost volume, link_gbps = rate of one link with all links busy.
+    Each rank sends (NDIR/world) passes x (1/world) of the rows to each peer: the exchange time is that over one link."""
+    c = -(-NDIR // world)
+    per_link_gb = c * lr_volume_gb / world
+    ex = per_link_gb / link_gbps * 1e3 if world > 1 else 0.0
+    k3 = k3_ms_of_passes.get(c)
+    tot = None if k3 is None else k2_ms + k3 + ex + wta_ms_full / world
+    return {"world": world, "passes_per_rank": c, "gb_per_link": per_link_gb, "exchange_ms": ex, "k3_ms": k3, "wta_ms": wta_ms_full / world,
+            "total_ms": tot, "link_gbps": link_gbps}

@@ -156,6 +156,14 @@ def test_driver_command_line_runs_the_extra_legs():
     dr = d["directions"]
     assert dr["ranks"] == 2 and dr["scaling"] == "strong" and dr["transport"] == "rccl"
     assert dr["rccl"]["rccl_ranks"] == 2 and dr["rccl"]["differs_from_single"] == 0 and dr["value"] == dr["rccl"]["value"]
+    # the self-diagnosis of a first node run (round 4): the link probe in the exchange's own pattern, the rounds of the
+    # exchange, DESIGN.md section 6's model evaluated with the measured link rate, and the pair split by run
+    lp = dr["rccl_link_probe"]
+    assert len(lp["gbps"]) == 2 and len(lp["gbps"][0]) == 1 and lp["min"] > 0 and lp["max"] >= lp["min"]
+    assert dr["rccl"]["exchange_rounds"] == 4  # 8 passes over 2 ranks
+    m = dr["model"]["prediction"]
+    assert m["world"] == 2 and m["passes_per_rank"] == 4 and m["exchange_ms"] > 0 and m["total_ms"] > m["exchange_ms"]
+    assert d["cfg4_pairs2"]["ranks"] == 2 and d["cfg4_pairs2"]["value"] > 0
     assert "extras_note" not in d
 
 
@@ -224,3 +232,17 @@ def _rounds_worker(rank, world, port, q):
         import time
         time.sleep(8)  # stay alive (connected) while rank 0 waits in vain
     os._exit(0)  # (a process group with a dead exchange is not torn down in an orderly way)
+
+
+def test_pairs2_mode_and_the_sharding_model():
+    """`--mode pairs2` (one pair per two GPUs, one mgm() run each) prints its one line on two stub ranks; DESIGN.md section 6's
+    model reproduces the table's figures from its inputs (8 GPUs, 1.61 GB per link at 153 GB/s = 10.5 ms)."""
+    from mgm_amd import dist as mdist
+    r, d, lines = _run_bench(["--gpus", "2", "--mode", "pairs2", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["workload"].startswith("cfg4")
+    m = mdist.sharding_model(8, 8, 12.885, {1: 7.8}, 17.3, 1.25, 153.0)
+    assert m["passes_per_rank"] == 1 and abs(m["gb_per_link"] - 1.6106) < 1e-3 and abs(m["exchange_ms"] - 10.53) < 0.05
+    assert abs(m["total_ms"] - (1.25 + 7.8 + m["exchange_ms"] + 17.3 / 8)) < 1e-9
+    m2 = mdist.sharding_model(2, 8, 12.885, {4: 14.0}, 17.3, 1.25, 153.0)
+    assert m2["passes_per_rank"] == 4 and abs(m2["exchange_ms"] - 168.4) < 0.5
