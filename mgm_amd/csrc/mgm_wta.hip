@@ -402,15 +402,11 @@ hipError_t launch_wta(const WtaParams &p, hipStream_t s)
     long long nb = (p.npix + 3) / 4;  // (an upper bound: waves take several pixels per iteration)
     static int per_cu = -1;  // MGM_HIP_WTA_WG_PER_CU=n overrides the grid bound (A/B timing)
     if (per_cu < 0) {
-        const char *e = getenv("MGM_HIP_WTA_WG_PER_CU");
-        per_cu = e ? atoi(e) : 0;
+        per_cu = (int)tune_num("wta_wg_per_cu", 0);
         if (per_cu < 0) per_cu = 0;
     }
     static int packed = -1;  // MGM_HIP_WTA_PACKED=0: one pixel per slab also at 128 / 64 labels (A/B timing)
-    if (packed < 0) {
-        const char *e = getenv("MGM_HIP_WTA_PACKED");
-        packed = e ? atoi(e) != 0 : 1;
-    }
+    if (packed < 0) packed = tune_num("wta_packed", 1) != 0;
     const bool use_packed = packed && p.Lreal == p.L && (p.L == 128 || p.L == 64) && p.npix % (256 / p.L) == 0;
     // A bounded grid (workgroups of 4 waves), grid-stride beyond it.  Measured at 1920x1080 (8 / 4 directions): one
     // pixel per slab is fastest at ~768 workgroups per CU (2.99 ms at 16 -> 2.73 ms: 6.4 TB/s, the read ceiling of the
@@ -419,19 +415,13 @@ hipError_t launch_wta(const WtaParams &p, hipStream_t s)
     if (nb > cap) nb = cap;
     const dim3 grid((unsigned)nb), block(256);
     static int wide4 = -1;  // MGM_HIP_WTA_WIDE4=0: the 8-direction instance also for NDIR <= 4 (A/B timing)
-    if (wide4 < 0) {
-        const char *e = getenv("MGM_HIP_WTA_WIDE4");
-        wide4 = e ? atoi(e) != 0 : 1;
-    }
+    if (wide4 < 0) wide4 = tune_num("wta_wide4", 1) != 0;
     if (p.L > kMaxLPL * 64) {  // beyond the widest k_wta instance
         hipLaunchKernelGGL(k_wta_any, grid, block, 0, s, p);
         return hipGetLastError();
     }
     static int quad = -1;  // MGM_HIP_WTA_QUAD=0: 192 / 384 labels on k_wta<3> / <6> (A/B timing)
-    if (quad < 0) {
-        const char *e = getenv("MGM_HIP_WTA_QUAD");
-        quad = e ? atoi(e) != 0 : 1;
-    }
+    if (quad < 0) quad = tune_num("wta_quad", 1) != 0;
     if (quad && p.Lreal == p.L && (p.L == 192 || p.L == 384) && p.npix % (768 / p.L) == 0 && !p.wlo && !p.clo && p.refine <= 1) {
         long long nq = (p.npix / (768 / p.L) + 3) / 4;
         const long long capq = (long long)(p.num_cu > 0 ? p.num_cu : 256) * (per_cu ? per_cu : 256);
