@@ -139,9 +139,6 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 ? 2 : (LPL + 3) / 
 #ifndef MGM_P2_WAVES_PER_EU
 #define MGM_P2_WAVES_PER_EU 8   // (compact unweighted kernels only; every other kernel is built for 4)
 #endif
-#ifndef MGM_P2_NODIAG
-#define MGM_P2_NODIAG 0         // 1: build without the anti-diagonal walk of passes 4-7 (pass2_item, DIAG)
-#endif
 #ifndef MGM_P2_ONEB_WPE
 #define MGM_P2_ONEB_WPE 4       // ... the queue kernels of launches that run ONE band per CU (k_pass2, ONEB)
 #endif
@@ -177,7 +174,7 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 ? 2 : (LPL + 3) / 
 #define MGM_P2_LEAD 2
 #endif
 // ---- geometry of the build --------------------------------------------------------
-template <int LPL, int NS, bool HASM, int C8, int MAXD = MGM_P2_MAXD, int EXTRA = 0, int HS = NS>
+template <int LPL, int NS, bool HASM, int C8, int MAXD = MGM_P2_MAXD, int EXTRA = 0>
 struct Plan {
     static constexpr int LP = LPL * 64;
     static constexpr int IPS = (LPL * 16 + 63) / 64;  // DMA pieces per fp32 slab
@@ -194,8 +191,7 @@ struct Plan {
     // hand-off slabs are not self-validating, see TAGS in k_pass2]
     // compact costs with two loaders: A = hand-off only, B = all C pieces
     // (EXTRA: one more 4-byte piece per step -- the weight-selector words of the lines, k_pass2 W2)
-    // (HS: slabs per hand-off slot -- NS, or 2 in the kernels that can walk anti-diagonals, k_pass2 DIAG)
-    static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + HS * IPS + (HASM ? 2 : 0) + EXTRA;
+    static constexpr int nA = ((C8 && NL == 2) ? 0 : NDMA) + NS * IPS + (HASM ? 2 : 0) + EXTRA;
     static constexpr int nB = (C8 && NL == 2) ? NDMA : (NC - NCA) * IPS;
     // Ring geometry: RT = T-ring slots per line (2 with barriers), RDEPTH = steps of C / hand-off data the rings
     // hold, D = steps of DMA kept in flight (D <= RDEPTH-1).  The largest of a few candidates that fits in LDS.
@@ -204,7 +200,7 @@ struct Plan {
     {
         return NC * rt * NS * LP       // T ring
                + NC * rt               // T minima
-               + rdepth * HS * LP      // hand-off ring
+               + rdepth * NS * LP      // hand-off ring
                + 2 * rdepth + 8 + 32   // hand-off minima, progress words, task word (+ spare)
                + cring_floats(rdepth)  // C ring
                + (C8 ? rdepth * 16 : 0)   // per line and ring slot: does the compact slab hold a +INF code?
@@ -212,7 +208,7 @@ struct Plan {
     }
     static constexpr bool fits(int rt, int rdepth, int d)
     {
-        return d >= 2 && d <= rdepth - 1 && lds_floats3(rt, rdepth) * 4 <= ((C8 && LPL <= 4 && NS == 1 && HS == 1) ? MGM_P2_LDS_KB : 160) * 1024 &&
+        return d >= 2 && d <= rdepth - 1 && lds_floats3(rt, rdepth) * 4 <= ((C8 && LPL <= 4 && NS == 1) ? MGM_P2_LDS_KB : 160) * 1024 &&
                nA * (d - 1) <= 63 && nB * (d - 1) <= 63;
     }
     static constexpr int pick(int what)  // 0: RT, 1: RDEPTH, 2: D
@@ -292,31 +288,16 @@ __device__ __forceinline__ void combine_w2(const float (&C)[LPL], const Nb<LPL, 
 // twelve 256-label volumes 48.5 -> 48.2.  The default of every compact unweighted launch (mgm_api.hip, run_passes); the
 // shallow build stays for A/B runs (MGM_HIP_DEEP=0).
 // where the work-item word lives in the workgroup's LDS (the layout of pass2_item, below)
-template <int LPL, bool FH, bool WEIGHTED, int MGM, int C8, bool DEEP, bool W2 = false, bool DIAG = false>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, int C8, bool DEEP, bool W2 = false>
 struct P2Lds {
     static constexpr int NS = (W2 || (WEIGHTED && !FH)) ? 2 : 1;
-    static constexpr int HS = DIAG ? 2 : NS;
     static constexpr bool pubE = W2 || (!WEIGHTED && !(FH && MGM == 2));
-    using PL = Plan<LPL, NS, !pubE, C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD, W2 ? 1 : 0, HS>;
+    using PL = Plan<LPL, NS, !pubE, C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD, W2 ? 1 : 0>;
     static constexpr int RD = PL::rd(PL::D);
-    static constexpr int task_off = PL::NC * PL::RT * NS * PL::LP + RD * HS * PL::LP + PL::cring_floats(RD) + PL::NC * PL::RT + RD + RD;  // floats
+    static constexpr int task_off = PL::NC * PL::RT * NS * PL::LP + RD * NS * PL::LP + PL::cring_floats(RD) + PL::NC * PL::RT + RD + RD;  // floats
 };
-// which kernels can walk the lines of a form-1 pass as ANTI-DIAGONALS (pass2_item, DIAG): the queue kernels built for one
-// band per CU, publishing E, up to three neighbours
-template <bool FH, bool WEIGHTED, int MGM, int C8, bool DEEP, bool XCDQ, bool ONEB, bool W2>
-constexpr bool can_diag() { return ONEB && XCDQ && DEEP && C8 != 0 && !W2 && !WEIGHTED && MGM <= 3 && !(FH && MGM == 2) && !MGM_P2_NODIAG; }
 
-// DIAG (round 4): the kernel can also walk a form-1 pass with at most three neighbours along its ANTI-DIAGONALS.  Such a pass
-// reads only the PREVIOUS line -- (i+1, j-1), (i-1, j-1), (i, j-1) -- so nothing orders the pixels of a line, and what the
-// wave-per-line walk pays for it is a chain of 2 steps per line (a line trails its predecessor by two pixels to see its
-// fwd neighbour): 2 NL + LL steps, the longest chains of a launch (1920x1080, column passes: 4920 steps against 3000 for
-// passes 0-3).  In the frame d = i + j (line), t = j (position) the three neighbours are (d, t-1), (d-2, t-1), (d-1, t-1):
-// all at the previous POSITION, on the wave's own line and the two lines before it.  So the waves of a band run in step at
-// the SAME position (slope 0), a band needs the last TWO lines of its predecessor one position back (two slabs per
-// hand-off slot), and the chain of the pass is NL + a hand-off lag per band that starts at position 0 -- 1920 + ~220.
-// Lines have different extents (line d spans t = max(0, d-LLo+1) .. min(NL-1, d)); a band walks the hull of its lines.
-// Same values by construction: the same neighbours enter the same sums in the same order.  Host side: make_geom_diag.
-template <int LPL, bool FH, bool WEIGHTED, int MGM, int C8, int SUBV, bool DEEP, bool XCDQ, bool W2 = false, bool DIAG = false>
+template <int LPL, bool FH, bool WEIGHTED, int MGM, int C8, int SUBV, bool DEEP, bool XCDQ, bool W2 = false>
 __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket)
 {
     static_assert(!W2 || (!WEIGHTED && C8 && DEEP && SUBV == 1 && LPL <= 4), "two-valued weights: the compact kernels with deep rings");
@@ -341,11 +322,8 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
     // have the time -- the FH kernels (cfg3 x 12: K3 50.1 -> 48.9 ms); the Hirschmueller kernels, whose loader is on the
     // critical path of a short step, lose 8-25 % with it (cfg2 x 16, cfg4) and keep decoding every byte.
     constexpr bool CFLAG = C8 && FH;
-    constexpr int HS = DIAG ? 2 : NS;  // slabs per hand-off slot and H-ring entry
-    static_assert(!DIAG || (pubE && NS == 1 && C8 != 0 && SUBV == 1 && MGM <= 3), "the anti-diagonal walk: compact kernels that publish E, up to three neighbours");
-    using PL = Plan<LPL, NS, !pubE, C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD, W2 ? 1 : 0, HS>;
+    using PL = Plan<LPL, NS, !pubE, C8, DEEP ? MGM_P2_DEEPD : MGM_P2_MAXD, W2 ? 1 : 0>;
     static_assert(!W2 || PL::NL == 1, "two-valued weights: one loader wave");
-    static_assert(!DIAG || PL::NL == 1, "the anti-diagonal walk: one loader wave");
     constexpr int LP = PL::LP, NC = PL::NC, NCA = PL::NCA, D = PL::D, IPS = PL::IPS;
     constexpr int LPS = PL::LPS, LPD = PL::LPD, NDMA = PL::NDMA;
     constexpr int LPW = NCA;   // C lines per loader wave (NC - NCA == NCA when there are two loaders)
@@ -356,11 +334,11 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Tring = smem;                          // [NC][RT][NS][LP]
     float *Hring = Tring + NC * RT * NS * LP;     // [RD][NS][LP]
-    float *Cring = Hring + RD * HS * LP;          // fp32: [NC][RD][LP]; compact: [RD][NDMA][1 KiB]   (Hring: [RD][HS][LP])
+    float *Cring = Hring + RD * NS * LP;          // fp32: [NC][RD][LP]; compact: [RD][NDMA][1 KiB]
     float *Tm = Cring + PL::cring_floats(RD);     // [NC][RT]
     float *Hm = Tm + NC * RT;                     // [RD]
     unsigned *Hprog = reinterpret_cast<unsigned *>(Hm + RD);  // [RD]
-    int *s_task = reinterpret_cast<int *>(smem + P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP, W2, DIAG>::task_off);  // (= Hprog + RD; the kernel's ticket word)
+    int *s_task = reinterpret_cast<int *>(smem + P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP, W2>::task_off);  // (= Hprog + RD; the kernel's ticket word)
     unsigned *Cflag = reinterpret_cast<unsigned *>(s_task + 40);  // [RD][16] (compact costs; behind the spare words)
     unsigned *Wring = Cflag + RD * 16;                             // [RD][64] (W2: lane r = line r's weight-selector word)
 
@@ -397,26 +375,17 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
     const bool mirror = strips && strip == 1;
     const long long istep = mirror ? -g.istep : g.istep;
     const long long gbase = mirror ? g.base + (long long)(LL - 1) * g.istep : g.base;
-    // anti-diagonal walk: lines d = band*NC + r, positions t; the band walks [t0, t1], the hull of its lines' extents
-    const bool diag = DIAG && form == 2;
-    const int LLo = g.split;  // (diag passes carry the ORIGINAL line length there: they never run as strips)
-    auto d_start = [&](int d) { return d - LLo + 1 > 0 ? d - LLo + 1 : 0; };
-    auto d_end = [&](int d) { return d < LL - 1 ? d : LL - 1; };
-    const int dfirst = band * NC, dlast = min(band * NC + NC - 1, NLn - 1);
-    const int t0 = diag ? d_start(dfirst) : 0, t1 = diag ? d_end(dlast) : LL - 1;
-    const int W = diag ? t1 - t0 + 1 : (!strips ? LL : min(LL, (strip == 0 ? g.split : LL - g.split) + NC - 1));  // pixels of the tile's first line
+    const int W = !strips ? LL : min(LL, (strip == 0 ? g.split : LL - g.split) + NC - 1);  // pixels of the tile's first line
     const int nsteps = ((W + 1 + SL * (NC - 1)) + 2) / 3 * 3;
     const bool from_global = band > 0;
 
     constexpr int NSLP = NS * LP;
-    constexpr int HSLP = HS * LP;
     // flag protocol: two slots per pass, alternating with the band's parity; TAGS: one slot per band
     const long long hslab = (long long)(vp / kMaxDirs) * P.hand_vstride + g.hand_base;
-    // (anti-diagonal passes: two slabs per position -- the band's last two lines --, slots [band][position][2])
-    float *hand_out = TAGS ? P.hand + (hslab + (long long)band * LL * (diag ? 2 : 1)) * NSLP : P.hand + ((long long)(vp * 2 + (band & 1)) * P.LLmax) * NSLP;
+    float *hand_out = TAGS ? P.hand + (hslab + (long long)band * LL) * NSLP : P.hand + ((long long)(vp * 2 + (band & 1)) * P.LLmax) * NSLP;
     float *handm_out = P.handm + (long long)(vp * 2 + (band & 1)) * P.LLmax;
     // (band 0 has no predecessor; its loader still issues the DMAs -- every step the same count -- from its own slots)
-    const float *hand_in = TAGS ? P.hand + (hslab + (long long)(band > 0 ? band - 1 : 0) * LL * (diag ? 2 : 1)) * NSLP
+    const float *hand_in = TAGS ? P.hand + (hslab + (long long)(band > 0 ? band - 1 : 0) * LL) * NSLP
                                 : P.hand + ((long long)(vp * 2 + ((band + 1) & 1)) * P.LLmax) * NSLP;
     const float *handm_in = P.handm + (long long)(vp * 2 + ((band + 1) & 1)) * P.LLmax;
     unsigned *prog_out = P.prog + vp * P.maxbands + band;
@@ -442,7 +411,6 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
         constexpr int NPIECE = C8 ? NDMA : LPW;
         const float *cptr[NPIECE];
         int ci[NPIECE];
-        int clo[NPIECE], chi[NPIECE];  // the pointer of a piece advances while lo <= ci < hi (plain walk: 0 and W-1)
         const long long cstride = C8 ? (istep * L * C8) / 4 : istep * L;  // in floats (compact: L * C8 bytes per pixel)
 #pragma unroll
         for (int q = 0; q < NPIECE; q++) {
@@ -450,23 +418,15 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
             r = r < NC ? r : NC - 1;
             int j = band * NC + r;
             j = j < NLn ? j : NLn - 1;
-            clo[q] = 0;
-            chi[q] = W - 1;
-            long long first = 0;  // position (in pixels along the walk) the pointer starts at
-            if (diag) {  // line j = anti-diagonal d: its own extent inside the band's hull, in positions local to t0
-                clo[q] = d_start(j) - t0;
-                chi[q] = d_end(j) - t0;
-                first = d_start(j);
-            }
             if constexpr (C8 && SUBV > 1) {
                 constexpr int CPV = LPS / SUBV;  // 16-byte chunks of a line's slab that belong to one volume
                 const int chunk = lane % LPS;
                 const uint8_t *c8 = P.vol[vgrp + chunk / CPV].C8;
                 cptr[q] = reinterpret_cast<const float *>(c8 + (gbase + (long long)j * g.jstep) * L + (chunk % CPV) * 16);
             } else if constexpr (C8 != 0)
-                cptr[q] = reinterpret_cast<const float *>(V.C8 + (gbase + (long long)j * g.jstep + first * istep) * L * C8 + (lane % LPS) * 16);
+                cptr[q] = reinterpret_cast<const float *>(V.C8 + (gbase + (long long)j * g.jstep) * L * C8 + (lane % LPS) * 16);
             else
-                cptr[q] = V.C + (gbase + (long long)j * g.jstep + first * istep) * L + lane * 4;
+                cptr[q] = V.C + (gbase + (long long)j * g.jstep) * L + lane * 4;
             ci[q] = -1 - SL * r;
         }
         // W2: the weight-selector word of every line's pixel travels like the costs -- lane r fetches line r's word of the
@@ -486,7 +446,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
         const long long hstep = mirror ? -(long long)NSLP : (long long)NSLP;  // (slots are indexed by the absolute pixel)
         const float *hptr = hand_in + (mirror ? (long long)(LL - 1) * NSLP : 0) + lane * 4;
         const float *hmptr = handm_in;
-        int ht = diag ? -2 : (SL == 2 ? 0 : -1);  // (anti-diagonals: the step that computes local position i needs position i-1)
+        int ht = SL == 2 ? 0 : -1;
 
         auto issue = [&](int slot) {  // everything the step `ht` needs, into ring slot `slot`
             const bool c_duty = !(C8 && PL::NL == 2) || wl == 1;  // with compact costs and two loaders, B fetches C
@@ -501,7 +461,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                     for (int c = 0; c < IPS; c++)
                         if (c * 64 + lane < ((xflags & 2) ? 1 : LPL * 16)) dma16<0>(cptr[q] + c * 256, dst + c * 256);
                 }
-                const bool adv = (ci[q] >= clo[q]) && (ci[q] < chi[q]);
+                const bool adv = (ci[q] >= 0) && (ci[q] < W - 1);
                 cptr[q] += adv ? cstride : 0;
                 ci[q]++;
             }
@@ -543,25 +503,12 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                     }
                     if (dbg) t_slow += wall_clock64() - t0;
                 }
-                if (DIAG && diag) {
-                    // both slabs of the slot of position t0 + ht (clamped into the pass: a slot outside the producer's extent
-                    // is fetched, never validated, never used)
-                    int pp = t0 + ht;
-                    pp = pp < 0 ? 0 : (pp > LL - 1 ? LL - 1 : pp);
-                    const float *hp = hand_in + (long long)pp * 2 * LP + lane * 4;
 #pragma unroll
-                    for (int q = 0; q < HS; q++)
+                for (int q = 0; q < NS; q++)
 #pragma unroll
-                        for (int c = 0; c < IPS; c++)
-                            if (c * 64 + lane < LPL * 16) dma16<AUX_SC1>(hp + q * LP + c * 256, Hring + (slot * HS + q) * LP + c * 256);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < HS; q++)  // (HS > NS: a kernel that can also walk anti-diagonals fetches the slab twice --
-#pragma unroll                                       //  every step issues the same number of DMAs, the counted waits rely on it)
-                        for (int c = 0; c < IPS; c++)
-                            if (c * 64 + lane < LPL * 16)
-                                dma16<AUX_SC1>(hptr + (q < NS ? q : 0) * LP + c * 256, Hring + (slot * HS + q) * LP + c * 256);
-                }
+                    for (int c = 0; c < IPS; c++)
+                        if (c * 64 + lane < LPL * 16)
+                            dma16<AUX_SC1>(hptr + q * LP + c * 256, Hring + (slot * NS + q) * LP + c * 256);
                 if constexpr (!TAGS) {
                     if (lane == 0) dma4<AUX_SC1>(hmptr, Hm + slot);
                     if (lane == 0) dma4<AUX_SC1>(prog_in, Hprog + slot);
@@ -581,37 +528,18 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
         // it is the predecessor band's, fetching it again until it is
         auto validate = [&](int t, int vslot) {
             if constexpr (TAGS) {
-                int h = SL == 2 ? t : t - 1;
-                bool need[HS];
-#pragma unroll
-                for (int q = 0; q < HS; q++) need[q] = q < NS;
-                if (DIAG && diag) {
-                    // the slot of position p = t0 + (t - 1) - 1; slab q is line band*NC - 2 + q of the previous band, which
-                    // wrote it iff p lies in that line's extent -- outside it the slab is not used either
-                    h = t0 + t - 2;
-#pragma unroll
-                    for (int q = 0; q < HS; q++) {
-                        const int dq = band * NC - 2 + q;
-                        need[q] = h >= d_start(dq) && h <= d_end(dq);
-                    }
-                    if (wl != 0 || !from_global || dead || (xflags & 4) || h < 0 || h > LL - 1) return;
-                    bool any = false;
-#pragma unroll
-                    for (int q = 0; q < HS; q++) any |= need[q];
-                    if (!any) return;
-                } else if (wl != 0 || !from_global || h < 0 || h > Hmax || dead || (xflags & 4))
-                    return;
-                const long long hslot = (DIAG && diag) ? (long long)h * 2 * LP : (long long)(mirror ? LL - 1 - h : h) * NSLP;
+                const int h = SL == 2 ? t : t - 1;
+                if (wl != 0 || !from_global || h < 0 || h > Hmax || dead || (xflags & 4)) return;
                 unsigned spins = 0;
-                const unsigned long long t0c = dbg ? wall_clock64() : 0;
+                const unsigned long long t0 = dbg ? wall_clock64() : 0;
                 for (;;) {
                     bool ok = true;
 #pragma unroll
-                    for (int q = 0; q < HS; q++)
+                    for (int q = 0; q < NS; q++)
 #pragma unroll
                         for (int c = 0; c < IPS; c++)
-                            if (need[q] && c * 64 + lane < LPL * 16) {
-                                const u32x4 v = lds_read_b128_opaque(Hring + vslot * HSLP + q * LP + c * 256 + lane * 4);
+                            if (c * 64 + lane < LPL * 16) {
+                                const u32x4 v = lds_read_b128_opaque(Hring + vslot * NSLP + q * LP + c * 256 + lane * 4);
                                 // all four sign bits must equal the expected tag
                                 ok = ok && (tag_in ? ((v.x & v.y & v.z & v.w) >> 31) != 0u : ((v.x | v.y | v.z | v.w) >> 31) == 0u);
                             }
@@ -620,11 +548,12 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                     n_spin++;
                     __builtin_amdgcn_s_sleep(4);
 #pragma unroll
-                    for (int q = 0; q < HS; q++)
+                    for (int q = 0; q < NS; q++)
 #pragma unroll
                         for (int c = 0; c < IPS; c++)
-                            if (need[q] && c * 64 + lane < LPL * 16)
-                                dma16<AUX_SC1>(hand_in + hslot + q * LP + c * 256 + lane * 4, Hring + vslot * HSLP + q * LP + c * 256);
+                            if (c * 64 + lane < LPL * 16)
+                                dma16<AUX_SC1>(hand_in + (long long)(mirror ? LL - 1 - h : h) * NSLP + q * LP + c * 256 + lane * 4,
+                                               Hring + vslot * NSLP + q * LP + c * 256);
                     wait_vmcnt<0>();
                     if (((++spins) & 255u) == 0) {
                         if (lane == 0) dma4<AUX_SC1>(P.err, Hprog);
@@ -637,7 +566,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                         }
                     }
                 }
-                if (dbg) t_slow += wall_clock64() - t0c;
+                if (dbg) t_slow += wall_clock64() - t0;
             }
         };
 
@@ -715,14 +644,12 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
     const bool line_ok = j < NLn;
     const bool has_prev = line_ok && (j >= 1);
     const bool to_lds = (r < NC - 1) && (j + 1 < NLn);
-    const bool to_global = (diag ? r >= NC - 2 : r == NC - 1) && (band + 1 < g.nbands);  // (anti-diagonals: the last TWO lines)
-    const int dlo = diag ? d_start(j) - t0 : 0, dhi = diag ? d_end(j) - t0 : 0;  // this line's extent, local to the band's t0
+    const bool to_global = (r == NC - 1) && (band + 1 < g.nbands);
     float *__restrict__ Lrb = P.vol[vgrp + (SUBV > 1 ? lane / LANES : 0)].Lr + (long long)(pass - P.pass0) * P.nvol;
-    const long long pix0 = gbase + (long long)j * g.jstep + (long long)t0 * istep;  // (t0 = 0 but for anti-diagonals)
+    const long long pix0 = gbase + (long long)j * g.jstep;
     const int Wr = strips ? W - r : LL;           // this line is walked over [0, Wr)
     const int Wx = Wr + 1 < LL ? Wr + 1 : LL;     // ... and reads the slabs [0, Wx) of the line before it
     const float *fwd_src0 = r > 0 ? Tring + (r - 1) * RT * NSLP + lane * LPL : Hring + lane * LPL;
-    const int fwd_stride = r > 0 ? NSLP : HSLP;  // floats between the ring slots of that source
     const float *fwd_m0 = r > 0 ? Tm + (r - 1) * RT : Hm;
     // fp32: own ring [RD][LP]; compact: byte (r%LPD)*LPS*16 + lane*LPL of piece r/LPD of the step's slot
     const float *c_src0 = C8 ? Cring + (r / LPD) * 256 : Cring + r * RD * LP + lane * LPL;
@@ -753,27 +680,9 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
             float *const q_here = qs;
             qs += dq;
             const unsigned long long c0 = prof ? clock64() : 0;
-            NbT D1, D2;  // (FORM 2) the slabs of the two lines before this one, one position back
-            if constexpr (FORM == 2) {
-                const int par = (i - 1) & (RT - 1);
-                const float *s1 = r > 0 ? Tring + ((r - 1) * RT + par) * NSLP + lane * LPL : Hring + (cslot * HS + 1) * LP + lane * LPL;
-                const float *s2 = r > 1 ? Tring + ((r - 2) * RT + par) * NSLP + lane * LPL : Hring + (cslot * HS + (r == 1 ? 1 : 0)) * LP + lane * LPL;
-#pragma unroll
-                for (int k = 0; k < LPL; k++) {
-                    D1.w[0][k] = s1[k];
-                    D2.w[0][k] = s2[k];
-                }
-                if (r == 0) {  // (wave-uniform) from the previous band: E >= +0, drop the hand-off tag
-#pragma unroll
-                    for (int k = 0; k < LPL; k++) D1.w[0][k] = __builtin_fabsf(D1.w[0][k]);
-                }
-                if (r <= 1) {
-#pragma unroll
-                    for (int k = 0; k < LPL; k++) D2.w[0][k] = __builtin_fabsf(D2.w[0][k]);
-                }
-            } else if (has_prev && i + NEWOFF >= 0 && i + NEWOFF < Wx) {
+            if (has_prev && i + NEWOFF >= 0 && i + NEWOFF < Wx) {
                 const int sl = r > 0 ? ((i + NEWOFF) & (RT - 1)) : cslot;
-                const float *src = fwd_src0 + sl * fwd_stride;
+                const float *src = fwd_src0 + sl * NSLP;
 #pragma unroll
                 for (int q = 0; q < NS; q++)
 #pragma unroll
@@ -787,7 +696,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                     }
                 if constexpr (!pubE) X.m = fwd_m0[sl];
             }
-            if (FORM == 2 ? (line_ok && i >= dlo && i <= dhi) : (line_ok && i >= 0 && i < Wr)) {
+            if (line_ok && i >= 0 && i < Wr) {
                 long long pix = 0;
                 if constexpr (WEIGHTED || MGM_P2_DEV) pix = pix0 + (long long)i * istep;
                 float Cv[LPL], Lv[LPL];
@@ -881,8 +790,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
 #pragma unroll
                     for (int k = 0; k < LPL; k++) Cv[k] = src[k];
                 }
-                // mgm_core.cc:538-541 (anti-diagonals: position t = t0 + i is the line index j of the pass, d - t the pixel index)
-                const bool interior = FORM == 2 ? (t0 + i >= 1 && j - (t0 + i) >= 1 && j - (t0 + i) <= LLo - 2) : (has_prev && i >= 1 && i <= LL - 2);
+                const bool interior = has_prev && i >= 1 && i <= LL - 2;  // mgm_core.cc:538-541
                 if (prof) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     asm volatile("" : "+v"(Cv[0]), "+v"(X.w[0][0]));
@@ -890,10 +798,9 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                 }
                 const unsigned long long c1 = prof ? clock64() : 0;
                 // neighbours of the previous line by role
-                // (FORM 2: fwd (i+1, j-1) is this line's previous position, same the line before, back the one before that)
-                const NbT &nb_same = FORM == 2 ? D1 : (SLOPE == 2 ? Z : X);
-                const NbT &nb_back = FORM == 2 ? D2 : (SLOPE == 2 ? Y : Z);
-                const NbT &nb_fwd = FORM == 2 ? nb_i : X;  // only read with SLOPE == 2
+                const NbT &nb_same = SLOPE == 2 ? Z : X;
+                const NbT &nb_back = SLOPE == 2 ? Y : Z;
+                const NbT &nb_fwd = X;  // only read with SLOPE == 2
                 if (interior) {
                     if constexpr (W2) {
                         // the selector word of THIS pixel: bit p = "the weight of plane p is not 1" (k_wsel)
@@ -905,7 +812,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                         if constexpr (pubE) {
                             if constexpr (FORM == 0)
                                 combine_unit_E<LPL, MGM, FH>(Cv, nb_i.w[0], nb_same.w[0], nb_back.w[0], nb_fwd.w[0], Lv);
-                            else  // (FORM 2, at most three neighbours: the fourth argument is not read)
+                            else
                                 combine_unit_E<LPL, MGM, FH>(Cv, nb_fwd.w[0], nb_back.w[0], nb_same.w[0], nb_i.w[0], Lv);
                         } else {
                             if constexpr (FORM == 0) combine_unit<LPL>(Cv, nb_i, nb_same, nb_back, nb_fwd, MGM, FH, Lv);
@@ -1046,8 +953,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
 #pragma unroll
                             for (int k = 0; k < LPL; k++)
                                 tagged[k] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, nb_i.w[q][k]) & 0x7fffffffu) | tag_out);  // (a NaN -- INF costs with P2 = INF -- may carry a sign of its own)
-                            float *hs = FORM == 2 ? hand_out + ((long long)(t0 + i) * 2 + (r - (NC - 2))) * LP
-                                                  : hand_out + ((long long)(mirror ? LL - 1 - i : i) * NS + q) * LP;
+                            float *hs = hand_out + ((long long)(mirror ? LL - 1 - i : i) * NS + q) * LP;
                             if constexpr (XCDQ) {
                                 if (plain_out) store_slab_plain<LPL>(hs, lane, tagged);
                                 else store_slab_sc1_wide<LPL>(hs, lane, tagged);
@@ -1103,11 +1009,6 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
             dbg[15] = ((fh_sweeps & 0xfffff) << 44) | ((unsigned long long)(fh_max & 0xff) << 36) | ((fh_n & 0x3ffff) << 18) | (fh_rep & 0x3ffff);
         }
     };
-    if constexpr (DIAG)
-        if (form == 2) {
-            run(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
-            return;
-        }
     if (form != 0) run(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
     else if (SL == 2) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
     else if constexpr (MGM <= 3) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -1136,8 +1037,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
                                   (LPL >= 12 ? 2 : ONEB ? MGM_P2_ONEB_WPE : (C8 && LPL <= 4 && !WEIGHTED) ? MGM_P2_WAVES_PER_EU : 4)) k_pass2(const PassParams P)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool DIAG = can_diag<FH, WEIGHTED, MGM, C8, DEEP, XCDQ, ONEB, W2>() && SUBV == 1;
-    int *s_ticket = reinterpret_cast<int *>(smem + P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP, W2, DIAG>::task_off);
+    int *s_ticket = reinterpret_cast<int *>(smem + P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP, W2>::task_off);
     if constexpr (!XCDQ) {
         if (threadIdx.x == 0) *s_ticket = (int)atomicAdd(P.ticket, 1u);
         __syncthreads();
@@ -1152,7 +1052,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             __syncthreads();
             const int t = *s_ticket;
             if (t >= qi.y) break;
-            pass2_item<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, true, W2, DIAG>(P, qi.x + t);
+            pass2_item<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, true, W2>(P, qi.x + t);
             wait_vmcnt<0>();   // (the loader's DMAs beyond the last step)
             __syncthreads();   // LDS and s_ticket are free again
         }
@@ -1171,8 +1071,7 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
 template <int LPL, bool FH, bool WEIGHTED, int MGM, int C8, int SUBV = 1, bool DEEP = false, bool XCDQ = false, bool ONEB = false, bool W2 = false>
 static hipError_t launch2_c8(const PassParams &p, int ntasks, hipStream_t s)
 {
-    constexpr bool DIAG = can_diag<FH, WEIGHTED, MGM, C8, DEEP, XCDQ, ONEB, W2>() && SUBV == 1;
-    using PL = typename P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP, W2, DIAG>::PL;
+    using PL = typename P2Lds<LPL, FH, WEIGHTED, MGM, C8, DEEP, W2>::PL;
     size_t shmem = sizeof(float) * (size_t)PL::lds_floats(PL::D);
     // Occupancy is chosen per launch through the LDS request: the compact unweighted kernels are built for two
     // workgroups per CU (<= 64 VGPRs, < 80 KB of LDS).  Two bands per CU hide each other's barrier and LDS stalls --

@@ -302,6 +302,43 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     // [0, layout_ndir) and is this protocol's alone (the other kernels' slots live in `hand2`), so neither a caller that
     // launches the passes one by one nor one that alternates weighted and unweighted runs makes it be cleared again.
     const bool tags = R2 && !wk && (w2 || !(fh && MGM == 2));
+    std::string tag_key;
+    float *hand_ptr = nullptr;
+    if (tags) {
+        long long per_vol = 0;
+        for (int q = 0; q < layout_ndir; q++) {
+            p.g[q].hand_base = per_vol;
+            per_vol += (long long)p.g[q].nbands * p.g[q].LL;
+        }
+        p.hand_vstride = per_vol;
+        const size_t bytes = sizeof(float) * (size_t)ngroups * per_vol * LPk;
+        const void *before = c->hand.p;
+        if ((r = reserve(c, c->hand, bytes))) return r;
+        char key[160];
+        snprintf(key, sizeof key, "%d %d %d %d %d %d %d", nx, ny, LPk, ngroups, layout_ndir, R, MGM <= 3 ? 1 : 0);  // (LPk tells the W2 layout apart)
+        if (c->hand.p != before || c->hand_key != key) {
+            HIPCHK(c, hipMemsetAsync(c->hand.p, 0xff, bytes, c->stream));
+            c->hand_key = key;
+            for (int q = 0; q < kMaxDirs; q++) c->hand_tags[q] = 0x80000000u;  // (what the cleared words look like)
+        }
+        for (int q = first; q < PEND; q++) {
+            c->hand_tags[q] ^= 0x80000000u;
+            p.hand_tag[q] = c->hand_tags[q];
+        }
+        // The tags are only good for a launch that really rewrites every slot of its passes: until the pass kernel has
+        // been enqueued the region counts as unknown (the next call clears it), so an error return between here and the
+        // launch cannot leave slots behind that carry the tag of the launch after next.
+        tag_key = c->hand_key;
+        c->hand_key.clear();
+        hand_ptr = (float *)c->hand.p;
+    } else {
+        if ((r = reserve(c, c->hand2, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * (subv > 1 ? Lk : LP)))) return r;
+        hand_ptr = (float *)c->hand2.p;
+        // progress words of this protocol: [volume*8 + pass][band]
+        HIPCHK(c, hipMemsetAsync(words + 4, 0, sizeof(unsigned) * (size_t)nb * kMaxDirs * kMaxBands, c->stream));
+    }
+    if ((r = reserve(c, c->handm, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL))) return r;
+
     double load_ratio = 0;  // band-steps per CU over the longest chain of the launch
     {
         // Two bands per CU pay when the launch is bound by throughput, not by the longest chain of bands: compare the
@@ -384,81 +421,6 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
                 p.g[q].split = p.g[q].LL / 2;
                 any_strips = true;
             }
-    // Passes 4-7 along their ANTI-DIAGONALS (k_pass2, DIAG; round 4): with at most three neighbours such a pass reads only
-    // the previous line, and walked line by line its chain is 2 steps per line -- the longest of the launch; along the
-    // anti-diagonals it is one step per line (mgm_pass2.hip, pass2_item).  For launches whose chains matter: the queue
-    // kernels at one band per CU below a load/chain of 4 (diag=2 forces it wherever those kernels run, diag=0 never).
-    // Supersedes the strips.
-    bool diag = false;
-    {
-        const long long dsw = tune_num("diag", 1);
-        diag = tags && !w2 && xcdq && p.wg_per_cu == 1 && dev().oneb && use_c8 && subv == 1 && MGM <= 3 && !(fh && MGM == 2) && dsw != 0 &&
-               (load_ratio < 4.0 || dsw == 2);
-        bool any_form1 = false;
-        for (int q = first; q < PEND; q++) any_form1 |= p.g[q].form == 1;
-        diag = diag && any_form1;
-        if (diag) {
-            any_strips = false;
-            maxLL = 0, maxbands = 0;
-            for (int q = 0; q < std::max(PEND, layout_ndir); q++) {
-                PassGeom &g = p.g[q];
-                g.nstrips = 1;
-                g.split = g.LL;
-                if (g.form == 1) {
-                    const int NLo = g.NL, LLo = g.LL;
-                    const long long is = g.istep, js = g.jstep;
-                    g.NL = NLo + LLo - 1;  // lines = anti-diagonals d = i + j
-                    g.LL = NLo;            // positions along one = the pass's line index j
-                    g.jstep = is;          // d -> d + 1 at a fixed position: one pixel further along the old line
-                    g.istep = js - is;     // t -> t + 1 on an anti-diagonal: next old line, one pixel back
-                    g.form = 2;
-                    g.slope = 0;
-                    g.nbands = (g.NL + R - 1) / R;
-                    g.split = LLo;         // (the kernel finds the old line length here: diagonal passes never run as strips)
-                }
-                maxLL = std::max(maxLL, g.LL);
-                maxbands = std::max(maxbands, g.nbands);
-            }
-            if (maxbands > kMaxBands) return fail(c, MGM_ERR_UNSUPPORTED, "image too large for the anti-diagonal walk");
-        }
-    }
-    std::string tag_key;
-    float *hand_ptr = nullptr;
-    if (tags) {
-        long long per_vol = 0;
-        for (int q = 0; q < layout_ndir; q++) {
-            p.g[q].hand_base = per_vol;
-            per_vol += (long long)p.g[q].nbands * p.g[q].LL * (p.g[q].form == 2 ? 2 : 1);  // (anti-diagonal passes: two slabs per position)
-        }
-        p.hand_vstride = per_vol;
-        const size_t bytes = sizeof(float) * (size_t)ngroups * per_vol * LPk;
-        const void *before = c->hand.p;
-        if ((r = reserve(c, c->hand, bytes))) return r;
-        char key[160];
-        snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d", nx, ny, LPk, ngroups, layout_ndir, R, MGM <= 3 ? 1 : 0, diag ? 1 : 0);  // (LPk tells the W2 layout apart)
-        if (c->hand.p != before || c->hand_key != key) {
-            HIPCHK(c, hipMemsetAsync(c->hand.p, 0xff, bytes, c->stream));
-            c->hand_key = key;
-            for (int q = 0; q < kMaxDirs; q++) c->hand_tags[q] = 0x80000000u;  // (what the cleared words look like)
-        }
-        for (int q = first; q < PEND; q++) {
-            c->hand_tags[q] ^= 0x80000000u;
-            p.hand_tag[q] = c->hand_tags[q];
-        }
-        // The tags are only good for a launch that really rewrites every slot of its passes: until the pass kernel has
-        // been enqueued the region counts as unknown (the next call clears it), so an error return between here and the
-        // launch cannot leave slots behind that carry the tag of the launch after next.
-        tag_key = c->hand_key;
-        c->hand_key.clear();
-        hand_ptr = (float *)c->hand.p;
-    } else {
-        if ((r = reserve(c, c->hand2, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * NS * (subv > 1 ? Lk : LP)))) return r;
-        hand_ptr = (float *)c->hand2.p;
-        // progress words of this protocol: [volume*8 + pass][band]
-        HIPCHK(c, hipMemsetAsync(words + 4, 0, sizeof(unsigned) * (size_t)nb * kMaxDirs * kMaxBands, c->stream));
-    }
-    if ((r = reserve(c, c->handm, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL))) return r;
-
     // bands per queue block: a pass stays on one XCD when the passes of the launch fill the eight queues evenly; otherwise
     // blocks of two bands, which spread four or twelve passes over all XCDs at the price of every second hand-off
     // crossing.
@@ -470,10 +432,10 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     if (dev().xcdq_k >= 0) QK = dev().xcdq_k;
     if (QK <= 0) QK = 1 << 20;
     if (tune_num("show_plan", 0))  // development aid: what the launch heuristics decided
-        fprintf(stderr, "[mgm plan] %dx%dx%d passes %d..%d x %d volumes: load/chain %.2f, %d wg/cu, deep %d, subv %d, strips %d, diagonals %d, xcd queues %d (block %d; xcc ids seen 0x%x)\n", nx, ny, L,
-                first, PEND - 1, nb, load_ratio, p.wg_per_cu, p.deep, subv, any_strips ? 1 : 0, diag ? 1 : 0, xcdq ? 1 : 0, QK >= (1 << 20) ? 0 : QK, (unsigned)c->xcc_mask);
+        fprintf(stderr, "[mgm plan] %dx%dx%d passes %d..%d x %d volumes: load/chain %.2f, %d wg/cu, deep %d, subv %d, strips %d, xcd queues %d (block %d; xcc ids seen 0x%x)\n", nx, ny, L,
+                first, PEND - 1, nb, load_ratio, p.wg_per_cu, p.deep, subv, any_strips ? 1 : 0, xcdq ? 1 : 0, QK >= (1 << 20) ? 0 : QK, (unsigned)c->xcc_mask);
     // task table: ticket -> (pass, band [, strip]); item (p, b, .) always follows the items (p, b-1, .)
-    const int tk_key = (((((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv) * 2 + (any_strips ? 1 : 0)) * 2 + (xcdq ? 1 : 0)) * 2 + (diag ? 1 : 0);
+    const int tk_key = ((((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv) * 2 + (any_strips ? 1 : 0)) * 2 + (xcdq ? 1 : 0);
     if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != tk_key || c->tk_r != R)
         for (auto &t : c->ttabs)
             if (t.nx == nx && t.ny == ny && t.key == tk_key && t.R == R) {  // a shape seen before: its table is still on the device
@@ -621,7 +583,7 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
             for (int v = 0; v < ngroups; v++)
                 for (int q = first; q < PEND; q++) {
                     const long long nw = (long long)(p.g[q].nbands - 1) * p.g[q].LL * LPk;
-                    if (nw <= 0 || p.g[q].form == 2) continue;  // (anti-diagonal passes write only the slots inside their lines' extents)
+                    if (nw <= 0) continue;
                     HIPCHK(c, launch_check_tags(hand_ptr + ((long long)v * p.hand_vstride + p.g[q].hand_base) * LPk, nw, p.hand_tag[q], words + 3, c->stream));
                 }
             HIPCHK(c, hipMemcpyAsync(c->h_words + 3, words + 3, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
