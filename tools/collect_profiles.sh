@@ -9,13 +9,19 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-PROFILED=${PROFILED:-"cfg3:12 cfg3:2 cfg3:1 cfg2:16 cfg2:2 cfg4:1 cfg4:2 cfg5:16"}
-MATRIX=${MATRIX:-"cfg3h:12 cfg2:16 cfg5:16 cfg4:1 cfg4:2 cfg3:8 cfg3:4 cfg3:2 cfg3:1 cfg3h:2 cfg3h:1 cfg2:8 cfg2:4 cfg2:2 cfg2:1"}
+PROFILED=${PROFILED:-"cfg3:12 cfg3:2 cfg3:1 cfg2:16 cfg2:2 cfg4:1 cfg5:16 cfg3w:12 cfg3hw:12 cfg3ad:12 cfg3ncc:12 cfg1s:16 cfg3L768:4"}
+MATRIX=${MATRIX:-"cfg3h:12 cfg2:16 cfg5:16 cfg4:1 cfg4:2 cfg3:8 cfg3:4 cfg3:2 cfg3:1 cfg3h:2 cfg3h:1 cfg2:8 cfg2:4 cfg2:2 cfg2:1 cfg3w:12 cfg3w:1 cfg3hw:12 cfg3hw:1 cfg3ad:12 cfg3ad:1 cfg3ad1:12 cfg3ncc:12 cfg3ncc:1 cfg1s:16 cfg1s:1 cfg3L768:4 cfg3L768:1"}
+# a stream of single pairs / small batches through a pipelined context (mgm_ctx_set_pipeline): workload:batch:depth
+PIPED=${PIPED:-"cfg3:1:2 cfg3:1:4 cfg3:1:12 cfg3h:1:4 cfg2:1:4 cfg2:1:8 cfg3:2:2"}
 : > "$OUT/bench_lines.jsonl"
 timeout 900 python bench.py 2> "$OUT/bench_default.stderr" | tail -1 >> "$OUT/bench_lines.jsonl"
 for wb in $MATRIX; do
   w=${wb%%:*}; b=${wb##*:}
   timeout 600 python bench.py --workload $w --batch $b --repeats 0 --no-cpu-baseline --no-parity 2>/dev/null | tail -1 >> "$OUT/bench_lines.jsonl"
+done
+for wbd in $PIPED; do
+  w=${wbd%%:*}; rest=${wbd#*:}; b=${rest%%:*}; d=${rest##*:}
+  timeout 600 python bench.py --workload $w --batch $b --pipeline $d --repeats 0 --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT/bench_lines.jsonl"
 done
 for wb in $PROFILED; do
   w=${wb%%:*}; b=${wb##*:}; tag=${w}_b${b}
@@ -34,6 +40,8 @@ for wb in $PROFILED; do
   fi
   rm -rf "$OUT/kt" "$OUT/fetch" "$OUT/write"
 done
+# the launch plan against every override on shapes it was not tuned on (tools/plan_sweep.py)
+timeout 1500 python tools/plan_sweep.py > "$OUT/plan_sweep.txt" 2> "$OUT/plan_sweep.err"
 # the single-GPU ingredients of DESIGN.md section 6's direction-sharding model, and the wall time of the whole command line
 timeout 600 python tools/time_passes.py cfg4 > "$OUT/cfg4_pass_blocks.txt" 2>&1
 for i in 1 2 3; do MGM_HIP_STATS=1 bash tools/cli_fullsize.sh 2>&1 | grep -v "^disp\|^cost"; sleep 2; done > "$OUT/cli_fullsize.txt" 2>&1
@@ -46,7 +54,8 @@ for l in open("gpurun_out/profiles/bench_lines.jsonl"):
     try: d = json.loads(l)
     except Exception: print("bad line", l[:100]); continue
     a = d["roofline"]["avg_launch_ms"]
-    print(d["config"]["workload"][:6], "B", d["config"].get("pairs_per_step"), "value", round(d["value"], 2), "ms/step", round(d["ms_per_step"], 2),
+    print(d["config"]["workload"][:8], "B", d["config"].get("pairs_per_step"), "D", d["config"].get("pipeline_depth"), "value", round(d["value"], 2), "ms/step", round(d["ms_per_step"], 2),
+          "K2", round(a.get("k_cost", 0), 3),
           "K3", round(a.get("k_pass2", a.get("k_pass", 0)), 2), "wta", round(a["k_wta"], 2), "frac", round(d["roofline"]["frac"], 3),
           "parity", (d.get("parity") or {}).get("status"), "cpu", d.get("cpu_baseline", {}).get("value"))
 PY
