@@ -15,7 +15,8 @@ FUZZ_N = int(os.environ.get("MGM_FUZZ_N", "0"))
 FUZZ_BASE = int(os.environ.get("MGM_FUZZ_BASE", "0"))
 FUZZ_SCALE = int(os.environ.get("MGM_FUZZ_SCALE", "1"))  # image sides up to 40 x 30 times this (several bands per pass from 2 on)
 
-LABELS = [1, 2, 3, 5, 31, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 511, 512]
+LABELS = [1, 2, 3, 5, 31, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 511, 512,
+          513, 700, 768, 769, 1000, 1024, 1025]  # (round 4: 513..1024 take the second build at 12 / 16 labels per lane)
 
 
 @pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_N or 160)))
@@ -27,6 +28,7 @@ def test_random_case_vs_oracle(ctx, oracle, seed):
     L = LABELS[int(rng.integers(0, len(LABELS)))]
     if nx * ny * L > 60000 * FUZZ_SCALE ** 2:
         L = LABELS[int(rng.integers(0, 8))]
+    maxcost = int(rng.choice([24, 24, 254, 3000]))  # (beyond 254: no one-byte form -- fp32 costs for an uploaded volume)
     NDIR = int(rng.integers(1, 9))
     MGM = int(rng.integers(1, 5))
     FH = int(rng.integers(0, 2))
@@ -34,7 +36,7 @@ def test_random_case_vs_oracle(ctx, oracle, seed):
     fix = int(rng.integers(0, 2))
     dmin = int(rng.integers(-300, 300))
     integer = rng.random() < 0.6
-    C = synth.raw_volume(nx, ny, L, seed=seed, inf_frac=float(rng.choice([0.0, 0.05, 0.5])))
+    C = synth.raw_volume(nx, ny, L, seed=seed, maxcost=maxcost, inf_frac=float(rng.choice([0.0, 0.05, 0.5])))
     if not integer:
         C = (C * np.float32(1.0 / 3.0)).astype(np.float32)
     w8 = None
@@ -75,7 +77,19 @@ def test_random_costvolume_vs_oracle(ctx, oracle, seed):
     v = rng.integers(0, 256, size=(nch, vny, vnx)).astype(np.float32)
     a = oracle.costvolume(u, v, dmin, dmin + L - 1, pre, dist, td, win)
     cv = ctx.costvolume_dev(ctx.upload_image(u), ctx.upload_image(v), dmin, dmin + L - 1, pre, dist, td, win)
-    assert ndiff(cv.download(), a) == 0, (nch, nx, ny, vnx, vny, L, dmin, pre, dist, win, td)
+    tag = (nch, nx, ny, vnx, vny, L, dmin, pre, dist, win, td)
+    assert ndiff(cv.download(), a) == 0, tag
+    # ... and through the aggregation: the compact copy K2 wrote next to the fp32 volume (one or two bytes per cost, or
+    # none) is what the pass kernels and the winner search read
+    if not np.isnan(a).any():
+        NDIR, MGM, FH = int(rng.integers(1, 9)), int(rng.integers(1, 5)), int(rng.integers(0, 2))
+        P1, P2 = [(8.0, 32.0), (2.0, 9.0), (6.0, 60000.0)][int(rng.integers(0, 3))]
+        So, oo, co = oracle.mgm(a, dmin, P1, P2, NDIR, MGM, FH, 1)
+        S, o, c = ctx.aggregate_dev(cv, P1, P2, NDIR, MGM, FH, 1, None, None, want_S=True)
+        assert ndiff(S.download(), So) == 0 and ndiff(c.download()[0], co) == 0, (tag, NDIR, MGM, FH, P1, P2)
+        fin = np.isfinite(co)
+        assert ndiff(o.download()[0][fin], oo[fin]) == 0, (tag, NDIR, MGM, FH)
+        S.free()
     cv.free()
 
 
