@@ -956,6 +956,29 @@ def main():
         line.guard(args.extras_timeout)
         ctx.trim()
         env.ctrl_barrier()  # (rank 0 may have spent a minute in the CPU legs)
+        # what north_star names beside the headline combination, in the driver's own line (round 4): per-edge weights, AD on a
+        # colour pair, clipped NCC, 768 labels, and a stream of single pairs through a pipelined context -- short legs (4 pairs
+        # per step where the workspace allows, 5 steps), same measurement as the headline, no CPU legs
+        try:
+            vres = {}
+            if rank == 0:
+                res["variants"] = vres
+            for vname, vb, vd in (("cfg3w", 4, 1), ("cfg3hw", 4, 1), ("cfg3ad", 4, 1), ("cfg3ncc", 4, 1), ("cfg3L768", 1, 1), ("cfg3", 1, 4), ("cfg2", 1, 8)):
+                vw = WORKLOADS[vname]
+                vm = pairs_leg(env, vw, vb, 8 if vd > 1 else 5, 1, 0, pipeline=vd)
+                if rank == 0:
+                    vsteps = 8 if vd > 1 else 5
+                    vr = roofline_of(vw, vb, vm["avg"], vname, step_ms=(vm["dt"] / vsteps * 1e3) if vd > 1 else None)
+                    pn = "k_pass2" if "k_pass2" in vm["avg"] else "k_pass"
+                    vres["%s x%d%s" % (vname, vb, (" pipeline %d" % vd) if vd > 1 else "")] = {
+                        "workload": vw["desc"], "value": shard.job_rate([vsteps * vb] * n_ranks, vm["dt"]), "unit": "disparity-volumes/s",
+                        "roofline_frac": vr["frac"], "time_basis": vr["time_basis"], "k2_ms": vm["avg"].get("k_cost"), "k3_ms": vm["avg"].get(pn),
+                        "wta_ms": vm["avg"].get("k_wta")}
+                ctx.trim()
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                res.setdefault("variants", {})["error"] = repr(e)[:300]
+        ctx.trim()
         try:
             r5 = replicas_leg(env, "cfg5", max(5, args.steps), min(args.warmup, 2))
             if rank == 0:
