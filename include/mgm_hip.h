@@ -127,8 +127,9 @@ int mgm_costvolume_build_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, i
  * (-m/-M files) give a volume over the hull of all ranges in which a pixel only owns the disparities of its own
  * range -- the others read +INF, as Dvec::operator[] does (dvec.cc:129), and are exempt from the "no finite cost"
  * rule; mgm_aggregate* then searches the winner and gates the refinement inside each pixel's range.  The hull may
- * span at most 8192 labels (up to 512 on the fast kernels, up to 2048 on the first build of the pass kernel, beyond that
- * on the generic ones); batched ragged volumes must share hull_min under FH potentials. */
+ * span any number of labels the device can hold (the reference's Dvec has no limit, dvec.cc:60; an index-arithmetic cap of
+ * 4 194 304 aside): up to 1024 on the fast kernels, up to 2048 on the first build of the pass kernel, beyond that on the
+ * generic ones (a second or more per full-HD volume); batched ragged volumes must share hull_min under FH potentials. */
 int mgm_costvolume_build(mgm_ctx *ctx, const float *u, const float *v, int nx, int ny, int nch, int vnx, int vny,
                          const float *dminI, const float *dmaxI, const char *prefilter, const char *distance,
                          float truncDist, int census_win, mgm_cv **C);

@@ -256,7 +256,7 @@ int mgm_ctx_destroy(mgm_ctx *c)
     (void)hipSetDevice(c->device);
     (void)pipe_join(c);  // (deferred calls of a pipelined context still write the caller's images)
     (void)hipStreamSynchronize(c->stream);
-    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->words, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
+    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->exact_scratch, &c->words, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);
         bufs.push_back(&c->pad8[v]);
@@ -296,7 +296,7 @@ int mgm_ctx_trim(mgm_ctx *c)
     if (!c) return MGM_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     if (int r = mgm_ctx_synchronize(c)) return r;
-    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
+    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->exact_scratch, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);
         bufs.push_back(&c->pad8[v]);
@@ -461,7 +461,7 @@ extern "C++" int cv_create(mgm_ctx *c, int nx, int ny, int dmin, int dmax, bool 
     if (!c || !out || nx <= 0 || ny <= 0 || dmax < dmin) return fail(c, MGM_ERR_INVALID, "mgm_cv_create: bad arguments");
     const long long L = (long long)dmax - dmin + 1;
     if (L > kMaxLabels)
-        return fail(c, MGM_ERR_UNSUPPORTED, "more than 8192 disparity labels per pixel are not supported");
+        return fail(c, MGM_ERR_UNSUPPORTED, "more than 4 194 304 disparity labels per pixel are not supported");
     HIPCHK(c, hipSetDevice(c->device));
     mgm_cv *cv = new mgm_cv();
     cv->d = nullptr;

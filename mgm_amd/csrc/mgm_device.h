@@ -7,7 +7,8 @@ namespace mgm {
 
 constexpr int kMaxDirs = 8;
 constexpr int kMaxLPL = 32;          // disparities per lane of the fast kernels -> L <= 2048 (the fastest stop at 8: 512 labels)
-constexpr int kMaxLabels = 8192;     // beyond 2048 labels: the generic kernels (mgm_pass_exact.hip, k_wta_any); 4 x L floats of LDS
+constexpr int kMaxLabels = 1 << 22;  // (index arithmetic; the reference's Dvec has no limit, dvec.cc:60) beyond 2048 labels: the generic
+                                     // kernels (mgm_pass_exact.hip, k_wta_any); FH beyond 8192: convolution arrays in global scratch
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kCensusMaxWords = 8;   // 32-bit census words per pixel
 
@@ -108,6 +109,8 @@ struct ExactParams {
     const float *C;      // [npix][L]
     float *Lr;           // this pass's volume [npix][L], initialised to C by the caller
     float *mins;         // [npix] slab minima of the pixels visited so far
+    float *fhscratch;    // FH potentials with more than 8192 labels: max(nx, ny) x 4 x L floats (the convolution arrays of a
+                         // diagonal's pixels, which fit the LDS up to 8192 labels), else unused
     const float *w8;     // 8 planes or nullptr
     const float *rlo, *rhi;  // ragged volume: per-pixel range images, or nullptr
     int nx, ny, L, dmin;

@@ -69,7 +69,7 @@ struct mgm_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // workspace
-    Buf exact_mins;  // slab minima of the operand-order-faithful pass kernel (mgm_pass_exact.hip)
+    Buf exact_mins, exact_scratch;  // slab minima / (FH beyond 8192 labels) convolution arrays of the operand-order-faithful pass kernel
     Buf lr, hand, hand2, handm, words, tasks, census_u, census_v, dbg, stmp, ones8;  // hand: self-validating slabs (TAGS); hand2: the other kernels' slots
     // Pipelined contexts (mgm_ctx_set_pipeline, depth >= 2): aggregation calls are DEFERRED and gathered -- up to `depth`
     // calls of the same geometry and settings become ONE launch of the pass kernel (see PendingAgg, pipe_flush)

@@ -119,13 +119,17 @@ __global__ void __launch_bounds__(64) k_pass_exact(const ExactParams P)
             // FH: the neighbours' values over THIS pixel's range, convolved there (197-219, 229-281)
             const int NN = rh - rl + 1;
             const int nk = P.mode == 2 ? 2 : hm;
+            // the convolution arrays: in LDS up to 8192 labels, beyond that in a slice of global scratch of this workgroup's
+            // own (one wave per workgroup; the block barriers below order its stores and loads)
+            float *const conv = P.fhscratch ? P.fhscratch + (size_t)blockIdx.x * 4 * (size_t)L : exact_smem;
             if (NN > 0) {
                 for (int k = 0; k < nk; k++)
-                    for (int o = lane; o < NN; o += 64) exact_smem[(size_t)k * NN + o] = Ln[k][rl + o];
+                    for (int o = lane; o < NN; o += 64) conv[(size_t)k * NN + o] = Ln[k][rl + o];
+                __threadfence_block();
                 __syncthreads();
                 if (lane < nk) {  // one lane per neighbour: the recurrences are sequential in fp32 (152-163)
                     const int k = lane;
-                    float *M = exact_smem + (size_t)k * NN;
+                    float *M = conv + (size_t)k * NN;
                     const float p1 = P.mode == 2 ? P.P1 : P.P1 * D[k], p2 = P.mode == 2 ? P.P2 : P.P2 * D[k];
                     if (P.mode == 2) {  // FixBounrady_for_minConvTruncatedLinear (166-186): I = the neighbour's own labels
                         const int imin = nl[k], imax = nh[k], mmin = rl, mmax = rh;
@@ -152,14 +156,15 @@ __global__ void __launch_bounds__(64) k_pass_exact(const ExactParams P)
                     if (p2 < __builtin_huge_valf())
                         for (int o = 0; o < NN; o++) M[o] = ref_min(M[o], mn[k] + p2);
                 }
+                __threadfence_block();
                 __syncthreads();
                 for (int o = lane; o < NN; o += 64) {
                     float v;
                     if (P.mode == 2) {
-                        v = Cp[rl + o] + (exact_smem[o] - mn[0] + exact_smem[(size_t)NN + o] - mn[1]) * 0.5f;
+                        v = Cp[rl + o] + (conv[o] - mn[0] + conv[(size_t)NN + o] - mn[1]) * 0.5f;
                     } else {
-                        float e = exact_smem[o] - mn[0];
-                        for (int k = 1; k < hm; k++) e += exact_smem[(size_t)k * NN + o] - mn[k];
+                        float e = conv[o] - mn[0];
+                        for (int k = 1; k < hm; k++) e += conv[(size_t)k * NN + o] - mn[k];
                         v = Cp[rl + o] + ref_div(e, hm);
                     }
                     Lp[rl + o] = v;
@@ -192,8 +197,12 @@ hipError_t launch_pass_exact(const ExactParams &base, hipStream_t s)
 {
     ExactParams p = base;
     const int maxii = p.row_major ? p.nx : p.ny, maxjj = p.row_major ? p.ny : p.nx;
-    const size_t shmem = (p.mode >= 2) ? sizeof(float) * 4 * (size_t)p.L : 0;
-    if (shmem > 160 * 1024) return hipErrorInvalidValue;
+    size_t shmem = (p.mode >= 2) ? sizeof(float) * 4 * (size_t)p.L : 0;
+    if (shmem > 128 * 1024) {  // (more than 8192 labels: the caller provides global scratch, mgm_plan.hip)
+        if (!p.fhscratch) return hipErrorInvalidValue;
+        shmem = 0;
+    } else
+        p.fhscratch = nullptr;
     if (shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pass_exact), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;

@@ -36,6 +36,8 @@ static int run_passes_exact(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *
     int r;
     if ((r = reserve(c, c->lr, sizeof(float) * (size_t)lr_stride * nslots * nb))) return r;
     if ((r = reserve(c, c->exact_mins, sizeof(float) * (size_t)npix))) return r;
+    const bool big_fh = fh && (size_t)L * 16 > 128 * 1024;  // the four convolution arrays of a pixel do not fit the LDS
+    if (big_fh && (r = reserve(c, c->exact_scratch, sizeof(float) * (size_t)std::max(nx, ny) * 4 * (size_t)L))) return r;
     ExactParams p{};
     p.nx = nx;
     p.ny = ny;
@@ -46,6 +48,7 @@ static int run_passes_exact(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *
     // which of the four update functions (mgm_core.cc:548-571)
     p.mode = weighted ? (fh ? 3 : 1) : (fh ? (MGM == 2 ? 2 : 3) : (MGM == 2 ? 0 : 1));
     p.mins = (float *)c->exact_mins.p;
+    p.fhscratch = big_fh ? (float *)c->exact_scratch.p : nullptr;
     for (int v = 0; v < nb; v++) {
         if ((r = ensure_f32(c, Cs[v]))) return r;
         p.C = Cs[v]->d;

@@ -253,14 +253,15 @@ def test_uploaded_volume_with_nan_costs_takes_the_exact_kernel(ctx, oracle):
         cv.free()
 
 
-@pytest.mark.parametrize("L", [513, 600, 768, 1000, 1024, 1300, 1536, 2048, 2049, 2500, 4096, 8192])
+@pytest.mark.parametrize("L", [513, 600, 768, 1000, 1024, 1300, 1536, 2048, 2049, 2500, 4096, 8192, 8193, 12000, 20001])
 @pytest.mark.parametrize("mode", [(8, 3, 0, 8.0, 32.0, False), (8, 3, 1, 2.0, 20000.0, False), (4, 2, 1, 2.0, 9.0, False),
                                   (8, 4, 0, 8.0, 32.0, True), (5, 1, 1, 1.5, 40.0, True)],
                          ids=["O8-T3", "O8-T3-FH", "O4-T2-FH", "O8-T4-w", "O5-T1-FH-w"])
 def test_more_than_512_labels(ctx, oracle, L, mode):
     """The reference's Dvec has no label limit (dvec.cc:55-64); 513..1024 labels take the second pass-kernel build (round 4;
     weighted ones and 1025..2048 labels the first build with bands of four lines: 12 / 16 / 24 / 32 labels per lane) and the
-    generic WTA instance, 2049..8192 the generic kernels (mgm_pass_exact.hip, k_wta_any)."""
+    generic WTA instance, beyond 2048 the generic kernels (mgm_pass_exact.hip, k_wta_any; FH beyond 8192 labels -- round 4 --
+    with its convolution arrays in global scratch instead of the LDS)."""
     NDIR, MGM, FH, P1, P2, weighted = mode
     nx, ny, dmin = (23, 19, -L // 3) if L <= 2048 else (13, 11, -L // 3)
     C = synth.raw_volume(nx, ny, L, seed=L, inf_frac=0.04)
@@ -311,10 +312,11 @@ def test_768_and_1024_labels_on_the_second_build(ctx, oracle, L, mode):
     S.free(), cv.free()
 
 
-def test_more_than_8192_labels_is_refused(ctx):
+def test_label_count_beyond_the_index_arithmetic_is_refused(ctx):
+    """No label limit but the index arithmetic's (4 194 304; the reference's Dvec has none, dvec.cc:60)."""
     import mgm_amd
     with pytest.raises(mgm_amd.MgmError) as e:
-        ctx.upload_volume(np.zeros((2, 2, 8193), np.float32), 0)
+        ctx.upload_volume(np.zeros((1, 1, (1 << 22) + 1), np.float32), 0)
     assert e.value.code == mgm_amd.MGM_ERR_UNSUPPORTED
 
 
