@@ -203,6 +203,29 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         // is NaN BY CONSTRUCTION, so there is no flag to read back -- a refilled volume costs no synchronisation
         (*out)->c8_state = 2;
         (*out)->nan_state = 2;
+    } else if (p.C8 && !p.rlo && (costfn == 0 || costfn == 1) && (pre == 0 || pre == 2) && dev().lazy_f32 && !(*out)->diff_failed) {
+        // Absolute / squared differences of (sobelx-filtered) 8-bit images are whole numbers: write the compact copy alone and
+        // read the flag word back -- the read-back the aggregation would do anyway (c8_resolve).  A volume that does not fit
+        // (float-valued images, a fractional truncDist) is filled again by the general kernel, fp32 volume and all, and so
+        // are its refills.
+        p.C = nullptr;
+        (*out)->f32_state = 0;
+        {
+            TimeScope t(c, "k_cost");
+            HIPCHK(c, launch_cost(p, c->stream));
+        }
+        HIPCHK(c, hipMemcpyAsync(c->h_words + 3, (*out)->bad8, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->h_words[3] == 0u) {
+            (*out)->c8_state = 2;
+            (*out)->nan_state = 2;
+            return MGM_OK;
+        }
+        (*out)->diff_failed = true;
+        HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
+        if ((r = cv_alloc_f32(c, *out))) return r;
+        p.C = (*out)->d;
+        (*out)->f32_state = 1;
     } else {
         if ((r = cv_alloc_f32(c, *out))) return r;
         p.C = (*out)->d;
@@ -371,8 +394,20 @@ extern "C++" int pipe_flush(mgm_ctx *c)
         Ks.insert(Ks.end(), a.outcost.begin(), a.outcost.end());
     }
     const auto &a = q[0];
-    return aggregate_batch_now(c, (int)Cs.size(), Cs.data(), Ws.empty() ? nullptr : Ws.data(), a.P1, a.P2, a.NDIR, a.MGM, a.use_fh,
-                               a.fix_overcount, a.has_refine ? a.refine.c_str() : nullptr, Os.data(), Ks.data(), nullptr);
+    int r = aggregate_batch_now(c, (int)Cs.size(), Cs.data(), Ws.empty() ? nullptr : Ws.data(), a.P1, a.P2, a.NDIR, a.MGM, a.use_fh,
+                                a.fix_overcount, a.has_refine ? a.refine.c_str() : nullptr, Os.data(), Ks.data(), nullptr);
+    if (r == MGM_ERR_UNSUPPORTED && q.size() > 1) {
+        // Calls that each are fine may not go into ONE launch (e.g. weight planes that are all ones beside real ones: "all
+        // weighted or all unweighted" is decided on the values): run them as the caller issued them.
+        r = MGM_OK;
+        for (const auto &b : q) {
+            const int rb = aggregate_batch_now(c, (int)b.C.size(), b.C.data(), b.w8.empty() ? nullptr : b.w8.data(), b.P1, b.P2, b.NDIR,
+                                               b.MGM, b.use_fh, b.fix_overcount, b.has_refine ? b.refine.c_str() : nullptr,
+                                               const_cast<mgm_img **>(b.out.data()), const_cast<mgm_img **>(b.outcost.data()), nullptr);
+            if (rb != MGM_OK && r == MGM_OK) r = rb;
+        }
+    }
+    return r;
 }
 
 int mgm_aggregate_batch_dev(mgm_ctx *c, int n, const mgm_cv *const *C, const mgm_img *const *w8, float P1, float P2, int NDIR,

@@ -325,6 +325,22 @@ hipError_t launch_nanscan(const float *C, long long n, unsigned *flag, hipStream
 }
 
 // the fp32 volume back from its compact copy (exact: every byte decodes to the float it was made from)
+__global__ void __launch_bounds__(256) k_expand16(const unsigned short *__restrict__ C16, long long n, float *__restrict__ C)
+{
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < n) {
+            const uint2 w = *reinterpret_cast<const uint2 *>(C16 + i);
+            float4 f;
+            f.x = c16_decode(w.x & 65535u);
+            f.y = c16_decode(w.x >> 16);
+            f.z = c16_decode(w.y & 65535u);
+            f.w = c16_decode(w.y >> 16);
+            *reinterpret_cast<float4 *>(C + i) = f;
+        } else {
+            for (int k = 0; k < 4 && i + k < n; k++) C[i + k] = c16_decode(C16[i + k]);
+        }
+    }
+}
 __global__ void __launch_bounds__(256) k_expand(const uint8_t *__restrict__ C8, long long n, float *__restrict__ C)
 {
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
@@ -342,9 +358,10 @@ __global__ void __launch_bounds__(256) k_expand(const uint8_t *__restrict__ C8, 
     }
 }
 
-hipError_t launch_expand(const uint8_t *C8, long long n, float *C, hipStream_t s)
+hipError_t launch_expand(const uint8_t *C8, int cbytes, long long n, float *C, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_expand, dim3(256 * 16), dim3(256), 0, s, C8, n, C);
+    if (cbytes == 2) hipLaunchKernelGGL(k_expand16, dim3(256 * 16), dim3(256), 0, s, reinterpret_cast<const unsigned short *>(C8), n, C);
+    else hipLaunchKernelGGL(k_expand, dim3(256 * 16), dim3(256), 0, s, C8, n, C);
     return hipGetLastError();
 }
 
@@ -604,6 +621,160 @@ __global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restric
     }
 }
 
+// ---- absolute / squared differences, compact form only (round 4) ---------------------------------------------------
+// computeC_AD / computeC_SD (mgm_costvolume.h:23-44) for a volume that is EXPECTED to fit the compact form (8-bit images:
+// whole-number differences): only the compact copy is written, CB bytes per cost, and the flag word says afterwards whether
+// every cost really had that form -- if one did not, mgm_costvolume_build_dev runs the general kernel, which writes the fp32
+// volume.  Work layout of k_cost_census8x: four consecutive pixels of a row and sixteen labels per lane, the four pixels
+// share NL + 3 samples of the right image per channel; one 16-byte store per lane and pixel (NL = 16 or 8 labels).
+//   * The sum over the channels runs in channel order from 0, as there.  x = max(d, -d) enters as |d| (a source modifier):
+//     the two differ in the sign of a zero or of a NaN only, and 0 + x, x * x and "NaN loses the comparison with truncDist"
+//     hide both.
+//   * truncDist is +INF or a non-negative number here (the caller checks), so min(e, truncDist) is v_min_f32: a NaN cost
+//     becomes truncDist exactly as with the reference's comparison.
+//   * Encoding: convert, and keep the largest cost and the largest fractional part of the lane's costs of a pixel -- only a
+//     lane that saw a cost outside [0, LIM] or a fraction (labels
+//     outside the right image with truncDist = +INF; volumes that will be filled again) takes the careful c8_encode /
+//     c16_encode path.
+// NCH = the channel count (1 or 3: the right-image samples of all channels are loaded up front), or 0 = any (channel loop
+// outermost, 64 accumulators).
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <int NL>
+__device__ __forceinline__ void diff_load(const CostParams &P, int t, unsigned p32, long long npix, long long vpix, int y, bool yin, int q0,
+                                          bool inside, float (&ut)[4], float (&vt)[NL + 4])
+{
+    const float4 u4 = *reinterpret_cast<const float4 *>(P.u + (long long)t * npix + p32);
+    ut[0] = u4.x; ut[1] = u4.y; ut[2] = u4.z; ut[3] = u4.w;
+    const float *row = P.v + (long long)t * vpix + (long long)(yin ? y : 0) * P.vnx;
+    if (inside) {
+#pragma unroll
+        for (int h = 0; h < NL / 4 + 1; h++) {
+            const f32x4_a4 w = *reinterpret_cast<const f32x4_a4 *>(row + q0 + 4 * h);
+            vt[4 * h] = w.x; vt[4 * h + 1] = w.y; vt[4 * h + 2] = w.z; vt[4 * h + 3] = w.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NL + 3; k++) {
+            const int q = q0 + k;
+            vt[k] = row[(yin && q >= 0 && q < P.vnx) ? q : 0];
+        }
+        vt[NL + 3] = 0.0f;
+    }
+}
+template <int CB, int NCH, bool SD>
+__global__ void __launch_bounds__(256) k_cost_diffx(const CostParams P)
+{
+    constexpr unsigned LIM = CB == 2 ? 65534u : 254u;  // the largest finite code
+    constexpr int NC = NCH ? NCH : 1;
+    constexpr int NL = 16 / CB;      // labels per lane: sixteen bytes, one store per pixel
+    const int L = P.L, LP = L / NL;  // lanes per group of four pixels
+    const int G = 64 / LP;           // groups per wave and iteration (192 / 384 / 768 labels: the last lanes of the wave idle)
+    const int nx = P.nx, vnx = P.vnx;
+    const long long npix = (long long)nx * P.ny, vpix = (long long)vnx * P.vny;  // (npix: a multiple of four)
+    const long long nchunk = (npix + 4 * G - 1) / (4 * G);
+    const int lane = threadIdx.x & 63, sub = lane / LP, part = lane - sub * LP;
+    const unsigned long long group = (LP == 64 ? ~0ull : ((1ull << (LP & 63)) - 1ull)) << ((sub * LP) & 63);
+    const float trunc = P.trunc, tclamp = __builtin_fminf(trunc, (float)(LIM + 2u));
+    bool odd = false;  // a cost without the compact form
+    for (long long chunk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < nchunk; chunk += (long long)gridDim.x * 4) {
+        const long long pix0 = (chunk * G + sub) * 4;
+        const bool live = sub < G && pix0 < npix;
+        const unsigned p32 = live ? (unsigned)pix0 : 0u;  // (npix < 2^31: checked by the caller)
+        const int y = (int)(p32 / (unsigned)nx), x = (int)(p32 - (unsigned)y * (unsigned)nx);  // x .. x+3: one row
+        const int q0 = x + P.dmin + part * NL;
+        const bool yin = y < P.vny;
+        const bool inside = yin && q0 >= 0 && q0 + NL + 4 <= vnx;  // every sample the four pixels need lies inside the right image
+        float uu[NC][4], v[NC][NL + 4];
+        float e[NCH ? 1 : 4][NL];
+        if constexpr (NCH != 0) {
+#pragma unroll
+            for (int t = 0; t < NCH; t++) diff_load<NL>(P, t, p32, npix, vpix, y, yin, q0, inside, uu[t], v[t]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int k = 0; k < NL; k++) e[i][k] = 0.0f;
+            for (int t = 0; t < P.nch; t++) {
+                diff_load<NL>(P, t, p32, npix, vpix, y, yin, q0, inside, uu[0], v[0]);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int k = 0; k < NL; k++) {
+                        const float d = uu[0][i] - v[0][i + k];
+                        e[i][k] += SD ? d * d : __builtin_fabsf(d);
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float c[NL];
+            unsigned b[NL];
+            float top = 0.0f, frac = 0.0f;  // the largest clamped cost and the largest fractional part
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                if constexpr (NCH != 0) {
+                    float a = 0.0f;  // (0 + x: the compiler drops it; x >= +0)
+#pragma unroll
+                    for (int t = 0; t < NCH; t++) {
+                        const float d = uu[t][i] - v[t][i + k];
+                        a += SD ? d * d : __builtin_fabsf(d);
+                    }
+                    c[k] = a;
+                } else {
+                    c[k] = e[i][k];
+                }
+                if (!inside) {  // a label outside the right image costs truncDist (mgm_costvolume.h:401-412)
+                    const int q = q0 + i + k;
+                    c[k] = (yin && q >= 0 && q < vnx) ? c[k] : trunc;
+                }
+                const float cc = __builtin_fminf(c[k], tclamp);  // in [0, LIM + 2]: the conversion is defined
+                b[k] = (unsigned)cc;
+                top = __builtin_fmaxf(top, cc);
+                frac = __builtin_fmaxf(frac, __builtin_amdgcn_fractf(cc));
+            }
+            bool fin = true;
+            if (frac > 0.0f || top > (float)LIM) {  // the careful path
+                fin = false;
+#pragma unroll
+                for (int k = 0; k < NL; k++) {
+                    const float ct = (c[k] < trunc) ? c[k] : trunc;
+                    fin |= finite_bits(ct);
+                    b[k] = CB == 2 ? c16_encode(ct) : c8_encode(ct);
+                    odd |= b[k] > LIM + 1u;
+                }
+            }
+            // no valid hypothesis for this pixel => all labels cost 0 (mgm_costvolume.h:414-421)
+            const bool anyfinite = (__builtin_amdgcn_ballot_w64(fin) & group) != 0ull;
+            if (!live) continue;
+            uint8_t *dst = P.C8 + ((pix0 + i) * L + part * NL) * CB;
+            if constexpr (CB == 2) {
+                unsigned w[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[k] = anyfinite ? ((b[2 * k] & 65535u) | (b[2 * k + 1] << 16)) : 0u;
+                reinterpret_cast<uint4 *>(dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+                unsigned w[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    w[k] = anyfinite ? ((b[4 * k] & 255u) | ((b[4 * k + 1] & 255u) << 8) | ((b[4 * k + 2] & 255u) << 16) | (b[4 * k + 3] << 24)) : 0u;
+                reinterpret_cast<uint4 *>(dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull && lane == 0) flag_once(P.bad8, 1u);
+}
+template <int CB, bool SD>
+static void launch_diffx(const CostParams &p, hipStream_t s)
+{
+    const long long npix = (long long)p.nx * p.ny;
+    long long nw = (npix * p.L * CB / 4096 + 3) / 4 + 1;
+    if (nw > 256 * 32) nw = 256 * 32;
+    const dim3 grid((unsigned)nw), block(256);
+    if (p.nch == 1) hipLaunchKernelGGL((k_cost_diffx<CB, 1, SD>), grid, block, 0, s, p);
+    else if (p.nch == 3) hipLaunchKernelGGL((k_cost_diffx<CB, 3, SD>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_cost_diffx<CB, 0, SD>), grid, block, 0, s, p);
+}
+
 // ---- clipped NCC, restructured (round 4) ---------------------------------------------------------------------------
 // computeC_clippedNCC (mgm_costvolume.h:137-165) accumulates five window sums per (pixel, label, channel) -- but mu1 and s1
 // depend on the left pixel alone and mu2, s2 on the right pixel alone: only the cross term is per cell.  Each sum is a
@@ -746,6 +917,13 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
                 break;
         }
         return e != hipSuccess ? e : hipGetLastError();
+    }
+    // (k_cost_diffx takes truncDist = +INF or a non-negative number, sign bit clear; anything else goes to k_cost below)
+    if (!p.C && p.C8 && (p.costfn == 0 || p.costfn == 1) && !p.rlo && p.nx % 4 == 0 && npix < 0x7fffffffll && c8_supported(p.L) &&
+        (p.cbytes == 1 || p.cbytes == 2) && p.L * p.cbytes <= 1024 && p.trunc >= 0.0f && !__builtin_signbit(p.trunc)) {
+        if (p.cbytes == 2) p.costfn == 1 ? launch_diffx<2, true>(p, s) : launch_diffx<2, false>(p, s);
+        else p.costfn == 1 ? launch_diffx<1, true>(p, s) : launch_diffx<1, false>(p, s);
+        return hipGetLastError();
     }
     if (!p.C && p.C8 && p.costfn == 2 && p.nch == 1 && c8_supported(p.L)) {
         const unsigned tb = p.trunc == __builtin_huge_valf() ? 255u : (unsigned)p.trunc;

@@ -511,7 +511,7 @@ extern "C++" int ensure_f32(mgm_ctx *c, const mgm_cv *ccv)
     if (!cv->d8 || cv->c8_state < 1) return fail(c, MGM_ERR_INTERNAL, "cost volume has neither an fp32 nor a compact copy");
     if (int r = cv_alloc_f32(c, cv)) return r;
     TimeScope t(c, "k_expand");
-    HIPCHK(c, launch_expand(cv->d8, (long long)cv->nx * cv->ny * (cv->dmax - cv->dmin + 1), cv->d, c->stream));
+    HIPCHK(c, launch_expand(cv->d8, cv->cbytes, (long long)cv->nx * cv->ny * (cv->dmax - cv->dmin + 1), cv->d, c->stream));
     cv->f32_state = 1;
     return MGM_OK;
 }

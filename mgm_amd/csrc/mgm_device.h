@@ -138,7 +138,7 @@ inline bool c8_supported(int L) { return L == 64 || L == 128 || L == 192 || L ==
 hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s);
 hipError_t launch_nanscan(const float *C, long long n, unsigned *flag, hipStream_t s);
 hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, int cbytes, unsigned *bad8, hipStream_t s);
-hipError_t launch_expand(const uint8_t *C8, long long n, float *C, hipStream_t s);
+hipError_t launch_expand(const uint8_t *C8, int cbytes, long long n, float *C, hipStream_t s);
 hipError_t launch_wta(const WtaParams &p, hipStream_t s);
 long long tune_num(const char *key, long long dflt);  // development switches (MGM_HIP_TUNE; mgm_ctx.hip)
 hipError_t launch_median(const float *u, int nx, int ny, int nch, int radius, float *out, hipStream_t s);

@@ -35,6 +35,7 @@ struct mgm_cv {
     // K2 skips the fp32 write when its costs are known to fit the compact form (single-word census):
     // nothing on the hot path reads `d` then, and it is decoded from d8 if somebody asks for it.
     int f32_state = 1;         // 1 current, 0 stale (d8 holds the volume)
+    bool diff_failed = false;  // an AD / SD filling of this volume did not fit the compact form: refills go straight to the general kernel
     mgm_ctx *owner = nullptr;
     // ragged volume: the per-pixel range images it was built from (device, nx*ny floats each), else nullptr.
     // dmin/dmax are then the hull of all ranges; labels outside a pixel's own range hold +INF.

@@ -86,3 +86,64 @@ def test_batch_of_colour_pairs(ctx, oracle):
             assert ndiff(outcs[b].download()[0], ca) == 0 and ndiff(outs[b].download()[0], oa) == 0, b
     finally:
         oracle.set_threads(1)
+
+
+# ---- compact-only filling (round 4): k_cost_diffx writes the compact copy alone; the fp32 volume only on demand --------------
+def _fill_case(ctx, oracle, nx, ny, vnx, vny, dmin, dmax, pre, cost, nch, trunc, scale=1.0, seed=5):
+    u, _, _ = synth.stereo_pair(nx, ny, dmin * 3 // 4, max(0, dmax * 3 // 4), seed=seed, nch=nch)
+    _, v, _ = synth.stereo_pair(vnx, vny, dmin * 3 // 4, max(0, dmax * 3 // 4), seed=seed, nch=nch)
+    u, v = (u * np.float32(scale)).astype(np.float32), (v * np.float32(scale)).astype(np.float32)
+    return u, v, oracle.costvolume(u, v, dmin, dmax, pre, cost, trunc, 3)
+
+
+@pytest.mark.parametrize("L", [64, 128, 192, 256, 384, 512, 768, 1024])
+@pytest.mark.parametrize("kind", ["ad-grey", "ad-colour", "sd-grey", "ad-colour-trunc", "ad-fractional-trunc", "ad-sobelx", "ad-float-images"])
+def test_compact_only_fill(ctx, oracle, L, kind):
+    """Widths that are multiples of four take k_cost_diffx; the volume read back (expanded from the compact copy, or written by the
+    general kernel where a cost did not fit: fractional truncDist, float-valued images, colour at one byte per cost) equals the
+    oracle's bit for bit, also where the right image is narrower and shorter than the left."""
+    cost = "sd" if kind.startswith("sd") else "ad"
+    nch = 3 if "colour" in kind else 1
+    trunc = 40.0 if kind == "ad-colour-trunc" else (12.5 if kind == "ad-fractional-trunc" else np.inf)
+    pre = "sobelx" if kind == "ad-sobelx" else "none"
+    scale = 0.37 if kind == "ad-float-images" else 1.0
+    nx, ny = 96, 14
+    dmin = -(L - 1) + L // 4
+    threads(oracle)
+    try:
+        for vnx, vny in ((nx, ny), (nx - 7, ny - 3), (nx + 9, ny)):
+            u, v, Ca = _fill_case(ctx, oracle, nx, ny, vnx, vny, dmin, dmin + L - 1, pre, cost, nch, trunc, scale)
+            du, dv = ctx.upload_image(u), ctx.upload_image(v)
+            cv = ctx.costvolume_dev(du, dv, dmin, dmin + L - 1, pre, cost, float(trunc), 3)
+            assert ndiff(cv.download(), Ca) == 0, (vnx, vny)
+            for h in (du, dv, cv):
+                h.free()
+    finally:
+        oracle.set_threads(1)
+
+
+def test_compact_only_fill_refills_and_aggregates(ctx, oracle):
+    """One volume refilled in turn with integer-valued, float-valued and again integer-valued pairs (the float-valued filling
+    sends the later ones to the general kernel), aggregated each time; and truncDist = NaN (every cost NaN)."""
+    nx, ny, dmin, dmax = 128, 40, -127, 0
+    cv = None
+    threads(oracle)
+    try:
+        for k, scale in enumerate((1.0, 0.37, 1.0)):
+            u, v, Ca = _fill_case(ctx, oracle, nx, ny, nx, ny, dmin, dmax, "none", "ad", 3, np.inf, scale, seed=11 + k)
+            du, dv = ctx.upload_image(u), ctx.upload_image(v)
+            cv = ctx.costvolume_dev(du, dv, dmin, dmax, "none", "ad", float("inf"), 3, into=cv)
+            S, o, kk = ctx.aggregate_dev(cv, 24.0, 96.0, 8, 3, 0, 1, None, "vfit", want_S=True)
+            Sa, oa, ca = oracle.mgm(Ca, dmin, 24.0, 96.0, 8, 3, 0, 1)
+            ra, rca = oracle.refine(Sa, dmin, "vfit", oa, ca)
+            assert (ndiff(cv.download(), Ca), ndiff(S.download(), Sa), ndiff(o.download()[0], ra), ndiff(kk.download()[0], rca)) == (0, 0, 0, 0), k
+            for h in (du, dv, S, o, kk):
+                h.free()
+        u, v, Ca = _fill_case(ctx, oracle, nx, ny, nx, ny, dmin, dmax, "none", "ad", 1, np.nan)
+        du, dv = ctx.upload_image(u), ctx.upload_image(v)
+        cv2 = ctx.costvolume_dev(du, dv, dmin, dmax, "none", "ad", float("nan"), 3)
+        assert ndiff(cv2.download(), Ca) == 0
+        for h in (du, dv, cv, cv2):
+            h.free()
+    finally:
+        oracle.set_threads(1)
