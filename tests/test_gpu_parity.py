@@ -140,7 +140,10 @@ COSTS = [(1, (40, 23), (-7, 8), "none", "ad", 3, np.inf), (3, (40, 23), (-7, 8),
          (1, (40, 23), (-7, 8), "none", "ncc", 3, np.inf), (3, (33, 17), (-20, 12), "none", "ncc", 5, 1.5),
          (1, (70, 23), (-40, 23), "gblur", "ncc", 7, np.inf), (1, (40, 23), (-7, 8), "none", "btad", 3, np.inf),
          (3, (33, 17), (-20, 12), "sobelx", "btsd", 3, 900.0), (1, (70, 23), (-40, 23), "none", "btsd", 3, 50.0),
-         (1, (2, 2), (-1, 1), "none", "btad", 3, np.inf)]
+         (1, (2, 2), (-1, 1), "none", "btad", 3, np.inf),
+         # k_cost_ncc: widths that leave a partial workgroup tile, 7x7 windows, label counts off the wave width
+         (1, (61, 19), (-60, 39), "none", "ncc", 7, np.inf), (3, (37, 11), (-33, 30), "none", "ncc", 3, 2.0),
+         (1, (130, 9), (-255, 0), "none", "ncc", 5, np.inf), (2, (35, 8), (-3, 70), "none", "ncc", 5, np.inf)]
 
 
 @pytest.mark.parametrize("case", COSTS, ids=lambda c: "%dch-%s-%s-w%d" % (c[0], c[3], c[4], c[5]))
@@ -159,6 +162,25 @@ def test_costvolume_vs_oracle(ctx, oracle, case):
         assert ndiff(S.download(), So) == 0 and ndiff(o, oo) == 0 and ndiff(c, co) == 0
         S.free()
     cv.free()
+
+
+@pytest.mark.parametrize("nch,win", [(1, 5), (3, 3), (1, 7)])
+def test_ncc_volume_of_a_few_million_cells(ctx, oracle, nch, win):
+    """The whole volume of k_cost_ncc (window statistics once per pixel, products per cell, the normalisation in double) at a
+    size where every rounding case of the normalisation turns up, cell by cell against the oracle."""
+    nx, ny, dmin, dmax = 400, 96, -127, 0
+    u, v, _ = synth.stereo_pair(nx, ny, -90, 0, seed=17 + win, nch=nch)
+    from oracle.oracle import usable_cpus
+    oracle.set_threads(min(16, usable_cpus()))
+    try:
+        a = oracle.costvolume(u, v, dmin, dmax, "none", "ncc", np.inf, win)
+    finally:
+        oracle.set_threads(1)
+    du, dv = ctx.upload_image(u), ctx.upload_image(v)
+    cv = ctx.costvolume_dev(du, dv, dmin, dmax, "none", "ncc", float("inf"), win)
+    assert ndiff(a, cv.download()) == 0
+    for h in (du, dv, cv):
+        h.free()
 
 
 def test_ragged_costvolume(ctx, oracle):
