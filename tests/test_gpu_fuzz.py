@@ -73,8 +73,13 @@ def test_random_costvolume_vs_oracle(ctx, oracle, seed):
     if "census" in (pre, dist) and (nch * (win * win - 1)) % 8:
         win = 3
     td = float(rng.choice([np.inf, 30.0, 7.0, 2.5]))
+    if rng.random() < 0.4:  # widths that are multiples of four take k_cost_diffx (absolute / squared differences, compact copy only)
+        vnx += (nx + 3) // 4 * 4 - nx
+        nx = (nx + 3) // 4 * 4
     u = rng.integers(0, 256, size=(nch, ny, nx)).astype(np.float32)
     v = rng.integers(0, 256, size=(nch, vny, vnx)).astype(np.float32)
+    if rng.random() < 0.15:  # half-integer samples: differences without a compact form (the volume is filled again in fp32)
+        u, v = u * np.float32(0.5), v * np.float32(0.5)
     a = oracle.costvolume(u, v, dmin, dmin + L - 1, pre, dist, td, win)
     cv = ctx.costvolume_dev(ctx.upload_image(u), ctx.upload_image(v), dmin, dmin + L - 1, pre, dist, td, win)
     tag = (nch, nx, ny, vnx, vny, L, dmin, pre, dist, win, td)
