@@ -140,11 +140,15 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
         w2cand = true;
         for (int v = 0; v < nb; v++) {
             const bool wv = w8s[v] && got[4 * v] != 0;
-            if (v && wv != weighted)
+            // Planes of ones beside real weights: with TSGM != 2 the reference calls the SAME update function either way
+            // (update_costW[_trunclinear] with DeltaI = 1.0, mgm_core.cc:563-575), so the launch simply runs weighted; with
+            // TSGM = 2 the unweighted volume is update_cost2's, a different function: not in one launch.
+            if (v && wv != weighted && (MGM == 2 || !w8s[v]))
                 return fail(c, MGM_ERR_UNSUPPORTED, "batched volumes must be all weighted or all unweighted");
-            weighted = wv;
-            w2cand = w2cand && wv && got[4 * v + 3] == 0 && got[4 * v + 1] == got[4 * v + 2];
-            memcpy(&w2a[v], &got[4 * v + 1], 4);
+            weighted = weighted || wv;
+            w2cand = w2cand && (!wv || (got[4 * v + 3] == 0 && got[4 * v + 1] == got[4 * v + 2]));
+            if (wv) memcpy(&w2a[v], &got[4 * v + 1], 4);
+            else w2a[v] = 1.0f;  // (planes of ones in a weighted launch: no selector bit is set, the other value is never used)
         }
         w2cand = w2cand && weighted;
     }

@@ -125,3 +125,28 @@ def test_calls_that_do_not_fit_run_the_waiting_ones_first(oracle):
         for C, dmin, w, o, kk in jobs:
             Sa, oa, ca = oracle.mgm(C, dmin, 8.0, 32.0, 8, 3, 0, 1, w)
             assert bits_equal(ca, kk.download()[0]) and bits_equal(oa, o.download()[0])
+
+
+@pytest.mark.parametrize("MGM", [2, 3])
+def test_gathered_calls_that_cannot_share_a_launch_run_one_by_one(oracle, MGM):
+    """Weighted calls are gathered by the presence of weight planes, but whether planes count as weights is decided on
+    their VALUES (all ones = unweighted).  With TSGM = 2 the two kinds are different update functions: the planner
+    refuses the gathered launch and the calls run as the caller issued them; with TSGM = 3 they are the same function and
+    one weighted launch serves all -- each call with its own result either way."""
+    from oracle.oracle import bits_equal
+    nx, ny, L = 90, 40, 64
+    with mgm_amd.Context(0) as c:
+        c.set_pipeline(3)
+        jobs = []
+        for k in range(3):
+            C = synth.raw_volume(nx, ny, L, seed=950 + k, inf_frac=0.02)
+            cv = c.upload_volume(C, -L // 2)
+            w = np.ones((8, ny, nx), np.float32)
+            if k == 1:
+                w = np.where(np.random.default_rng(k).random((8, ny, nx)) < 0.4, np.float32(4.0), np.float32(1.0)).astype(np.float32)
+            _, o, kk = c.aggregate_dev(cv, 8.0, 32.0, 8, MGM, 1, 1, c.upload_image(w), None)
+            jobs.append((C, w, o, kk))
+        c.synchronize()
+        for C, w, o, kk in jobs:
+            Sa, oa, ca = oracle.mgm(C, -L // 2, 8.0, 32.0, 8, MGM, 1, 1, w)
+            assert bits_equal(ca, kk.download()[0]) and bits_equal(oa, o.download()[0])

@@ -103,3 +103,28 @@ def test_what_the_two_valued_kernels_do_not_cover_still_works(ctx, oracle, kind)
         assert check(ctx, oracle, C, -64, w, 8.0, 32.0, 8, 3, 0) == (0, 0, 0)
     finally:
         oracle.set_threads(1)
+
+
+@pytest.mark.parametrize("FH,P1,P2", [(0, 8.0, 32.0), (1, 2.0, 20000.0)])
+@pytest.mark.parametrize("MGM", [1, 3, 4])
+def test_batch_with_planes_of_ones_beside_real_weights(ctx, oracle, MGM, FH, P1, P2):
+    """One launch, four volumes, two of them with weight planes that are all ones: with TSGM != 2 the reference's update is
+    the same function with DeltaI = 1.0 (mgm_core.cc:563-575), so the launch runs weighted for all -- two-valued kernels
+    included -- and every volume gets the result of its own call."""
+    nx, ny, L = 333, 120, 128
+    rng = np.random.default_rng(MGM * 10 + FH)
+    Cs = [np.rint(synth.raw_volume(nx, ny, L, seed=400 + b, maxcost=60, inf_frac=0.02)).astype(np.float32) for b in range(4)]
+    ws = [np.ones((8, ny, nx), np.float32) if b % 2 else np.where(rng.random((8, ny, nx)) < 0.45, np.float32(4.0), np.float32(1.0)).astype(np.float32)
+          for b in range(4)]
+    cvs = [ctx.upload_volume(C, -L // 2) for C in Cs]
+    dws = [ctx.upload_image(w) for w in ws]
+    S, outs, outcs = ctx.aggregate_batch_dev(cvs, P1, P2, 8, MGM, FH, 1, dws, None, want_S=True)
+    big_threads(oracle)
+    try:
+        for b in range(4):
+            Sa, oa, ca = oracle.mgm(Cs[b], -L // 2, P1, P2, 8, MGM, FH, 1, ws[b])
+            assert (ndiff(S[b].download(), Sa), ndiff(outcs[b].download()[0], ca), ndiff(outs[b].download()[0], oa)) == (0, 0, 0), b
+    finally:
+        oracle.set_threads(1)
+    for h in cvs + dws + list(S) + outs + outcs:
+        h.free()
