@@ -82,6 +82,8 @@ WORKLOADS = {
                     desc="1920x1080 synthetic pair, 256 disparities, -t ncc (CENSUS_NCC_WIN=5), -O 8 TSGM=3, FH"),
     "cfg1s": dict(nx=700, ny=500, dmin=-120, dmax=30, win=3, NDIR=4, MGM=2, FH=0, P1=24.0, P2=96.0, cost="ad", nch=3,
                   desc="BASELINE config 1's shape on a synthetic RGB pair: 700x500, -r -120 -R 30 (151 labels, padded to 192), -t ad, -O 4 TSGM=2"),
+    "cfg3L200": dict(nx=1920, ny=1080, dmin=-199, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0,
+                     desc="1920x1080 synthetic pair, 200 disparities (a count off the kernels' widths: runs in 256 label slots), CENSUS 5x5, -O 8 TSGM=3, FH"),
     "cfg3L768": dict(nx=1920, ny=1080, dmin=-767, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0,
                      desc="1920x1080 synthetic pair, 768 disparities (beyond the second build's 512), CENSUS 5x5, -O 8 TSGM=3"),
 }

@@ -79,6 +79,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     p.bad8 = (*out)->bad8;
     HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
     (*out)->c8_state = 0;
+    (*out)->p8_state = 0;
     (*out)->nan_state = 1;  // K2 flags NaN costs as it writes them
     if (rloI) {  // the volume keeps its own copy of the range images: K4-K6 need them again
         const size_t nb = sizeof(float) * (size_t)u->nx * u->ny;
@@ -119,6 +120,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     p.vny = v->ny;
     p.dmin = dmin;
     p.L = dmax - dmin + 1;
+    p.Lreal = p.L;
     p.costfn = costfn;
     p.hwin = census_win / 2;  // computeC_clippedNCC: CENSUS_NCC_WIN()/2
     p.nch = u->nch;
@@ -194,6 +196,42 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     // A census cost over one descriptor word is a bit count 0..32, clipped to `trunc`: with trunc = +INF
     // or an integer up to 254 every cost fits the compact form, and the fp32 volume -- which neither K3
     // nor k_wta reads then -- is only materialised on demand (ensure_f32).
+    // A label count that the pass kernels run padded (151 -> 192 slots, ...): the same two families of costs write the PADDED
+    // compact copy themselves (mgm_cv::p8; the slots beyond the real count +INF) instead of an fp32 volume that every
+    // aggregation call would pad and encode again.  The flag word is read back at once; a volume that does not fit takes
+    // the general kernel below, fp32 volume and all, and so do its refills.
+    const int LP = (!c8_supported(p.L) && dev().c8 && dev().pad && dev().lazy_f32 && !p.rlo) ? padded_labels(p.L) : 0;
+    const bool census_fits = costfn == 2 && p.nch == 1 &&
+                             (p.trunc == __builtin_huge_valf() || (p.trunc >= 0.0f && p.trunc <= 254.0f && p.trunc == rintf(p.trunc)));
+    const bool diff_may_fit = (costfn == 0 || costfn == 1) && (pre == 0 || pre == 2) && p.trunc >= 0.0f && !std::signbit(p.trunc) &&
+                              u->nx % 4 == 0 && (long long)u->nx * u->ny < 0x7fffffffll;  // (what k_cost_diffx takes)
+    if (LP && !(*out)->diff_failed && (census_fits || diff_may_fit)) {
+        const int pcb = (costfn == 2 || (costfn == 0 && u->nch == 1) || LP > 512) ? 1 : 2;
+        if ((r = p8_alloc(c, *out, LP, pcb))) return r;
+        CostParams q = p;
+        q.C = nullptr;
+        q.C8 = (*out)->p8;
+        q.cbytes = pcb;
+        q.L = LP;
+        {
+            TimeScope t(c, "k_cost");
+            HIPCHK(c, launch_cost(q, c->stream));
+        }
+        bool fits = census_fits;  // (min(popcount, trunc) in integers: fits and is NaN-free by construction, nothing to read back)
+        if (!fits) {
+            HIPCHK(c, hipMemcpyAsync(c->h_words + 3, (*out)->bad8, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            fits = c->h_words[3] == 0u;
+        }
+        if (fits) {
+            (*out)->p8_state = 2;
+            (*out)->f32_state = 0;
+            (*out)->nan_state = 2;
+            return MGM_OK;
+        }
+        (*out)->diff_failed = true;
+        HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
+    }
     if (p.C8 && !p.rlo && costfn == 2 && p.nch == 1 &&
         (p.trunc == __builtin_huge_valf() || (p.trunc >= 0.0f && p.trunc <= 254.0f && p.trunc == rintf(p.trunc))) &&
         dev().lazy_f32) {

@@ -358,6 +358,22 @@ __global__ void __launch_bounds__(256) k_expand(const uint8_t *__restrict__ C8, 
     }
 }
 
+// the fp32 volume [pix][L] from a padded compact copy [pix][LP] (the slots L..LP-1 are dropped); one wave per pixel
+__global__ void __launch_bounds__(256) k_expand_padded(const uint8_t *__restrict__ C8, int cbytes, long long npix, int L, int LP, float *__restrict__ C)
+{
+    const int lane = threadIdx.x & 63;
+    for (long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (long long)gridDim.x * 4)
+        for (int o = lane; o < L; o += 64)
+            C[pix * L + o] = cbytes == 2 ? c16_decode(reinterpret_cast<const unsigned short *>(C8)[pix * LP + o]) : c8_decode(C8[pix * LP + o]);
+}
+hipError_t launch_expand_padded(const uint8_t *C8, int cbytes, long long npix, int L, int LP, float *C, hipStream_t s)
+{
+    long long nb = (npix + 3) / 4;
+    if (nb > 256 * 32) nb = 256 * 32;
+    hipLaunchKernelGGL(k_expand_padded, dim3((unsigned)nb), dim3(256), 0, s, C8, cbytes, npix, L, LP, C);
+    return hipGetLastError();
+}
+
 hipError_t launch_expand(const uint8_t *C8, int cbytes, long long n, float *C, hipStream_t s)
 {
     if (cbytes == 2) hipLaunchKernelGGL(k_expand16, dim3(256 * 16), dim3(256), 0, s, reinterpret_cast<const unsigned short *>(C8), n, C);
@@ -414,7 +430,7 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <int LPL>
 __global__ void __launch_bounds__(256) k_cost_census8(const uint32_t *__restrict__ cu, const uint32_t *__restrict__ cv,
                                                       int nx, int ny, int vnx, int vny, int dmin, unsigned tb,
-                                                      uint8_t *__restrict__ C8)
+                                                      uint8_t *__restrict__ C8, int Lreal)
 {
     constexpr int L = LPL * 64;
     const long long npix = (long long)nx * ny;
@@ -426,7 +442,7 @@ __global__ void __launch_bounds__(256) k_cost_census8(const uint32_t *__restrict
         const bool yin = y < vny;
         const uint32_t *row = cv + (long long)(yin ? y : 0) * vnx;
         unsigned b[LPL];
-        if (yin && q0 >= 0 && q0 + LPL <= vnx) {  // the whole group lies inside the right image
+        if (yin && q0 >= 0 && q0 + LPL <= vnx && (lane + 1) * LPL <= Lreal) {  // the whole group lies inside the right image
             uint32_t wv[LPL];
             if constexpr (LPL % 4 == 0) {
 #pragma unroll
@@ -450,26 +466,28 @@ __global__ void __launch_bounds__(256) k_cost_census8(const uint32_t *__restrict
                 const bool in = yin && q >= 0 && q < vnx;
                 const unsigned pc = (unsigned)__builtin_popcount(wu ^ row[in ? q : 0]);
                 b[k] = in ? (pc < tb ? pc : tb) : tb;
+                if (lane * LPL + k >= Lreal) b[k] = 255u;  // a slot of the padded layout: +INF
             }
         }
         bool fin = false;
 #pragma unroll
         for (int k = 0; k < LPL; k++) fin |= b[k] != 255u;
-        const bool anyfinite = __builtin_amdgcn_ballot_w64(fin) != 0ull;
+        if (__builtin_amdgcn_ballot_w64(fin) == 0ull) {  // no valid hypothesis: zeros (the slots of a padded layout stay +INF)
+#pragma unroll
+            for (int k = 0; k < LPL; k++) b[k] = lane * LPL + k >= Lreal ? 255u : 0u;
+        }
         uint8_t *dst = C8 + pix * L + lane * LPL;
         if constexpr (LPL == 1) {
-            dst[0] = (uint8_t)(anyfinite ? b[0] : 0u);
+            dst[0] = (uint8_t)b[0];
         } else if constexpr (LPL == 2) {
-            *reinterpret_cast<unsigned short *>(dst) = (unsigned short)(anyfinite ? (b[0] | (b[1] << 8)) : 0u);
+            *reinterpret_cast<unsigned short *>(dst) = (unsigned short)(b[0] | (b[1] << 8));
         } else if constexpr (LPL % 4 == 0) {
 #pragma unroll
-            for (int h = 0; h < LPL / 4; h++) {
-                const unsigned w = b[4 * h] | (b[4 * h + 1] << 8) | (b[4 * h + 2] << 16) | (b[4 * h + 3] << 24);
-                reinterpret_cast<unsigned *>(dst)[h] = anyfinite ? w : 0u;
-            }
+            for (int h = 0; h < LPL / 4; h++)
+                reinterpret_cast<unsigned *>(dst)[h] = b[4 * h] | (b[4 * h + 1] << 8) | (b[4 * h + 2] << 16) | (b[4 * h + 3] << 24);
         } else {
 #pragma unroll
-            for (int k = 0; k < LPL; k++) dst[k] = (uint8_t)(anyfinite ? b[k] : 0u);
+            for (int k = 0; k < LPL; k++) dst[k] = (uint8_t)b[k];
         }
     }
 }
@@ -547,7 +565,7 @@ __global__ void __launch_bounds__(256) k_cost_census8w(const uint32_t *__restric
 template <int L>
 __global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restrict__ cu, const uint32_t *__restrict__ cv,
                                                        int nx, int ny, int vnx, int vny, int dmin, unsigned tb,
-                                                       uint8_t *__restrict__ C8)
+                                                       uint8_t *__restrict__ C8, int Lreal)
 {
     static_assert(L % 16 == 0 && L >= 16 && L <= 1024, "sixteen labels per lane");
     constexpr int LP = L / 16;    // lanes per pixel group
@@ -568,7 +586,14 @@ __global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restric
         const uint32_t *row = cv + (long long)(yin ? y : 0) * vnx;
         unsigned w[4][4];
         bool fin[4] = {false, false, false, false};
-        if (yin && q0 >= 0 && q0 + 20 <= vnx) {  // every word the four pixels need lies inside the right image
+        unsigned pad[4];  // what a pixel without a valid hypothesis gets: zeros, the slots of a padded layout +INF
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            pad[h] = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) pad[h] |= (part * 16 + 4 * h + k >= Lreal ? 255u : 0u) << (8 * k);
+        }
+        if (yin && q0 >= 0 && q0 + 20 <= vnx && (part + 1) * 16 <= Lreal) {  // every word the four pixels need lies inside the right image
             unsigned v[20];
 #pragma unroll
             for (int h = 0; h < 5; h++) {
@@ -604,6 +629,7 @@ __global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restric
                         const bool in = yin && q >= 0 && q < vnx;
                         const unsigned pc = (unsigned)__builtin_popcount(wu[i] ^ row[in ? q : 0]);
                         b[k] = in ? (pc < tb ? pc : tb) : tb;
+                        if (part * 16 + 4 * h + k >= Lreal) b[k] = 255u;  // a slot of the padded layout: +INF
                         fin[i] |= b[k] != 255u;
                     }
                     w[i][h] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
@@ -614,7 +640,7 @@ __global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restric
             const bool anyfinite = (__builtin_amdgcn_ballot_w64(fin[i]) & group) != 0ull;  // of this pixel's labels
             if (live) {
                 uint4 o;
-                o.x = anyfinite ? w[i][0] : 0u; o.y = anyfinite ? w[i][1] : 0u; o.z = anyfinite ? w[i][2] : 0u; o.w = anyfinite ? w[i][3] : 0u;
+                o.x = anyfinite ? w[i][0] : pad[0]; o.y = anyfinite ? w[i][1] : pad[1]; o.z = anyfinite ? w[i][2] : pad[2]; o.w = anyfinite ? w[i][3] : pad[3];
                 *reinterpret_cast<uint4 *>(C8 + (pix0 + i) * L + part * 16) = o;
             }
         }
@@ -675,6 +701,7 @@ __global__ void __launch_bounds__(256) k_cost_diffx(const CostParams P)
     const int lane = threadIdx.x & 63, sub = lane / LP, part = lane - sub * LP;
     const unsigned long long group = (LP == 64 ? ~0ull : ((1ull << (LP & 63)) - 1ull)) << ((sub * LP) & 63);
     const float trunc = P.trunc, tclamp = __builtin_fminf(trunc, (float)(LIM + 2u));
+    const bool padlane = (part + 1) * NL > P.Lreal;  // this lane holds label slots of a padded layout (P.Lreal < P.L)
     bool odd = false;  // a cost without the compact form
     for (long long chunk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < nchunk; chunk += (long long)gridDim.x * 4) {
         const long long pix0 = (chunk * G + sub) * 4;
@@ -727,7 +754,8 @@ __global__ void __launch_bounds__(256) k_cost_diffx(const CostParams P)
                     const int q = q0 + i + k;
                     c[k] = (yin && q >= 0 && q < vnx) ? c[k] : trunc;
                 }
-                const float cc = __builtin_fminf(c[k], tclamp);  // in [0, LIM + 2]: the conversion is defined
+                float cc = __builtin_fminf(c[k], tclamp);  // in [0, LIM + 2]: the conversion is defined
+                if (padlane && part * NL + k >= P.Lreal) cc = (float)(LIM + 1u);  // a slot of the padded layout: +INF, as its code
                 b[k] = (unsigned)cc;
                 top = __builtin_fmaxf(top, cc);
                 frac = __builtin_fmaxf(frac, __builtin_amdgcn_fractf(cc));
@@ -737,7 +765,7 @@ __global__ void __launch_bounds__(256) k_cost_diffx(const CostParams P)
                 fin = false;
 #pragma unroll
                 for (int k = 0; k < NL; k++) {
-                    const float ct = (c[k] < trunc) ? c[k] : trunc;
+                    const float ct = (padlane && part * NL + k >= P.Lreal) ? __builtin_huge_valf() : ((c[k] < trunc) ? c[k] : trunc);
                     fin |= finite_bits(ct);
                     b[k] = CB == 2 ? c16_encode(ct) : c8_encode(ct);
                     odd |= b[k] > LIM + 1u;
@@ -750,13 +778,17 @@ __global__ void __launch_bounds__(256) k_cost_diffx(const CostParams P)
             if constexpr (CB == 2) {
                 unsigned w[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) w[k] = anyfinite ? ((b[2 * k] & 65535u) | (b[2 * k + 1] << 16)) : 0u;
+                for (int k = 0; k < 4; k++)
+                    w[k] = anyfinite ? ((b[2 * k] & 65535u) | (b[2 * k + 1] << 16))
+                                     : ((padlane && part * NL + 2 * k >= P.Lreal ? 65535u : 0u) | (padlane && part * NL + 2 * k + 1 >= P.Lreal ? 65535u << 16 : 0u));
                 reinterpret_cast<uint4 *>(dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
             } else {
                 unsigned w[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    w[k] = anyfinite ? ((b[4 * k] & 255u) | ((b[4 * k + 1] & 255u) << 8) | ((b[4 * k + 2] & 255u) << 16) | (b[4 * k + 3] << 24)) : 0u;
+                    w[k] = anyfinite ? ((b[4 * k] & 255u) | ((b[4 * k + 1] & 255u) << 8) | ((b[4 * k + 2] & 255u) << 16) | (b[4 * k + 3] << 24))
+                                     : ((padlane && part * NL + 4 * k >= P.Lreal ? 255u : 0u) | (padlane && part * NL + 4 * k + 1 >= P.Lreal ? 255u << 8 : 0u) |
+                                        (padlane && part * NL + 4 * k + 2 >= P.Lreal ? 255u << 16 : 0u) | (padlane && part * NL + 4 * k + 3 >= P.Lreal ? 255u << 24 : 0u));
                 reinterpret_cast<uint4 *>(dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
@@ -935,18 +967,18 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
             if (nw > 256 * 32) nw = 256 * 32;
             const dim3 gridw((unsigned)nw);
             switch (p.L) {
-                case 64: hipLaunchKernelGGL(k_cost_census8x<64>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-                case 128: hipLaunchKernelGGL(k_cost_census8x<128>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-                case 192: hipLaunchKernelGGL(k_cost_census8x<192>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-                case 256: hipLaunchKernelGGL(k_cost_census8x<256>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-                case 384: hipLaunchKernelGGL(k_cost_census8x<384>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-                case 512: hipLaunchKernelGGL(k_cost_census8x<512>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-                case 768: hipLaunchKernelGGL(k_cost_census8x<768>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-                default: hipLaunchKernelGGL(k_cost_census8x<1024>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+                case 64: hipLaunchKernelGGL(k_cost_census8x<64>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+                case 128: hipLaunchKernelGGL(k_cost_census8x<128>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+                case 192: hipLaunchKernelGGL(k_cost_census8x<192>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+                case 256: hipLaunchKernelGGL(k_cost_census8x<256>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+                case 384: hipLaunchKernelGGL(k_cost_census8x<384>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+                case 512: hipLaunchKernelGGL(k_cost_census8x<512>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+                case 768: hipLaunchKernelGGL(k_cost_census8x<768>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+                default: hipLaunchKernelGGL(k_cost_census8x<1024>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
             }
             return hipGetLastError();
         }
-        if ((p.L == 64 || p.L == 128 || p.L == 256 || p.L == 512) && npix < 0x7fffffffll) {
+        if ((p.L == 64 || p.L == 128 || p.L == 256 || p.L == 512) && npix < 0x7fffffffll && p.Lreal == p.L) {
             long long nw = (npix * p.L / 1024 + 3) / 4 + 1;
             if (nw > 256 * 32) nw = 256 * 32;
             const dim3 gridw((unsigned)nw);
@@ -960,17 +992,18 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
         }
         const dim3 grid((unsigned)nb);
         switch (p.L / 64) {
-            case 1: hipLaunchKernelGGL(k_cost_census8<1>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-            case 2: hipLaunchKernelGGL(k_cost_census8<2>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-            case 3: hipLaunchKernelGGL(k_cost_census8<3>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-            case 4: hipLaunchKernelGGL(k_cost_census8<4>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-            case 6: hipLaunchKernelGGL(k_cost_census8<6>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-            case 8: hipLaunchKernelGGL(k_cost_census8<8>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-            case 12: hipLaunchKernelGGL(k_cost_census8<12>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
-            default: hipLaunchKernelGGL(k_cost_census8<16>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8); break;
+            case 1: hipLaunchKernelGGL(k_cost_census8<1>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+            case 2: hipLaunchKernelGGL(k_cost_census8<2>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+            case 3: hipLaunchKernelGGL(k_cost_census8<3>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+            case 4: hipLaunchKernelGGL(k_cost_census8<4>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+            case 6: hipLaunchKernelGGL(k_cost_census8<6>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+            case 8: hipLaunchKernelGGL(k_cost_census8<8>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+            case 12: hipLaunchKernelGGL(k_cost_census8<12>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+            default: hipLaunchKernelGGL(k_cost_census8<16>, grid, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
         }
         return hipGetLastError();
     }
+    if (p.Lreal != p.L) return hipErrorInvalidValue;  // (padded layouts: only the kernels above write them)
     hipLaunchKernelGGL(k_cost, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, p);
     return hipGetLastError();
 }

@@ -500,6 +500,7 @@ int mgm_cv_upload(mgm_ctx *c, const float *dense, int nx, int ny, int dmin, int 
         return r;
     }
     (*out)->c8_state = 0;
+    (*out)->p8_state = 0;
     (*out)->nan_state = 0;
     return MGM_OK;
 }
@@ -508,6 +509,13 @@ extern "C++" int ensure_f32(mgm_ctx *c, const mgm_cv *ccv)
 {
     mgm_cv *cv = const_cast<mgm_cv *>(ccv);
     if (cv->f32_state) return MGM_OK;
+    if (cv->p8_state == 2) {  // K2 wrote the padded compact copy alone
+        if (int r = cv_alloc_f32(c, cv)) return r;
+        TimeScope t(c, "k_expand");
+        HIPCHK(c, launch_expand_padded(cv->p8, cv->p8_cb, (long long)cv->nx * cv->ny, cv->dmax - cv->dmin + 1, cv->p8_L, cv->d, c->stream));
+        cv->f32_state = 1;
+        return MGM_OK;
+    }
     if (!cv->d8 || cv->c8_state < 1) return fail(c, MGM_ERR_INTERNAL, "cost volume has neither an fp32 nor a compact copy");
     if (int r = cv_alloc_f32(c, cv)) return r;
     TimeScope t(c, "k_expand");
@@ -541,6 +549,7 @@ void *mgm_cv_device_ptr(mgm_cv *cv)
     if (!cv) return nullptr;
     if (cv->owner && ensure_f32(cv->owner, cv)) return nullptr;
     cv->c8_state = 0;  // the caller may write through the pointer: re-derive the compact copy at the next use
+    cv->p8_state = 0;
     cv->nan_state = 0;
     cv->gen = next_cv_generation();
     return cv->d;
@@ -559,6 +568,7 @@ int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
                 if (o->last_cvs[v] == cv) o->last_cvs[v] = nullptr;
     if (cv->d) (void)hipFree(cv->d);
     if (cv->d8) (void)hipFree(cv->d8);
+    if (cv->p8) (void)hipFree(cv->p8);
     if (cv->bad8) (void)hipFree(cv->bad8);
     if (cv->rlo) (void)hipFree(cv->rlo);
     if (cv->rhi) (void)hipFree(cv->rhi);
@@ -586,6 +596,27 @@ int c8_alloc(mgm_ctx *c, mgm_cv *cv, int cb)
         cv->d8_cap = n;
     }
     cv->cbytes = cb;
+    return MGM_OK;
+}
+// room for a padded compact copy of LP label slots, cb bytes each (mgm_cv::p8)
+int p8_alloc(mgm_ctx *c, mgm_cv *cv, int LP, int cb)
+{
+    const size_t n = (size_t)cv->nx * cv->ny * (size_t)LP * cb + 64;
+    if (cv->p8 && cv->p8_cap < n) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(cv->p8);
+        cv->p8 = nullptr;
+    }
+    if (!cv->p8) {
+        if (dev_malloc((void **)&cv->p8, n) != hipSuccess) {
+            cv->p8 = nullptr;
+            cv->p8_cap = 0;
+            return fail(c, MGM_ERR_NOMEM, "hipMalloc of the padded compact cost volume failed");
+        }
+        cv->p8_cap = n;
+    }
+    cv->p8_L = LP;
+    cv->p8_cb = cb;
     return MGM_OK;
 }
 // Decide (once per filling of the volume) whether the compact copy can stand in for C, and whether the volume

@@ -139,6 +139,7 @@ hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *ba
 hipError_t launch_nanscan(const float *C, long long n, unsigned *flag, hipStream_t s);
 hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, int cbytes, unsigned *bad8, hipStream_t s);
 hipError_t launch_expand(const uint8_t *C8, int cbytes, long long n, float *C, hipStream_t s);
+hipError_t launch_expand_padded(const uint8_t *C8, int cbytes, long long npix, int L, int LP, float *C, hipStream_t s);
 hipError_t launch_wta(const WtaParams &p, hipStream_t s);
 long long tune_num(const char *key, long long dflt);  // development switches (MGM_HIP_TUNE; mgm_ctx.hip)
 hipError_t launch_median(const float *u, int nx, int ny, int nch, int radius, float *out, hipStream_t s);
@@ -160,6 +161,7 @@ struct CostParams {
     unsigned *bad8;              // set to 1 if some cost is not representable in the compact form
     int nx, ny, vnx, vny, nch;   // nch = channels of the (prefiltered) images
     int dmin, L;
+    int Lreal;                   // k_cost_diffx / k_cost_census8*: the label slots Lreal..L-1 of the (padded) layout get +INF; else = L
     int costfn;                  // 0 ad, 1 sd, 2 census, 3 ncc, 4 btad, 5 btsd
     int hwin;                    // ncc: half window (CENSUS_NCC_WIN / 2)
     float trunc;                 // truncDist * nch

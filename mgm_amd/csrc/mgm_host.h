@@ -36,6 +36,13 @@ struct mgm_cv {
     // nothing on the hot path reads `d` then, and it is decoded from d8 if somebody asks for it.
     int f32_state = 1;         // 1 current, 0 stale (d8 holds the volume)
     bool diff_failed = false;  // an AD / SD filling of this volume did not fit the compact form: refills go straight to the general kernel
+    // A label count that the pass kernels run PADDED (151 -> 192, ...): K2 may write the padded compact copy itself --
+    // [npix][p8_L] costs of p8_cb bytes, the label slots beyond the real count +INF -- instead of an fp32 volume that every
+    // aggregation call pads and encodes again (run_passes).  p8_state 2: valid (and then the ONLY copy until somebody asks
+    // for the fp32 volume: f32_state 0), 0: none.
+    uint8_t *p8 = nullptr;
+    size_t p8_cap = 0;
+    int p8_L = 0, p8_cb = 1, p8_state = 0;
     mgm_ctx *owner = nullptr;
     // ragged volume: the per-pixel range images it was built from (device, nx*ny floats each), else nullptr.
     // dmin/dmax are then the hull of all ranges; labels outside a pixel's own range hold +INF.
@@ -108,6 +115,7 @@ struct mgm_ctx {
     Buf padf[kMaxBatch], pad8[kMaxBatch];  // padded copies of the cost volumes of a launch whose label count was padded
     Buf wsel[kMaxBatch], wvals;            // two-valued weights (k_pass2, W2): selector words per volume; the value scan's words
     bool last_pad_c8 = false;
+    const uint8_t *last_pad_ptr[kMaxBatch] = {};  // ... where they are: the context's pad8 buffers, or the volumes' own padded copies (mgm_cv::p8)
     int last_pad_cb = 1;  // ... bytes per compact cost of those padded copies
     const mgm_cv *last_cvs[kMaxBatch] = {};  // the volumes of the last aggregation (identity only, never dereferenced) ...
     unsigned long long last_gens[kMaxBatch] = {};  // ... and their generations at that time
@@ -219,6 +227,7 @@ int c8_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *use);
 
 // the launch plan (mgm_plan.hip)
 int padded_labels(int L);
+int p8_alloc(mgm_ctx *c, mgm_cv *cv, int LP, int cb);
 int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int nb, float P1, float P2, int MGM, int use_fh, int first,
                int count, bool allow_pad = false, int slot0 = 0, int nslots = 0, int layout_ndir = 0);
 int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const float *lr, long long lr_stride, int NDIR, int fix_overcount,

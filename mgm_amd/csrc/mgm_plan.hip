@@ -203,7 +203,13 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     }
     if (exact) return run_passes_exact(c, Cs, w8s, nb, P1, P2, MGM, fh, weighted_given, first, count, slot0, nslots);
     int cb = 1;  // bytes per compact cost of this launch
-    if (padded) {
+    // padded launch whose volumes all carry the padded compact copy K2 wrote (mgm_cv::p8): nothing to pad or encode
+    bool own_padded = padded && dev().c8;
+    for (int v = 0; v < nb && own_padded; v++)
+        own_padded = Cs[v]->p8_state == 2 && Cs[v]->p8_L == L && Cs[v]->p8_cb == Cs[0]->p8_cb;
+    if (own_padded) {
+        cb = Cs[0]->p8_cb;
+    } else if (padded) {
         // padded copies of the costs: a compact form if every volume allows it -- the one that worked for the first volume
         // last time first (mgm_cv::pad_hint), then the other --, else fp32
         int tries[3] = {Cs[0]->pad_hint == 2 ? 2 : 1, Cs[0]->pad_hint == 2 ? 1 : 2, 0};
@@ -241,8 +247,10 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     // Two bytes per cost: read by the unweighted kernels with deep rings that publish E, up to 512 labels (k_pass2, C8 == 2);
     // everything else reads the fp32 volume (which K2 always writes next to a two-byte copy).
     if (use_c8 && cb == 2 && (weighted || (fh && MGM == 2) || pass_lpl(L) > 8 || dev().deep == 0)) {
+        own_padded = false;
         if (padded)
             for (int v = 0; v < nb; v++) {
+                if ((r = ensure_f32(c, Cs[v]))) return r;
                 if ((r = reserve(c, c->padf[v], sizeof(float) * (size_t)npix * L))) return r;
                 TimeScope t(c, "k_pad");
                 HIPCHK(c, launch_pad(Cs[v]->d, npix, Lreal, L, (float *)c->padf[v].p, nullptr, 1, nullptr, c->stream));
@@ -517,7 +525,7 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     for (int v = 0; v < nb; v++) {
         if (!use_c8 && (r = ensure_f32(c, Cs[v]))) return r;
         p.vol[v].C = padded ? (const float *)c->padf[v].p : Cs[v]->d;
-        p.vol[v].C8 = use_c8 ? (padded ? (const uint8_t *)c->pad8[v].p : Cs[v]->d8) : nullptr;
+        p.vol[v].C8 = use_c8 ? (padded ? (own_padded ? Cs[v]->p8 : (const uint8_t *)c->pad8[v].p) : Cs[v]->d8) : nullptr;
         p.vol[v].Lr = (float *)c->lr.p + ((size_t)v * nslots + slot0) * lr_stride;
         p.vol[v].w8 = ones8 ? ones8 : (weighted ? w8s[v]->d : nullptr);
         p.vol[v].rlo = (fh && ragged) ? Cs[v]->rlo : nullptr;
@@ -676,6 +684,7 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     c->last_Lk = L;
     c->last_pad_c8 = padded && use_c8;
     c->last_pad_cb = cb;
+    for (int v = 0; v < nb; v++) c->last_pad_ptr[v] = (padded && use_c8) ? (own_padded ? Cs[v]->p8 : (const uint8_t *)c->pad8[v].p) : nullptr;
     for (int v = 0; v < kMaxBatch; v++) {
         c->last_cvs[v] = v < nb ? Cs[v] : nullptr;
         c->last_gens[v] = v < nb ? Cs[v]->gen : 0;
@@ -697,7 +706,7 @@ int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const f
     if (padded) {
         w.C = c->last_pad_c8 ? nullptr : (const float *)c->padf[slot].p + pix0 * L;
         w.cbytes = c->last_pad_c8 ? c->last_pad_cb : 1;
-        w.C8 = c->last_pad_c8 ? (const uint8_t *)c->pad8[slot].p + pix0 * L * w.cbytes : nullptr;
+        w.C8 = c->last_pad_c8 ? c->last_pad_ptr[slot] + pix0 * L * w.cbytes : nullptr;
     } else {
         // (two-byte costs: the exact k_wta instances and k_wta_q read them -- label counts of the compact pass kernels)
         w.cbytes = C->cbytes;

@@ -147,3 +147,35 @@ def test_compact_only_fill_refills_and_aggregates(ctx, oracle):
             h.free()
     finally:
         oracle.set_threads(1)
+
+
+@pytest.mark.parametrize("L", [7, 100, 151, 300, 600, 1000])
+@pytest.mark.parametrize("kind", ["census", "census-trunc", "ad-grey", "ad-colour", "sd-grey", "ad-float-images"])
+def test_padded_compact_only_fill(ctx, oracle, L, kind):
+    """Label counts that the pass kernels run padded (7 -> 64 ... 1000 -> 1024): K2 writes the padded compact copy itself
+    (mgm_cv::p8), the aggregation reads it as it is, the fp32 volume exists only once somebody asks for it.  Aggregated
+    first, read back second -- and the other way round on a second volume -- against the oracle; widths that take the
+    four-pixel kernels and one that does not; a right image narrower and shorter than the left."""
+    cost = "census" if kind.startswith("census") else ("sd" if kind.startswith("sd") else "ad")
+    nch = 3 if "colour" in kind else 1
+    trunc = 7.0 if kind == "census-trunc" else np.inf
+    scale = 0.37 if kind == "ad-float-images" else 1.0
+    dmin = -(L - 1) + L // 4
+    threads(oracle)
+    try:
+        for k, (nx, ny, vnx, vny) in enumerate(((96, 14, 96, 14), (61, 9, 61, 9), (96, 14, 89, 11))):
+            u, v, Ca = _fill_case(ctx, oracle, nx, ny, vnx, vny, dmin, dmin + L - 1, "none", cost, nch, trunc, scale, seed=30 + k)
+            du, dv = ctx.upload_image(u), ctx.upload_image(v)
+            cv = ctx.costvolume_dev(du, dv, dmin, dmin + L - 1, "none", cost, float(trunc), 3)
+            if k == 1:
+                assert ndiff(cv.download(), Ca) == 0, (nx, vnx)
+            FH, P1, P2 = ((0, 8.0, 32.0), (1, 2.0, 20000.0), (1, 1.5, 9.0))[k]
+            S, o, kk = ctx.aggregate_dev(cv, P1, P2, 8, 3, FH, 1, None, "vfit", want_S=True)
+            Sa, oa, ca = oracle.mgm(Ca, dmin, P1, P2, 8, 3, FH, 1)
+            ra, rca = oracle.refine(Sa, dmin, "vfit", oa, ca)
+            assert (ndiff(S.download(), Sa), ndiff(o.download()[0], ra), ndiff(kk.download()[0], rca)) == (0, 0, 0), (nx, vnx, FH)
+            assert ndiff(cv.download(), Ca) == 0, (nx, vnx)
+            for h in (du, dv, cv, S, o, kk):
+                h.free()
+    finally:
+        oracle.set_threads(1)
