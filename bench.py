@@ -959,13 +959,15 @@ def main():
         ctx.trim()
         env.ctrl_barrier()  # (rank 0 may have spent a minute in the CPU legs)
         # what north_star names beside the headline combination, in the driver's own line (round 4): per-edge weights, AD on a
-        # colour pair, clipped NCC, 768 labels, and a stream of single pairs through a pipelined context -- short legs (4 pairs
+        # colour pair, clipped NCC, label counts off the kernels' widths (200, 151), 768 labels, and a stream of single pairs
+        # through a pipelined context -- short legs (4 pairs
         # per step where the workspace allows, 5 steps), same measurement as the headline, no CPU legs
         try:
             vres = {}
             if rank == 0:
                 res["variants"] = vres
-            for vname, vb, vd in (("cfg3w", 4, 1), ("cfg3hw", 4, 1), ("cfg3ad", 4, 1), ("cfg3ncc", 4, 1), ("cfg3L768", 1, 1), ("cfg3", 1, 4), ("cfg2", 1, 8)):
+            for vname, vb, vd in (("cfg3w", 4, 1), ("cfg3hw", 4, 1), ("cfg3ad", 4, 1), ("cfg3ncc", 4, 1), ("cfg3L200", 4, 1), ("cfg1s", 4, 1),
+                                  ("cfg3L768", 1, 1), ("cfg3", 1, 4), ("cfg2", 1, 8)):
                 vw = WORKLOADS[vname]
                 vm = pairs_leg(env, vw, vb, 8 if vd > 1 else 5, 1, 0, pipeline=vd)
                 if rank == 0:
