@@ -80,6 +80,8 @@ WORKLOADS = {
                     desc="1920x1080 synthetic grey pair, 256 disparities, -t ad (costs 0..255), -O 8 TSGM=3, FH"),
     "cfg3ncc": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, cost="ncc",
                     desc="1920x1080 synthetic pair, 256 disparities, -t ncc (CENSUS_NCC_WIN=5), -O 8 TSGM=3, FH"),
+    "cfg3bt": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, cost="btad", nch=1,
+                   desc="1920x1080 synthetic grey pair, 256 disparities, -t btad (Birchfield-Tomasi, costs in halves: fp32 volumes), -O 8 TSGM=3, FH"),
     "cfg1s": dict(nx=700, ny=500, dmin=-120, dmax=30, win=3, NDIR=4, MGM=2, FH=0, P1=24.0, P2=96.0, cost="ad", nch=3,
                   desc="BASELINE config 1's shape on a synthetic RGB pair: 700x500, -r -120 -R 30 (151 labels, padded to 192), -t ad, -O 4 TSGM=2"),
     "cfg3L200": dict(nx=1920, ny=1080, dmin=-199, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0,

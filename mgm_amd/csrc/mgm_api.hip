@@ -192,6 +192,14 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         p.ncc_u = (float *)c->census_u.p;
         p.ncc_v = (float *)c->census_v.p;
     }
+    if (costfn >= 4 && pre == 0 && !rloI) {
+        // Birchfield-Tomasi on the plain images: the interval every sample spans is computed once (k_bt_spans), in the census
+        // buffers, which this combination leaves free
+        if ((r = reserve(c, c->census_u, sizeof(float) * (size_t)u->nx * u->ny * 2 * u->nch))) return r;
+        if ((r = reserve(c, c->census_v, sizeof(float) * (size_t)v->nx * v->ny * 2 * v->nch))) return r;
+        p.ncc_u = (float *)c->census_u.p;
+        p.ncc_v = (float *)c->census_v.p;
+    }
     p.trunc = truncDist * (float)p.nch;  // mgm_costvolume.h:401,405
     // A census cost over one descriptor word is a bit count 0..32, clipped to `trunc`: with trunc = +INF
     // or an integer up to 254 every cost fits the compact form, and the fp32 volume -- which neither K3

@@ -807,6 +807,108 @@ static void launch_diffx(const CostParams &p, hipStream_t s)
     else hipLaunchKernelGGL((k_cost_diffx<CB, 0, SD>), grid, block, 0, s, p);
 }
 
+// ---- Birchfield-Tomasi costs, restructured (round 4) --------------------------------------------------------------------
+// computeC_BTAD / computeC_BTSD (mgm_costvolume.h:82-135) look at three samples of each image per cell -- but the interval a
+// sample spans depends on its own image alone: k_bt_spans writes the two ends once per sample (2*nch planes per image, same
+// operations as bt_span above), and k_cost_btx is left with two three-way maxima and a minimum per cell and channel.  Work
+// layout of k_cost_diffx: a wave takes four consecutive pixels of a row, a lane four consecutive labels of them (and the
+// next 256 labels in its next turn): one 16-byte store of fp32 costs per lane and pixel -- the costs are multiples of one
+// half, there is no compact form for them.
+__global__ void __launch_bounds__(256) k_bt_spans(const float *__restrict__ u, int nx, int ny, int nch, float *__restrict__ sp)
+{
+    const long long npix = (long long)nx * ny;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * nch) return;
+    const int t = (int)(idx / npix);
+    const long long p = idx - t * npix;
+    const int y = (int)(p / nx), x = (int)(p - (long long)y * nx);
+    const BtSpan a = bt_span(u + t * npix + (long long)y * nx, nx, x);
+    sp[idx] = a.lo;
+    sp[idx + npix * nch] = a.hi;
+}
+template <bool SD>
+__global__ void __launch_bounds__(256) k_cost_btx(const CostParams P)
+{
+    const int nx = P.nx, vnx = P.vnx, L = P.L, nch = P.nch;
+    const long long npix = (long long)nx * P.ny, vpix = (long long)vnx * P.vny;  // (npix: a multiple of four)
+    const long long ngroup = npix / 4;
+    const int lane = threadIdx.x & 63;
+    const float trunc = P.trunc;
+    bool nanv = false;
+    for (long long grp = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); grp < ngroup; grp += (long long)gridDim.x * 4) {
+        const long long pix0 = grp * 4;
+        const int y = (int)(pix0 / nx), x = (int)(pix0 - (long long)y * nx);  // x .. x+3: one row
+        const bool yin = y < P.vny;
+        bool fin[4] = {false, false, false, false};
+        for (int o0 = lane * 4; o0 < L; o0 += 256) {
+            const int q0 = x + P.dmin + o0;
+            const bool inside = yin && q0 >= 0 && q0 + 8 <= vnx;  // every sample the four pixels need lies inside the right image
+            float e[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) e[i][k] = 0.0f;
+            for (int t = 0; t < nch; t++) {
+                const float4 ac4 = *reinterpret_cast<const float4 *>(P.u + (long long)t * npix + pix0);
+                const float4 al4 = *reinterpret_cast<const float4 *>(P.ncc_u + (long long)t * npix + pix0);
+                const float4 ah4 = *reinterpret_cast<const float4 *>(P.ncc_u + (long long)(nch + t) * npix + pix0);
+                const float ac[4] = {ac4.x, ac4.y, ac4.z, ac4.w}, al[4] = {al4.x, al4.y, al4.z, al4.w}, ah[4] = {ah4.x, ah4.y, ah4.z, ah4.w};
+                const long long rowoff = (long long)(yin ? y : 0) * vnx;
+                const float *rc = P.v + (long long)t * vpix + rowoff, *rl = P.ncc_v + (long long)t * vpix + rowoff,
+                            *rh = P.ncc_v + (long long)(nch + t) * vpix + rowoff;
+                float bc[8], bl[8], bh[8];
+                if (inside) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const f32x4_a4 c4 = *reinterpret_cast<const f32x4_a4 *>(rc + q0 + 4 * h);
+                        const f32x4_a4 l4 = *reinterpret_cast<const f32x4_a4 *>(rl + q0 + 4 * h);
+                        const f32x4_a4 h4 = *reinterpret_cast<const f32x4_a4 *>(rh + q0 + 4 * h);
+                        bc[4 * h] = c4.x; bc[4 * h + 1] = c4.y; bc[4 * h + 2] = c4.z; bc[4 * h + 3] = c4.w;
+                        bl[4 * h] = l4.x; bl[4 * h + 1] = l4.y; bl[4 * h + 2] = l4.z; bl[4 * h + 3] = l4.w;
+                        bh[4 * h] = h4.x; bh[4 * h + 1] = h4.y; bh[4 * h + 2] = h4.z; bh[4 * h + 3] = h4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 7; k++) {
+                        const int q = q0 + k;
+                        const int qq = (yin && q >= 0 && q < vnx) ? q : 0;
+                        bc[k] = rc[qq]; bl[k] = rl[qq]; bh[k] = rh[qq];
+                    }
+                    bc[7] = bl[7] = bh[7] = 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float a_to_b = tri_high(0.0f, ac[i] - bh[i + k], bl[i + k] - ac[i]);
+                        const float b_to_a = tri_high(0.0f, bc[i + k] - ah[i], al[i] - bc[i + k]);
+                        const float r = __builtin_fabsf(a_to_b < b_to_a ? a_to_b : b_to_a);
+                        e[i][k] += SD ? r * r : r;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float c[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int q = q0 + i + k;
+                    c[k] = (inside || (yin && q >= 0 && q < vnx)) ? e[i][k] : trunc;  // outside the right image: truncDist (401-412)
+                    c[k] = (c[k] < trunc) ? c[k] : trunc;
+                    fin[i] |= finite_bits(c[k]);
+                    nanv |= c[k] != c[k];
+                }
+                *reinterpret_cast<float4 *>(P.C + (pix0 + i) * L + o0) = make_float4(c[0], c[1], c[2], c[3]);
+            }
+        }
+        // no valid hypothesis for this pixel => all labels cost 0 (mgm_costvolume.h:414-421)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (__builtin_amdgcn_ballot_w64(fin[i]) == 0ull)
+                for (int o0 = lane * 4; o0 < L; o0 += 256) *reinterpret_cast<float4 *>(P.C + (pix0 + i) * L + o0) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (P.bad8 && __builtin_amdgcn_ballot_w64(nanv) != 0ull && lane == 0) flag_once(P.bad8, 2u);
+}
+
 // ---- clipped NCC, restructured (round 4) ---------------------------------------------------------------------------
 // computeC_clippedNCC (mgm_costvolume.h:137-165) accumulates five window sums per (pixel, label, channel) -- but mu1 and s1
 // depend on the left pixel alone and mu2, s2 on the right pixel alone: only the cross term is per cell.  Each sum is a
@@ -949,6 +1051,17 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
                 break;
         }
         return e != hipSuccess ? e : hipGetLastError();
+    }
+    if (p.costfn >= 4 && p.ncc_u && p.ncc_v && p.C && !p.C8 && !p.rlo && p.nx % 4 == 0 && p.L % 4 == 0) {
+        const long long vpix = (long long)p.vnx * p.vny;
+        hipLaunchKernelGGL(k_bt_spans, dim3((unsigned)((npix * p.nch + 255) / 256)), dim3(256), 0, s, p.u, p.nx, p.ny, p.nch, p.ncc_u);
+        hipLaunchKernelGGL(k_bt_spans, dim3((unsigned)((vpix * p.nch + 255) / 256)), dim3(256), 0, s, p.v, p.vnx, p.vny, p.nch, p.ncc_v);
+        long long nw = (npix / 4 + 3) / 4;
+        if (nw > 256 * 64) nw = 256 * 64;
+        if (nw < 1) nw = 1;
+        if (p.costfn == 5) hipLaunchKernelGGL(k_cost_btx<true>, dim3((unsigned)nw), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(k_cost_btx<false>, dim3((unsigned)nw), dim3(256), 0, s, p);
+        return hipGetLastError();
     }
     // (k_cost_diffx takes truncDist = +INF or a non-negative number, sign bit clear; anything else goes to k_cost below)
     if (!p.C && p.C8 && (p.costfn == 0 || p.costfn == 1) && !p.rlo && p.nx % 4 == 0 && npix < 0x7fffffffll && c8_supported(p.L) &&

@@ -171,7 +171,8 @@ struct CostParams {
     const float *rlo, *rhi;
     // ncc: scratch for the per-pixel window statistics of the two images (k_ncc_stats): (2*nch + 1) planes of nx*ny /
     // vnx*vny floats each -- mean and variance term per channel, then the "window inside the image and NaN-free" flag --
-    // or nullptr (the general kernel recomputes every window for every label)
+    // or nullptr (the general kernel recomputes every window for every label).  Birchfield-Tomasi costs: the two ends of the
+    // interval every sample spans (k_bt_spans), 2*nch planes per image.
     float *ncc_u, *ncc_v;
 };
 hipError_t launch_cost(const CostParams &p, hipStream_t s);
