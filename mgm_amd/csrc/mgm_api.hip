@@ -103,7 +103,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     // Which compact form: census costs are bit counts (one byte); absolute differences of a one-channel 8-bit pair stay below
     // 256, of a colour pair below 766, squared differences below 65026 per channel: two bytes (up to 512 labels: the pass
     // kernels that read them).  The flag word tells afterwards whether every cost really had the form.
-    const int cb = (costfn == 2 || (costfn == 0 && u->nch == 1) || dmax - dmin + 1 > 512) ? 1 : 2;
+    const int cb = (costfn == 2 || (costfn == 0 && u->nch == 1 && !(*out)->diff_wide) || dmax - dmin + 1 > 512) ? 1 : 2;
     if (c8_supported(dmax - dmin + 1) && dev().c8) {
         if (may_be_integer) {
             if ((r = c8_alloc(c, *out, cb))) return r;
@@ -214,31 +214,39 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     const bool diff_may_fit = (costfn == 0 || costfn == 1) && (pre == 0 || pre == 2) && p.trunc >= 0.0f && !std::signbit(p.trunc) &&
                               u->nx % 4 == 0 && (long long)u->nx * u->ny < 0x7fffffffll;  // (what k_cost_diffx takes)
     if (LP && !(*out)->diff_failed && (census_fits || diff_may_fit)) {
-        const int pcb = (costfn == 2 || (costfn == 0 && u->nch == 1) || LP > 512) ? 1 : 2;
-        if ((r = p8_alloc(c, *out, LP, pcb))) return r;
-        CostParams q = p;
-        q.C = nullptr;
-        q.C8 = (*out)->p8;
-        q.cbytes = pcb;
-        q.L = LP;
-        {
-            TimeScope t(c, "k_cost");
-            HIPCHK(c, launch_cost(q, c->stream));
-        }
-        bool fits = census_fits;  // (min(popcount, trunc) in integers: fits and is NaN-free by construction, nothing to read back)
-        if (!fits) {
-            HIPCHK(c, hipMemcpyAsync(c->h_words + 3, (*out)->bad8, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            fits = c->h_words[3] == 0u;
-        }
-        if (fits) {
-            (*out)->p8_state = 2;
-            (*out)->f32_state = 0;
-            (*out)->nan_state = 2;
-            return MGM_OK;
+        int pcb = (costfn == 2 || (costfn == 0 && u->nch == 1 && !(*out)->diff_wide) || LP > 512) ? 1 : 2;
+        for (;;) {
+            if ((r = p8_alloc(c, *out, LP, pcb))) return r;
+            CostParams q = p;
+            q.C = nullptr;
+            q.C8 = (*out)->p8;
+            q.cbytes = pcb;
+            q.L = LP;
+            {
+                TimeScope t(c, "k_cost");
+                HIPCHK(c, launch_cost(q, c->stream));
+            }
+            bool fits = census_fits;  // (min(popcount, trunc) in integers: fits and is NaN-free by construction, nothing to read back)
+            if (!fits) {
+                HIPCHK(c, hipMemcpyAsync(c->h_words + 3, (*out)->bad8, 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                fits = c->h_words[3] == 0u;
+            }
+            if (fits) {
+                (*out)->p8_state = 2;
+                (*out)->f32_state = 0;
+                (*out)->nan_state = 2;
+                return MGM_OK;
+            }
+            HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
+            if (pcb == 1 && c->h_words[3] == 1u && LP <= 512) {  // one byte per cost was too narrow, two will do
+                (*out)->diff_wide = true;
+                pcb = 2;
+                continue;
+            }
+            break;
         }
         (*out)->diff_failed = true;
-        HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
     }
     if (p.C8 && !p.rlo && costfn == 2 && p.nch == 1 &&
         (p.trunc == __builtin_huge_valf() || (p.trunc >= 0.0f && p.trunc <= 254.0f && p.trunc == rintf(p.trunc))) &&
@@ -256,19 +264,30 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         // are its refills.
         p.C = nullptr;
         (*out)->f32_state = 0;
-        {
-            TimeScope t(c, "k_cost");
-            HIPCHK(c, launch_cost(p, c->stream));
-        }
-        HIPCHK(c, hipMemcpyAsync(c->h_words + 3, (*out)->bad8, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->h_words[3] == 0u) {
-            (*out)->c8_state = 2;
-            (*out)->nan_state = 2;
-            return MGM_OK;
+        for (;;) {
+            {
+                TimeScope t(c, "k_cost");
+                HIPCHK(c, launch_cost(p, c->stream));
+            }
+            HIPCHK(c, hipMemcpyAsync(c->h_words + 3, (*out)->bad8, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->h_words[3] == 0u) {
+                (*out)->c8_state = 2;
+                (*out)->nan_state = 2;
+                return MGM_OK;
+            }
+            HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
+            // one byte per cost was too narrow (a grey pair with a difference of 255), two would do (k_cost_diffx says so)
+            if (p.cbytes == 1 && c->h_words[3] == 1u && p.L <= 512) {
+                (*out)->diff_wide = true;
+                if ((r = c8_alloc(c, *out, 2))) return r;
+                p.C8 = (*out)->d8;
+                p.cbytes = 2;
+                continue;
+            }
+            break;
         }
         (*out)->diff_failed = true;
-        HIPCHK(c, hipMemsetAsync((*out)->bad8, 0, 4, c->stream));
         if ((r = cv_alloc_f32(c, *out))) return r;
         p.C = (*out)->d;
         (*out)->f32_state = 1;

@@ -284,10 +284,26 @@ __global__ void __launch_bounds__(256) k_cost(const CostParams P)
 
 // compact copy of an existing fp32 volume (uploaded by the caller); flag bit 0: some cost has no compact form,
 // bit 1: some cost is NaN (the scan-line kernels are built NaN-free; see run_passes)
+__global__ void __launch_bounds__(256) k_compact16(const float *__restrict__ C, long long n, unsigned short *__restrict__ C16, unsigned *bad8)
+{
+    bool bad = false;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+        unsigned w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            w[k] = c16_encode((i + k < n) ? C[i + k] : 0.0f);
+            bad |= w[k] > 65535u;
+        }
+        if (i + 3 < n) *reinterpret_cast<uint2 *>(C16 + i) = make_uint2((w[0] & 65535u) | (w[1] << 16), (w[2] & 65535u) | (w[3] << 16));
+        else
+            for (int k = 0; k < 4 && i + k < n; k++) C16[i + k] = (unsigned short)w[k];
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) flag_once(bad8, 1u);
+}
 __global__ void __launch_bounds__(256) k_compact(const float *__restrict__ C, long long n, uint8_t *__restrict__ C8,
                                                  unsigned *bad8)
 {
-    bool bad = false, nanv = false;
+    bool bad = false, nanv = false, hopeless = false;
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
         unsigned w = 0;
 #pragma unroll
@@ -296,6 +312,7 @@ __global__ void __launch_bounds__(256) k_compact(const float *__restrict__ C, lo
             const unsigned b = c8_encode(x);
             nanv |= x != x;
             bad |= b > 255u;
+            if (b > 255u) hopeless |= c16_encode(x) > 65535u;
             w |= (b & 255u) << (8 * k);
         }
         if (i + 3 < n) *reinterpret_cast<unsigned *>(C8 + i) = w;
@@ -304,6 +321,7 @@ __global__ void __launch_bounds__(256) k_compact(const float *__restrict__ C, lo
     }
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) flag_once(bad8, 1u);
     if (__builtin_amdgcn_ballot_w64(nanv) != 0ull && (threadIdx.x & 63) == 0) flag_once(bad8, 2u);
+    if (__builtin_amdgcn_ballot_w64(hopeless) != 0ull && (threadIdx.x & 63) == 0) flag_once(bad8, 8u);  // ... nor in two bytes
 }
 
 // NaN scan alone, for volumes that get no compact copy (flag bit 1)
@@ -415,9 +433,10 @@ hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, 
     return hipGetLastError();
 }
 
-hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s)
+hipError_t launch_compact(const float *C, long long n, uint8_t *C8, int cbytes, unsigned *bad8, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_compact, dim3(256 * 16), dim3(256), 0, s, C, n, C8, bad8);
+    if (cbytes == 2) hipLaunchKernelGGL(k_compact16, dim3(256 * 16), dim3(256), 0, s, C, n, reinterpret_cast<unsigned short *>(C8), bad8);
+    else hipLaunchKernelGGL(k_compact, dim3(256 * 16), dim3(256), 0, s, C, n, C8, bad8);
     return hipGetLastError();
 }
 
@@ -702,7 +721,7 @@ __global__ void __launch_bounds__(256) k_cost_diffx(const CostParams P)
     const unsigned long long group = (LP == 64 ? ~0ull : ((1ull << (LP & 63)) - 1ull)) << ((sub * LP) & 63);
     const float trunc = P.trunc, tclamp = __builtin_fminf(trunc, (float)(LIM + 2u));
     const bool padlane = (part + 1) * NL > P.Lreal;  // this lane holds label slots of a padded layout (P.Lreal < P.L)
-    bool odd = false;  // a cost without the compact form
+    bool odd = false, hopeless = CB == 2;  // a cost without the compact form of this width / of either width
     for (long long chunk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < nchunk; chunk += (long long)gridDim.x * 4) {
         const long long pix0 = (chunk * G + sub) * 4;
         const bool live = sub < G && pix0 < npix;
@@ -769,6 +788,7 @@ __global__ void __launch_bounds__(256) k_cost_diffx(const CostParams P)
                     fin |= finite_bits(ct);
                     b[k] = CB == 2 ? c16_encode(ct) : c8_encode(ct);
                     odd |= b[k] > LIM + 1u;
+                    if (CB == 1) hopeless |= c16_encode(ct) > 65535u;  // (... nor in two bytes)
                 }
             }
             // no valid hypothesis for this pixel => all labels cost 0 (mgm_costvolume.h:414-421)
@@ -793,7 +813,9 @@ __global__ void __launch_bounds__(256) k_cost_diffx(const CostParams P)
             }
         }
     }
+    // flag bit 0: some cost has no compact form of this width; bit 3: ... and a wider one would not help either
     if (__builtin_amdgcn_ballot_w64(odd) != 0ull && lane == 0) flag_once(P.bad8, 1u);
+    if (__builtin_amdgcn_ballot_w64(odd && hopeless) != 0ull && lane == 0) flag_once(P.bad8, 8u);
 }
 template <int CB, bool SD>
 static void launch_diffx(const CostParams &p, hipStream_t s)

@@ -635,7 +635,7 @@ int c8_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *use)
         if (r) return r;
         HIPCHK(c, hipMemsetAsync(cv->bad8, 0, 4, c->stream));
         TimeScope t(c, "k_compact");
-        HIPCHK(c, launch_compact(cv->d, n, cv->d8, cv->bad8, c->stream));
+        HIPCHK(c, launch_compact(cv->d, n, cv->d8, 1, cv->bad8, c->stream));
         cv->c8_state = 1;
         cv->nan_state = 1;
         launched = true;
@@ -651,6 +651,19 @@ int c8_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *use)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (cv->c8_state == 1) cv->c8_state = (c->h_words[3] & 1u) ? -1 : 2;
         if (cv->nan_state == 1) cv->nan_state = (c->h_words[3] & 2u) ? -1 : 2;
+        // an uploaded volume of whole numbers beyond 254 (absolute differences of a colour pair computed elsewhere): the
+        // two-byte form, where the pass kernels read it (up to 512 labels) -- k_compact says whether it would fit
+        if (launched && cv->c8_state < 0 && cv->nan_state == 2 && !(c->h_words[3] & 8u) && L <= 512 && cv->f32_state) {
+            if (int r = c8_alloc(c, cv, 2)) return r;
+            HIPCHK(c, hipMemsetAsync(cv->bad8, 0, 4, c->stream));
+            {
+                TimeScope t(c, "k_compact");
+                HIPCHK(c, launch_compact(cv->d, n, cv->d8, 2, cv->bad8, c->stream));
+            }
+            HIPCHK(c, hipMemcpyAsync(c->h_words + 3, cv->bad8, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            cv->c8_state = (c->h_words[3] & 1u) ? -1 : 2;
+        }
         if (cv->c8_state < 0 && !cv->f32_state)
             return fail(c, MGM_ERR_INTERNAL, "cost volume predicted to fit the compact form does not");
     }

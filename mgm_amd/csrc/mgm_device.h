@@ -135,7 +135,7 @@ template <int LPL>
 hipError_t launch_pass2_lpl(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s);
 // compact-cost support: labels per lane for which the C8 forms of K3 / k_wta exist
 inline bool c8_supported(int L) { return L == 64 || L == 128 || L == 192 || L == 256 || L == 384 || L == 512 || L == 768 || L == 1024; }
-hipError_t launch_compact(const float *C, long long n, uint8_t *C8, unsigned *bad8, hipStream_t s);
+hipError_t launch_compact(const float *C, long long n, uint8_t *C8, int cbytes, unsigned *bad8, hipStream_t s);
 hipError_t launch_nanscan(const float *C, long long n, unsigned *flag, hipStream_t s);
 hipError_t launch_pad(const float *C, long long npix, int L, int LP, float *Cp, uint8_t *C8p, int cbytes, unsigned *bad8, hipStream_t s);
 hipError_t launch_expand(const uint8_t *C8, int cbytes, long long n, float *C, hipStream_t s);

@@ -36,6 +36,7 @@ struct mgm_cv {
     // nothing on the hot path reads `d` then, and it is decoded from d8 if somebody asks for it.
     int f32_state = 1;         // 1 current, 0 stale (d8 holds the volume)
     bool diff_failed = false;  // an AD / SD filling of this volume did not fit the compact form: refills go straight to the general kernel
+    bool diff_wide = false;    // ... did not fit ONE byte per cost but does fit two (a grey pair with a difference of 255): refills start there
     // A label count that the pass kernels run PADDED (151 -> 192, ...): K2 may write the padded compact copy itself --
     // [npix][p8_L] costs of p8_cb bytes, the label slots beyond the real count +INF -- instead of an fp32 volume that every
     // aggregation call pads and encodes again (run_passes).  p8_state 2: valid (and then the ONLY copy until somebody asks

@@ -179,3 +179,51 @@ def test_padded_compact_only_fill(ctx, oracle, L, kind):
                 h.free()
     finally:
         oracle.set_threads(1)
+
+
+@pytest.mark.parametrize("L", [128, 151])
+def test_grey_pair_with_a_difference_of_255_takes_two_bytes(ctx, oracle, L):
+    """One byte per cost ends at 254: a grey pair that holds a 0 opposite a 255 is filled again with two bytes per cost (not with
+    fp32 costs), also in a padded layout, and so are the refills of that volume."""
+    nx, ny, dmin = 96, 20, -(L - 1)
+    threads(oracle)
+    try:
+        cv = None
+        for k in range(2):
+            u, v, _ = synth.stereo_pair(nx, ny, dmin * 3 // 4, 0, seed=70 + k)
+            u[0, 3, 40:44], v[0, 3, :] = 0.0, 255.0
+            Ca = oracle.costvolume(u, v, dmin, dmin + L - 1, "none", "ad", np.inf, 3)
+            assert Ca[np.isfinite(Ca)].max() == 255.0
+            du, dv = ctx.upload_image(u), ctx.upload_image(v)
+            cv = ctx.costvolume_dev(du, dv, dmin, dmin + L - 1, "none", "ad", float("inf"), 3, into=cv)
+            S, o, kk = ctx.aggregate_dev(cv, 6.0, 60000.0, 8, 3, 1, 1, None, "vfit", want_S=True)
+            Sa, oa, ca = oracle.mgm(Ca, dmin, 6.0, 60000.0, 8, 3, 1, 1)
+            ra, rca = oracle.refine(Sa, dmin, "vfit", oa, ca)
+            assert (ndiff(cv.download(), Ca), ndiff(S.download(), Sa), ndiff(o.download()[0], ra), ndiff(kk.download()[0], rca)) == (0, 0, 0, 0), k
+            for h in (du, dv, S, o, kk):
+                h.free()
+        cv.free()
+    finally:
+        oracle.set_threads(1)
+
+
+@pytest.mark.parametrize("L,top", [(128, 700.0), (256, 65534.0), (768, 700.0), (128, 70000.0)])
+def test_uploaded_volume_of_whole_numbers_beyond_one_byte(ctx, oracle, L, top):
+    """A volume computed elsewhere and uploaded (the drop-in path for the reference's own cost volumes): whole-number costs up
+    to 65534 are aggregated from a two-byte copy where the pass kernels read one (up to 512 labels), anything else from the
+    fp32 volume -- same results either way."""
+    nx, ny = 333, 60
+    C = np.rint(synth.raw_volume(nx, ny, L, seed=L + int(top) % 97, maxcost=60, inf_frac=0.02)).astype(np.float32)
+    C[5, 7, 3], C[9, 100, L // 2] = np.float32(top), np.float32(255.0)
+    cv = ctx.upload_volume(C, -L // 2)
+    threads(oracle)
+    try:
+        for FH, P1, P2 in ((0, 8.0, 32.0), (1, 2.0, 20000.0)):
+            S, o, kk = ctx.aggregate_dev(cv, P1, P2, 8, 3, FH, 1, None, None, want_S=True)
+            Sa, oa, ca = oracle.mgm(C, -L // 2, P1, P2, 8, 3, FH, 1)
+            assert (ndiff(S.download(), Sa), ndiff(o.download()[0], oa), ndiff(kk.download()[0], ca)) == (0, 0, 0), FH
+            for h in (S, o, kk):
+                h.free()
+    finally:
+        oracle.set_threads(1)
+    cv.free()
