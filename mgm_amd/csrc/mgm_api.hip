@@ -201,9 +201,6 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         p.ncc_v = (float *)c->census_v.p;
     }
     p.trunc = truncDist * (float)p.nch;  // mgm_costvolume.h:401,405
-    // A census cost over one descriptor word is a bit count 0..32, clipped to `trunc`: with trunc = +INF
-    // or an integer up to 254 every cost fits the compact form, and the fp32 volume -- which neither K3
-    // nor k_wta reads then -- is only materialised on demand (ensure_f32).
     // A label count that the pass kernels run padded (151 -> 192 slots, ...): the same two families of costs write the PADDED
     // compact copy themselves (mgm_cv::p8; the slots beyond the real count +INF) instead of an fp32 volume that every
     // aggregation call would pad and encode again.  The flag word is read back at once; a volume that does not fit takes
@@ -248,6 +245,9 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         }
         (*out)->diff_failed = true;
     }
+    // A census cost over one descriptor word is a bit count 0..32, clipped to `trunc`: with trunc = +INF
+    // or an integer up to 254 every cost fits the compact form, and the fp32 volume -- which neither K3
+    // nor k_wta reads then -- is only materialised on demand (ensure_f32).
     if (p.C8 && !p.rlo && costfn == 2 && p.nch == 1 &&
         (p.trunc == __builtin_huge_valf() || (p.trunc >= 0.0f && p.trunc <= 254.0f && p.trunc == rintf(p.trunc))) &&
         dev().lazy_f32) {
