@@ -80,6 +80,8 @@ WORKLOADS = {
                     desc="1920x1080 synthetic grey pair, 256 disparities, -t ad (costs 0..255), -O 8 TSGM=3, FH"),
     "cfg3ncc": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, cost="ncc",
                     desc="1920x1080 synthetic pair, 256 disparities, -t ncc (CENSUS_NCC_WIN=5), -O 8 TSGM=3, FH"),
+    "cfg3c7": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=7, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0,
+                   desc="1920x1080 synthetic pair, 256 disparities, CENSUS 7x7 (48 descriptor bits: two words, costs in halves: fp32 volumes), -O 8 TSGM=3, FH"),
     "cfg3bt": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, cost="btad", nch=1,
                    desc="1920x1080 synthetic grey pair, 256 disparities, -t btad (Birchfield-Tomasi, costs in halves: fp32 volumes), -O 8 TSGM=3, FH"),
     "cfg1s": dict(nx=700, ny=500, dmin=-120, dmax=30, win=3, NDIR=4, MGM=2, FH=0, P1=24.0, P2=96.0, cost="ad", nch=3,
@@ -174,6 +176,8 @@ def cost_bytes(w):
     if os.environ.get("MGM_HIP_C8", "1") == "0":
         return 4.0
     if L in (64, 128, 192, 256, 384, 512, 768, 1024) or L < 1024:  # (other label counts run padded to the next of these)
+        if cost_of(w) == "census" and w.get("nch", 1) * (w["win"] ** 2 - 1) > 32:
+            return 4.0  # (a descriptor of several words: costs in halves or thirds of bit counts)
         if cost_of(w) == "census" or (cost_of(w) == "ad" and w.get("nch", 1) == 1):
             return 1.0
         if cost_of(w) in ("ad", "sd") and L <= 512 and not weighted(w):

@@ -99,7 +99,11 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     p.rhi = (*out)->rhi;
     // (NCC costs are (nch - clipped NCC) * 64 and Birchfield-Tomasi costs are built on half-way interpolants: practically
     // never whole numbers, so no compact copy is attempted -- one byte store per label of K2, for nothing)
-    const bool may_be_integer = costfn <= 2;
+    // Neither is one attempted for census over several descriptor words (thirds or halves of bit counts), for differences of
+    // blurred images or of descriptor words read as floats, nor for a volume whose last two fillings did not fit: those
+    // write the fp32 volume alone (k_cost_btx).
+    const int census_words = pre == 1 ? (u->nch * ((census_win / 2 * 2 + 1) * (census_win / 2 * 2 + 1) - 1) / 8 + 3) / 4 : 0;
+    const bool may_be_integer = costfn == 2 ? census_words == 1 : (costfn <= 1 && (pre == 0 || pre == 2) && (*out)->diff_fails < 2);
     // Which compact form: census costs are bit counts (one byte); absolute differences of a one-channel 8-bit pair stay below
     // 256, of a colour pair below 766, squared differences below 65026 per channel: two bytes (up to 512 labels: the pass
     // kernels that read them).  The flag word tells afterwards whether every cost really had the form.
@@ -210,7 +214,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
                              (p.trunc == __builtin_huge_valf() || (p.trunc >= 0.0f && p.trunc <= 254.0f && p.trunc == rintf(p.trunc)));
     const bool diff_may_fit = (costfn == 0 || costfn == 1) && (pre == 0 || pre == 2) && p.trunc >= 0.0f && !std::signbit(p.trunc) &&
                               u->nx % 4 == 0 && (long long)u->nx * u->ny < 0x7fffffffll;  // (what k_cost_diffx takes)
-    if (LP && !(*out)->diff_failed && (census_fits || diff_may_fit)) {
+    if (LP && (*out)->diff_fails < 2 && (census_fits || diff_may_fit)) {
         int pcb = (costfn == 2 || (costfn == 0 && u->nch == 1 && !(*out)->diff_wide) || LP > 512) ? 1 : 2;
         for (;;) {
             if ((r = p8_alloc(c, *out, LP, pcb))) return r;
@@ -230,6 +234,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
                 fits = c->h_words[3] == 0u;
             }
             if (fits) {
+                (*out)->diff_fails = 0;
                 (*out)->p8_state = 2;
                 (*out)->f32_state = 0;
                 (*out)->nan_state = 2;
@@ -243,7 +248,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
             }
             break;
         }
-        (*out)->diff_failed = true;
+        (*out)->diff_fails++;
     }
     // A census cost over one descriptor word is a bit count 0..32, clipped to `trunc`: with trunc = +INF
     // or an integer up to 254 every cost fits the compact form, and the fp32 volume -- which neither K3
@@ -257,7 +262,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         // is NaN BY CONSTRUCTION, so there is no flag to read back -- a refilled volume costs no synchronisation
         (*out)->c8_state = 2;
         (*out)->nan_state = 2;
-    } else if (p.C8 && !p.rlo && (costfn == 0 || costfn == 1) && (pre == 0 || pre == 2) && dev().lazy_f32 && !(*out)->diff_failed) {
+    } else if (p.C8 && !p.rlo && (costfn == 0 || costfn == 1) && (pre == 0 || pre == 2) && dev().lazy_f32 && (*out)->diff_fails < 2) {
         // Absolute / squared differences of (sobelx-filtered) 8-bit images are whole numbers: write the compact copy alone and
         // read the flag word back -- the read-back the aggregation would do anyway (c8_resolve).  A volume that does not fit
         // (float-valued images, a fractional truncDist) is filled again by the general kernel, fp32 volume and all, and so
@@ -272,6 +277,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
             HIPCHK(c, hipMemcpyAsync(c->h_words + 3, (*out)->bad8, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (c->h_words[3] == 0u) {
+                (*out)->diff_fails = 0;
                 (*out)->c8_state = 2;
                 (*out)->nan_state = 2;
                 return MGM_OK;
@@ -287,9 +293,12 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
             }
             break;
         }
-        (*out)->diff_failed = true;
+        (*out)->diff_fails++;
         if ((r = cv_alloc_f32(c, *out))) return r;
         p.C = (*out)->d;
+        p.C8 = nullptr;  // (no compact form: the fp32 volume alone)
+        (*out)->c8_state = -1;
+        (*out)->nan_state = 1;
         (*out)->f32_state = 1;
     } else {
         if ((r = cv_alloc_f32(c, *out))) return r;

@@ -848,9 +848,13 @@ __global__ void __launch_bounds__(256) k_bt_spans(const float *__restrict__ u, i
     sp[idx] = a.lo;
     sp[idx + npix * nch] = a.hi;
 }
-template <bool SD>
+// FN = the cost function (CostParams::costfn): 4 / 5 Birchfield-Tomasi as described; 0 / 1 absolute / squared differences and 2
+// census over several descriptor words, for the volumes of those that have no compact form (float-valued or blurred
+// images, costs that are thirds or halves of bit counts) and used to take the general kernel: the same layout, fp32 out.
+template <int FN>
 __global__ void __launch_bounds__(256) k_cost_btx(const CostParams P)
 {
+    constexpr bool BT = FN >= 4, SD = FN == 5 || FN == 1;
     const int nx = P.nx, vnx = P.vnx, L = P.L, nch = P.nch;
     const long long npix = (long long)nx * P.ny, vpix = (long long)vnx * P.vny;  // (npix: a multiple of four)
     const long long ngroup = npix / 4;
@@ -872,40 +876,59 @@ __global__ void __launch_bounds__(256) k_cost_btx(const CostParams P)
                 for (int k = 0; k < 4; k++) e[i][k] = 0.0f;
             for (int t = 0; t < nch; t++) {
                 const float4 ac4 = *reinterpret_cast<const float4 *>(P.u + (long long)t * npix + pix0);
-                const float4 al4 = *reinterpret_cast<const float4 *>(P.ncc_u + (long long)t * npix + pix0);
-                const float4 ah4 = *reinterpret_cast<const float4 *>(P.ncc_u + (long long)(nch + t) * npix + pix0);
-                const float ac[4] = {ac4.x, ac4.y, ac4.z, ac4.w}, al[4] = {al4.x, al4.y, al4.z, al4.w}, ah[4] = {ah4.x, ah4.y, ah4.z, ah4.w};
+                const float ac[4] = {ac4.x, ac4.y, ac4.z, ac4.w};
+                float al[4] = {}, ah[4] = {};
+                if constexpr (BT) {
+                    const float4 al4 = *reinterpret_cast<const float4 *>(P.ncc_u + (long long)t * npix + pix0);
+                    const float4 ah4 = *reinterpret_cast<const float4 *>(P.ncc_u + (long long)(nch + t) * npix + pix0);
+                    al[0] = al4.x; al[1] = al4.y; al[2] = al4.z; al[3] = al4.w;
+                    ah[0] = ah4.x; ah[1] = ah4.y; ah[2] = ah4.z; ah[3] = ah4.w;
+                }
                 const long long rowoff = (long long)(yin ? y : 0) * vnx;
-                const float *rc = P.v + (long long)t * vpix + rowoff, *rl = P.ncc_v + (long long)t * vpix + rowoff,
-                            *rh = P.ncc_v + (long long)(nch + t) * vpix + rowoff;
-                float bc[8], bl[8], bh[8];
+                const float *rc = P.v + (long long)t * vpix + rowoff;
+                const float *rl = BT ? P.ncc_v + (long long)t * vpix + rowoff : rc, *rh = BT ? P.ncc_v + (long long)(nch + t) * vpix + rowoff : rc;
+                float bc[8], bl[8] = {}, bh[8] = {};
                 if (inside) {
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const f32x4_a4 c4 = *reinterpret_cast<const f32x4_a4 *>(rc + q0 + 4 * h);
-                        const f32x4_a4 l4 = *reinterpret_cast<const f32x4_a4 *>(rl + q0 + 4 * h);
-                        const f32x4_a4 h4 = *reinterpret_cast<const f32x4_a4 *>(rh + q0 + 4 * h);
                         bc[4 * h] = c4.x; bc[4 * h + 1] = c4.y; bc[4 * h + 2] = c4.z; bc[4 * h + 3] = c4.w;
-                        bl[4 * h] = l4.x; bl[4 * h + 1] = l4.y; bl[4 * h + 2] = l4.z; bl[4 * h + 3] = l4.w;
-                        bh[4 * h] = h4.x; bh[4 * h + 1] = h4.y; bh[4 * h + 2] = h4.z; bh[4 * h + 3] = h4.w;
+                        if constexpr (BT) {
+                            const f32x4_a4 l4 = *reinterpret_cast<const f32x4_a4 *>(rl + q0 + 4 * h);
+                            const f32x4_a4 h4 = *reinterpret_cast<const f32x4_a4 *>(rh + q0 + 4 * h);
+                            bl[4 * h] = l4.x; bl[4 * h + 1] = l4.y; bl[4 * h + 2] = l4.z; bl[4 * h + 3] = l4.w;
+                            bh[4 * h] = h4.x; bh[4 * h + 1] = h4.y; bh[4 * h + 2] = h4.z; bh[4 * h + 3] = h4.w;
+                        }
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < 7; k++) {
                         const int q = q0 + k;
                         const int qq = (yin && q >= 0 && q < vnx) ? q : 0;
-                        bc[k] = rc[qq]; bl[k] = rl[qq]; bh[k] = rh[qq];
+                        bc[k] = rc[qq];
+                        if constexpr (BT) {
+                            bl[k] = rl[qq];
+                            bh[k] = rh[qq];
+                        }
                     }
-                    bc[7] = bl[7] = bh[7] = 0.0f;
+                    bc[7] = 0.0f;
                 }
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const float a_to_b = tri_high(0.0f, ac[i] - bh[i + k], bl[i + k] - ac[i]);
-                        const float b_to_a = tri_high(0.0f, bc[i + k] - ah[i], al[i] - bc[i + k]);
-                        const float r = __builtin_fabsf(a_to_b < b_to_a ? a_to_b : b_to_a);
-                        e[i][k] += SD ? r * r : r;
+                        if constexpr (BT) {
+                            const float a_to_b = tri_high(0.0f, ac[i] - bh[i + k], bl[i + k] - ac[i]);
+                            const float b_to_a = tri_high(0.0f, bc[i + k] - ah[i], al[i] - bc[i + k]);
+                            const float r = __builtin_fabsf(a_to_b < b_to_a ? a_to_b : b_to_a);
+                            e[i][k] += SD ? r * r : r;
+                        } else if constexpr (FN == 2) {  // the samples are descriptor words (mgm_costvolume.h:65-78)
+                            e[i][k] += (float)__builtin_popcount(__builtin_bit_cast(unsigned, ac[i]) ^ __builtin_bit_cast(unsigned, bc[i + k]));
+                        } else {  // computeC_AD / computeC_SD (23-44)
+                            float d = ac[i] - bc[i + k];
+                            d = (d > -d) ? d : -d;
+                            e[i][k] += SD ? d * d : d;
+                        }
                     }
             }
 #pragma unroll
@@ -914,7 +937,9 @@ __global__ void __launch_bounds__(256) k_cost_btx(const CostParams P)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int q = q0 + i + k;
-                    c[k] = (inside || (yin && q >= 0 && q < vnx)) ? e[i][k] : trunc;  // outside the right image: truncDist (401-412)
+                    float v = e[i][k];
+                    if constexpr (FN == 2) v = (float)((double)v * 1.0 / (double)nch);
+                    c[k] = (inside || (yin && q >= 0 && q < vnx)) ? v : trunc;  // outside the right image: truncDist (401-412)
                     c[k] = (c[k] < trunc) ? c[k] : trunc;
                     fin[i] |= finite_bits(c[k]);
                     nanv |= c[k] != c[k];
@@ -1081,8 +1106,18 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
         long long nw = (npix / 4 + 3) / 4;
         if (nw > 256 * 64) nw = 256 * 64;
         if (nw < 1) nw = 1;
-        if (p.costfn == 5) hipLaunchKernelGGL(k_cost_btx<true>, dim3((unsigned)nw), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(k_cost_btx<false>, dim3((unsigned)nw), dim3(256), 0, s, p);
+        if (p.costfn == 5) hipLaunchKernelGGL(k_cost_btx<5>, dim3((unsigned)nw), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(k_cost_btx<4>, dim3((unsigned)nw), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
+    // differences / multi-word census without a compact form: fp32 volume only (see mgm_costvolume_build_dev)
+    if (p.costfn <= 2 && p.C && !p.C8 && !p.rlo && p.nx % 4 == 0 && p.L % 4 == 0) {
+        long long nw = (npix / 4 + 3) / 4;
+        if (nw > 256 * 64) nw = 256 * 64;
+        if (nw < 1) nw = 1;
+        if (p.costfn == 0) hipLaunchKernelGGL(k_cost_btx<0>, dim3((unsigned)nw), dim3(256), 0, s, p);
+        else if (p.costfn == 1) hipLaunchKernelGGL(k_cost_btx<1>, dim3((unsigned)nw), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(k_cost_btx<2>, dim3((unsigned)nw), dim3(256), 0, s, p);
         return hipGetLastError();
     }
     // (k_cost_diffx takes truncDist = +INF or a non-negative number, sign bit clear; anything else goes to k_cost below)

@@ -35,7 +35,8 @@ struct mgm_cv {
     // K2 skips the fp32 write when its costs are known to fit the compact form (single-word census):
     // nothing on the hot path reads `d` then, and it is decoded from d8 if somebody asks for it.
     int f32_state = 1;         // 1 current, 0 stale (d8 holds the volume)
-    bool diff_failed = false;  // an AD / SD filling of this volume did not fit the compact form: refills go straight to the general kernel
+    int diff_fails = 0;        // AD / SD fillings of this volume in a row that did not fit the compact form: after two, refills go straight
+                               // to the fp32 kernel (a filling that fits resets the count)
     bool diff_wide = false;    // ... did not fit ONE byte per cost but does fit two (a grey pair with a difference of 255): refills start there
     // A label count that the pass kernels run PADDED (151 -> 192, ...): K2 may write the padded compact copy itself --
     // [npix][p8_L] costs of p8_cb bytes, the label slots beyond the real count +INF -- instead of an fp32 volume that every

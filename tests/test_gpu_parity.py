@@ -147,7 +147,12 @@ COSTS = [(1, (40, 23), (-7, 8), "none", "ad", 3, np.inf), (3, (40, 23), (-7, 8),
          # k_bt_spans + k_cost_btx (widths and label counts that are multiples of four): several label turns per lane, a
          # colour pair, truncation, a count off the wave width
          (1, (64, 21), (-100, 27), "none", "btad", 3, np.inf), (3, (36, 11), (-300, 211), "none", "btsd", 3, 50.0),
-         (1, (96, 9), (-40, 27), "none", "btad", 3, 2.5), (2, (8, 5), (-3, 0), "none", "btsd", 3, np.inf)]
+         (1, (96, 9), (-40, 27), "none", "btad", 3, 2.5), (2, (8, 5), (-3, 0), "none", "btsd", 3, np.inf),
+         # the same kernel writes the fp32 volumes of costs without a compact form: census over two / three descriptor words
+         # (halves / thirds of bit counts), differences of blurred images, of float-valued ones after sobelx
+         (1, (64, 21), (-100, 27), "none", "census", 7, np.inf), (3, (36, 11), (-60, 3), "none", "census", 5, 20.0),
+         (1, (64, 21), (-40, 23), "gblur", "ad", 3, 30.0), (3, (36, 11), (-300, 211), "gblur", "sd", 3, np.inf),
+         (1, (300, 8), (-255, 0), "none", "census", 7, 11.5)]
 
 
 @pytest.mark.parametrize("case", COSTS, ids=lambda c: "%dch-%s-%s-w%d" % (c[0], c[3], c[4], c[5]))
