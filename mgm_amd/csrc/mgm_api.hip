@@ -213,7 +213,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     const bool census_fits = costfn == 2 && p.nch == 1 &&
                              (p.trunc == __builtin_huge_valf() || (p.trunc >= 0.0f && p.trunc <= 254.0f && p.trunc == rintf(p.trunc)));
     const bool diff_may_fit = (costfn == 0 || costfn == 1) && (pre == 0 || pre == 2) && p.trunc >= 0.0f && !std::signbit(p.trunc) &&
-                              u->nx % 4 == 0 && (long long)u->nx * u->ny < 0x7fffffffll;  // (what k_cost_diffx takes)
+                              (long long)u->nx * u->ny < 0x7fffffffll;  // (what k_cost_diffx takes)
     if (LP && (*out)->diff_fails < 2 && (census_fits || diff_may_fit)) {
         int pcb = (costfn == 2 || (costfn == 0 && u->nch == 1 && !(*out)->diff_wide) || LP > 512) ? 1 : 2;
         for (;;) {

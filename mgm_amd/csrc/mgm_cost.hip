@@ -684,12 +684,23 @@ __global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restric
 // NCH = the channel count (1 or 3: the right-image samples of all channels are loaded up front), or 0 = any (channel loop
 // outermost, 64 accumulators).
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+// four consecutive samples starting at p (a group of four pixels of one row; `n` < 4 of them exist at the end of a row whose
+// width is not a multiple of four: the others repeat the first)
+__device__ __forceinline__ void load4_row(const float *__restrict__ p, int n, float (&o)[4])
+{
+    if (n >= 4) {
+        const f32x4_a4 w = *reinterpret_cast<const f32x4_a4 *>(p);
+        o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = w.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = p[i < n ? i : 0];
+    }
+}
 template <int NL>
-__device__ __forceinline__ void diff_load(const CostParams &P, int t, unsigned p32, long long npix, long long vpix, int y, bool yin, int q0,
+__device__ __forceinline__ void diff_load(const CostParams &P, int t, long long pix0, int nlive, long long npix, long long vpix, int y, bool yin, int q0,
                                           bool inside, float (&ut)[4], float (&vt)[NL + 4])
 {
-    const float4 u4 = *reinterpret_cast<const float4 *>(P.u + (long long)t * npix + p32);
-    ut[0] = u4.x; ut[1] = u4.y; ut[2] = u4.z; ut[3] = u4.w;
+    load4_row(P.u + (long long)t * npix + pix0, nlive, ut);
     const float *row = P.v + (long long)t * vpix + (long long)(yin ? y : 0) * P.vnx;
     if (inside) {
 #pragma unroll
@@ -715,18 +726,21 @@ __global__ void __launch_bounds__(256) k_cost_diffx(const CostParams P)
     const int L = P.L, LP = L / NL;  // lanes per group of four pixels
     const int G = 64 / LP;           // groups per wave and iteration (192 / 384 / 768 labels: the last lanes of the wave idle)
     const int nx = P.nx, vnx = P.vnx;
-    const long long npix = (long long)nx * P.ny, vpix = (long long)vnx * P.vny;  // (npix: a multiple of four)
-    const long long nchunk = (npix + 4 * G - 1) / (4 * G);
+    const long long npix = (long long)nx * P.ny, vpix = (long long)vnx * P.vny;
+    const int gpr = (nx + 3) / 4;  // groups of four pixels per row (the last one of a row may hold fewer)
+    const long long ngrp = (long long)gpr * P.ny, nchunk = (ngrp + G - 1) / G;
     const int lane = threadIdx.x & 63, sub = lane / LP, part = lane - sub * LP;
     const unsigned long long group = (LP == 64 ? ~0ull : ((1ull << (LP & 63)) - 1ull)) << ((sub * LP) & 63);
     const float trunc = P.trunc, tclamp = __builtin_fminf(trunc, (float)(LIM + 2u));
     const bool padlane = (part + 1) * NL > P.Lreal;  // this lane holds label slots of a padded layout (P.Lreal < P.L)
     bool odd = false, hopeless = CB == 2;  // a cost without the compact form of this width / of either width
     for (long long chunk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < nchunk; chunk += (long long)gridDim.x * 4) {
-        const long long pix0 = (chunk * G + sub) * 4;
-        const bool live = sub < G && pix0 < npix;
-        const unsigned p32 = live ? (unsigned)pix0 : 0u;  // (npix < 2^31: checked by the caller)
-        const int y = (int)(p32 / (unsigned)nx), x = (int)(p32 - (unsigned)y * (unsigned)nx);  // x .. x+3: one row
+        const long long grp = chunk * G + sub;
+        const bool live = sub < G && grp < ngrp;
+        const unsigned g32 = live ? (unsigned)grp : 0u;  // (npix < 2^31: checked by the caller)
+        const int y = (int)(g32 / (unsigned)gpr), x = (int)(g32 - (unsigned)y * (unsigned)gpr) * 4;  // x .. x+3: one row
+        const long long pix0 = (long long)y * nx + x;
+        const int nlive = live ? (nx - x < 4 ? nx - x : 4) : 0, nload = nx - x < 4 ? nx - x : 4;
         const int q0 = x + P.dmin + part * NL;
         const bool yin = y < P.vny;
         const bool inside = yin && q0 >= 0 && q0 + NL + 4 <= vnx;  // every sample the four pixels need lies inside the right image
@@ -734,14 +748,14 @@ __global__ void __launch_bounds__(256) k_cost_diffx(const CostParams P)
         float e[NCH ? 1 : 4][NL];
         if constexpr (NCH != 0) {
 #pragma unroll
-            for (int t = 0; t < NCH; t++) diff_load<NL>(P, t, p32, npix, vpix, y, yin, q0, inside, uu[t], v[t]);
+            for (int t = 0; t < NCH; t++) diff_load<NL>(P, t, pix0, nload, npix, vpix, y, yin, q0, inside, uu[t], v[t]);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int k = 0; k < NL; k++) e[i][k] = 0.0f;
             for (int t = 0; t < P.nch; t++) {
-                diff_load<NL>(P, t, p32, npix, vpix, y, yin, q0, inside, uu[0], v[0]);
+                diff_load<NL>(P, t, pix0, nload, npix, vpix, y, yin, q0, inside, uu[0], v[0]);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -787,13 +801,13 @@ __global__ void __launch_bounds__(256) k_cost_diffx(const CostParams P)
                     const float ct = (padlane && part * NL + k >= P.Lreal) ? __builtin_huge_valf() : ((c[k] < trunc) ? c[k] : trunc);
                     fin |= finite_bits(ct);
                     b[k] = CB == 2 ? c16_encode(ct) : c8_encode(ct);
-                    odd |= b[k] > LIM + 1u;
+                    odd |= b[k] > LIM + 1u && i < nlive;  // (i >= nlive: not a pixel of the image, see load4_row)
                     if (CB == 1) hopeless |= c16_encode(ct) > 65535u;  // (... nor in two bytes)
                 }
             }
             // no valid hypothesis for this pixel => all labels cost 0 (mgm_costvolume.h:414-421)
             const bool anyfinite = (__builtin_amdgcn_ballot_w64(fin) & group) != 0ull;
-            if (!live) continue;
+            if (i >= nlive) continue;
             uint8_t *dst = P.C8 + ((pix0 + i) * L + part * NL) * CB;
             if constexpr (CB == 2) {
                 unsigned w[4];
@@ -821,7 +835,7 @@ template <int CB, bool SD>
 static void launch_diffx(const CostParams &p, hipStream_t s)
 {
     const long long npix = (long long)p.nx * p.ny;
-    long long nw = (npix * p.L * CB / 4096 + 3) / 4 + 1;
+    long long nw = ((long long)((p.nx + 3) / 4) * p.ny * 4 * p.L * CB / 4096 + 3) / 4 + 1;
     if (nw > 256 * 32) nw = 256 * 32;
     const dim3 grid((unsigned)nw), block(256);
     if (p.nch == 1) hipLaunchKernelGGL((k_cost_diffx<CB, 1, SD>), grid, block, 0, s, p);
@@ -851,19 +865,21 @@ __global__ void __launch_bounds__(256) k_bt_spans(const float *__restrict__ u, i
 // FN = the cost function (CostParams::costfn): 4 / 5 Birchfield-Tomasi as described; 0 / 1 absolute / squared differences and 2
 // census over several descriptor words, for the volumes of those that have no compact form (float-valued or blurred
 // images, costs that are thirds or halves of bit counts) and used to take the general kernel: the same layout, fp32 out.
-template <int FN>
+template <int FN, bool W4>  // W4: the image width is a multiple of four (every group is whole: no guarded loads and stores)
 __global__ void __launch_bounds__(256) k_cost_btx(const CostParams P)
 {
     constexpr bool BT = FN >= 4, SD = FN == 5 || FN == 1;
     const int nx = P.nx, vnx = P.vnx, L = P.L, nch = P.nch;
-    const long long npix = (long long)nx * P.ny, vpix = (long long)vnx * P.vny;  // (npix: a multiple of four)
-    const long long ngroup = npix / 4;
+    const long long npix = (long long)nx * P.ny, vpix = (long long)vnx * P.vny;
+    const int gpr = (nx + 3) / 4;  // groups of four pixels per row (the last one of a row may hold fewer)
+    const long long ngroup = (long long)gpr * P.ny;
     const int lane = threadIdx.x & 63;
     const float trunc = P.trunc;
     bool nanv = false;
     for (long long grp = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); grp < ngroup; grp += (long long)gridDim.x * 4) {
-        const long long pix0 = grp * 4;
-        const int y = (int)(pix0 / nx), x = (int)(pix0 - (long long)y * nx);  // x .. x+3: one row
+        const int y = (int)(grp / gpr), x = (int)(grp - (long long)y * gpr) * 4;  // x .. x+3: one row
+        const long long pix0 = (long long)y * nx + x;
+        const int nlive = W4 ? 4 : (nx - x < 4 ? nx - x : 4);
         const bool yin = y < P.vny;
         bool fin[4] = {false, false, false, false};
         for (int o0 = lane * 4; o0 < L; o0 += 256) {
@@ -875,14 +891,11 @@ __global__ void __launch_bounds__(256) k_cost_btx(const CostParams P)
 #pragma unroll
                 for (int k = 0; k < 4; k++) e[i][k] = 0.0f;
             for (int t = 0; t < nch; t++) {
-                const float4 ac4 = *reinterpret_cast<const float4 *>(P.u + (long long)t * npix + pix0);
-                const float ac[4] = {ac4.x, ac4.y, ac4.z, ac4.w};
-                float al[4] = {}, ah[4] = {};
+                float ac[4], al[4] = {}, ah[4] = {};
+                load4_row(P.u + (long long)t * npix + pix0, nlive, ac);
                 if constexpr (BT) {
-                    const float4 al4 = *reinterpret_cast<const float4 *>(P.ncc_u + (long long)t * npix + pix0);
-                    const float4 ah4 = *reinterpret_cast<const float4 *>(P.ncc_u + (long long)(nch + t) * npix + pix0);
-                    al[0] = al4.x; al[1] = al4.y; al[2] = al4.z; al[3] = al4.w;
-                    ah[0] = ah4.x; ah[1] = ah4.y; ah[2] = ah4.z; ah[3] = ah4.w;
+                    load4_row(P.ncc_u + (long long)t * npix + pix0, nlive, al);
+                    load4_row(P.ncc_u + (long long)(nch + t) * npix + pix0, nlive, ah);
                 }
                 const long long rowoff = (long long)(yin ? y : 0) * vnx;
                 const float *rc = P.v + (long long)t * vpix + rowoff;
@@ -944,13 +957,13 @@ __global__ void __launch_bounds__(256) k_cost_btx(const CostParams P)
                     fin[i] |= finite_bits(c[k]);
                     nanv |= c[k] != c[k];
                 }
-                *reinterpret_cast<float4 *>(P.C + (pix0 + i) * L + o0) = make_float4(c[0], c[1], c[2], c[3]);
+                if (i < nlive) *reinterpret_cast<float4 *>(P.C + (pix0 + i) * L + o0) = make_float4(c[0], c[1], c[2], c[3]);
             }
         }
         // no valid hypothesis for this pixel => all labels cost 0 (mgm_costvolume.h:414-421)
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            if (__builtin_amdgcn_ballot_w64(fin[i]) == 0ull)
+            if (__builtin_amdgcn_ballot_w64(fin[i]) == 0ull && i < nlive)
                 for (int o0 = lane * 4; o0 < L; o0 += 256) *reinterpret_cast<float4 *>(P.C + (pix0 + i) * L + o0) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (P.bad8 && __builtin_amdgcn_ballot_w64(nanv) != 0ull && lane == 0) flag_once(P.bad8, 2u);
@@ -1072,6 +1085,12 @@ __global__ void __launch_bounds__(256) k_cost_ncc(const CostParams P)
     }
 }
 
+template <int FN>
+static void launch_btx(const CostParams &p, long long nw, hipStream_t s)
+{
+    if (p.nx % 4) hipLaunchKernelGGL((k_cost_btx<FN, false>), dim3((unsigned)nw), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_cost_btx<FN, true>), dim3((unsigned)nw), dim3(256), 0, s, p);
+}
 hipError_t launch_cost(const CostParams &p, hipStream_t s)
 {
     const long long npix = (long long)p.nx * p.ny;
@@ -1099,29 +1118,29 @@ hipError_t launch_cost(const CostParams &p, hipStream_t s)
         }
         return e != hipSuccess ? e : hipGetLastError();
     }
-    if (p.costfn >= 4 && p.ncc_u && p.ncc_v && p.C && !p.C8 && !p.rlo && p.nx % 4 == 0 && p.L % 4 == 0) {
+    if (p.costfn >= 4 && p.ncc_u && p.ncc_v && p.C && !p.C8 && !p.rlo && p.L % 4 == 0) {
         const long long vpix = (long long)p.vnx * p.vny;
         hipLaunchKernelGGL(k_bt_spans, dim3((unsigned)((npix * p.nch + 255) / 256)), dim3(256), 0, s, p.u, p.nx, p.ny, p.nch, p.ncc_u);
         hipLaunchKernelGGL(k_bt_spans, dim3((unsigned)((vpix * p.nch + 255) / 256)), dim3(256), 0, s, p.v, p.vnx, p.vny, p.nch, p.ncc_v);
-        long long nw = (npix / 4 + 3) / 4;
+        long long nw = ((long long)((p.nx + 3) / 4) * p.ny + 3) / 4;
         if (nw > 256 * 64) nw = 256 * 64;
         if (nw < 1) nw = 1;
-        if (p.costfn == 5) hipLaunchKernelGGL(k_cost_btx<5>, dim3((unsigned)nw), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(k_cost_btx<4>, dim3((unsigned)nw), dim3(256), 0, s, p);
+        if (p.costfn == 5) launch_btx<5>(p, nw, s);
+        else launch_btx<4>(p, nw, s);
         return hipGetLastError();
     }
     // differences / multi-word census without a compact form: fp32 volume only (see mgm_costvolume_build_dev)
-    if (p.costfn <= 2 && p.C && !p.C8 && !p.rlo && p.nx % 4 == 0 && p.L % 4 == 0) {
-        long long nw = (npix / 4 + 3) / 4;
+    if (p.costfn <= 2 && p.C && !p.C8 && !p.rlo && p.L % 4 == 0) {
+        long long nw = ((long long)((p.nx + 3) / 4) * p.ny + 3) / 4;
         if (nw > 256 * 64) nw = 256 * 64;
         if (nw < 1) nw = 1;
-        if (p.costfn == 0) hipLaunchKernelGGL(k_cost_btx<0>, dim3((unsigned)nw), dim3(256), 0, s, p);
-        else if (p.costfn == 1) hipLaunchKernelGGL(k_cost_btx<1>, dim3((unsigned)nw), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(k_cost_btx<2>, dim3((unsigned)nw), dim3(256), 0, s, p);
+        if (p.costfn == 0) launch_btx<0>(p, nw, s);
+        else if (p.costfn == 1) launch_btx<1>(p, nw, s);
+        else launch_btx<2>(p, nw, s);
         return hipGetLastError();
     }
     // (k_cost_diffx takes truncDist = +INF or a non-negative number, sign bit clear; anything else goes to k_cost below)
-    if (!p.C && p.C8 && (p.costfn == 0 || p.costfn == 1) && !p.rlo && p.nx % 4 == 0 && npix < 0x7fffffffll && c8_supported(p.L) &&
+    if (!p.C && p.C8 && (p.costfn == 0 || p.costfn == 1) && !p.rlo && npix < 0x7fffffffll && c8_supported(p.L) &&
         (p.cbytes == 1 || p.cbytes == 2) && p.L * p.cbytes <= 1024 && p.trunc >= 0.0f && !__builtin_signbit(p.trunc)) {
         if (p.cbytes == 2) p.costfn == 1 ? launch_diffx<2, true>(p, s) : launch_diffx<2, false>(p, s);
         else p.costfn == 1 ? launch_diffx<1, true>(p, s) : launch_diffx<1, false>(p, s);
