@@ -99,7 +99,7 @@ def _fill_case(ctx, oracle, nx, ny, vnx, vny, dmin, dmax, pre, cost, nch, trunc,
 @pytest.mark.parametrize("L", [64, 128, 192, 256, 384, 512, 768, 1024])
 @pytest.mark.parametrize("kind", ["ad-grey", "ad-colour", "sd-grey", "ad-colour-trunc", "ad-fractional-trunc", "ad-sobelx", "ad-float-images"])
 def test_compact_only_fill(ctx, oracle, L, kind):
-    """Widths that are multiples of four take k_cost_diffx; the volume read back (expanded from the compact copy, or written by the
+    """k_cost_diffx; the volume read back (expanded from the compact copy, or written by the
     general kernel where a cost did not fit: fractional truncDist, float-valued images, colour at one byte per cost) equals the
     oracle's bit for bit, also where the right image is narrower and shorter than the left."""
     cost = "sd" if kind.startswith("sd") else "ad"

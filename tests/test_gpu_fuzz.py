@@ -73,7 +73,7 @@ def test_random_costvolume_vs_oracle(ctx, oracle, seed):
     if "census" in (pre, dist) and (nch * (win * win - 1)) % 8:
         win = 3
     td = float(rng.choice([np.inf, 30.0, 7.0, 2.5]))
-    if rng.random() < 0.4:  # widths that are multiples of four take k_cost_diffx (absolute / squared differences, compact copy only)
+    if rng.random() < 0.4:  # widths that are multiples of four: every group of four pixels of k_cost_diffx / k_cost_btx / k_cost_census8x is whole
         vnx += (nx + 3) // 4 * 4 - nx
         nx = (nx + 3) // 4 * 4
     u = rng.integers(0, 256, size=(nch, ny, nx)).astype(np.float32)

@@ -144,7 +144,7 @@ COSTS = [(1, (40, 23), (-7, 8), "none", "ad", 3, np.inf), (3, (40, 23), (-7, 8),
          # k_cost_ncc: widths that leave a partial workgroup tile, 7x7 windows, label counts off the wave width
          (1, (61, 19), (-60, 39), "none", "ncc", 7, np.inf), (3, (37, 11), (-33, 30), "none", "ncc", 3, 2.0),
          (1, (130, 9), (-255, 0), "none", "ncc", 5, np.inf), (2, (35, 8), (-3, 70), "none", "ncc", 5, np.inf),
-         # k_bt_spans + k_cost_btx (widths and label counts that are multiples of four): several label turns per lane, a
+         # k_bt_spans + k_cost_btx (label counts that are multiples of four, any width): several label turns per lane, a
          # colour pair, truncation, a count off the wave width
          (1, (64, 21), (-100, 27), "none", "btad", 3, np.inf), (3, (36, 11), (-300, 211), "none", "btsd", 3, 50.0),
          (1, (96, 9), (-40, 27), "none", "btad", 3, 2.5), (2, (8, 5), (-3, 0), "none", "btsd", 3, np.inf),
