@@ -23,7 +23,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract
 UNITS = [("mgm_pass.hip", "", ["-fno-honor-nans"])]
 P2_EXTRA = os.environ.get("MGM_P2_DEFINES", "").split()  # e.g. "-DMGM_P2_MAXD=3" (tuning experiments)
 UNITS += [("mgm_pass2.hip", "_lpl%d" % n, ["-fno-honor-nans", "-DMGM_P2_LPL=%d" % n] + P2_EXTRA) for n in (1, 2, 3, 4, 6, 8, 12, 16)]
-UNITS += [("mgm_pass2_dispatch.hip", "", P2_EXTRA), ("mgm_cost.hip", "", []), ("mgm_wta.hip", "", []), ("mgm_post.hip", "", []),
+UNITS += [("mgm_pass2_dispatch.hip", "", P2_EXTRA), ("mgm_cost.hip", "", []), ("mgm_cost_fast.hip", "", []), ("mgm_wta.hip", "", []), ("mgm_post.hip", "", []),
           ("mgm_api.hip", "", []), ("mgm_ctx.hip", "", []), ("mgm_plan.hip", "", []), ("mgm_multi.hip", "", []),
           ("mgm_pass_exact.hip", "", [])]  # (no -fno-honor-nans: this one exists for the NaNs)
 
@@ -53,7 +53,7 @@ def _read(path):
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
-    headers = [os.path.join(CSRC, "mgm_device.h"), os.path.join(CSRC, "mgm_pass_common.h"), os.path.join(CSRC, "mgm_host.h"),
+    headers = [os.path.join(CSRC, "mgm_device.h"), os.path.join(CSRC, "mgm_pass_common.h"), os.path.join(CSRC, "mgm_host.h"), os.path.join(CSRC, "mgm_cost_common.h"),
                os.path.join(HERE, "..", "include", "mgm_hip.h"),
                os.path.abspath(__file__)]
     jobs = []

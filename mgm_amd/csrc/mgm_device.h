@@ -176,6 +176,7 @@ struct CostParams {
     float *ncc_u, *ncc_v;
 };
 hipError_t launch_cost(const CostParams &p, hipStream_t s);
+hipError_t launch_cost_fast(const CostParams &p, hipStream_t s, bool *taken);  // (mgm_cost_fast.hip; called by launch_cost)
 hipError_t launch_filter2d(const float *u, int nx, int ny, int nch, const float *taps, int fnx, int fny, float *out,
                            hipStream_t s);
 hipError_t launch_weights(const float *u, int nx, int ny, int nch, float aP, float aThresh, float *w8,
