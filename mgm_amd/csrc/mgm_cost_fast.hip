@@ -146,11 +146,12 @@ __global__ void __launch_bounds__(256) k_cost_census8w(const uint32_t *__restric
     }
 }
 
-// The same again with FOUR consecutive pixels of a row per lane (image widths that are multiples of four; any compact
+// The same again with FOUR consecutive pixels of a row per lane (any image width: see W4; any compact
 // label count -- at 192 / 384 labels a pixel group takes 12 / 24 lanes and the last 4 / 16 lanes of the wave idle): the sixteen
 // labels of a lane slide along the right image by one word per pixel, so the four pixels share 19 census words where
 // four separate lanes load 64 -- the kernel above is bound by those (L1-resident, unaligned) loads, not by its stores.
-template <int L>
+template <int L, bool W4>  // W4: the image width is a multiple of four (every group whole and 16-byte aligned); else the last
+                            // group of a row holds fewer pixels and the loads / stores are guarded
 __global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restrict__ cu, const uint32_t *__restrict__ cv,
                                                        int nx, int ny, int vnx, int vny, int dmin, unsigned tb,
                                                        uint8_t *__restrict__ C8, int Lreal)
@@ -158,17 +159,28 @@ __global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restric
     static_assert(L % 16 == 0 && L >= 16 && L <= 1024, "sixteen labels per lane");
     constexpr int LP = L / 16;    // lanes per pixel group
     constexpr int G = 64 / LP;    // groups of four pixels per wave and iteration (192 / 384 labels: 4 / 16 lanes of the wave idle)
-    const long long npix = (long long)nx * ny;  // (a multiple of four)
-    const long long nchunk = (npix + 4 * G - 1) / (4 * G);
+    const int gpr = (nx + 3) / 4;  // groups of four pixels per row
+    const long long ngrp = (long long)gpr * ny, nchunk = (ngrp + G - 1) / G;
     const int lane = threadIdx.x & 63, sub = lane / LP, part = lane % LP;
     const unsigned long long group = (LP == 64 ? ~0ull : ((1ull << (LP % 64)) - 1ull)) << ((sub * LP) & 63);
     for (long long chunk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < nchunk; chunk += (long long)gridDim.x * 4) {
-        const long long pix0 = (chunk * G + sub) * 4;
-        const bool live = sub < G && pix0 < npix;
-        const unsigned p32 = live ? (unsigned)pix0 : 0u;  // (npix < 2^31: checked by the caller)
-        const int y = (int)(p32 / (unsigned)nx), x = (int)(p32 - (unsigned)y * (unsigned)nx);  // x .. x+3: one row
-        const uint4 wu4 = *reinterpret_cast<const uint4 *>(cu + p32);
-        const unsigned wu[4] = {wu4.x, wu4.y, wu4.z, wu4.w};
+        const long long grp = chunk * G + sub;
+        const bool live = sub < G && grp < ngrp;
+        const unsigned g32 = live ? (unsigned)grp : 0u;  // (npix < 2^31: checked by the caller)
+        const int y = (int)(g32 / (unsigned)gpr), x = (int)(g32 - (unsigned)y * (unsigned)gpr) * 4;  // x .. x+3: one row
+        const long long pix0 = (long long)y * nx + x;
+        const int nhere = W4 ? 4 : (nx - x < 4 ? nx - x : 4);  // pixels of this group that exist
+        unsigned wu[4];
+        if (W4) {
+            const uint4 wu4 = *reinterpret_cast<const uint4 *>(cu + pix0);
+            wu[0] = wu4.x; wu[1] = wu4.y; wu[2] = wu4.z; wu[3] = wu4.w;
+        } else if (nhere == 4) {
+            const u32x4_a4 wu4 = *reinterpret_cast<const u32x4_a4 *>(cu + pix0);
+            wu[0] = wu4.x; wu[1] = wu4.y; wu[2] = wu4.z; wu[3] = wu4.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) wu[i] = cu[pix0 + (i < nhere ? i : 0)];
+        }
         const int q0 = x + dmin + part * 16;
         const bool yin = y < vny;
         const uint32_t *row = cv + (long long)(yin ? y : 0) * vnx;
@@ -226,7 +238,7 @@ __global__ void __launch_bounds__(256) k_cost_census8x(const uint32_t *__restric
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const bool anyfinite = (__builtin_amdgcn_ballot_w64(fin[i]) & group) != 0ull;  // of this pixel's labels
-            if (live) {
+            if (live && i < nhere) {
                 uint4 o;
                 o.x = anyfinite ? w[i][0] : pad[0]; o.y = anyfinite ? w[i][1] : pad[1]; o.z = anyfinite ? w[i][2] : pad[2]; o.w = anyfinite ? w[i][3] : pad[3];
                 *reinterpret_cast<uint4 *>(C8 + (pix0 + i) * L + part * 16) = o;
@@ -659,6 +671,12 @@ static void launch_btx(const CostParams &p, long long nw, hipStream_t s)
     if (p.nx % 4) hipLaunchKernelGGL((k_cost_btx<FN, false>), dim3((unsigned)nw), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_cost_btx<FN, true>), dim3((unsigned)nw), dim3(256), 0, s, p);
 }
+template <int L>
+static void launch_census8x(const CostParams &p, dim3 grid, unsigned tb, hipStream_t s)
+{
+    if (p.nx % 4) hipLaunchKernelGGL((k_cost_census8x<L, false>), grid, dim3(256), 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal);
+    else hipLaunchKernelGGL((k_cost_census8x<L, true>), grid, dim3(256), 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal);
+}
 // Launches the restructured kernel that serves `p`, if there is one (*taken), else leaves the volume to the general kernel.
 hipError_t launch_cost_fast(const CostParams &p, hipStream_t s, bool *taken)
 {
@@ -721,19 +739,19 @@ hipError_t launch_cost_fast(const CostParams &p, hipStream_t s, bool *taken)
         long long nb = (npix + 3) / 4;
         if (nb > 256 * 32) nb = 256 * 32;
         const dim3 block(256);
-        if (npix < 0x7fffffffll && p.nx % 4 == 0) {  // (every compact label count is a multiple of 16)
-            long long nw = (npix * p.L / 4096 + 3) / 4 + 1;
+        if (npix < 0x7fffffffll) {  // (every compact label count is a multiple of 16)
+            long long nw = ((long long)((p.nx + 3) / 4) * p.ny * 4 * p.L / 4096 + 3) / 4 + 1;
             if (nw > 256 * 32) nw = 256 * 32;
             const dim3 gridw((unsigned)nw);
             switch (p.L) {
-                case 64: hipLaunchKernelGGL(k_cost_census8x<64>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
-                case 128: hipLaunchKernelGGL(k_cost_census8x<128>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
-                case 192: hipLaunchKernelGGL(k_cost_census8x<192>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
-                case 256: hipLaunchKernelGGL(k_cost_census8x<256>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
-                case 384: hipLaunchKernelGGL(k_cost_census8x<384>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
-                case 512: hipLaunchKernelGGL(k_cost_census8x<512>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
-                case 768: hipLaunchKernelGGL(k_cost_census8x<768>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
-                default: hipLaunchKernelGGL(k_cost_census8x<1024>, gridw, block, 0, s, p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, p.dmin, tb, p.C8, p.Lreal); break;
+                case 64: launch_census8x<64>(p, gridw, tb, s); break;
+                case 128: launch_census8x<128>(p, gridw, tb, s); break;
+                case 192: launch_census8x<192>(p, gridw, tb, s); break;
+                case 256: launch_census8x<256>(p, gridw, tb, s); break;
+                case 384: launch_census8x<384>(p, gridw, tb, s); break;
+                case 512: launch_census8x<512>(p, gridw, tb, s); break;
+                case 768: launch_census8x<768>(p, gridw, tb, s); break;
+                default: launch_census8x<1024>(p, gridw, tb, s); break;
             }
             return hipGetLastError();
         }
