@@ -97,8 +97,13 @@ int mgm_timing_get(mgm_ctx *ctx, int idx, const char **kernel_name, float *ms);
 /* ---- images (struct Img, img.h:9-59) ----------------------------------- */
 int mgm_img_create(mgm_ctx *ctx, int nx, int ny, int nch, mgm_img **img);
 int mgm_img_upload(mgm_ctx *ctx, const float *host, int nx, int ny, int nch, mgm_img **img);
+/* Refill an existing image from a host buffer of its own size (no allocation; synchronises, so the buffer is the caller's
+ * again on return): a caller with a stream of same-sized inputs keeps its device images (src/mgm_main.cc, resident mode). */
+int mgm_img_update(mgm_ctx *ctx, mgm_img *img, const float *host);
 int mgm_img_download(mgm_ctx *ctx, const mgm_img *img, float *host);
 int mgm_img_dims(const mgm_img *img, int *nx, int *ny, int *nch);
+/* The raw device pointer.  Does NOT synchronise and does NOT run deferred work: on a pipelined context
+ * (mgm_ctx_set_pipeline) call mgm_ctx_synchronize first if the image is an output of a deferred aggregation. */
 void *mgm_img_device_ptr(mgm_img *img);
 int mgm_img_device(const mgm_img *img); /* HIP device ordinal the pixels live on (-1: NULL) */
 int mgm_img_free(mgm_ctx *ctx, mgm_img *img);

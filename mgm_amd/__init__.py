@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "mgm_wta_windowed_dev", "mgm_update_ranges_dev", "mgm_costvolume_build_ranged_dev",
     "mgm_multi_create", "mgm_multi_destroy", "mgm_multi_size", "mgm_multi_ctx", "mgm_multi_last_error", "mgm_multi_plan",
     "mgm_multi_aggregate", "mgm_multi_transport", "mgm_img_device", "mgm_cv_device", "mgm_aggregate_passes_at_dev",
-    "mgm_ctx_set_workspace_limit", "mgm_ctx_mem_info", "mgm_ctx_set_pipeline",
+    "mgm_ctx_set_workspace_limit", "mgm_ctx_mem_info", "mgm_ctx_set_pipeline", "mgm_img_update",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -71,6 +71,7 @@ def load_library():
     L.mgm_img_create.argtypes = [vp, i, i, i, pp]
     L.mgm_img_upload.argtypes = [vp, fp, i, i, i, pp]
     L.mgm_img_download.argtypes = [vp, vp, fp]
+    L.mgm_img_update.argtypes = [vp, vp, fp]
     L.mgm_img_dims.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.mgm_img_device_ptr.argtypes = [vp]
     L.mgm_img_device_ptr.restype = vp
@@ -148,6 +149,13 @@ class Image:
         out = np.empty(self.shape, np.float32)
         self.ctx._chk(self.ctx.lib.mgm_img_download(self.ctx.h, self.h, _ptr(out)))
         return out
+
+    def update(self, a):
+        """Refill from a host array of the image's own shape (no allocation)."""
+        a = np.ascontiguousarray(a, np.float32)
+        if a.size != int(np.prod(self.shape)):
+            raise ValueError("Image.update: %r does not match the image's shape %r" % (a.shape, self.shape))
+        self.ctx._chk(self.ctx.lib.mgm_img_update(self.ctx.h, self.h, _ptr(a)))
 
     def free(self):
         if self.h:

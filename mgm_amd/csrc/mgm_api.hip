@@ -40,6 +40,17 @@ static int costvolume_build(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int 
     if (!c || !u || !v || !out) return fail(c, MGM_ERR_INVALID, "mgm_costvolume_build: null argument");
     const bool provided = *out != nullptr;
     const int r = costvolume_fill(c, u, v, dmin, dmax, rloI, rhiI, prefilter, distance, truncDist, census_win, out);
+    if (*out) {
+        // A provided volume whose refill failed after its state had been touched (a reservation that ran out of memory, a
+        // kernel launch error) must not pass for a filled one: no compact copy, no "NaN-free" verdict, and the mark
+        // that makes mgm_aggregate* refuse it.
+        (*out)->unfilled = r != MGM_OK;
+        if (r != MGM_OK) {
+            (*out)->c8_state = -1;
+            (*out)->p8_state = 0;
+            (*out)->nan_state = 0;
+        }
+    }
     if (r != MGM_OK && !provided && *out) {
         const std::string msg = c->err;  // (mgm_cv_free synchronises and may touch the message)
         mgm_cv_free(c, *out);
@@ -62,6 +73,12 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         pre = 1;
     }
 
+    if (pre == 1) {  // (checked before a provided volume is touched: a bad window leaves it as it was)
+        const int wr0 = census_win / 2, side0 = 2 * wr0 + 1, nbits0 = u->nch * (side0 * side0 - 1);
+        if (wr0 < 1 || nbits0 % 8)  // census_tools.cc:81 asserts this
+            return fail(c, MGM_ERR_INVALID, "census: nch*(win*win-1) must be a positive multiple of 8");
+        if ((nbits0 / 8 + 3) / 4 > kCensusMaxWords) return fail(c, MGM_ERR_UNSUPPORTED, "census descriptor longer than 256 bits");
+    }
     int r = MGM_OK;
     if (*out) {  // caller-provided volume to refill (must have the right geometry)
         if ((*out)->nx != u->nx || (*out)->ny != u->ny || (*out)->dmin != dmin || (*out)->dmax != dmax)
@@ -381,6 +398,8 @@ static int check_aggregate_args(mgm_ctx *c, int n, const mgm_cv *const *C, const
     if (MGM < 1 || MGM > 4) return fail(c, MGM_ERR_INVALID, "MGM (TSGM) must be 1..4");
     for (int v = 0; v < n; v++)
         if (!C[v] || !out[v] || !outcost[v]) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: null argument");
+    for (int v = 0; v < n; v++)
+        if (C[v]->unfilled) return fail(c, MGM_ERR_INVALID, "mgm_aggregate: the last mgm_costvolume_build of this volume failed; it holds no costs");
     const int nx = C[0]->nx, ny = C[0]->ny, L = C[0]->dmax - C[0]->dmin + 1;
     for (int v = 0; v < n; v++) {
         if (C[v]->nx != nx || C[v]->ny != ny || C[v]->dmax - C[v]->dmin + 1 != L)
@@ -539,6 +558,7 @@ int mgm_aggregate_passes_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, flo
 {
     if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !C) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes: null argument");
+    if (C->unfilled) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes: the last mgm_costvolume_build of this volume failed; it holds no costs");
     if (first_pass < 0 || n_passes < 1 || first_pass + n_passes > kMaxDirs)
         return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes: passes must lie in 0..7");
     if (MGM < 1 || MGM > 4) return fail(c, MGM_ERR_INVALID, "MGM (TSGM) must be 1..4");
@@ -556,6 +576,7 @@ int mgm_aggregate_passes_at_dev(mgm_ctx *c, const mgm_cv *C, const mgm_img *w8, 
 {
     if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!c || !C) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes_at: null argument");
+    if (C->unfilled) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes: the last mgm_costvolume_build of this volume failed; it holds no costs");
     if (first_pass < 0 || n_passes < 1 || first_pass + n_passes > kMaxDirs || NDIR_total > kMaxDirs)
         return fail(c, MGM_ERR_INVALID, "mgm_aggregate_passes_at: passes must lie in 0..7");
     if (slot0 < 0 || n_slots < slot0 + n_passes || n_slots > kMaxDirs)

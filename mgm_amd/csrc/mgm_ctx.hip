@@ -410,6 +410,16 @@ int mgm_img_upload(mgm_ctx *c, const float *host, int nx, int ny, int nch, mgm_i
     }
     return MGM_OK;
 }
+// Refill an existing image from the host (same size): no allocation, what a caller with a stream of same-sized inputs wants.
+int mgm_img_update(mgm_ctx *c, mgm_img *im, const float *host)
+{
+    if (int jr = pipe_join(c)) return jr;  // (pipelined context: a deferred call may still read or write the image)
+    if (!c || !im || !host) return fail(c, MGM_ERR_INVALID, "mgm_img_update: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(im->d, host, sizeof(float) * (size_t)im->nx * im->ny * im->nch, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (the host buffer is the caller's again on return)
+    return MGM_OK;
+}
 int mgm_img_download(mgm_ctx *c, const mgm_img *im, float *host)
 {
     if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
@@ -558,6 +568,8 @@ int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
 {
     if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
     if (!cv) return MGM_OK;
+    // (freed through another context, or with none: the context that made the volume may still hold deferred calls on it)
+    if (cv->owner && cv->owner != c && pipe_uses(cv->owner, cv)) (void)pipe_join(cv->owner);
     if (c) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);

@@ -75,6 +75,7 @@ struct PassParams {
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA, 4 ignore
                               // inter-band waits, 8 skip step barriers, 16 Lr stores into a cache-resident window (-DMGM_P2_XFLAG16 builds only); all of them need a -DMGM_P2_DEV=1 build
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
+    unsigned long long *tl;   // nullptr, or 8 words per ticket of the queue kernels' timeline (-DMGM_P2_TIMELINE=1 builds; MGM_HIP_TIMELINE)
     long long npix, nvol;
     int L, MGM, NDIR, dmin;
     int fh2_ragged;     // 1: FH, TSGM = 2, no weights, ragged volume: update_cost2_trunclinear with its boundary fix-up
@@ -130,6 +131,7 @@ int pass_lpl(int L);                  // disparities per lane the pass kernel is
 // second build (LDS-DMA loader waves); pass2_lines(L) = lines per band, 0 if L is not supported by it
 int pass2_lines(int L, bool c8);
 bool pass2_devtools();  // built with -DMGM_P2_DEV=1 (MGM_HIP_DEBUG_STATS / MGM_HIP_XFLAGS are honoured)
+bool pass2_timeline();  // built with -DMGM_P2_TIMELINE=1 (MGM_HIP_TIMELINE is honoured)
 hipError_t launch_pass2(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s);
 template <int LPL>
 hipError_t launch_pass2_lpl(const PassParams &p, int ntasks, bool fh, int wmode, hipStream_t s);

@@ -61,6 +61,9 @@ struct mgm_cv {
     // bumped whenever the contents may have changed: contexts remember (pointer, generation) of the volumes of their
     // last aggregation, so a refilled volume, or a new one at a recycled address, is not mistaken for one of them
     unsigned long long gen = 0;
+    // a caller-provided volume whose refill FAILED half-way holds neither its old costs nor new ones: mgm_aggregate*
+    // refuses it (MGM_ERR_INVALID) until a later mgm_costvolume_build* has filled it
+    bool unfilled = false;
 };
 unsigned long long next_cv_generation();
 

@@ -152,6 +152,9 @@ constexpr int sc1_store_count() { return LPL == 3 || LPL == 6 ? 2 : (LPL + 3) / 
 #define MGM_P2_DEV 0   // 1: in-kernel timers and experiment switches (development builds: MGM_P2_DEFINES=-DMGM_P2_DEV=1);
 #endif                 // the run-time tests alone cost the issue-bound FH kernel 6 %, so product builds compile them out
 
+#ifndef MGM_P2_TIMELINE
+#define MGM_P2_TIMELINE 0  // 1: the queue kernels record, per work item, start / end / time waited for the predecessor band / where it
+#endif                     // ran (PassParams::tl; MGM_HIP_TIMELINE=<file>; tools/timeline.py).  Variant builds only: tools/sweep_build.sh tl -DMGM_P2_TIMELINE=1
 #ifndef MGM_P2_C8_NL
 #define MGM_P2_C8_NL 1
 #endif
@@ -399,7 +402,8 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
         const int r0 = wl == 0 ? 0 : NCA;
         unsigned known = 0;
         bool dead = false;
-        unsigned long long n_slow = 0, t_slow = 0, n_spin = 0, t_ret = 0, t_bar = 0, t_iss = 0;
+        unsigned long long n_slow = 0, t_slow = 0, n_spin = 0, t_ret = 0, t_bar = 0, t_iss = 0, tl_wait = 0;
+        (void)tl_wait;
         (void)n_slow;
         (void)n_spin;
 
@@ -532,6 +536,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                 if (wl != 0 || !from_global || h < 0 || h > Hmax || dead || (xflags & 4)) return;
                 unsigned spins = 0;
                 const unsigned long long t0 = dbg ? wall_clock64() : 0;
+                unsigned long long tl0 = 0;
                 for (;;) {
                     bool ok = true;
 #pragma unroll
@@ -545,6 +550,8 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                             }
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                     if (spins == 0) n_slow++;
+                    if constexpr (MGM_P2_TIMELINE != 0 && XCDQ)
+                        if (spins == 0 && P.tl) tl0 = wall_clock64();
                     n_spin++;
                     __builtin_amdgcn_s_sleep(4);
 #pragma unroll
@@ -567,6 +574,8 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                     }
                 }
                 if (dbg) t_slow += wall_clock64() - t0;
+                if constexpr (MGM_P2_TIMELINE != 0 && XCDQ)
+                    if (tl0) tl_wait += wall_clock64() - tl0;
             }
         };
 
@@ -627,6 +636,12 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                 t_bar += td - tc;
             }
         }
+        if constexpr (MGM_P2_TIMELINE != 0 && XCDQ)
+            if (P.tl && wl == 0 && lane == 0) {
+                P.tl[(long long)ticket * 8 + 2] = tl_wait;
+                P.tl[(long long)ticket * 8 + 3] = n_slow;
+                P.tl[(long long)ticket * 8 + 5] = (unsigned long long)nsteps;
+            }
         if (dbg && wl == 0 && lane == 0) {
             dbg[2] = wall_clock64();
             dbg[6] = t_slow;
@@ -1052,9 +1067,18 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             __syncthreads();
             const int t = *s_ticket;
             if (t >= qi.y) break;
+            if constexpr (MGM_P2_TIMELINE != 0)
+                if (P.tl && threadIdx.x == 0) {
+                    unsigned hwid;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                    P.tl[(long long)(qi.x + t) * 8 + 0] = wall_clock64();
+                    P.tl[(long long)(qi.x + t) * 8 + 4] = ((unsigned long long)xcc << 32) | hwid;
+                }
             pass2_item<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, true, W2>(P, qi.x + t);
             wait_vmcnt<0>();   // (the loader's DMAs beyond the last step)
             __syncthreads();   // LDS and s_ticket are free again
+            if constexpr (MGM_P2_TIMELINE != 0)
+                if (P.tl && threadIdx.x == 0) P.tl[(long long)(qi.x + t) * 8 + 1] = wall_clock64();
         }
         if (threadIdx.x == 0) {
             const unsigned left = atomicAdd(P.qticket + 8, 1u) + 1u;

@@ -16,6 +16,10 @@ namespace mgm {
 
 // whether the second build carries its in-kernel timers / experiment switches (MGM_HIP_DEBUG_STATS, MGM_HIP_XFLAGS)
 bool pass2_devtools() { return MGM_P2_DEV != 0; }
+#ifndef MGM_P2_TIMELINE
+#define MGM_P2_TIMELINE 0
+#endif
+bool pass2_timeline() { return MGM_P2_TIMELINE != 0; }
 
 // lines per band of the second build (0 = this L is not supported by it)
 int pass2_lines(int L, bool c8)

@@ -245,7 +245,10 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
         cb = use_c8 ? Cs[0]->cbytes : 1;
     }
     // Two bytes per cost: read by the unweighted kernels with deep rings that publish E, up to 512 labels (k_pass2, C8 == 2);
-    // everything else reads the fp32 volume (which K2 always writes next to a two-byte copy).
+    // everything else reads the fp32 volume.  Since round 4 K2 writes AD / SD volumes compact-ONLY (f32_state 0), so a
+    // weighted launch, FH with TSGM = 2 or a shallow-ring launch on such a volume pays an expansion (ensure_f32: k_expand
+    // plus a W*H*L fp32 allocation) the first time -- correct, but four times the cost bytes; bench.py's cost_bytes prices
+    // weighted launches on fp32 costs for that reason.
     if (use_c8 && cb == 2 && (weighted || (fh && MGM == 2) || pass_lpl(L) > 8 || dev().deep == 0)) {
         own_padded = false;
         if (padded)
@@ -573,8 +576,17 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     // P1 = 2, P2 = 20000, is such a case).
     if (fh && tags && use_c8 && P1 >= 0.0f && P2 >= 4.0f * (float)Lk * P1 + 4096.0f) p.P2 = __builtin_huge_valf();
     p.dbg = nullptr;
+    p.tl = nullptr;
     p.xflags = 0;
     p.xflags = dev().xflags;
+    // MGM_HIP_TIMELINE=<file> with a -DMGM_P2_TIMELINE=1 build of the pass kernels: one line per work item of every queue
+    // launch (tools/timeline.py reads them) -- where the compute units' time goes in a single launch
+    const char *tl_file = (xcdq && R2 && pass2_timeline()) ? getenv("MGM_HIP_TIMELINE") : nullptr;
+    if (tl_file && *tl_file) {
+        if ((r = reserve(c, c->dbg, sizeof(unsigned long long) * 8 * (size_t)c->ntasks))) return r;
+        HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, sizeof(unsigned long long) * 8 * (size_t)c->ntasks, c->stream));
+        p.tl = (unsigned long long *)c->dbg.p;
+    }
     if ((p.xflags || c->debug_stats) && R2 && !pass2_devtools())
         return fail(c, MGM_ERR_UNSUPPORTED, "MGM_HIP_XFLAGS / MGM_HIP_DEBUG_STATS need a development build of the pass kernels "
                                             "(MGM_P2_DEFINES=-DMGM_P2_DEV=1 python -m mgm_amd.build --force)");
@@ -611,6 +623,33 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     }
     HIPCHK(c, hipMemcpyAsync(c->h_words + 1, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     c->pending_check = true;
+    if (p.tl) {
+        std::vector<unsigned long long> d((size_t)c->ntasks * 8);
+        std::vector<int2> tk((size_t)c->ntasks + 8);
+        HIPCHK(c, hipMemcpyAsync(d.data(), p.tl, d.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(tk.data(), (const int2 *)c->tasks.p, tk.size() * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (FILE *f = fopen(tl_file, "a")) {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int i = 0; i < c->ntasks; i++) {
+                if (d[(size_t)i * 8]) t0 = std::min(t0, d[(size_t)i * 8]);
+                t1 = std::max(t1, d[(size_t)i * 8 + 1]);
+            }
+            const double tick = 1e-2;  // wall_clock64: 100 MHz -> 0.01 us
+            fprintf(f, "launch %d %d %d %d %d %.1f volumes %d fh %d mgm %d strips %d\n", nx, ny, L, c->ntasks, p.wg_per_cu, (double)(t1 - t0) * tick, nb,
+                    fh ? 1 : 0, MGM, any_strips ? 1 : 0);
+            for (int i = 0; i < c->ntasks; i++) {
+                int queue = 0;
+                for (int q = 0; q < 8; q++)
+                    if (i >= tk[q].x && i < tk[q].x + tk[q].y) queue = q;
+                const int2 t = tk[(size_t)i + 8];
+                const unsigned long long *w = &d[(size_t)i * 8];
+                fprintf(f, "item %d %d %d %d %d %.2f %.2f %.2f %llu %llu %llu %llu\n", i, t.x, t.y & 0xffff, (t.y >> 16) & 0xff, queue,
+                        (double)(w[0] - t0) * tick, (double)(w[1] - t0) * tick, (double)w[2] * tick, w[3], w[4] & 0xffffffffull, w[4] >> 32, w[5]);
+            }
+            fclose(f);
+        }
+    }
     if (p.dbg) {  // development aid: where does K3's time go?
         std::vector<unsigned long long> d((size_t)c->ntasks * 16);
         std::vector<int2> tk(c->ntasks);

@@ -6,9 +6,9 @@ cd "$(dirname "$0")/.."
 mkdir -p mgm_amd/lib/variants
 while [ $# -gt 0 ]; do
   name="$1"; defs="$2"; shift 2
-  MGM_P2_DEFINES="$defs" python mgm_amd/build.py --force >/dev/null
+  MGM_P2_DEFINES="$defs" python mgm_amd/build.py >/dev/null
   mkdir -p mgm_amd/lib/variants/$name
   cp mgm_amd/lib/libmgm_hip.so mgm_amd/lib/variants/$name/
   echo "built $name: $defs"
 done
-python mgm_amd/build.py --force >/dev/null
+python mgm_amd/build.py >/dev/null   # (objects whose command line changed are rebuilt: the pass kernels)
