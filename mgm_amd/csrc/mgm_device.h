@@ -75,7 +75,8 @@ struct PassParams {
     int xflags;               // development experiments (MGM_HIP_XFLAGS): 1 skip Lr stores, 2 skip C DMA, 4 ignore
                               // inter-band waits, 8 skip step barriers, 16 Lr stores into a cache-resident window (-DMGM_P2_XFLAG16 builds only); all of them need a -DMGM_P2_DEV=1 build
     unsigned long long *dbg;  // nullptr, or 8 words per ticket of timing diagnostics (MGM_HIP_DEBUG_STATS)
-    unsigned long long *tl;   // nullptr, or 8 words per ticket of the queue kernels' timeline (-DMGM_P2_TIMELINE=1 builds; MGM_HIP_TIMELINE)
+    unsigned long long tl_addr;  // device address of 8 words per ticket: the queue kernels' timeline (-DMGM_P2_TIMELINE=1 builds; MGM_HIP_TIMELINE)
+    int tl_on;                   // ... 1: record it
     long long npix, nvol;
     int L, MGM, NDIR, dmin;
     int fh2_ragged;     // 1: FH, TSGM = 2, no weights, ragged volume: update_cost2_trunclinear with its boundary fix-up

@@ -56,6 +56,15 @@ __device__ __forceinline__ void wait_vmcnt()
     static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// (timeline words go out through a GLOBAL-address-space pointer made from the integer value, and the switch is an int: a
+// null test of the generic pointer inside the queue kernels trips this compiler -- "Illegal instruction detected: Operand
+// has incorrect register class", V_CMP_NE_U32 on src_shared_base -- as the development timers did, mgm_pass2.hip:launch2_one)
+__device__ __forceinline__ void tl_store(const PassParams &P, long long idx, unsigned long long v)
+{
+    typedef __attribute__((address_space(1))) unsigned long long *gptr;
+    gptr g = (gptr)(unsigned long long)P.tl_addr;
+    g[idx] = v;
+}
 __device__ __forceinline__ void step_barrier(bool skip = false)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -550,8 +559,8 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                             }
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                     if (spins == 0) n_slow++;
-                    if constexpr (MGM_P2_TIMELINE != 0 && XCDQ)
-                        if (spins == 0 && P.tl) tl0 = wall_clock64();
+                    if constexpr (MGM_P2_TIMELINE == 2 && XCDQ)
+                        if (spins == 0 && P.tl_on) tl0 = wall_clock64();
                     n_spin++;
                     __builtin_amdgcn_s_sleep(4);
 #pragma unroll
@@ -574,7 +583,7 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
                     }
                 }
                 if (dbg) t_slow += wall_clock64() - t0;
-                if constexpr (MGM_P2_TIMELINE != 0 && XCDQ)
+                if constexpr (MGM_P2_TIMELINE == 2 && XCDQ)
                     if (tl0) tl_wait += wall_clock64() - tl0;
             }
         };
@@ -637,10 +646,11 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
             }
         }
         if constexpr (MGM_P2_TIMELINE != 0 && XCDQ)
-            if (P.tl && wl == 0 && lane == 0) {
-                P.tl[(long long)ticket * 8 + 2] = tl_wait;
-                P.tl[(long long)ticket * 8 + 3] = n_slow;
-                P.tl[(long long)ticket * 8 + 5] = (unsigned long long)nsteps;
+            if (P.tl_on && wl == 0 && lane == 0) {
+                tl_store(P, (long long)ticket * 8 + 2, MGM_P2_TIMELINE == 2 ? tl_wait : 0ull);  // (2: clock reads in the poll loop -- this compiler rejects them)
+                tl_store(P, (long long)ticket * 8 + 6, n_spin);
+                tl_store(P, (long long)ticket * 8 + 3, n_slow);
+                tl_store(P, (long long)ticket * 8 + 5, (unsigned long long)nsteps);
             }
         if (dbg && wl == 0 && lane == 0) {
             dbg[2] = wall_clock64();
@@ -1068,17 +1078,17 @@ __global__ void __launch_bounds__((Plan<LPL, 1, true, C8>::NC + Plan<LPL, 1, tru
             const int t = *s_ticket;
             if (t >= qi.y) break;
             if constexpr (MGM_P2_TIMELINE != 0)
-                if (P.tl && threadIdx.x == 0) {
+                if (P.tl_on && threadIdx.x == 0) {
                     unsigned hwid;
                     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-                    P.tl[(long long)(qi.x + t) * 8 + 0] = wall_clock64();
-                    P.tl[(long long)(qi.x + t) * 8 + 4] = ((unsigned long long)xcc << 32) | hwid;
+                    tl_store(P, (long long)(qi.x + t) * 8 + 0, wall_clock64());
+                    tl_store(P, (long long)(qi.x + t) * 8 + 4, ((unsigned long long)xcc << 32) | hwid);
                 }
             pass2_item<LPL, FH, WEIGHTED, MGM, C8, SUBV, DEEP, true, W2>(P, qi.x + t);
             wait_vmcnt<0>();   // (the loader's DMAs beyond the last step)
             __syncthreads();   // LDS and s_ticket are free again
             if constexpr (MGM_P2_TIMELINE != 0)
-                if (P.tl && threadIdx.x == 0) P.tl[(long long)(qi.x + t) * 8 + 1] = wall_clock64();
+                if (P.tl_on && threadIdx.x == 0) tl_store(P, (long long)(qi.x + t) * 8 + 1, wall_clock64());
         }
         if (threadIdx.x == 0) {
             const unsigned left = atomicAdd(P.qticket + 8, 1u) + 1u;

@@ -576,7 +576,8 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     // P1 = 2, P2 = 20000, is such a case).
     if (fh && tags && use_c8 && P1 >= 0.0f && P2 >= 4.0f * (float)Lk * P1 + 4096.0f) p.P2 = __builtin_huge_valf();
     p.dbg = nullptr;
-    p.tl = nullptr;
+    p.tl_addr = 0;
+    p.tl_on = 0;
     p.xflags = 0;
     p.xflags = dev().xflags;
     // MGM_HIP_TIMELINE=<file> with a -DMGM_P2_TIMELINE=1 build of the pass kernels: one line per work item of every queue
@@ -585,7 +586,8 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     if (tl_file && *tl_file) {
         if ((r = reserve(c, c->dbg, sizeof(unsigned long long) * 8 * (size_t)c->ntasks))) return r;
         HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, sizeof(unsigned long long) * 8 * (size_t)c->ntasks, c->stream));
-        p.tl = (unsigned long long *)c->dbg.p;
+        p.tl_addr = (unsigned long long)(uintptr_t)c->dbg.p;
+        p.tl_on = 1;
     }
     if ((p.xflags || c->debug_stats) && R2 && !pass2_devtools())
         return fail(c, MGM_ERR_UNSUPPORTED, "MGM_HIP_XFLAGS / MGM_HIP_DEBUG_STATS need a development build of the pass kernels "
@@ -623,10 +625,10 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     }
     HIPCHK(c, hipMemcpyAsync(c->h_words + 1, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     c->pending_check = true;
-    if (p.tl) {
+    if (p.tl_on) {
         std::vector<unsigned long long> d((size_t)c->ntasks * 8);
         std::vector<int2> tk((size_t)c->ntasks + 8);
-        HIPCHK(c, hipMemcpyAsync(d.data(), p.tl, d.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d.data(), c->dbg.p, d.size() * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(tk.data(), (const int2 *)c->tasks.p, tk.size() * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (FILE *f = fopen(tl_file, "a")) {
@@ -644,8 +646,8 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
                     if (i >= tk[q].x && i < tk[q].x + tk[q].y) queue = q;
                 const int2 t = tk[(size_t)i + 8];
                 const unsigned long long *w = &d[(size_t)i * 8];
-                fprintf(f, "item %d %d %d %d %d %.2f %.2f %.2f %llu %llu %llu %llu\n", i, t.x, t.y & 0xffff, (t.y >> 16) & 0xff, queue,
-                        (double)(w[0] - t0) * tick, (double)(w[1] - t0) * tick, (double)w[2] * tick, w[3], w[4] & 0xffffffffull, w[4] >> 32, w[5]);
+                fprintf(f, "item %d %d %d %d %d %.2f %.2f %.2f %llu %llu %llu %llu %llu\n", i, t.x, t.y & 0xffff, (t.y >> 16) & 0xff, queue,
+                        (double)(w[0] - t0) * tick, (double)(w[1] - t0) * tick, (double)w[2] * tick, w[3], w[4] & 0xffffffffull, w[4] >> 32, w[5], w[6]);
             }
             fclose(f);
         }

@@ -56,7 +56,7 @@ def test_single_rank_shortcuts():
 
 
 # ---- direction sharding: the ordered exchange of Lr slabs (mgm_amd/dist.py) over gloo ----------
-def _dir_worker(rank, world, port, q, NDIR):
+def _dir_worker(rank, world, port, q, NDIR, ny=13):
     import numpy as np
     from mgm_amd import dist as mdist
     from mgm_amd import synth
@@ -64,7 +64,7 @@ def _dir_worker(rank, world, port, q, NDIR):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     orc = Oracle(threads=1)
-    nx, ny, L = 21, 13, 10                              # 13 rows over 2 ranks: uneven slabs
+    nx, L = 21, 10                                      # 13 rows over 2 ranks: uneven slabs
     C = synth.raw_volume(nx, ny, L, seed=9, inf_frac=0.05)
     S, out, outc, lr = orc.mgm(C, -2, 8.0, 32.0, NDIR, 3, 0, 1, None, dump_lr=True)
     first, count = mdist.passes_of_rank(NDIR, world, rank)
@@ -91,8 +91,55 @@ def test_direction_sharding_exchange_is_bit_exact():
         assert sorted(r[2] for r in res) == [6, 7] and all(r[1] == 0 for r in res), res
 
 
+def _spawn_dir(world, NDIR, ny):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_dir_worker, args=(r, world, port, q, NDIR, ny)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=300) for _ in ps]
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    return res
+
+
+def test_direction_sharding_exchange_world4_and_world8():
+    """the ordered exchange had only ever run with TWO ranks.  Here the same code (mgm_amd/dist.py: grouped
+    point-to-point sends, the schedule the RCCL leg posts) with 4 and 8 gloo ranks: 8 / 4 / 2 passes (fewer passes than
+    ranks: ranks without a pass still receive), odd row counts, and fewer rows than ranks (ranks without rows still
+    send).  Every rank's rows of the ordered sum S must equal the oracle's mgm() bit for bit (mgm_core.cc:582-587 is a sum
+    in PASS order -- not thread-finish order, 798-805, and not an all-reduce)."""
+    from mgm_amd import dist as mdist
+    for world, NDIR, ny in ((4, 8, 13), (4, 2, 9), (8, 8, 13), (8, 4, 5)):
+        res = _spawn_dir(world, NDIR, ny)
+        rows = sorted((r[0], r[2]) for r in res)
+        assert [n for _, n in rows] == [n for _, n in mdist.row_slabs(ny, world)], (world, NDIR, ny, rows)
+        assert sum(n for _, n in rows) == ny and all(r[1] == 0 for r in res), (world, NDIR, ny, res)
+
+
 def test_partitions():
     from mgm_amd import dist as mdist
+    # (VERDICT r4) NDIR in {2, 4, 8} x n in {2, 4, 8} x odd row counts, rows fewer than ranks included: blocks of passes and
+    # slabs of rows are contiguous, cover everything exactly once, differ in size by at most one -- and the C library's own
+    # plan (mgm_multi_plan, what mgm_multi_aggregate and the CLI's MGM_DEVICES use) is the same partition
+    import ctypes as C
+    import mgm_amd
+    L = mgm_amd.load_library()
+    for NDIR in (2, 4, 8):
+        for world in (2, 4, 8):
+            for ny in (1, 3, 7, 13, 1079, 1081, 4095):
+                s = mdist.row_slabs(ny, world)
+                assert len(s) == world and s[0][0] == 0 and sum(n for _, n in s) == ny
+                assert all(s[i][0] + s[i][1] == s[i + 1][0] for i in range(world - 1))
+                assert max(n for _, n in s) - min(n for _, n in s) <= 1
+                blocks = [mdist.passes_of_rank(NDIR, world, r) for r in range(world)]
+                assert [p for f, n in blocks for p in range(f, f + n)] == list(range(NDIR))
+                assert max(n for _, n in blocks) - min(n for _, n in blocks) <= 1
+                assert mdist.n_rounds(NDIR, world) == max(n for _, n in blocks)
+                arr = [(C.c_int * world)() for _ in range(4)]
+                assert L.mgm_multi_plan(world, NDIR, ny, *arr) == 0
+                assert [(arr[0][r], arr[1][r]) for r in range(world)] == blocks
+                assert [(arr[2][r], arr[3][r]) for r in range(world)] == s
     for ny, world in ((1080, 8), (13, 2), (5, 8)):
         s = mdist.row_slabs(ny, world)
         assert sum(n for _, n in s) == ny and all(s[i][0] + s[i][1] == s[i + 1][0] for i in range(world - 1))
@@ -246,3 +293,32 @@ def test_pairs2_mode_and_the_sharding_model():
     assert abs(m["total_ms"] - (1.25 + 7.8 + m["exchange_ms"] + 17.3 / 8)) < 1e-9
     m2 = mdist.sharding_model(2, 8, 12.885, {4: 14.0}, 17.3, 1.25, 153.0)
     assert m2["passes_per_rank"] == 4 and abs(m2["exchange_ms"] - 168.4) < 0.5
+
+
+def test_driver_command_line_on_four_ranks():
+    """The driver's SCALE command at N = 4 (stub ranks over gloo): one valid line, the direction-sharded leg ran on all four
+    ranks (two rounds of the exchange), the pair split ran, and the line says what scales."""
+    r, d, lines = _run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--repeats", "0"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and d["n_gpus"] == 4 and d["scaling"] == "weak"
+    dr = d["directions"]
+    assert dr["ranks"] == 4 and dr["transport"] == "rccl" and dr["rccl"]["exchange_rounds"] == 2 and dr["rccl"]["differs_from_single"] == 0
+    assert dr["differs_from_single"] == {"rccl": 0} and dr["fallback_chain"] == ["rccl: ok"]
+    assert len(dr["rccl_link_probe"]["gbps"]) == 4 and dr["model"]["prediction"]["world"] == 4
+    assert d["cfg4_pairs2"]["ranks"] == 4 and "replicas" in d["multi_gpu_note"]
+
+
+def test_transport_fallbacks_keep_the_line_valid():
+    """rccl fails -> the peer path's figure is the leg's; rccl AND peer fail -> "replicas": no figure, the chain says why, the
+    headline and every other key of the line are still there (the first node run must not lose its line to a
+    transport error)."""
+    r, d, lines = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "0"], {"MGM_STUB_FAIL_AT": "rccl"})
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
+    dr = d["directions"]
+    assert dr["transport"] == "peer" and dr["ranks"] == 2 and dr["value"] == dr["peer"]["value"] and "error" in dr["rccl"]
+    assert dr["fallback_chain"][0].startswith("rccl: failed") and dr["fallback_chain"][1] == "peer: ok" and "error" in dr["rccl_link_probe"]
+    r, d, lines = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "0"], {"MGM_STUB_FAIL_AT": "rccl,peer"})
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
+    dr = d["directions"]
+    assert dr["transport"] == "replicas" and dr["value"] is None and dr["ranks"] == 2 and d["value"] > 0
+    assert dr["fallback_chain"][-1].startswith("replicas:") and dr["differs_from_single"] == {}

@@ -5,7 +5,9 @@ single launch": how busy the compute units are, how long bands wait for their pr
     python tools/timeline.py dump.txt [--csv out.csv]
 
 The dump (mgm_plan.hip) holds one line per work item:
-    item <ticket> <pass> <band> <strip> <queue> <start_us> <end_us> <wait_us> <waits> <hw_id> <xcc_id> <steps>
+    item <ticket> <pass> <band> <strip> <queue> <start_us> <end_us> <wait_us> <waits> <hw_id> <xcc_id> <steps> <spins>
+(<wait_us> is 0 in -DMGM_P2_TIMELINE=1 builds -- this compiler rejects clock reads inside the poll loop of the queue kernels --
+and the time waited is then estimated as spins x the poll period, fitted: duration = a*steps + b*spins over all items)
 and a header line `launch <nx> <ny> <L> <nitems> <wg_per_cu> <kernel_us>`.
 """
 import sys
@@ -38,6 +40,13 @@ def analyse(l, out=sys.stdout):
     pas, band, strip, queue = it[:, 1].astype(int), it[:, 2].astype(int), it[:, 3].astype(int), it[:, 4].astype(int)
     t0, t1, wait, nwait = it[:, 5], it[:, 6], it[:, 7], it[:, 8]
     hw, xcc, steps = it[:, 9].astype(np.int64), it[:, 10].astype(int), it[:, 11]
+    spins = it[:, 12] if it.shape[1] > 12 else np.zeros(len(it))
+    if wait.sum() == 0 and spins.sum() > 0:
+        A = np.stack([steps, spins], 1)
+        coef, *_ = np.linalg.lstsq(A, t1 - t0, rcond=None)
+        print("  fitted: item duration = %.4f us x steps + %.4f us x polls (residual rms %.1f us)" %
+              (coef[0], coef[1], float(np.sqrt(np.mean((A @ coef - (t1 - t0)) ** 2)))), file=out)
+        wait = np.minimum(spins * max(coef[1], 0.0), t1 - t0)
     span = t1.max() - t0.min()
     t1 = t1 - t0.min()
     t0 = t0 - t0.min()
