@@ -107,7 +107,9 @@ struct mgm_ctx {
     struct TaskTab {
         int nx, ny, key, R, ntasks;
         Buf buf;
+        bool one_queue;  // dealt to ONE queue for all XCDs (the plan's simulation preferred it: mgm_plan.hip)
     };
+    bool tk_one_queue = false;  // ... of the table in use
     std::vector<TaskTab> ttabs;
     int force_build = 0;  // 0 auto, 1 first build only (MGM_HIP_PASS_BUILD=1)
     int ntasks = 0;

@@ -2,6 +2,8 @@
 // strips, occupancy), its workspace and hand-off regions, the task table; and the winner search behind it.  See mgm_host.h.
 #include "mgm_host.h"
 
+#include <functional>
+
 // ---- aggregation ----------------------------------------------------------------
 // K3 for the passes [first, first+count) of the reference's table; pass p's Lr volume goes to
 // workspace slot p - first.  Shared by mgm_aggregate_dev and the direction-sharded multi-GPU path.
@@ -84,6 +86,92 @@ static int run_passes_exact(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *
         c->last_gens[v] = v < nb ? Cs[v]->gen : 0;
     }
     return MGM_OK;
+}
+
+// The launch as a list-scheduling problem, simulated on the host (run_passes, order 2).  A chain = the bands of one pass (or
+// one strip of it) of one volume, band b READY once band b-1 (of both strips) started `skew` steps earlier; `nqueues` queues of
+// `slots` band slots each, band b of chain k belonging to queue (b / QK + k.chain) % nqueues; a free slot starts, among the
+// heads of the chains whose next band belongs to its queue, the ready one with the longest remaining chain (none ready: the
+// one that will be first).  Returns the makespan in steps; `order` = the items by their start in that schedule -- per queue,
+// the order in which the queue hands them out.
+struct SimChain {
+    int x, st, nb, sib, chain;
+    double skew, len;
+};
+static double simulate_schedule(const std::vector<SimChain> &chains, int nqueues, int slots, int QK, std::vector<int2> &order)
+{
+    const int n = (int)chains.size();
+    std::vector<std::vector<double>> start(n), end(n);
+    std::vector<int> next(n, 0);
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+        start[i].assign(chains[i].nb, 0.0);
+        end[i].assign(chains[i].nb, 0.0);
+        total += (size_t)chains[i].nb;
+    }
+    auto queue_of = [&](int i, int b) { return nqueues <= 1 ? 0 : (b / QK + chains[i].chain) % nqueues; };
+    typedef std::pair<double, int> Slot;  // (free at, queue)
+    std::vector<Slot> heap;
+    for (int q = 0; q < std::max(1, nqueues); q++)
+        for (int k = 0; k < slots; k++) heap.push_back(Slot(0.0, q));
+    std::make_heap(heap.begin(), heap.end(), std::greater<Slot>());
+    order.clear();
+    const double INF = 1e300;
+    double makespan = 0.0;
+    size_t guard = 0;
+    while (order.size() < total && !heap.empty() && guard++ < 64 * total + 4096) {
+        std::pop_heap(heap.begin(), heap.end(), std::greater<Slot>());
+        const Slot sl = heap.back();
+        heap.pop_back();
+        const double t = sl.first;
+        int best = -1;
+        double best_rem = -1, best_ready = INF;
+        bool best_is_ready = false, later = false;
+        for (int i = 0; i < n; i++) {
+            const SimChain &k = chains[i];
+            if (next[i] >= k.nb) continue;
+            const int b = next[i];
+            if (queue_of(i, b) != sl.second) {
+                for (int bb = b + 1; bb < k.nb && !later; bb += std::max(1, QK)) later = queue_of(i, bb) == sl.second;
+                continue;
+            }
+            double ready = 0.0;
+            if (b > 0) {
+                ready = start[i][b - 1] + k.skew;
+                if (k.sib >= 0) ready = next[k.sib] > b - 1 ? std::max(ready, start[k.sib][b - 1] + k.skew) : INF;
+            }
+            const double rem = (double)(k.nb - 1 - b) * k.skew + k.len;
+            const bool is_ready = ready <= t;
+            const bool better = best < 0 || (is_ready != best_is_ready ? is_ready : (is_ready ? rem > best_rem : (ready != best_ready ? ready < best_ready : rem > best_rem)));
+            if (better) best = i, best_rem = rem, best_ready = ready, best_is_ready = is_ready;
+        }
+        if (best < 0 || best_ready >= INF) {
+            // nothing of this queue can start yet (its next bands follow bands of other queues, or the other strip): look again
+            // when the next slot frees; a queue with nothing left retires its slots
+            if (best < 0 && !later) continue;
+            const double again = heap.empty() ? t + 1.0 : std::max(t, heap.front().first) + 1.0;
+            heap.push_back(Slot(again, sl.second));
+            std::push_heap(heap.begin(), heap.end(), std::greater<Slot>());
+            continue;
+        }
+        const SimChain &k = chains[best];
+        const int b = next[best]++;
+        const double st_eff = std::max(t, best_ready);
+        double en = st_eff + k.len;
+        if (b > 0) en = std::max(en, end[best][b - 1] + k.skew);  // (it cannot overtake its predecessor)
+        start[best][b] = st_eff;
+        end[best][b] = en;
+        makespan = std::max(makespan, en);
+        heap.push_back(Slot(en, sl.second));
+        std::push_heap(heap.begin(), heap.end(), std::greater<Slot>());
+        order.push_back(make_int2(k.x, b + (k.st << 16)));
+    }
+    if (order.size() < total) {  // (cannot happen; never lose an item to the model)
+        for (int i = 0; i < n; i++)
+            for (int b = next[i]; b < chains[i].nb; b++) order.push_back(make_int2(chains[i].x, b + (chains[i].st << 16)));
+        makespan = INF;
+    }
+    return makespan;
 }
 
 // slot0 / nslots: pass p's Lr volume goes to workspace slot slot0 + (p - first) of nslots (a caller that launches the
@@ -446,6 +534,7 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     // x 4 17.7 / 18.4 / 17.9 (19.1); Hirschmueller x 3 13.0 / 13.35 / 13.4 (13.5); 128 labels x 1 (four passes) 2.85 / 2.08 /
     // 2.07 (2.35); 4096x4096x192 x 1 27.2 / 27.5 / 26.4 (27.65) -- lines that long keep far more bands in flight than an
     // XCD has CUs, and a pinned pass that takes longer than the others leaves the other XCDs idle at the end.
+    bool one_queue = xcdq && (dev().xcdq == 2 || tune_num("one_queue", -1) > 0);  // (order 2: decided by the simulated schedules, below)
     int QK = ((ngroups * count) % nq == 0 && maxLL <= 3000) ? 0 : 2;
     if (dev().xcdq_k >= 0) QK = dev().xcdq_k;
     if (QK <= 0) QK = 1 << 20;
@@ -453,12 +542,14 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
         fprintf(stderr, "[mgm plan] %dx%dx%d passes %d..%d x %d volumes: load/chain %.2f, %d wg/cu, deep %d, subv %d, strips %d, xcd queues %d (block %d; xcc ids seen 0x%x)\n", nx, ny, L,
                 first, PEND - 1, nb, load_ratio, p.wg_per_cu, p.deep, subv, any_strips ? 1 : 0, xcdq ? 1 : 0, QK >= (1 << 20) ? 0 : QK, (unsigned)c->xcc_mask);
     // task table: ticket -> (pass, band [, strip]); item (p, b, .) always follows the items (p, b-1, .)
-    const int tk_key = ((((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv) * 2 + (any_strips ? 1 : 0)) * 2 + (xcdq ? 1 : 0);
+    const int tk_key = (((((PEND * 16 + first) * kMaxBatch + nb - 1) * 8 + subv) * 2 + (any_strips ? 1 : 0)) * 2 + (xcdq ? 1 : 0)) * 4 +
+                       (p.wg_per_cu >= 2 ? 2 : 0);  // (the simulated schedule depends on the band slots)
     if (c->tk_nx != nx || c->tk_ny != ny || c->tk_ndir != tk_key || c->tk_r != R)
         for (auto &t : c->ttabs)
             if (t.nx == nx && t.ny == ny && t.key == tk_key && t.R == R) {  // a shape seen before: its table is still on the device
                 c->tasks = t.buf;
                 c->ntasks = t.ntasks;
+                c->tk_one_queue = t.one_queue;
                 c->tk_nx = nx, c->tk_ny = ny, c->tk_ndir = tk_key, c->tk_r = R;
                 break;
             }
@@ -471,10 +562,71 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
             for (int q = first; q < PEND; q++)
                 for (int b = 0; b < p.g[q].nbands; b++)
                     for (int st = 0; st < p.g[q].nstrips; st++) tasks.push_back(make_int2(v * kMaxDirs + q, b + (st << 16)));
-        std::stable_sort(tasks.begin(), tasks.end(), [&](const int2 &a, const int2 &b) {
-            const long long ka = (long long)(a.y & 0xffff) * p.g[b.x % kMaxDirs].nbands, kb = (long long)(b.y & 0xffff) * p.g[a.x % kMaxDirs].nbands;
-            return ka != kb ? ka < kb : a.x < b.x;
-        });
+        // Round 5 (tools/timeline.py on the queue kernels: 14-24 % of a single launch's CU-time was TAIL -- compute units
+        // with nothing left while the 2 ms items of the row passes, dealt last like everybody's last bands, ran out): the
+        // items are dealt by their LATEST START TIME instead, i.e. longest remaining chain first -- item (p, b) is followed,
+        // band after band, by (nbands - 1 - b) hand-offs of slope * R + lag steps and its own walk; what has the longest
+        // way to go to the end of its pass starts first, and the launch ends on the SHORT items (the strips of the
+        // column passes).  Within a pass the order is still by band (the remaining chain shrinks with b).
+        const int order = (int)tune_num("order", 2);  // (0: the relative-progress order of rounds 1-4, 1: longest remaining chain first -- for A/B runs)
+        if (order == 0) {
+            std::stable_sort(tasks.begin(), tasks.end(), [&](const int2 &a, const int2 &b) {
+                const long long ka = (long long)(a.y & 0xffff) * p.g[b.x % kMaxDirs].nbands, kb = (long long)(b.y & 0xffff) * p.g[a.x % kMaxDirs].nbands;
+                return ka != kb ? ka < kb : a.x < b.x;
+            });
+        } else if (order >= 2) {
+            // LIST SCHEDULING, simulated (simulate_schedule, above): the tickets come out in the order in which a machine of
+            // band slots that always starts, among the items whose predecessor band is far enough ahead (READY), the one with
+            // the longest remaining chain would start them.  The launch then follows that schedule by itself -- every free
+            // workgroup takes the next ticket of its queue -- as far as its step times match the model's (one step = one time
+            // unit for every pass), and an item taken early merely waits, as it always could.  What the plain
+            // longest-remaining-chain order gets wrong is the START of the launch: it hands the first 256 tickets to some sixty
+            // consecutive bands of the two longest chains, of which band k cannot move before k * (slope * R) steps have
+            // passed (timeline, round 5: 43 % of the CUs waiting through the first millisecond).
+            // The same simulation DECIDES between the per-XCD queues and one queue for all XCDs (write-through hand-offs
+            // everywhere): a pass pinned to an XCD runs in whole rounds of that XCD's 32 CUs -- 72 row bands of 2.3 ms are three
+            // rounds, the last one a quarter full (1920x1080x256 FH x 1, K3: pinned 6.08 ms, one queue 5.76; two volumes, two
+            // passes per XCD: 10.25 against 11.04) -- so the plan takes the single queue where its simulated makespan is
+            // shorter by more than what the crossing hand-offs cost (4 %).
+            const double lagS = tags ? 5.0 : 12.0;
+            std::vector<SimChain> ch;
+            for (int v = 0; v < ngroups; v++)
+                for (int q = first; q < PEND; q++)
+                    for (int st = 0; st < p.g[q].nstrips; st++) {
+                        const PassGeom &g = p.g[q];
+                        SimChain k;
+                        k.x = v * kMaxDirs + q, k.st = st, k.nb = g.nbands, k.chain = v * count + (q - first);
+                        k.sib = g.nstrips == 2 ? (int)ch.size() + (st == 0 ? 1 : -1) : -1;
+                        k.skew = (double)g.slope * R + lagS;
+                        k.len = (g.nstrips == 2 ? (st == 0 ? g.split : g.LL - g.split) + R - 1 : g.LL) + (double)g.slope * (R - 1) + 3.0;
+                        ch.push_back(k);
+                    }
+            const int slots = std::max(1, c->num_cu * std::max(1, p.wg_per_cu));
+            std::vector<int2> ord_one, ord_q;
+            const double t_one = simulate_schedule(ch, 1, slots, 1 << 20, ord_one);
+            double t_q = t_one;
+            if (xcdq) t_q = simulate_schedule(ch, nq, std::max(1, slots / nq), QK, ord_q);
+            const long long forced = tune_num("one_queue", -1);
+            // (launches that run two bands per CU keep their queues: with the doubled step the pinned dealing measured 5 % FASTER
+            // for two and four 256-label FH volumes although the model says otherwise -- 9.67 against 10.18 ms, 17.7 against 18.3)
+            one_queue = xcdq && (dev().xcdq == 2 || forced > 0 || (forced < 0 && p.wg_per_cu < 2 && t_one * 1.04 < t_q));
+            tasks = (xcdq && !one_queue) ? ord_q : ord_one;
+            if (tune_num("show_plan", 0))
+                fprintf(stderr, "[mgm plan] simulated makespan (steps): one queue %.0f, %d queues (block %d) %.0f -> %s\n", t_one, nq, QK >= (1 << 20) ? 0 : QK, t_q,
+                        one_queue ? "one queue" : (xcdq ? "per-XCD queues" : "ticket counter"));
+        } else {
+            const double lag = tags ? 3.0 : 10.0;
+            auto remaining = [&](const int2 &t) {
+                const PassGeom &g = p.g[t.x % kMaxDirs];
+                const int b = t.y & 0xffff, st = (t.y >> 16) & 0xff;
+                const double walk = (g.nstrips == 2 ? (st == 0 ? g.split : g.LL - g.split) + R - 1 : g.LL) + (double)g.slope * R;
+                return (double)(g.nbands - 1 - b) * (g.slope * R + lag) + walk;
+            };
+            std::stable_sort(tasks.begin(), tasks.end(), [&](const int2 &a, const int2 &b) {
+                const double ra = remaining(a), rb = remaining(b);
+                return ra != rb ? ra > rb : a.x < b.x;
+            });
+        }
         if (c->ttabs.size() >= 24) {  // (bounded: drop the oldest; the stream is synchronised below before anything is reused)
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (c->ttabs.front().buf.p == c->tasks.p) {  // (the table the cached key still names)
@@ -495,7 +647,7 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
                 const int v = t.x / kMaxDirs, q = t.x % kMaxDirs, b = t.y & 0xffff;
                 const int chain = v * count + (q - first);
                 const bool same = b + 1 < p.g[q].nbands && (b + 1) / QK == b / QK;
-                if (dev().xcdq == 2) qs[0].push_back(t);  // (A/B setting: one queue, write-through hand-offs)
+                if (one_queue) qs[0].push_back(t);  // (one queue for all XCDs, write-through hand-offs)
                 else qs[(b / QK + chain) % nq].push_back(make_int2(t.x, t.y | (same ? 1 << 24 : 0)));
             }
             int at = 0;
@@ -516,15 +668,17 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
             (void)hipFree(fresh.p);
             return hipfail(c, ce, "task table upload");
         }
-        c->ttabs.push_back(mgm_ctx::TaskTab{nx, ny, tk_key, R, (int)tasks.size(), fresh});
+        c->ttabs.push_back(mgm_ctx::TaskTab{nx, ny, tk_key, R, (int)tasks.size(), fresh, one_queue});
         c->tasks = fresh;
         c->ntasks = (int)tasks.size();
+        c->tk_one_queue = one_queue;
         c->tk_nx = nx;
         c->tk_ny = ny;
         c->tk_ndir = tk_key;
         c->tk_r = R;
     }
 
+    one_queue = xcdq && c->tk_one_queue;  // (what the table in use was dealt for)
     for (int v = 0; v < nb; v++) {
         if (!use_c8 && (r = ensure_f32(c, Cs[v]))) return r;
         p.vol[v].C = padded ? (const float *)c->padf[v].p : Cs[v]->d;
@@ -549,7 +703,7 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     p.err = words + 1;
     p.prog = words + 4;
     p.tasks = (const int2 *)c->tasks.p + 8;  // (behind the header)
-    p.xcdq = xcdq ? (dev().xcdq == 2 ? 2 : 1) : 0;
+    p.xcdq = xcdq ? (one_queue ? 2 : 1) : 0;
     p.oneb = (xcdq && p.wg_per_cu < 2 && dev().oneb) ? 1 : 0;
     p.cbytes = use_c8 ? cb : 1;
     p.qticket = words + 4;  // (the progress words of the other protocol: the kernels with tags do not use them)
