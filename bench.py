@@ -90,6 +90,31 @@ WORKLOADS = {
                      desc="1920x1080 synthetic pair, 200 disparities (a count off the kernels' widths: runs in 256 label slots), CENSUS 5x5, -O 8 TSGM=3, FH"),
     "cfg3L768": dict(nx=1920, ny=1080, dmin=-767, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0,
                      desc="1920x1080 synthetic pair, 768 disparities (beyond the second build's 512), CENSUS 5x5, -O 8 TSGM=3"),
+    # ---- round 5: what had no number at all -- ragged ranges and TSGM_ITER, and the FALL-BACK
+    # kernels: weights that are not two-valued, more than 1024 labels, negative penalties, NaN costs, ragged + P2 = inf.
+    # Optional keys: ragged (half width of the per-pixel window around the synthetic pair's true disparity: -m/-M images),
+    # iter (TSGM_ITER), w8 ("three": three-valued planes, what a free-form w[8][H][W] of matlab/mgm_o.cc looks like to the
+    # library), nan (one NaN cost in an uploaded volume: the operand-order-faithful kernel).
+    "cfg3r": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, ragged=24,
+                  desc="cfg3 with range images: per-pixel windows of +-24 labels inside the 256-label hull (-m/-M; 49 of 256 labels exist per pixel)"),
+    "cfg3hr": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0, ragged=24,
+                   desc="cfg3h with range images: per-pixel windows of +-24 labels inside the 256-label hull"),
+    "cfg3i2": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, iter=2,
+                   desc="cfg3 with TSGM_ITER=2: a second winner search in ranges narrowed around the first solution (mgm.cc:377-388)"),
+    "cfg3w3": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, w8="three",
+                   desc="cfg3 with free-form per-edge weights (three values: 1, 2.5, 4): the general weighted kernels, FH"),
+    "cfg3hw3": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0, w8="three",
+                    desc="cfg3h with free-form per-edge weights (three values): the general weighted kernels, Hirschmueller"),
+    "cfg3L1536": dict(nx=1920, ny=1080, dmin=-1535, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0,
+                      desc="1920x1080 synthetic pair, 1536 disparities (first build of the pass kernel), CENSUS 5x5, -O 8 TSGM=3"),
+    "cfg3L2048": dict(nx=1920, ny=1080, dmin=-2047, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0,
+                      desc="1920x1080 synthetic pair, 2048 disparities (first build of the pass kernel), CENSUS 5x5, -O 8 TSGM=3"),
+    "cfg3neg": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=-2.0, P2=32.0,
+                    desc="cfg3h with a negative penalty P1 = -2 (the tags of the queue kernels need E >= 0: first build)"),
+    "cfg3nan": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0, nan=1,
+                    desc="cfg3h on an UPLOADED volume holding one NaN cost: the operand-order-faithful kernel (k_pass_exact)"),
+    "cfg3rinf": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=float("inf"), ragged=24,
+                     desc="cfg3hr with P2 = inf: all-INF slabs, INF - INF: the operand-order-faithful kernel (k_pass_exact)"),
 }
 # Set ONLY by a test driver that imports this module (tests/run_bench_stub.py) to drive the launcher, the rendezvous and the
 # JSON contract on CPU ranks; nothing in the environment or on the command line can set it, and the line such a run prints
@@ -455,19 +480,55 @@ def pairs_leg(env, w, B, steps, warmup, repeats, keep=False, pipeline=1):
     sets = [{"cv": [None] * B, "w8": [None] * B, "o": [ctx.new_image(nx, ny) for _ in range(B)], "c": [ctx.new_image(nx, ny) for _ in range(B)]}
             for _ in range(D)]  # (the W*H*L volumes and the weight planes are allocated by a set's first step and refilled after)
     count = [0]
+    # round 5 workloads: range images (-m/-M), free-form weights, an uploaded volume with a NaN -- resident inputs, like the pairs
+    rlo, rhi, w8fixed, nanvol, ilo, ihi = [], [], [], [], [], []
+    for b in range(B):
+        if w.get("ragged"):
+            gt = pair_of(w, rank * B + b)[2].astype(np.float32)
+            rlo.append(ctx.upload_image(np.clip(gt - w["ragged"], w["dmin"], w["dmax"])[None]))
+            rhi.append(ctx.upload_image(np.clip(gt + w["ragged"], w["dmin"], w["dmax"])[None]))
+        if w.get("w8") == "three":
+            rng = np.random.default_rng(77 + rank * B + b)
+            w8fixed.append(ctx.upload_image(rng.choice(np.array([1.0, 2.5, 4.0], np.float32), size=(8, ny, nx), p=[0.7, 0.2, 0.1])))
+        if w.get("nan"):
+            from mgm_amd import synth
+            vol = synth.raw_volume(nx, ny, labels_of(w), seed=5 + b)
+            vol[ny // 2, nx // 2, 7] = np.nan
+            nanvol.append(ctx.upload_volume(vol, w["dmin"]))
+        if w.get("iter", 1) > 1:
+            ilo.append(ctx.new_image(nx, ny))
+            ihi.append(ctx.new_image(nx, ny))
+    flat_lo = np.full((1, ny, nx), w["dmin"], np.float32)
+    flat_hi = np.full((1, ny, nx), w["dmax"], np.float32)
 
     def step():
         # one step = one batch: the cost volume (and, weighted workloads, the edge weights) of every pair, ONE pass launch
         # over the batch, WTA + vfit per volume
         st = sets[count[0] % D]
         count[0] += 1
-        st["cv"] = [ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w), w["win"], into=cv)
-                    for du, dv, cv in zip(dus, dvs, st["cv"])]
+        if nanvol:
+            st["cv"] = nanvol  # (uploaded once: the leg measures the aggregation of a volume that holds a NaN)
+        elif rlo:
+            st["cv"] = [ctx.costvolume_ranged_dev(du, dv, lo, hi, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w), w["win"], into=cv)
+                        for du, dv, lo, hi, cv in zip(dus, dvs, rlo, rhi, st["cv"])]
+        else:
+            st["cv"] = [ctx.costvolume_dev(du, dv, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w), w["win"], into=cv)
+                        for du, dv, cv in zip(dus, dvs, st["cv"])]
         if weighted(w):
             for b in range(B):
                 st["w8"][b] = ctx.weights_dev(dus[b], w["aP2"], w["aThresh"], into=st["w8"][b])
-        ctx.aggregate_batch_dev(st["cv"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, st["w8"] if weighted(w) else None, "vfit",
+        w8s = st["w8"] if weighted(w) else (w8fixed if w8fixed else None)
+        ctx.aggregate_batch_dev(st["cv"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, w8s, "vfit",
                                 st["o"], st["c"], want_S=False)
+        for it in range(1, int(w.get("iter", 1))):  # main()'s loop, mgm.cc:377-388: ranges narrowed around the solution, winner search again
+            for b in range(B):
+                if it == 1:
+                    ilo[b].update(flat_lo)
+                    ihi[b].update(flat_hi)
+                ctx.update_ranges_dev(st["o"][b], ilo[b], ihi[b], 3, 2)
+                if B > 1:  # (the windowed search works on the Lr volumes of the context's LAST aggregation: one volume)
+                    raise RuntimeError("TSGM_ITER > 1 workloads run one pair per step")
+                ctx.wta_windowed_dev(st["cv"][b], w["NDIR"], 1, "vfit", ilo[b], ihi[b], st["o"][b], st["c"][b])
         return st
 
     def timed_block():
@@ -500,16 +561,18 @@ def pairs_leg(env, w, B, steps, warmup, repeats, keep=False, pipeline=1):
         ctx.set_pipeline(1)
     if keep:
         m["outs"], m["outcs"] = last["o"], last["c"]
+    freed = set()
     for st in sets:
         for h in st["cv"] + st["w8"] + ([] if (keep and st is last) else st["o"] + st["c"]):
-            if h is not None:
+            if h is not None and id(h) not in freed:
+                freed.add(id(h))
                 h.free()
-    for h in dus + dvs:
+    for h in dus + dvs + rlo + rhi + w8fixed + ilo + ihi + [v for v in nanvol if id(v) not in freed]:
         h.free()
     return m
 
 
-def roofline_of(w, B, avg, workload, step_ms=None):
+def roofline_of(w, B, avg, workload, step_ms=None, per_step=None):
     """SURVEY.md 8(d): the aggregation = K3 (pass kernel, one launch per batch) + K4-K6 (k_wta, one launch per volume);
     ALGORITHMIC bytes = 12 B per cell per direction (read C, read S, write S in fp32).  `frac` is that figure over the
     measured launch times; `frac_counter` prices the same time against the HBM bytes the PMC counters saw (committed summary
@@ -517,8 +580,10 @@ def roofline_of(w, B, avg, workload, step_ms=None):
     one byte per label), so that none of them can exceed the peak."""
     nx, ny, L = w["nx"], w["ny"], labels_of(w)
     cells = float(nx) * ny * L
-    pass_name = "k_pass2" if "k_pass2" in avg else "k_pass"
+    pass_name = "k_pass2" if "k_pass2" in avg else ("k_pass" if "k_pass" in avg else "k_pass_exact")
     agg_ms = avg[pass_name] + B * avg["k_wta"]
+    if pass_name == "k_pass_exact" and per_step:  # (one launch per diagonal and pass: the step's SUM, not an average launch)
+        agg_ms = per_step[pass_name] + per_step["k_wta"]
     if step_ms is not None:
         # pipelined steps: one pass launch serves D steps, so per-launch durations are not per-step figures; the aggregation
         # is priced against the WHOLE step's wall time instead -- an upper bound of its time (the step also holds K1 / K2)
@@ -546,7 +611,12 @@ def roofline_of(w, B, avg, workload, step_ms=None):
     fmt_total = sum(b * (B if k == "k_wta" else 1) for k, b in fmt.items() if k in avg and k != "k_cost")
     moved = traffic if traffic else fmt_total
     moved_gbs = moved / (agg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "%s (one launch per batch of %d volumes) + k_wta (one launch per volume): the %d-direction aggregation" % (pass_name, B, w["NDIR"]),
+    extra = {}
+    if w.get("ragged"):  # what a range-proportional layout would be priced on: the labels that EXIST (mgm_costvolume.h:275-299)
+        own = float(nx) * ny * (2 * w["ragged"] + 1)
+        extra = {"existing_cells_over_hull_cells": own / cells, "frac_range_proportional": 12.0 * w["NDIR"] * own * B / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "note": "frac prices the dense HULL (what the kernels walk); frac_range_proportional prices only the labels each pixel owns"}
+    return {**extra, "bound": "hbm", "kernel": "%s (one launch per batch of %d volumes) + k_wta (one launch per volume): the %d-direction aggregation" % (pass_name, B, w["NDIR"]),
             "moved_over_algorithmic": moved / alg_bytes, "moved_basis": "pmc counters" if traffic else "format bytes of the kernels' data layout",
             "frac_of_achievable": moved_gbs / HBM_ACHIEVABLE_GBS, "achievable_peak": HBM_ACHIEVABLE_GBS,
             "saturated": bool(moved_gbs / HBM_ACHIEVABLE_GBS >= 0.9),
@@ -965,7 +1035,7 @@ def main():
                        "edge_weights": ("-aP2 %g -aThresh %g" % (w["aP2"], w["aThresh"])) if weighted(w) else None,
                        "pipeline_depth": args.pipeline,
                        "parallelism": ("independent pairs, %d per step and GPU, no data-path collective" % B) if n_ranks > 1 else "1 GPU"},
-            "roofline": roofline_of(w, B, m["avg"], wname, step_ms=(dt / args.steps * 1e3) if args.pipeline > 1 else None),
+            "roofline": roofline_of(w, B, m["avg"], wname, step_ms=(dt / args.steps * 1e3) if args.pipeline > 1 else None, per_step=m["per_step"]),
             # (say it HERE, not only in DESIGN.md) what scales on a node and what does not
             "multi_gpu_note": ("`value` is the weak-scaling mode: every rank aggregates its own pairs, no data-path collective (replicas). "
                                "Sharding ONE volume by direction (`directions`, cfg4) is link-bound by construction -- fp32 Lr row slabs, summed in pass "
@@ -984,7 +1054,11 @@ def main():
         from oracle.oracle import usable_cpus
         T = min(32, usable_cpus())
         if not args.no_parity:
-            if cells > PARITY_MAX_CELLS:
+            special = [k for k in ("ragged", "iter", "w8", "nan") if w.get(k)]
+            if special:
+                parity = {"status": "skipped", "why": "workload keys %s: beyond the in-run dense oracle (compared with the reference binary / the oracle in "
+                                                      "tests/test_gpu_cli.py, test_gpu_windowed.py, test_gpu_parity.py, test_gpu_fuzz.py)" % special}
+            elif cells > PARITY_MAX_CELLS:
                 parity = {"status": "skipped", "why": "%.1f G cells: beyond the in-run oracle (covered by tests/test_gpu_fullsize.py)" % (cells / 1e9)}
             else:
                 got_o, got_c = m["outs"][gate].download()[0], m["outcs"][gate].download()[0]
@@ -996,7 +1070,7 @@ def main():
                 if bad:
                     line.code = 3
             res["parity"] = parity
-        if n_ranks == 1 and not args.no_cpu_baseline and cells <= PARITY_MAX_CELLS:
+        if n_ranks == 1 and not args.no_cpu_baseline and cells <= PARITY_MAX_CELLS and not any(w.get(k) for k in ("ragged", "iter", "w8", "nan")):
             res["cpu_baseline"], ref_out = cpu_baseline(w, whole_s, T, pair=gate)
             if ref_out and parity is not None and parity.get("status") != "skipped":  # the reference's own maps, while we have them
                 got_o, got_c = m["outs"][gate].download()[0], m["outcs"][gate].download()[0]

@@ -273,6 +273,14 @@ class Context:
                                                     distance.encode(), truncDist, census_win, C.byref(h)))
         return into if into is not None else CostVolume(self, h)
 
+    def costvolume_ranged_dev(self, u, v, dminI, dmaxI, hull_min, hull_max, prefilter="none", distance="ad", truncDist=float("inf"),
+                              census_win=3, into=None):
+        """Device form with per-pixel range images (device Images): the ragged volume over [hull_min, hull_max]."""
+        h = C.c_void_p(into.h.value) if into is not None else C.c_void_p()
+        self._chk(self.lib.mgm_costvolume_build_ranged_dev(self.h, u.h, v.h, dminI.h, dmaxI.h, hull_min, hull_max, prefilter.encode(),
+                                                           distance.encode(), truncDist, census_win, C.byref(h)))
+        return into if into is not None else CostVolume(self, h)
+
     def costvolume(self, u, v, dminI, dmaxI, prefilter="none", distance="ad", truncDist=float("inf"), census_win=3):
         """Host-buffer form with per-pixel range images, like the reference."""
         u, v = _f32(u), _f32(v)

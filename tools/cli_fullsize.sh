@@ -13,7 +13,7 @@ for n, a in (("u", u), ("v", v)):
     Image.fromarray(np.clip(np.round(a[0]), 0, 255).astype(np.uint8)).save("%s/%s.png" % (sys.argv[1], n))
 PY
 ARGS="-r -255 -R 0 -t census -s vfit -O 8 -P1 2 -P2 20000"
-export CENSUS_NCC_WIN=5 TSGM=3 USE_TRUNCATED_LINEAR_POTENTIALS=1 MEDIAN=1
+export CENSUS_NCC_WIN=5 TSGM=3 USE_TRUNCATED_LINEAR_POTENTIALS=1 MEDIAN=1 MGM_HIP_STATS=1
 for rep in 1 2; do
   s=$(date +%s%N); ./mgm_amd/bin/mgm $ARGS $T/u.png $T/v.png $T/o_disp.tif $T/o_cost.tif > $T/o.log; e=$(date +%s%N)
   echo "ours: $(( (e - s) / 1000000 )) ms wall"
