@@ -580,7 +580,7 @@ def roofline_of(w, B, avg, workload, step_ms=None, per_step=None):
     one byte per label), so that none of them can exceed the peak."""
     nx, ny, L = w["nx"], w["ny"], labels_of(w)
     cells = float(nx) * ny * L
-    pass_name = "k_pass2" if "k_pass2" in avg else ("k_pass" if "k_pass" in avg else "k_pass_exact")
+    pass_name = next((k for k in ("k_pass2", "k_pass", "k_pass_rel", "k_pass_exact") if k in avg), "k_pass2")
     agg_ms = avg[pass_name] + B * avg["k_wta"]
     if pass_name == "k_pass_exact" and per_step:  # (one launch per diagonal and pass: the step's SUM, not an average launch)
         agg_ms = per_step[pass_name] + per_step["k_wta"]
@@ -637,7 +637,7 @@ def replicas_leg(env, name, steps, warmup):
     m = pairs_leg(env, w, B, steps, warmup, 0)
     from mgm_amd import shard
     rf = roofline_of(w, B, m["avg"], name)
-    pass_name = "k_pass2" if "k_pass2" in m["avg"] else "k_pass"
+    pass_name = next((k for k in ("k_pass2", "k_pass", "k_pass_rel", "k_pass_exact") if k in m["avg"]), "k_pass2")
     return {"workload": "%s: %s" % (name, w["desc"]), "value": shard.job_rate([steps * B] * env.n_ranks, m["dt"]), "unit": "disparity-volumes/s",
             "n_gpus": env.n_ranks, "pairs_per_step_per_gpu": B, "steps": steps, "warmup": warmup, "ms_per_step": m["dt"] / steps * 1e3,
             "scaling": "weak", "parallelism": "replicas only: independent pairs, no data-path collective",
@@ -1103,7 +1103,7 @@ def main():
                 if rank == 0:
                     vsteps = 8 if vd > 1 else 5
                     vr = roofline_of(vw, vb, vm["avg"], vname, step_ms=(vm["dt"] / vsteps * 1e3) if vd > 1 else None)
-                    pn = "k_pass2" if "k_pass2" in vm["avg"] else "k_pass"
+                    pn = next((k for k in ("k_pass2", "k_pass", "k_pass_rel", "k_pass_exact") if k in vm["avg"]), "k_pass2")
                     vres["%s x%d%s" % (vname, vb, (" pipeline %d" % vd) if vd > 1 else "")] = {
                         "workload": vw["desc"], "value": shard.job_rate([vsteps * vb] * n_ranks, vm["dt"]), "unit": "disparity-volumes/s",
                         "roofline_frac": vr["frac"], "frac_of_achievable": vr["frac_of_achievable"], "saturated": vr["saturated"],

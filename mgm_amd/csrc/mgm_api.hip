@@ -325,6 +325,27 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         TimeScope t(c, "k_cost");
         HIPCHK(c, launch_cost(p, c->stream));
     }
+    // A ragged volume also gets its RANGE-PROPORTIONAL copy (mgm_pass_rel.hip): 64 cost bytes per pixel at the pixel's own
+    // window -- what the aggregation then walks instead of the hull, if every window is at most 62 labels wide and every
+    // cost a byte (the flag word is read back by the first aggregation).
+    (*out)->rel_state = 0;
+    if (p.rlo && p.C && rel_enabled()) {
+        const size_t npix = (size_t)u->nx * u->ny, need = npix * 64 + npix * 16 + 16;
+        if ((*out)->rel_cap < need) {
+            if ((*out)->relbuf) (void)hipFree((*out)->relbuf);
+            (*out)->relbuf = nullptr;
+            (*out)->rel_cap = 0;
+            if (dev_malloc((void **)&(*out)->relbuf, need) == hipSuccess) (*out)->rel_cap = need;
+        }
+        if ((*out)->relbuf) {
+            unsigned *flag = reinterpret_cast<unsigned *>((*out)->relbuf + npix * 64 + npix * 16);
+            HIPCHK(c, hipMemsetAsync(flag, 0, 4, c->stream));
+            TimeScope t(c, "k_rel_gather");
+            HIPCHK(c, launch_rel_gather(p.C, p.rlo, p.rhi, (long long)npix, p.L, dmin, (*out)->relbuf, reinterpret_cast<int *>((*out)->relbuf + npix * 64), flag,
+                                        c->stream));
+            (*out)->rel_state = 1;
+        }
+    }
     return MGM_OK;
 }
 
@@ -426,6 +447,23 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
     const long long npix = (long long)nx * ny;
     if (S)
         for (int v = 0; v < n; v++) S[v] = nullptr;
+    // Ragged volumes whose range-proportional copies are usable take the kernels that walk the pixels' own windows
+    // (mgm_pass_rel.hip): not when S is wanted (a dense volume), with TSGM = 2 (unweighted: other update functions), with
+    // P2 = +INF (all-INF slabs: the operand-order-faithful kernel).
+    // Measured (round 5, 1920x1080, windows of 49 labels in a hull of 256, K3 + search): FH 21.3 + 3.9 ms on the hull (the general
+    // weighted kernels: the min-convolution runs over the RECEIVING pixel's range) -> 14.0 + 1.5 ms; free-form weights,
+    // Hirschmueller: 11.4 + 3.9 -> 7.1 + 1.5; unit weights, Hirschmueller: 4.75 + 3.9 on the hull's queue kernels against
+    // 7.1 + 1.5 + 0.45 (gather) -- a tie, and those keep the hull (MGM_HIP_TUNE=rel=2 sends them here too).
+    const bool rel_pays = use_fh > 0 || (w8 && w8[0]) || tune_num("rel", 1) >= 2;
+    if (!S && MGM != 2 && P2 < __builtin_huge_valf() && rel_pays && rel_enabled()) {
+        bool all = true;
+        for (int v = 0; v < n && all; v++) {
+            bool u = false;
+            if ((r = rel_resolve(c, C[v], &u))) return r;
+            all = u;
+        }
+        if (all) return run_rel(c, C, (w8 && w8[0]) ? w8 : nullptr, n, P1, P2, MGM, use_fh, NDIR, fix_overcount, ridx, out, outcost);
+    }
     // The Lr volumes of a launch take NDIR x W x H x L floats per volume.  A batch that does not fit the caller's
     // workspace limit (mgm_ctx_set_workspace_limit), or the device (hipMalloc fails), is run as several launches over
     // the largest sub-batches that do -- multiples of four / two volumes first, so that volumes keep sharing waves at
@@ -680,6 +718,11 @@ int mgm_wta_windowed_dev(mgm_ctx *c, const mgm_cv *C, int NDIR, int fix_overcoun
     const int nx = C->nx, ny = C->ny, L = C->dmax - C->dmin + 1;
     for (const mgm_img *im : {dminI, dmaxI, (const mgm_img *)out, (const mgm_img *)outcost})
         if (im->nx != nx || im->ny != ny || im->nch != 1) return fail(c, MGM_ERR_INVALID, "mgm_wta_windowed: image size mismatch");
+    for (int v = 0; v < c->rel_last_batch; v++)  // the context's last aggregation of this volume ran on its range-proportional copy
+        if (c->rel_last_cvs[v] == C && c->rel_last_gens[v] == C->gen && c->rel_last_ndir == NDIR) {
+            HIPCHK(c, hipSetDevice(c->device));
+            return run_wta_rel(c, C, v, NDIR, fix_overcount, refinement_index(refine), dminI->d, dmaxI->d, out->d, outcost->d);
+        }
     int slot = -1;
     for (int v = 0; v < c->last_batch; v++)
         if (c->last_cvs[v] == C && c->last_gens[v] == C->gen) slot = v;

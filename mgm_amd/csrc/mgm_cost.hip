@@ -502,6 +502,45 @@ hipError_t launch_wsel(const float *w8, long long npix, unsigned *sel, hipStream
     return hipGetLastError();
 }
 
+// Two-valued weights, round 5: which of its two published transforms will anybody READ?  A pixel q is a neighbour of at most MGM
+// pixels per pass -- p = q - d_k, k < MGM (the pass table, mgm_core.cc:463-471) -- and reader p picks E_1 or E_a by the bit of
+// ITS edge to q (plane kPassToChannel[k][pass] of its selector word).  out[q] = sel[q] | need << 8, need bit 2*pass (+1) = some
+// reader of q in that pass picks E_1 (E_a): the producer computes only those (image-driven weights: the edges around a pixel
+// mostly agree, so most pixels need ONE min-convolution instead of two).  Readers that never update (image border) count too:
+// a superset costs time, never a wrong value.
+struct WneedTab {
+    int d[8][4][2];
+    int plane[8][4];
+};
+__global__ void __launch_bounds__(256) k_wneed(const unsigned *__restrict__ sel, int nx, int ny, int MGM, WneedTab T, unsigned *__restrict__ out)
+{
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long long)nx * ny) return;
+    const int x = (int)(q % nx), y = (int)(q / nx);
+    unsigned need = 0;
+    for (int p = 0; p < 8; p++)
+        for (int k = 0; k < MGM; k++) {
+            const int px = x - T.d[p][k][0], py = y - T.d[p][k][1];
+            if (px < 0 || px >= nx || py < 0 || py >= ny) continue;
+            const unsigned bit = (sel[(long long)py * nx + px] >> T.plane[p][k]) & 1u;
+            need |= (bit ? 2u : 1u) << (2 * p);
+        }
+    out[q] = (sel[q] & 0xffu) | (need << 8);
+}
+hipError_t launch_wneed(const unsigned *sel, int nx, int ny, int MGM, const int (*d)[4][2], const int (*plane)[4], unsigned *out, hipStream_t s)
+{
+    WneedTab T;
+    for (int p = 0; p < 8; p++)
+        for (int k = 0; k < 4; k++) {
+            T.d[p][k][0] = d[p][k][0];
+            T.d[p][k][1] = d[p][k][1];
+            T.plane[p][k] = plane[p][k];
+        }
+    const long long n = (long long)nx * ny;
+    hipLaunchKernelGGL(k_wneed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sel, nx, ny, MGM, T, out);
+    return hipGetLastError();
+}
+
 // Debug check of the self-validating hand-off slabs (mgm_pass2.hip, TAGS): after a launch EVERY word of the slots its
 // passes own must carry the launch's tag in its sign bit -- the invariant the protocol rests on ("each slot is written
 // exactly once per launch of its pass").  Counts the words that do not.

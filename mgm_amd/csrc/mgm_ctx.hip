@@ -296,7 +296,10 @@ int mgm_ctx_trim(mgm_ctx *c)
     if (!c) return MGM_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     if (int r = mgm_ctx_synchronize(c)) return r;
-    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->exact_scratch, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
+    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->exact_scratch, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8,
+                               &c->lr_rel, &c->hand_rel, &c->tasks_rel};
+    c->tasks_rel_key.clear();
+    c->rel_last_batch = 0;
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);
         bufs.push_back(&c->pad8[v]);
@@ -582,6 +585,11 @@ int mgm_cv_free(mgm_ctx *c, mgm_cv *cv)
     if (cv->d8) (void)hipFree(cv->d8);
     if (cv->p8) (void)hipFree(cv->p8);
     if (cv->bad8) (void)hipFree(cv->bad8);
+    if (cv->relbuf) (void)hipFree(cv->relbuf);
+    for (mgm_ctx *o : {c, cv->owner})
+        if (o)
+            for (int v = 0; v < kMaxBatch; v++)
+                if (o->rel_last_cvs[v] == cv) o->rel_last_cvs[v] = nullptr;
     if (cv->rlo) (void)hipFree(cv->rlo);
     if (cv->rhi) (void)hipFree(cv->rhi);
     delete cv;

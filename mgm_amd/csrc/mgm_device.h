@@ -106,6 +106,44 @@ struct WtaParams {
     int num_cu;                      // compute units of the device (grid sizing)
 };
 
+// ---- ragged volumes in the range-proportional layout (mgm_pass_rel.hip, k_wta_rel): 64 label slots per pixel placed at the
+// pixel's own window, slot k <-> disparity base + k
+struct RelVolume {
+    const uint8_t *c8;       // [npix][64] cost bytes (255 = +INF: the slot is not a disparity of the pixel, or its cost is +INF)
+    const int *base;         // [npix][4] the pixel's record: disparity of slot 0 (= its lowest disparity - 1), lowest, highest, 0
+    const float *rlo, *rhi;  // [npix] the pixel's own range (the volume's range images)
+    float *Lr;               // NDIR volumes [npix][64], pass p at Lr + (p - pass0)*nvol
+    const float *w8;         // 8 planes [npix] or nullptr
+};
+struct RelParams {
+    RelVolume vol[kMaxBatch];
+    float *hand;        // hand-off slots [volume*8 + pass][2][LLmax][NS*64 + 2]: slab(s), minimum, base
+    unsigned *prog;     // progress words [volume*8 + pass][maxbands]
+    unsigned *ticket, *err;
+    const int2 *tasks;  // ticket -> (volume*8 + pass, band)
+    long long npix, nvol;
+    int MGM, NDIR, pass0, LLmax, maxbands, weighted;
+    float P1, P2;
+    PassGeom g[kMaxDirs];
+};
+hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi, long long npix, int L, int dmin, uint8_t *rel8, int *relb,
+                             unsigned *flag, hipStream_t s);
+hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, hipStream_t s);
+int pass_rel_lines();
+int pass_rel_hand_floats(bool fh);
+struct WtaRelParams {
+    const uint8_t *c8;
+    const int *base;
+    const float *rlo, *rhi;
+    const float *Lr;
+    const float *wlo, *whi;  // nullptr: the window is the pixel's own range
+    float *out, *outcost;
+    long long npix, nvol;
+    int NDIR, FIX, refine;   // refine: index into the reference's table (0 none, 1 vfit, 2 parabola, 3 cubic, 4 parabolaOCV)
+    int num_cu;
+};
+hipError_t launch_wta_rel(const WtaRelParams &p, hipStream_t s);
+
 // the slow, operand-order-faithful pass kernel (mgm_pass_exact.hip): one pass of one volume
 struct ExactParams {
     const float *C;      // [npix][L]
@@ -191,6 +229,9 @@ hipError_t launch_any_not_one(const float *w, long long n, unsigned *flag, hipSt
 hipError_t launch_weight_values(const float *w, long long n, unsigned *out4, hipStream_t s);
 // selector words of two-valued weights: sel[p] bit k = (w[k*npix + p] != 1.0f), k = 0..7
 hipError_t launch_wsel(const float *w8, long long npix, unsigned *sel, hipStream_t s);
+// ... and which of the two transforms of a pixel anybody reads: out[q] = sel[q] | need << 8 (k_wneed; d[pass][k] = neighbour offsets
+// of the reference's pass table, plane[pass][k] = their weight planes)
+hipError_t launch_wneed(const unsigned *sel, int nx, int ny, int MGM, const int (*d)[4][2], const int (*plane)[4], unsigned *out, hipStream_t s);
 hipError_t launch_check_tags(const float *slabs, long long nwords, unsigned tag, unsigned *count, hipStream_t s);
 hipError_t launch_xcc_census(unsigned *mask, hipStream_t s);
 

@@ -61,6 +61,12 @@ struct mgm_cv {
     // bumped whenever the contents may have changed: contexts remember (pointer, generation) of the volumes of their
     // last aggregation, so a refilled volume, or a new one at a recycled address, is not mistaken for one of them
     unsigned long long gen = 0;
+    // ragged volume, range-proportional copy (round 5; mgm_pass_rel.hip): 64 cost bytes per pixel placed at its own window +
+    // the disparity of slot 0 + a flag word, one allocation [npix*64 bytes][npix ints][flag]; rel_state 0 none, 1 written (flag
+    // not read back yet), 2 usable, -1 not usable (a window wider than 62 labels, a cost that is not a byte)
+    uint8_t *relbuf = nullptr;
+    size_t rel_cap = 0;
+    int rel_state = 0;
     // a caller-provided volume whose refill FAILED half-way holds neither its old costs nor new ones: mgm_aggregate*
     // refuses it (MGM_ERR_INVALID) until a later mgm_costvolume_build* has filled it
     bool unfilled = false;
@@ -84,6 +90,15 @@ struct mgm_ctx {
     // workspace
     Buf exact_mins, exact_scratch;  // slab minima / (FH beyond 8192 labels) convolution arrays of the operand-order-faithful pass kernel
     Buf lr, hand, hand2, handm, words, tasks, census_u, census_v, dbg, stmp, ones8;  // hand: self-validating slabs (TAGS); hand2: the other kernels' slots
+    // range-proportional aggregation of ragged volumes (mgm_pass_rel.hip): its Lr volumes [volume][pass][npix][64], hand-off slots,
+    // task table (+ what it was made for), and what the last such aggregation ran on (mgm_wta_windowed_dev searches it again)
+    Buf lr_rel, hand_rel, tasks_rel;
+    std::string tasks_rel_key;
+    int ntasks_rel = 0;
+    int rel_last_batch = 0, rel_last_ndir = 0;
+    long long rel_last_stride = 0;
+    const mgm_cv *rel_last_cvs[kMaxBatch] = {};
+    unsigned long long rel_last_gens[kMaxBatch] = {};
     // Pipelined contexts (mgm_ctx_set_pipeline, depth >= 2): aggregation calls are DEFERRED and gathered -- up to `depth`
     // calls of the same geometry and settings become ONE launch of the pass kernel (see PendingAgg, pipe_flush)
     struct PendingAgg {
@@ -239,6 +254,13 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
                int count, bool allow_pad = false, int slot0 = 0, int nslots = 0, int layout_ndir = 0);
 int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const float *lr, long long lr_stride, int NDIR, int fix_overcount,
             int ridx, float *out, float *outcost, float *Sout, const float *wlo = nullptr, const float *whi = nullptr, int slot = -1);
+// the range-proportional path of ragged volumes (mgm_plan.hip): is this call one it takes?  then the passes + the winner search
+bool rel_enabled();
+int rel_resolve(mgm_ctx *c, const mgm_cv *cv, bool *usable);
+int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int nb, float P1, float P2, int MGM, int use_fh, int NDIR,
+            int fix_overcount, int ridx, mgm_img *const *outs, mgm_img *const *outcosts);
+int run_wta_rel(mgm_ctx *c, const mgm_cv *C, int slot, int NDIR, int fix_overcount, int ridx, const float *wlo, const float *whi, float *out,
+                float *outcost);
 int run_wta_refine(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const float *lr, long long lr_stride, int NDIR,
                    int fix_overcount, int ridx, float *out, float *outcost, float *Sout, const float *wlo = nullptr,
                    const float *whi = nullptr, int slot = -1);

@@ -921,8 +921,11 @@ __device__ __forceinline__ void pass2_item(const PassParams &P, const int ticket
 #pragma unroll
                         for (int k = 0; k < LPL; k++) nb_i.w[0][k] = nb_i.w[1][k] = Lv[k];
                         unsigned sw = 0;
-                        fh_minconv<LPL, false, 1>(nb_i.w[0], m, P1, P2, lane, P.Lreal, sw);
-                        fh_minconv<LPL, false, 1>(nb_i.w[1], m, P1a, P2a, lane, P.Lreal, sw);
+                        // (round 5) only the transforms some reader of this pixel picks in this pass: bits 8 + 2*pass (E_1) and
+                        // 9 + 2*pass (E_a) of the pixel's word (k_wneed) -- wave-uniform; the slab nobody reads goes out as L - m
+                        const unsigned need = ((unsigned)__builtin_amdgcn_readfirstlane((int)Wring[cslot * 64 + r]) >> (8 + 2 * pass)) & 3u;
+                        if (need & 1u) fh_minconv<LPL, false, 1>(nb_i.w[0], m, P1, P2, lane, P.Lreal, sw);
+                        if (need & 2u) fh_minconv<LPL, false, 1>(nb_i.w[1], m, P1a, P2a, lane, P.Lreal, sw);
 #pragma unroll
                         for (int k = 0; k < LPL; k++) {
                             nb_i.w[0][k] -= m;

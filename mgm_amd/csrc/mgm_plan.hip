@@ -688,9 +688,19 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
         p.vol[v].rlo = (fh && ragged) ? Cs[v]->rlo : nullptr;
         p.vol[v].rhi = (fh && ragged) ? Cs[v]->rhi : nullptr;
         if (w2) {
-            if ((r = reserve(c, c->wsel[v], sizeof(unsigned) * (size_t)npix))) return r;
+            if ((r = reserve(c, c->wsel[v], sizeof(unsigned) * 2 * (size_t)npix))) return r;
             HIPCHK(c, launch_wsel(w8s[v]->d, npix, (unsigned *)c->wsel[v].p, c->stream));
-            p.vol[v].wsel = (const unsigned *)c->wsel[v].p;
+            {   // ... + which of a pixel's two transforms its readers pick (k_wneed): what the kernel gets is the combined word
+                int dd[8][4][2], pl[8][4];
+                for (int q = 0; q < 8; q++)
+                    for (int k = 0; k < 4; k++) {
+                        dd[q][k][0] = kPasses[q].d[k][0];
+                        dd[q][k][1] = kPasses[q].d[k][1];
+                        pl[q][k] = kPassToChannel[k][q];
+                    }
+                HIPCHK(c, launch_wneed((const unsigned *)c->wsel[v].p, nx, ny, MGM, dd, pl, (unsigned *)c->wsel[v].p + npix, c->stream));
+            }
+            p.vol[v].wsel = (const unsigned *)c->wsel[v].p + npix;
             p.vol[v].p1a = P1 * w2a[v];  // (fp32 products, rounded once: what update_costW computes for D = a)
             p.vol[v].p2a = P2 * w2a[v];
             // (FH: the cap min(., m + P2*a) is skipped where it cannot bind, as for the unit penalties below)
@@ -871,6 +881,7 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
                         fsw / fn, fmx, 100.0 * frep / fn);
         }
     }
+    c->rel_last_batch = 0;  // (the context's last aggregation is this dense one)
     c->last_nvol = nvol;
     c->last_stride = lr_stride;
     c->last_ndir = nslots;
@@ -958,5 +969,156 @@ int run_wta_refine(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, 
     TimeScope t(c, "k_refine");
     HIPCHK(c, launch_refine(Sout, npix, L, C->dmin, ridx, wlo ? wlo + pix0 : nullptr, whi ? whi + pix0 : nullptr, vout, out,
                             outcost, c->stream));
+    return MGM_OK;
+}
+
+
+// ---- ragged volumes on their range-proportional copies (mgm_pass_rel.hip, k_wta_rel; round 5) -------------------------------
+// MGM_HIP_REL=0 (read at every call: tests switch it inside one process): ragged volumes keep the dense-hull kernels
+bool rel_enabled()
+{
+    const char *e = getenv("MGM_HIP_REL");
+    return !(e && atoi(e) == 0) && tune_num("rel", 1) != 0;
+}
+
+int rel_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *usable)
+{
+    mgm_cv *cv = const_cast<mgm_cv *>(ccv);
+    *usable = false;
+    if (!cv->rlo || !cv->relbuf || cv->rel_state == 0 || cv->rel_state == -1) return MGM_OK;
+    if (cv->rel_state == 1) {
+        const size_t npix = (size_t)cv->nx * cv->ny;
+        HIPCHK(c, hipSetDevice(c->device));
+        if (int r = ensure_words(c)) return r;
+        HIPCHK(c, hipMemcpyAsync(c->h_words + 3, cv->relbuf + npix * 64 + npix * 16, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        cv->rel_state = c->h_words[3] == 0u ? 2 : -1;
+    }
+    *usable = cv->rel_state == 2;
+    return MGM_OK;
+}
+
+int run_wta_rel(mgm_ctx *c, const mgm_cv *C, int slot, int NDIR, int fix_overcount, int ridx, const float *wlo, const float *whi, float *out,
+                float *outcost)
+{
+    const size_t npix = (size_t)C->nx * C->ny;
+    WtaRelParams w{};
+    w.c8 = C->relbuf;
+    w.base = reinterpret_cast<const int *>(C->relbuf + npix * 64);
+    w.rlo = C->rlo;
+    w.rhi = C->rhi;
+    w.Lr = (const float *)c->lr_rel.p + (size_t)slot * NDIR * c->rel_last_stride;
+    w.wlo = wlo;
+    w.whi = whi;
+    w.out = out;
+    w.outcost = outcost;
+    w.npix = (long long)npix;
+    w.nvol = c->rel_last_stride;
+    w.NDIR = NDIR;
+    w.FIX = fix_overcount;
+    w.refine = ridx;
+    w.num_cu = c->num_cu;
+    TimeScope t(c, "k_wta");
+    HIPCHK(c, launch_wta_rel(w, c->stream));
+    return MGM_OK;
+}
+
+int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int nb, float P1, float P2, int MGM, int use_fh, int NDIR,
+            int fix_overcount, int ridx, mgm_img *const *outs, mgm_img *const *outcosts)
+{
+    const mgm_cv *C = Cs[0];
+    const int nx = C->nx, ny = C->ny;
+    const long long npix = (long long)nx * ny;
+    const bool fh = use_fh > 0;
+    const int R = pass_rel_lines(), HS = pass_rel_hand_floats(fh);
+    int r;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int r0 = check_watchdog(c, false)) return r0;
+    if ((r = ensure_words(c))) return r;
+    unsigned *words = (unsigned *)c->words.p;
+    RelParams p{};
+    int maxLL = 0, maxbands = 0;
+    for (int q = 0; q < NDIR; q++) {
+        if (!make_geom(q, nx, ny, R, 4, false, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
+        maxLL = std::max(maxLL, p.g[q].LL);
+        maxbands = std::max(maxbands, p.g[q].nbands);
+    }
+    if (maxbands > kMaxBands) return fail(c, MGM_ERR_UNSUPPORTED, "image side exceeds 65536 pixels");
+    const long long stride = npix * 64 + lr_pad_floats();
+    if ((r = reserve(c, c->lr_rel, sizeof(float) * (size_t)stride * NDIR * nb))) return r;
+    if ((r = reserve(c, c->hand_rel, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * HS))) return r;
+    // the task table: the simulated list schedule of the launch (one ticket counter), cached per shape
+    char key[96];
+    snprintf(key, sizeof key, "%d %d %d %d", nx, ny, NDIR, nb);
+    if (c->tasks_rel_key != key) {
+        std::vector<SimChain> ch;
+        for (int v = 0; v < nb; v++)
+            for (int q = 0; q < NDIR; q++) {
+                SimChain k;
+                k.x = v * kMaxDirs + q, k.st = 0, k.nb = p.g[q].nbands, k.sib = -1, k.chain = v * NDIR + q;
+                k.skew = 2.0 * R + 14.0;  // (the lock-step diagonal has slope 2 for every pass here; progress words + loader lead: ~14 steps of lag)
+                k.len = p.g[q].LL + 2.0 * (R - 1) + 1.0;
+                ch.push_back(k);
+            }
+        std::vector<int2> order;
+        (void)simulate_schedule(ch, 1, std::max(1, c->num_cu * 2), 1 << 20, order);
+        for (int2 &t : order) t.y &= 0xffff;
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // (a launch that still reads the old table)
+        if ((r = reserve(c, c->tasks_rel, sizeof(int2) * order.size()))) return r;
+        HIPCHK(c, hipMemcpyAsync(c->tasks_rel.p, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->tasks_rel_key = key;
+        c->ntasks_rel = (int)order.size();
+    }
+    bool weighted = false;
+    for (int v = 0; v < nb; v++) {
+        const size_t np = (size_t)npix;
+        p.vol[v].c8 = Cs[v]->relbuf;
+        p.vol[v].base = reinterpret_cast<const int *>(Cs[v]->relbuf + np * 64);
+        p.vol[v].rlo = Cs[v]->rlo;
+        p.vol[v].rhi = Cs[v]->rhi;
+        p.vol[v].Lr = (float *)c->lr_rel.p + (size_t)v * NDIR * stride;
+        p.vol[v].w8 = (w8s && w8s[v]) ? w8s[v]->d : nullptr;
+        weighted = weighted || p.vol[v].w8;
+    }
+    if (weighted)
+        for (int v = 0; v < nb; v++)
+            if (!p.vol[v].w8) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: weights for all volumes or for none");
+    p.hand = (float *)c->hand_rel.p;
+    p.prog = words + 4;
+    p.ticket = words + 0;
+    p.err = words + 1;
+    p.tasks = (const int2 *)c->tasks_rel.p;
+    p.npix = npix;
+    p.nvol = stride;
+    p.MGM = MGM;
+    p.NDIR = NDIR;
+    p.pass0 = 0;
+    p.LLmax = maxLL;
+    p.maxbands = kMaxBands;
+    p.weighted = weighted ? 1 : 0;
+    p.P1 = P1;
+    p.P2 = P2;
+    HIPCHK(c, hipMemsetAsync(words, 0, sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(words + 4, 0, sizeof(unsigned) * (size_t)nb * kMaxDirs * kMaxBands, c->stream));
+    {
+        TimeScope t(c, "k_pass_rel");
+        HIPCHK(c, launch_pass_rel(p, c->ntasks_rel, fh, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_words + 1, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    c->pending_check = true;
+    // what the context's last aggregation was: this one (the dense Lr workspace no longer belongs to these volumes)
+    c->last_batch = 0;
+    c->last_ndir = 0;
+    for (int v = 0; v < kMaxBatch; v++) c->last_cvs[v] = nullptr;
+    c->rel_last_batch = nb;
+    c->rel_last_ndir = NDIR;
+    c->rel_last_stride = stride;
+    for (int v = 0; v < kMaxBatch; v++) {
+        c->rel_last_cvs[v] = v < nb ? Cs[v] : nullptr;
+        c->rel_last_gens[v] = v < nb ? Cs[v]->gen : 0;
+    }
+    for (int v = 0; v < nb; v++)
+        if ((r = run_wta_rel(c, Cs[v], v, NDIR, fix_overcount, ridx, nullptr, nullptr, outs[v]->d, outcosts[v]->d))) return r;
     return MGM_OK;
 }

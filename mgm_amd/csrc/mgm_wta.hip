@@ -9,6 +9,7 @@
 //
 // Compiled with default floating point: S may hold NaN (inf - inf) and the
 // refinement must propagate NaN/inf exactly as IEEE arithmetic does on the CPU.
+#include <algorithm>
 #include <cstdlib>
 
 #include "mgm_device.h"
@@ -559,6 +560,95 @@ __device__ __forceinline__ void cubicfit(const float (&p)[4], float &out_pmin, f
     }
     out_pmin = pmin;
     out_xmin = xmin;
+}
+
+// K4-K6 on the RANGE-PROPORTIONAL layout (mgm_pass_rel.hip): one wavefront per pixel, one label slot per lane.  The same
+// arithmetic and rules as k_wta / k_wta_any + k_refine on the dense hull -- S = ((0 + L0) + L1) + ... in pass order, the
+// over-count term, the first strict minimum among the finite entries of the pixel's window scanned by rising disparity,
+// the refinement gate of mgm_refine.h:58 on the window -- with "a disparity the pixel does not own" = `vout` (what the
+// reference's S holds there: 0 - (NDIR-1)*INF, or 0 without the over-count fix) instead of a stored value.
+__global__ void __launch_bounds__(256) k_wta_rel(const WtaRelParams P)
+{
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float f = (float)(P.NDIR - 1);
+    float vout = 0.0f;
+    if (P.FIX == 1) vout = vout - f * f_inf();
+    const bool vfin = finite_bits(vout);
+    for (long long pix = (long long)blockIdx.x * 4 + wv; pix < P.npix; pix += (long long)gridDim.x * 4) {
+        const int4 rec = reinterpret_cast<const int4 *>(P.base)[pix];  // (the pixel's record: disparity of slot 0, its own range)
+        const int b = rec.x, lo = rec.y, hi = rec.z;
+        const bool windowed = P.wlo != nullptr;
+        const int wl = windowed ? (int)P.wlo[pix] : lo, wh = windowed ? (int)P.whi[pix] : hi;
+        const int d = b + lane;
+        float a = 0.0f;
+        for (int p = 0; p < P.NDIR; p++) a = a + P.Lr[(long long)p * P.nvol + pix * 64 + lane];
+        if (P.FIX == 1) a = a - f * c8_decode(P.c8[pix * 64 + lane]);
+        const bool own = d >= lo && d <= hi;
+        const float val = own ? a : vout;
+        // (1) the window's disparities below the pixel's own range: all `vout`, the first of them is the candidate
+        float best = f_inf();
+        int bi = 0x7fffffff;
+        if (wl < lo && wl <= wh && vfin) {
+            best = vout;
+            bi = wl;
+        }
+        // (2) its own disparities inside the window
+        float cb = f_inf();
+        int ci = 0x7fffffff;
+        if (own && d >= wl && d <= wh && finite_bits(val)) {
+            cb = val;
+            ci = d;
+        }
+#pragma unroll
+        for (int x = 32; x >= 1; x >>= 1) {
+            const float ov = __shfl_xor(cb, x);
+            const int oi = __shfl_xor(ci, x);
+            if (ov < cb || (ov == cb && oi < ci)) {
+                cb = ov;
+                ci = oi;
+            }
+        }
+        if (ci != 0x7fffffff && best > cb) {
+            best = cb;
+            bi = ci;
+        }
+        // (3) the window's disparities above the own range
+        const int hi0 = wl > hi + 1 ? wl : hi + 1;
+        if (wh > hi && hi0 <= wh && vfin && vout < best) {
+            best = vout;
+            bi = hi0;
+        }
+        float outv, outc = best;
+        if (bi == 0x7fffffff) outv = __builtin_nanf("");  // the reference leaves minP uninitialised here
+        else outv = (float)bi;
+        if (P.refine >= 1 && bi != 0x7fffffff && bi - 1 >= wl && bi + 2 <= wh) {  // mgm_refine.h:58 (S allocated over the window)
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int sl = bi - 1 + k - b;  // slot of that disparity
+                const float x = __shfl(val, sl & 63);
+                v[k] = (sl >= 0 && sl < 64) ? x : vout;
+            }
+            float vmin = outc, dx = 0;
+            if (P.refine == 1) vfit(v[0], v[1], v[2], vmin, dx);
+            else if (P.refine == 2) parabolafit(v, vmin, dx);
+            else if (P.refine == 3) cubicfit(v, vmin, dx);
+            else parabolafit_ocv(v, vmin, dx);
+            outv = (float)bi + dx;
+            outc = vmin;
+        }
+        if (lane == 0) {
+            P.out[pix] = outv;
+            P.outcost[pix] = outc;
+        }
+    }
+}
+hipError_t launch_wta_rel(const WtaRelParams &p, hipStream_t s)
+{
+    const long long groups = (p.npix + 3) / 4;
+    const long long cap = (long long)p.num_cu * 64;
+    hipLaunchKernelGGL(k_wta_rel, dim3((unsigned)std::max(1ll, std::min(groups, cap))), dim3(256), 0, s, p);
+    return hipGetLastError();
 }
 
 // Stand-alone refinement on a materialised (corrected) S: one thread per pixel (subpixel_refinement_sgm,

@@ -61,6 +61,20 @@ CASES = [
     ("ragged ranges, FH, TSGM=2 without weights, 3 channels, TSGM_ITER=2", 3,
      "-P1 1.5 -P2 40 -r -16 -R 8 -t ad -O 4 -m {ranges}/lo.npy -M {ranges}/hi.npy",
      dict(TSGM="2", TSGM_ITER="2", USE_TRUNCATED_LINEAR_POTENTIALS="1")),
+    # round 5: ragged volumes of byte costs with windows of at most 62 labels run on their range-proportional copies
+    # (mgm_pass_rel.hip, k_wta_rel): every update function, weight, refinement and TSGM_ITER combination that path takes
+    ("ragged ranges (range-proportional kernels): census, weights, TSGM=4, cubic", 1,
+     "-r -16 -R 8 -t census -O 8 -aP2 4 -aThresh 12 -s cubic -m {ranges}/lo.npy -M {ranges}/hi.npy", dict(TSGM="4", CENSUS_NCC_WIN="5")),
+    ("ragged ranges (range-proportional kernels): census, FH, weights, TSGM=3, TSGM_ITER=2, parabola", 1,
+     "-P1 2 -P2 9 -r -16 -R 8 -t census -O 8 -aP2 4 -aThresh 12 -s parabola -m {ranges}/lo.npy -M {ranges}/hi.npy",
+     dict(TSGM="3", TSGM_ITER="2", CENSUS_NCC_WIN="5", USE_TRUNCATED_LINEAR_POTENTIALS="1")),
+    ("ragged ranges (range-proportional kernels): census, TSGM=1, O 2, no over-count fix, TSGM_ITER=3, parabolaOCV", 1,
+     "-r -16 -R 8 -t census -O 2 -s parabolaOCV -m {ranges}/lo.npy -M {ranges}/hi.npy", dict(TSGM="1", TSGM_ITER="3", TSGM_FIX_OVERCOUNT="0", CENSUS_NCC_WIN="3")),
+    ("ragged ranges (range-proportional kernels): grey ad (byte costs), FH TSGM=4, median, O 4", 1,
+     "-P1 2 -P2 30 -r -16 -R 8 -t ad -truncDist 100 -O 4 -s vfit -m {ranges}/lo.npy -M {ranges}/hi.npy",
+     dict(TSGM="4", MEDIAN="1", USE_TRUNCATED_LINEAR_POTENTIALS="1")),
+    ("ragged ranges (range-proportional kernels): census 3x3 colour, Hirschmueller TSGM=3, TSGM_ITER=2", 3,
+     "-r -16 -R 8 -t census -O 8 -s vfit -m {ranges}/lo.npy -M {ranges}/hi.npy", dict(TSGM="3", TSGM_ITER="2", CENSUS_NCC_WIN="3")),
     # mgm_naive_parallelism (mgm_core.cc:632-831): with one thread the reference accumulates S in pass order
     ("WITH_MGM2=1 (direction-parallel driver), census FH vfit, reference on one thread", 1, "-P1 2 -P2 20000 -r -16 -R 8 -t census -s vfit -O 8",
      dict(TSGM="3", WITH_MGM2="1", OMP_NUM_THREADS="1", CENSUS_NCC_WIN="5", USE_TRUNCATED_LINEAR_POTENTIALS="1")),

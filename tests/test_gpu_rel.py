@@ -1,0 +1,101 @@
+"""Ragged volumes on their RANGE-PROPORTIONAL copies (mgm_pass_rel.hip, k_wta_rel; round 5) against the dense-hull kernels
+of the same library, bit for bit, inside one process (MGM_HIP_REL is read at every call) -- the dense-hull path is what
+tests/test_gpu_cli.py pins on the reference binary for ragged ranges, and those command lines now run through the new
+kernels as well.  The timings tell which kernels really ran."""
+import os
+
+import numpy as np
+import pytest
+
+import mgm_amd
+from helpers import ndiff
+from mgm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def ranges(gt, dmin, dmax, half, seed, jitter=3):
+    rng = np.random.default_rng(seed)
+    lo = gt - half + rng.integers(-jitter, jitter + 1, size=gt.shape)
+    hi = gt + half + rng.integers(-jitter, jitter + 1, size=gt.shape)
+    lo, hi = np.clip(lo, dmin, dmax), np.clip(hi, dmin, dmax)
+    hi = np.maximum(hi, lo)
+    return lo.astype(np.float32), hi.astype(np.float32)
+
+
+CASES = [
+    # nx, ny, dmin, dmax, half window, FH, MGM, NDIR, P1, P2, weights, refine, fix
+    (96, 64, -40, 10, 6, 0, 3, 8, 8.0, 32.0, None, "vfit", 1),
+    (96, 64, -40, 10, 6, 1, 3, 8, 2.0, 20000.0, None, "vfit", 1),
+    (131, 77, -100, 20, 24, 1, 3, 8, 2.0, 20000.0, None, "vfit", 1),     # the bench's window (+-24 of a wide hull)
+    (131, 77, -100, 20, 24, 0, 4, 8, 8.0, 32.0, None, "cubic", 1),
+    (131, 77, -100, 20, 24, 0, 1, 4, 8.0, 32.0, None, "parabola", 0),    # no over-count fix: labels outside a range hold 0
+    (96, 64, -40, 10, 10, 1, 4, 8, 1.5, 9.0, "three", "parabolaOCV", 1),  # free-form weights, small P2 (the cap binds)
+    (96, 64, -40, 10, 10, 0, 3, 8, 8.0, 32.0, "three", None, 1),
+    (96, 64, -40, 10, 10, 1, 1, 2, 2.0, 30.0, None, "vfit", 0),
+    (64, 200, -70, 0, 27, 1, 3, 8, 2.0, 20000.0, None, "vfit", 1),       # tall image: several bands per pass; windows of up to 61 labels
+    (300, 40, -30, 30, 3, 0, 3, 8, 8.0, 32.0, None, "vfit", 1),          # narrow windows, large shifts between neighbours
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_w%d_fh%d_t%d_o%d" % (c[0], c[1], c[4], c[5], c[6], c[7]))
+def test_rel_matches_dense_hull(case):
+    nx, ny, dmin, dmax, half, FH, MGM, NDIR, P1, P2, wkind, refine, fix = case
+    u, v, gt = synth.stereo_pair(nx, ny, dmin * 3 // 4, max(0, dmax * 3 // 4), seed=11 + nx)
+    lo, hi = ranges(gt, dmin, dmax, half, 5 + ny)
+    os.environ["MGM_HIP_REL"] = "2"  # (2: unit-weight Hirschmueller volumes too -- the plan keeps those on the hull by default)
+    with mgm_amd.Context(0) as ctx:
+        cv = ctx.costvolume(u, v, lo, hi, "none", "census", float("inf"), 5)
+        w8 = None
+        if wkind == "three":
+            rng = np.random.default_rng(3)
+            w8 = ctx.upload_image(rng.choice(np.array([1.0, 2.5, 4.0], np.float32), size=(8, ny, nx), p=[0.6, 0.25, 0.15]))
+        res = {}
+        for mode in ("2", "0"):
+            os.environ["MGM_HIP_REL"] = mode
+            ctx.timing(True)
+            ctx.timing_reset()
+            _, o, c = ctx.aggregate_dev(cv, P1, P2, NDIR, MGM, FH, fix, w8, refine)
+            names = [n for n, _ in ctx.timings()]
+            ctx.timing(False)
+            res[mode] = (o.download(), c.download(), names)
+            # TSGM_ITER's second search in narrowed windows, on whatever Lr volumes that aggregation left
+            wlo = ctx.upload_image(np.clip(gt - 3, dmin - 2, dmax)[None].astype(np.float32))
+            whi = ctx.upload_image(np.clip(gt + 4, dmin, dmax + 3)[None].astype(np.float32))
+            o2, c2 = ctx.wta_windowed_dev(cv, NDIR, fix, refine, wlo, whi)
+            res[mode] += (o2.download(), c2.download())
+            for h in (o, c, o2, c2, wlo, whi):
+                h.free()
+        os.environ.pop("MGM_HIP_REL", None)
+    assert "k_pass_rel" in res["2"][2], res["2"][2]
+    assert "k_pass_rel" not in res["0"][2], res["0"][2]
+    for k, what in ((0, "disparity"), (1, "cost"), (3, "windowed disparity"), (4, "windowed cost")):
+        a, b = res["2"][k], res["0"][k]
+        # a pixel without a finite S: NaN label on both sides
+        assert ndiff(a, b) == 0, (what, int(ndiff(a, b)))
+
+
+def test_rel_is_not_taken_where_it_does_not_apply():
+    nx, ny, dmin, dmax = 80, 48, -90, 10
+    u, v, gt = synth.stereo_pair(nx, ny, -60, 0, seed=3)
+    os.environ.pop("MGM_HIP_REL", None)
+    with mgm_amd.Context(0) as ctx:
+        # windows wider than 62 labels -> the dense hull
+        lo, hi = ranges(gt, dmin, dmax, 40, 9)
+        cv = ctx.costvolume(u, v, lo, hi, "none", "census", float("inf"), 5)
+        ctx.timing(True)
+        ctx.aggregate_dev(cv, 8.0, 32.0, 8, 3, 0, 1, None, "vfit")
+        assert "k_pass_rel" not in [n for n, _ in ctx.timings()]
+        # TSGM = 2 without weights is another update function -> the dense hull; S wanted -> the dense hull
+        lo, hi = ranges(gt, dmin, dmax, 8, 9)
+        cv2 = ctx.costvolume(u, v, lo, hi, "none", "census", float("inf"), 5)
+        ctx.timing_reset()
+        ctx.aggregate_dev(cv2, 8.0, 32.0, 4, 2, 0, 1, None, "vfit")
+        S, _, _ = ctx.aggregate_dev(cv2, 8.0, 32.0, 4, 3, 0, 1, None, "vfit", want_S=True)
+        assert "k_pass_rel" not in [n for n, _ in ctx.timings()] and S is not None
+        ctx.timing_reset()
+        ctx.aggregate_dev(cv2, 8.0, 32.0, 4, 3, 0, 1, None, "vfit")  # unit weights, Hirschmueller: a tie -> the hull's queue kernels
+        assert "k_pass_rel" not in [n for n, _ in ctx.timings()]
+        ctx.timing_reset()
+        ctx.aggregate_dev(cv2, 2.0, 30.0, 4, 3, 1, 1, None, "vfit")  # FH: the range-proportional kernels
+        assert "k_pass_rel" in [n for n, _ in ctx.timings()]
