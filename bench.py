@@ -441,6 +441,10 @@ class Env:
         else:
             import mgm_amd
             self.ctx = mgm_amd.Context(self.local)
+            # a long-lived context: let it pick the fastest of a few physical placements of every new workspace (round 5:
+            # identical launches sit on plateaus up to 16 % apart depending on the pages hipMalloc handed out; the tuning runs in
+            # the warm-up steps, never in a timed region -- a timed block only ever reuses the workspace of the steps before it)
+            self.ctx.set_placement_tries(int(os.environ.get("MGM_BENCH_PLACE_TRIES", "4")))
 
     def sync_all(self):
         if not self.stub:

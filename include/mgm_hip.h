@@ -80,6 +80,15 @@ int mgm_ctx_set_workspace_limit(mgm_ctx *ctx, unsigned long long bytes);
  * returned by the call that made it run.  A call that does not fit the waiting ones (other geometry or settings, S
  * wanted) makes them run first.  Synchronises; MGM_ERR_INVALID for a depth outside 1..16. */
 int mgm_ctx_set_pipeline(mgm_ctx *ctx, int depth);
+/* PLACEMENT of the Lr workspace.  Identical launches run on plateaus up to 16 % apart depending on which physical pages the
+ * allocator handed out for the workspace (docs/experiments.md, rounds 4 and 5: same code, data and virtual address).  With
+ * tries = n >= 2 the context, whenever an aggregation has just (re)allocated its workspace, times that aggregation's pass
+ * launch on up to n allocations -- the earlier ones held meanwhile, so that each lands on other pages -- and keeps the
+ * fastest.  Results do not change (the launch is simply repeated on the same inputs); the first aggregation after a
+ * (re)allocation takes n - 1 allocations and 2 n - 1 launches longer, and needs room for two workspaces (skipped when the
+ * device does not have it).  0 (default) / 1: take what the allocator gives.  For long-lived contexts (resident mode,
+ * services, benchmarks); a one-shot command line would pay more than it gains. */
+int mgm_ctx_set_placement_tries(mgm_ctx *ctx, int tries);
 /* Free and total device memory in bytes as the runtime sees them now (hipMemGetInfo on the context's device): what a
  * caller sizes its batches -- or mgm_ctx_set_workspace_limit -- with.  Either pointer may be NULL. */
 int mgm_ctx_mem_info(mgm_ctx *ctx, unsigned long long *free_bytes, unsigned long long *total_bytes);
@@ -245,6 +254,11 @@ int mgm_multi_aggregate(mgm_multi *m, const mgm_cv *const *C, const mgm_img *con
 /* Test/diagnostic aid: copy pass `pass`'s Lr volume of the LAST mgm_aggregate
  * call on this ctx into `dense` ([ny][nx][L]). */
 int mgm_debug_download_lr(mgm_ctx *ctx, int pass, float *dense);
+
+/* Diagnostic (tools/bimodal_probe.py): the rate, in GB/s, at which the store pattern of the pass kernels -- `nstreams`
+ * volumes at the stride of the context's last aggregation, written side by side -- lands on the Lr workspace where the
+ * allocator placed it.  MGM_ERR_INVALID before the context's first aggregation. */
+int mgm_debug_probe_workspace(mgm_ctx *ctx, int nstreams, float *gbps);
 
 /* Device self-test: compares the kernels' three-operation exact x/3 against IEEE
  * division for all 2^32 float32 inputs; *nbad receives the number of inputs

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "mgm_wta_windowed_dev", "mgm_update_ranges_dev", "mgm_costvolume_build_ranged_dev",
     "mgm_multi_create", "mgm_multi_destroy", "mgm_multi_size", "mgm_multi_ctx", "mgm_multi_last_error", "mgm_multi_plan",
     "mgm_multi_aggregate", "mgm_multi_transport", "mgm_img_device", "mgm_cv_device", "mgm_aggregate_passes_at_dev",
-    "mgm_ctx_set_workspace_limit", "mgm_ctx_mem_info", "mgm_ctx_set_pipeline", "mgm_img_update",
+    "mgm_ctx_set_workspace_limit", "mgm_ctx_mem_info", "mgm_ctx_set_pipeline", "mgm_img_update", "mgm_debug_probe_workspace", "mgm_ctx_set_placement_tries",
 ]
 
 MGM_OK, MGM_ERR_INVALID, MGM_ERR_UNSUPPORTED, MGM_ERR_HIP, MGM_ERR_NOMEM, MGM_ERR_INTERNAL = range(6)
@@ -72,6 +72,8 @@ def load_library():
     L.mgm_img_upload.argtypes = [vp, fp, i, i, i, pp]
     L.mgm_img_download.argtypes = [vp, vp, fp]
     L.mgm_img_update.argtypes = [vp, vp, fp]
+    L.mgm_debug_probe_workspace.argtypes = [vp, i, C.POINTER(f)]
+    L.mgm_ctx_set_placement_tries.argtypes = [vp, i]
     L.mgm_img_dims.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.mgm_img_device_ptr.argtypes = [vp]
     L.mgm_img_device_ptr.restype = vp
@@ -394,6 +396,14 @@ class Context:
     def wta_rows_dev(self, Cv, row0, nrows, lr_slabs_ptr, NDIR, fix_overcount, refine, out_ptr, outcost_ptr):
         self._chk(self.lib.mgm_wta_rows_dev(self.h, Cv.h, row0, nrows, lr_slabs_ptr, NDIR, fix_overcount,
                                             refine.encode() if refine else None, out_ptr, outcost_ptr))
+
+    def set_placement_tries(self, tries):
+        self._chk(self.lib.mgm_ctx_set_placement_tries(self.h, tries))
+
+    def probe_workspace(self, nstreams=8):
+        g = C.c_float()
+        self._chk(self.lib.mgm_debug_probe_workspace(self.h, nstreams, C.byref(g)))
+        return g.value
 
     def selftest_div3(self):
         n = C.c_ulonglong(0)

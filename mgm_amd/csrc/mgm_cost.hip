@@ -541,6 +541,21 @@ hipError_t launch_wneed(const unsigned *sel, int nx, int ny, int MGM, const int 
     return hipGetLastError();
 }
 
+// Placement probe (round 5): the store pattern of the pass kernels on the Lr workspace without their arithmetic -- `nstreams`
+// volumes `stride` floats apart written at the same offsets at once, 16 bytes per lane.  What it is for: mgm_ctx.hip, reserve_lr.
+__global__ void __launch_bounds__(256) k_probe_streams(float *base, long long stride, int nstreams, long long floats_per_stream)
+{
+    const long long n4 = floats_per_stream / 4;
+    const float4 v = make_float4(1.0f, 2.0f, 3.0f, 4.0f);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        for (int q = 0; q < nstreams; q++) reinterpret_cast<float4 *>(base + q * stride)[i] = v;
+}
+hipError_t launch_probe_streams(float *base, long long stride, int nstreams, long long floats_per_stream, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_probe_streams, dim3(256 * 16), dim3(256), 0, s, base, stride, nstreams, floats_per_stream);
+    return hipGetLastError();
+}
+
 // Debug check of the self-validating hand-off slabs (mgm_pass2.hip, TAGS): after a launch EVERY word of the slots its
 // passes own must carry the launch's tag in its sign bit -- the invariant the protocol rests on ("each slot is written
 // exactly once per launch of its pass").  Counts the words that do not.

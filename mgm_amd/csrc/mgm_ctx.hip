@@ -330,6 +330,13 @@ int mgm_ctx_set_workspace_limit(mgm_ctx *c, unsigned long long bytes)
     return MGM_OK;
 }
 
+int mgm_ctx_set_placement_tries(mgm_ctx *c, int tries)
+{
+    if (!c || tries < 0 || tries > 8) return MGM_ERR_INVALID;
+    c->place_tries = tries;
+    return MGM_OK;
+}
+
 int mgm_ctx_mem_info(mgm_ctx *c, unsigned long long *free_bytes, unsigned long long *total_bytes)
 {
     if (!c) return MGM_ERR_INVALID;

@@ -232,6 +232,7 @@ hipError_t launch_wsel(const float *w8, long long npix, unsigned *sel, hipStream
 // ... and which of the two transforms of a pixel anybody reads: out[q] = sel[q] | need << 8 (k_wneed; d[pass][k] = neighbour offsets
 // of the reference's pass table, plane[pass][k] = their weight planes)
 hipError_t launch_wneed(const unsigned *sel, int nx, int ny, int MGM, const int (*d)[4][2], const int (*plane)[4], unsigned *out, hipStream_t s);
+hipError_t launch_probe_streams(float *base, long long stride, int nstreams, long long floats_per_stream, hipStream_t s);
 hipError_t launch_check_tags(const float *slabs, long long nwords, unsigned tag, unsigned *count, hipStream_t s);
 hipError_t launch_xcc_census(unsigned *mask, hipStream_t s);
 

@@ -112,6 +112,11 @@ struct mgm_ctx {
     };
     int pipe_depth = 1;
     std::vector<PendingAgg> pend;
+    // mgm_ctx_set_placement_tries: how many physical placements of a NEW Lr workspace the context may try (0: take what the
+    // allocator gives); placed_ptr / placed_cap: the allocation that has been through it
+    int place_tries = 0;
+    const void *placed_ptr = nullptr;
+    size_t placed_cap = 0;
     size_t ws_limit = 0;  // mgm_ctx_set_workspace_limit: cap on the Lr + hand-off workspace of one pass launch (0 = none)
     int debug_stats = 0;  // MGM_HIP_DEBUG_STATS=1: per-workgroup timing summary of K3 on stderr
     unsigned *h_words = nullptr;  // pinned mirror of the control words

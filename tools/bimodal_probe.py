@@ -9,7 +9,9 @@ import mgm_amd
 
 w = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+import os
 with mgm_amd.Context(0) as c:
+    c.set_placement_tries(int(os.environ.get("PLACE_TRIES", "0")))  # mgm_ctx_set_placement_tries: keep the fastest of n placements
     ims = []
     for b in range(B):
         u, v, _ = bench.pair_of(w, b)
@@ -27,6 +29,8 @@ with mgm_amd.Context(0) as c:
             _, outs, outcs = c.aggregate_batch_dev(cvs, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, None, "vfit", outs, outcs)
         c.synchronize()
         t = [ms for n, ms in c.timings() if n.startswith("k_pass")]
-        print("allocation %d: lr at 0x%x  K3 min %.2f  median %.2f  max %.2f ms" % (rep, c.lr_device_ptr(0) or 0, min(t), float(np.median(t)), max(t)), flush=True)
+        probes = [c.probe_workspace(n) for n in (1, 4, 8, 16)]
+        print("allocation %d: lr at 0x%x  K3 min %.2f  median %.2f  max %.2f ms   store-pattern probe (1/4/8/16 streams) %s GB/s" %
+              (rep, c.lr_device_ptr(0) or 0, min(t), float(np.median(t)), max(t), " ".join("%.0f" % g for g in probes)), flush=True)
         ballast = c.new_image(1024, 1024 * (1 + rep * 3))  # shift where the next allocation lands
         c.trim()
