@@ -13,6 +13,9 @@ class _Handle:
     def free(self):
         pass
 
+    def update(self, a):
+        pass
+
 
 class StubContext:
     def __init__(self, device=0):
@@ -28,6 +31,21 @@ class StubContext:
         if self._timing:
             self._t += [("k_census", 0.01), ("k_census", 0.01), ("k_cost", 0.1)]
         return into if into is not None else _Handle()
+
+    def costvolume_ranged_dev(self, u, v, dminI, dmaxI, hull_min, hull_max, prefilter="none", distance="ad", truncDist=float("inf"),
+                              census_win=3, into=None):
+        return self.costvolume_dev(u, v, hull_min, hull_max, prefilter, distance, truncDist, census_win, into)
+
+    def upload_volume(self, dense, dmin):
+        return _Handle(getattr(dense, "shape", None))
+
+    def update_ranges_dev(self, outoff, dminI, dmaxI, slack=3, radius=2):
+        pass
+
+    def wta_windowed_dev(self, Cv, NDIR, fix_overcount, refine, dminI, dmaxI, out=None, outcost=None):
+        if self._timing:
+            self._t += [("k_wta", 0.5)]
+        return out, outcost
 
     def weights_dev(self, u, aP, aThresh, into=None):
         return into if into is not None else _Handle()

@@ -229,6 +229,14 @@ def test_single_rank_default_line_has_both_legs():
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1 and d["n_gpus"] == 1
     assert d["cfg5_replicas"]["n_gpus"] == 1 and d["directions"]["ranks"] == 1 and d["directions"]["transport"] == "single"
+    # the driver's line carries the one-pair legs and the round-5 legs (range images, TSGM_ITER, the fall-back kernels)
+    v = d["variants"]
+    assert "error" not in v, v.get("error")
+    for k in ("cfg3 x1", "cfg3 x2", "cfg2 x1", "cfg2 x2", "cfg1s x2", "cfg3r x1", "cfg3i2 x1", "cfg3w3 x1", "cfg3L1536 x1", "cfg3nan x1"):
+        assert v[k]["value"] > 0 and "roofline_frac" in v[k], k
+    assert "frac_range_proportional" in v["cfg3r x1"]
+    r = d["roofline"]
+    assert 0 < r["moved_over_algorithmic"] <= 1.0 and r["frac_of_achievable"] > 0 and isinstance(r["saturated"], bool)
 
 
 def test_exchange_rounds_and_timeout():
