@@ -99,3 +99,49 @@ def test_rel_is_not_taken_where_it_does_not_apply():
         ctx.timing_reset()
         ctx.aggregate_dev(cv2, 2.0, 30.0, 4, 3, 1, 1, None, "vfit")  # FH: the range-proportional kernels
         assert "k_pass_rel" in [n for n, _ in ctx.timings()]
+
+
+FUZZ_N = int(os.environ.get("MGM_FUZZ_N", "0"))
+FUZZ_BASE = int(os.environ.get("MGM_FUZZ_BASE", "0"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + (FUZZ_N or 24)))
+def test_rel_random_cases_match_dense_hull(seed):
+    """Random shapes, windows, potentials, neighbour counts, weights, refinements: range-proportional kernels == dense hull."""
+    rng = np.random.default_rng(991000 + seed)
+    nx, ny = int(rng.integers(20, 140)), int(rng.integers(18, 100))
+    dmin = -int(rng.integers(20, 120))
+    dmax = int(rng.integers(0, 30))
+    half = int(rng.integers(1, 29))
+    FH = int(rng.integers(0, 2))
+    MGM = int(rng.choice([1, 3, 4]))
+    NDIR = int(rng.choice([1, 2, 4, 8]))
+    P1 = float(rng.choice([0.75, 1.5, 2.0, 8.0]))
+    P2 = float(rng.choice([9.0, 32.0, 40.0, 20000.0]))
+    wkind = rng.choice(["none", "three", "image"])
+    refine = rng.choice([None, "vfit", "parabola", "cubic", "parabolaOCV"])
+    fix = int(rng.integers(0, 2))
+    win = int(rng.choice([3, 5]))
+    u, v, gt = synth.stereo_pair(nx, ny, dmin * 3 // 4, max(0, dmax * 3 // 4), seed=seed)
+    lo, hi = ranges(gt, dmin, dmax, half, seed, jitter=int(rng.integers(0, 3)))
+    os.environ["MGM_HIP_REL"] = "2"
+    res = {}
+    with mgm_amd.Context(0) as ctx:
+        cv = ctx.costvolume(u, v, lo, hi, "none", "census", float("inf"), win)
+        w8 = None
+        if wkind == "three":
+            w8 = ctx.upload_image(rng.choice(np.array([1.0, 2.5, 4.0], np.float32), size=(8, ny, nx), p=[0.6, 0.25, 0.15]))
+        elif wkind == "image":
+            w8 = ctx.weights_dev(ctx.upload_image(u), 4.0, 12.0)
+        for mode in ("2", "0"):
+            os.environ["MGM_HIP_REL"] = mode
+            ctx.timing(True)
+            ctx.timing_reset()
+            _, o, c = ctx.aggregate_dev(cv, P1, P2, NDIR, MGM, FH, fix, w8, refine)
+            names = [n for n, _ in ctx.timings()]
+            ctx.timing(False)
+            res[mode] = (o.download(), c.download(), names)
+        os.environ.pop("MGM_HIP_REL", None)
+    what = (seed, nx, ny, dmin, dmax, half, FH, MGM, NDIR, P1, P2, wkind, refine, fix, win)
+    assert "k_pass_rel" in res["2"][2] and "k_pass_rel" not in res["0"][2], what
+    assert ndiff(res["2"][0], res["0"][0]) == 0 and ndiff(res["2"][1], res["0"][1]) == 0, what

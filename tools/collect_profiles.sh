@@ -40,8 +40,8 @@ for wb in $PROFILED; do
   fi
   rm -rf "$OUT/kt" "$OUT/fetch" "$OUT/write"
 done
-# the launch plan against every override on shapes it was not tuned on (tools/plan_sweep.py)
-timeout 1500 python tools/plan_sweep.py > "$OUT/plan_sweep.txt" 2> "$OUT/plan_sweep.err"
+# the launch plan against every override on shapes it was not tuned on (tools/plan_sweep.py; SKIP_SWEEP=1 leaves it out)
+[ -z "${SKIP_SWEEP:-}" ] && timeout 1500 python tools/plan_sweep.py > "$OUT/plan_sweep.txt" 2> "$OUT/plan_sweep.err"
 # the single-GPU ingredients of DESIGN.md section 6's direction-sharding model, and the wall time of the whole command line
 timeout 600 python tools/time_passes.py cfg4 > "$OUT/cfg4_pass_blocks.txt" 2>&1
 for i in 1 2 3; do MGM_HIP_STATS=1 bash tools/cli_fullsize.sh 2>&1 | grep -v "^disp\|^cost"; sleep 2; done > "$OUT/cli_fullsize.txt" 2>&1
@@ -56,6 +56,6 @@ for l in open("gpurun_out/profiles/bench_lines.jsonl"):
     a = d["roofline"]["avg_launch_ms"]
     print(d["config"]["workload"][:8], "B", d["config"].get("pairs_per_step"), "D", d["config"].get("pipeline_depth"), "value", round(d["value"], 2), "ms/step", round(d["ms_per_step"], 2),
           "K2", round(a.get("k_cost", 0), 3),
-          "K3", round(a.get("k_pass2", a.get("k_pass", 0)), 2), "wta", round(a["k_wta"], 2), "frac", round(d["roofline"]["frac"], 3),
+          "K3", round(next((a[k] for k in ("k_pass2", "k_pass", "k_pass_rel", "k_pass_exact") if k in a), 0), 2), "wta", round(a["k_wta"], 2), "frac", round(d["roofline"]["frac"], 3),
           "parity", (d.get("parity") or {}).get("status"), "cpu", d.get("cpu_baseline", {}).get("value"))
 PY

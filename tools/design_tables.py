@@ -14,7 +14,7 @@ lines = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", rnd + "_benc
 def row(d):
     a, c = d["roofline"]["avg_launch_ms"], d["config"]
     return (c["workload"].split(":")[0], c.get("pairs_per_step"), c.get("pipeline_depth", 1), d["value"], a.get("k_cost", 0),
-            a.get("k_pass2", a.get("k_pass", 0)), a.get("k_wta", 0), d["roofline"]["frac"])
+            next((a[k] for k in ("k_pass2", "k_pass", "k_pass_rel", "k_pass_exact") if k in a), 0), a.get("k_wta", 0), d["roofline"]["frac"])
 
 
 rows = [row(d) for d in lines]
