@@ -610,7 +610,24 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
             // (launches that run two bands per CU keep their queues: with the doubled step the pinned dealing measured 5 % FASTER
             // for two and four 256-label FH volumes although the model says otherwise -- 9.67 against 10.18 ms, 17.7 against 18.3)
             one_queue = xcdq && (dev().xcdq == 2 || forced > 0 || (forced < 0 && p.wg_per_cu < 2 && t_one * 1.04 < t_q));
-            tasks = (xcdq && !one_queue) ? ord_q : ord_one;
+            const bool sim_ok = ((xcdq && !one_queue) ? t_q : t_one) < 1e299 && ((xcdq && !one_queue) ? ord_q : ord_one).size() == tasks.size();
+            if (sim_ok) {
+                tasks = (xcdq && !one_queue) ? ord_q : ord_one;
+            } else {
+                // (never seen: the simulation gave up.  Its leftovers are NOT a valid order -- a strip's band would precede the
+                // other strip's band before it -- so the launch takes the sorted order: longest remaining chain first, which is one)
+                const double lag1 = tags ? 3.0 : 10.0;
+                auto rem1 = [&](const int2 &t) {
+                    const PassGeom &g = p.g[t.x % kMaxDirs];
+                    const int b = t.y & 0xffff, st = (t.y >> 16) & 0xff;
+                    const double walk = (g.nstrips == 2 ? (st == 0 ? g.split : g.LL - g.split) + R - 1 : g.LL) + (double)g.slope * R;
+                    return (double)(g.nbands - 1 - b) * (g.slope * R + lag1) + walk;
+                };
+                std::stable_sort(tasks.begin(), tasks.end(), [&](const int2 &a, const int2 &b) {
+                    const double ra = rem1(a), rb = rem1(b);
+                    return ra != rb ? ra > rb : a.x < b.x;
+                });
+            }
             if (tune_num("show_plan", 0))
                 fprintf(stderr, "[mgm plan] simulated makespan (steps): one queue %.0f, %d queues (block %d) %.0f -> %s\n", t_one, nq, QK >= (1 << 20) ? 0 : QK, t_q,
                         one_queue ? "one queue" : (xcdq ? "per-XCD queues" : "ticket counter"));
