@@ -454,7 +454,10 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
     // weighted kernels: the min-convolution runs over the RECEIVING pixel's range) -> 14.0 + 1.5 ms; free-form weights,
     // Hirschmueller: 11.4 + 3.9 -> 7.1 + 1.5; unit weights, Hirschmueller: 4.75 + 3.9 on the hull's queue kernels against
     // 7.1 + 1.5 + 0.45 (gather) -- a tie, and those keep the hull (MGM_HIP_TUNE=rel=2 sends them here too).
-    const bool rel_pays = use_fh > 0 || (w8 && w8[0]) || tune_num("rel", 1) >= 2;
+    // (round 5, later: unit-weight Hirschmueller volumes publish E on the producer side there, k_pass_rel PUBE: one volume 7.5 + 1.5 +
+    // 0.45 ms against 4.6 + 3.9 -- still a tie --, two 10.5 + 2.9 + 0.9 against 9.2 + 7.7, four 16.0 + 5.9 + 1.7 against 15.2 + 14.8:
+    // batches of them go)
+    const bool rel_pays = use_fh > 0 || (w8 && w8[0]) || n >= 2 || tune_num("rel", 1) >= 2;
     if (!S && MGM != 2 && P2 < __builtin_huge_valf() && rel_pays && rel_enabled()) {
         bool all = true;
         for (int v = 0; v < n && all; v++) {

@@ -128,9 +128,9 @@ struct RelParams {
 };
 hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi, long long npix, int L, int dmin, uint8_t *rel8, int *relb,
                              unsigned *flag, hipStream_t s);
-hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, hipStream_t s);
+hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, bool one_per_cu, hipStream_t s);
 int pass_rel_lines();
-int pass_rel_hand_floats(bool fh);
+int pass_rel_hand_floats(bool one_slab);
 struct WtaRelParams {
     const uint8_t *c8;
     const int *base;

@@ -70,6 +70,19 @@ hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi,
     return hipGetLastError();
 }
 
+// write-through (sc1) stores in 16-byte pieces: narrow sc1 stores are one fabric write each (MI355X_MICROARCH.md, "stores of each
+// flavour"; the second build's hand-off learned it in round 3) -- the band hand-off below leaves as 16 x 16 bytes per slab, not 64 x 4
+typedef float relf4 __attribute__((ext_vector_type(4)));
+typedef float relf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rel_st_sc1_x4(float *p, relf4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void rel_st_sc1_x2(float *p, relf2 v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 // ---- the kernel ----------------------------------------------------------------------------------------------------------
 // Memory side on a LOADER wave (the 16th of the workgroup), as in the second build: everything a step reads from memory --
 // the cost bytes and records of the band's 15 pixels (one 16-byte load per lane: lane 4 r + c fetches bytes 16 c .. of line
@@ -77,11 +90,16 @@ hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi,
 // written to LDS rings one step ahead; the compute waves touch only LDS and issue stores, so nothing makes them wait for
 // memory (the first version loaded in the compute waves and spent 4-9 us per step in vmcnt(0) drains: 19 ms for a
 // 1920x1080 volume of 49-label windows; the step is now what its arithmetic costs).
-template <bool FH>
+// PUBE (unit weights, Hirschmueller): the transform does not depend on the reader then, so the producer publishes
+// E[k] = fmin(fmin(L[k], N[k] + P1), m + P2) - m once (one slab; its "minimum" word carries FAR = (m + P2) - m, what the
+// expression gives for a disparity the neighbour does not have: L = N = +INF there) and the reader only adds -- the
+// terms of update_costW with DeltaI = 1 (mgm_core.cc:104-137; P1 * 1.0f is P1), in its order.
+template <bool FH, bool PUBE>
 __global__ void __launch_bounds__((RR + 1) * 64) k_pass_rel(const RelParams P)
 {
-    constexpr int NS = FH ? 1 : 2;
-    constexpr int HS = NS * 64 + 2;  // floats per hand-off slot: slab(s), minimum, base
+    static_assert(!(FH && PUBE), "FH potentials convolve over the RECEIVING pixel's range: consumer side only");
+    constexpr int NS = (FH || PUBE) ? 1 : 2;
+    constexpr int HS = NS * 64 + 4;  // floats per hand-off slot: slab(s), minimum, base (+ 2 of padding: 16-byte pieces)
     using NbT = Nb<1, NS>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *ring = smem;                                   // [RR + 1][RD4][NS][64]   (row RR: the previous band's last line)
@@ -127,6 +145,10 @@ __global__ void __launch_bounds__((RR + 1) * 64) k_pass_rel(const RelParams P)
         uint4 Cst[LD];
         int4 Mst[LD];
         float Wst[LD], Hst[2][NS], Hx[2];  // (the hand-off slab is requested TWO steps ahead only: every step of lead is a step of lag per band)
+        // the producer's progress word, read WITHOUT waiting: requested every step, looked at two steps later -- in the steady state
+        // (this band a hand-off lag behind its predecessor) that value already covers what the step needs and the blocking poll
+        // below never runs (it did every fourth step -- the word moves in fours --, ~1.5 us of round trip each: a third of the step)
+        unsigned Pst[2] = {0u, 0u};
         unsigned known = 0;
         bool dead = false;
         auto ensure = [&](unsigned need) {  // wait until the producer band has published slabs [0, need)
@@ -163,6 +185,8 @@ __global__ void __launch_bounds__((RR + 1) * 64) k_pass_rel(const RelParams P)
         auto issue_hand = [&](int t, int u) {  // the previous band's slab that step t reads
             if (from_global) {
                 const int h = t;  // the first line of the band is at pixel t - 1 and reads pixel t of the line before it
+                known = Pst[u] > known ? Pst[u] : known;  // (requested two steps ago)
+                Pst[u] = __hip_atomic_load(prog_in, RLX_AGENT);
                 if (h >= 0 && h < LL) {
                     ensure((unsigned)h + 1u);
                     const unsigned *src = reinterpret_cast<const unsigned *>(hand_in + (long long)h * HS);
@@ -229,9 +253,9 @@ __global__ void __launch_bounds__((RR + 1) * 64) k_pass_rel(const RelParams P)
         const int idx = lane + sh;
         const bool in = (unsigned)idx < 64u;
         const float *src = ring + ((row * RD4 + slot) * NS) * 64;
-#pragma unroll
-        for (int q = 0; q < NS; q++) nb.w[q][0] = in ? src[q * 64 + (in ? idx : 0)] : f_inf();
         nb.m = ringm[row * RD4 + slot];
+#pragma unroll
+        for (int q = 0; q < NS; q++) nb.w[q][0] = in ? src[q * 64 + (in ? idx : 0)] : (PUBE ? nb.m : f_inf());
     };
 
     lds_barrier();  // B0: the loader's first step has landed
@@ -258,7 +282,15 @@ __global__ void __launch_bounds__((RR + 1) * 64) k_pass_rel(const RelParams P)
                 if (!f0 || MGM >= 4) fetch(prow, i + 1, bp, nb_f);
                 const float4 w4 = *reinterpret_cast<const float4 *>(wring + (sl * RR + r) * 4);
                 const float D[4] = {w4.x, w4.y, w4.z, w4.w};
-                if constexpr (!FH) {
+                if constexpr (PUBE) {
+                    // e = 0; e += t1 - m1; ... in the pass's order (0 + x is x: x >= +0); Lp = C + e / howmany
+                    const NbT &n1 = f0 ? nb_i : nb_f, &n2 = f0 ? nb_s : nb_b, &n3 = f0 ? nb_b : nb_s, &n4 = f0 ? nb_f : nb_i;
+                    float e = n1.w[0][0];
+                    if (MGM >= 2) e += n2.w[0][0];
+                    if (MGM >= 3) e += n3.w[0][0];
+                    if (MGM >= 4) e += n4.w[0][0];
+                    Lv[0] = Cv[0] + div_small_rt(e, MGM);
+                } else if constexpr (!FH) {
                     if (f0) combine_whirsch<1>(Cv, nb_i, nb_s, nb_b, nb_f, D, P1, P2, MGM, Lv);
                     else combine_whirsch<1>(Cv, nb_f, nb_b, nb_s, nb_i, D, P1, P2, MGM, Lv);
                 } else {
@@ -275,29 +307,41 @@ __global__ void __launch_bounds__((RR + 1) * 64) k_pass_rel(const RelParams P)
             const float m = slab_min<1>(Lv);
             float N[1] = {f_inf()};
             if constexpr (!FH) neighbour_min<1>(Lv, N);
+            float pub0 = Lv[0], pubm = m;  // what goes out: the raw slab and its minimum -- or (PUBE) E and FAR
+            if constexpr (PUBE) {
+                const float cap = m + P2;
+                pub0 = fminf(fminf(Lv[0], N[0] + P1), cap) - m;
+                pubm = cap - m;
+            }
             {
                 const int slot = i & (RD4 - 1);
                 float *dst = ring + ((r * RD4 + slot) * NS) * 64 + lane;
-                dst[0] = Lv[0];
-                if constexpr (!FH) dst[64] = N[0];
+                dst[0] = pub0;
+                if constexpr (NS == 2) dst[64] = N[0];
                 if (lane == 0) {
-                    ringm[r * RD4 + slot] = m;
+                    ringm[r * RD4 + slot] = pubm;
                     ringb[r * RD4 + slot] = bp;
                 }
             }
             if (to_global) {
-                unsigned *dst = reinterpret_cast<unsigned *>(hand_out + (long long)i * HS);
-                __hip_atomic_store(dst + lane, __builtin_bit_cast(unsigned, Lv[0]), RLX_AGENT);
-                if constexpr (!FH) __hip_atomic_store(dst + 64 + lane, __builtin_bit_cast(unsigned, N[0]), RLX_AGENT);
+                // the slab(s) just written to the ring, read back as 16-byte pieces by 16 lanes per slab (same wave: the LDS
+                // write has retired) and stored write-through; minimum and base as one 8-byte piece
+                float *dstg = hand_out + (long long)i * HS;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 16 * NS) {
+                    const float *srcl = ring + ((r * RD4 + (i & (RD4 - 1))) * NS) * 64 + lane * 4;
+                    const relf4 v = {srcl[0], srcl[1], srcl[2], srcl[3]};
+                    rel_st_sc1_x4(dstg + lane * 4, v);
+                }
                 if (lane == 0) {
-                    __hip_atomic_store(dst + NS * 64, __builtin_bit_cast(unsigned, m), RLX_AGENT);
-                    __hip_atomic_store(dst + NS * 64 + 1, (unsigned)bp, RLX_AGENT);
+                    const relf2 v = {pubm, __builtin_bit_cast(float, bp)};
+                    rel_st_sc1_x2(dstg + NS * 64, v);
                 }
                 // Progress is published PL steps LATE, every fourth pixel: this wave only issues stores, they retire in order,
                 // so once at most PL steps' worth of them are outstanding every store of pixel i - PL has reached memory -- a
                 // counted wait instead of draining the queue (which stalled the whole band for a store round trip every eighth
                 // step, and the band behind it for up to eight pixels more)
-                constexpr int SPS = 1 + NS + 2 + 1, PL = 3;  // store instructions per step (Lr, slab(s), minimum, base; + the word itself)
+                constexpr int SPS = 1 + 1 + 1 + 1, PL = 3;  // store instructions per step (Lr, slab pieces, minimum + base; + the word itself)
                 if (i == LL - 1) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_store(prog_out, (unsigned)LL, RLX_AGENT);
@@ -312,23 +356,27 @@ __global__ void __launch_bounds__((RR + 1) * 64) k_pass_rel(const RelParams P)
     }
 }
 
-hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, hipStream_t s)
+template <bool FH, bool PUBE>
+static hipError_t launch_rel_one(const RelParams &p, int ntasks, bool one_per_cu, hipStream_t s)
 {
-    const size_t shmem = sizeof(float) * ((size_t)(RR + 1) * RD4 * (fh ? 1 : 2) * 64 + 2 * (RR + 1) * RD4 + 2 * 4 * RR * 4) + 4 * RR * 64 + 16;
-    if (fh) {
-        auto kern = k_pass_rel<true>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(ntasks), dim3((RR + 1) * 64), shmem, s, p);
-    } else {
-        auto kern = k_pass_rel<false>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(ntasks), dim3((RR + 1) * 64), shmem, s, p);
-    }
+    constexpr int NS = (FH || PUBE) ? 1 : 2;
+    size_t shmem = sizeof(float) * ((size_t)(RR + 1) * RD4 * NS * 64 + 2 * (RR + 1) * RD4 + 2 * 4 * RR * 4) + 4 * RR * 64 + 16;
+    // Occupancy through the LDS request, as for the second build: two of these workgroups fit a CU and each then steps ~1.7x
+    // slower -- right for a batch (throughput), wrong for a launch bound by its chains of bands (one or two volumes)
+    if (one_per_cu && shmem < 81 * 1024) shmem = 81 * 1024;
+    auto kern = k_pass_rel<FH, PUBE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(ntasks), dim3((RR + 1) * 64), shmem, s, p);
     return hipGetLastError();
 }
+// pube: unit weights with Hirschmueller potentials (the producer publishes E)
+hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, bool one_per_cu, hipStream_t s)
+{
+    if (fh) return launch_rel_one<true, false>(p, ntasks, one_per_cu, s);
+    return pube ? launch_rel_one<false, true>(p, ntasks, one_per_cu, s) : launch_rel_one<false, false>(p, ntasks, one_per_cu, s);
+}
 int pass_rel_lines() { return RR; }
-int pass_rel_hand_floats(bool fh) { return (fh ? 1 : 2) * 64 + 2; }
+int pass_rel_hand_floats(bool one_slab) { return (one_slab ? 1 : 2) * 64 + 4; }
 
 }  // namespace mgm

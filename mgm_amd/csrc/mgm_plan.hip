@@ -1047,7 +1047,8 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     const int nx = C->nx, ny = C->ny;
     const long long npix = (long long)nx * ny;
     const bool fh = use_fh > 0;
-    const int R = pass_rel_lines(), HS = pass_rel_hand_floats(fh);
+    const bool pube = !fh && !(w8s && w8s[0]);  // unit weights, Hirschmueller: the producer publishes E (k_pass_rel, PUBE)
+    const int R = pass_rel_lines(), HS = pass_rel_hand_floats(fh || pube);
     int r;
     HIPCHK(c, hipSetDevice(c->device));
     if (int r0 = check_watchdog(c, false)) return r0;
@@ -1078,7 +1079,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
                 ch.push_back(k);
             }
         std::vector<int2> order;
-        (void)simulate_schedule(ch, 1, std::max(1, c->num_cu * 2), 1 << 20, order);
+        (void)simulate_schedule(ch, 1, std::max(1, c->num_cu * (nb <= 1 ? 1 : 2)), 1 << 20, order);
         for (int2 &t : order) t.y &= 0xffff;
         HIPCHK(c, hipStreamSynchronize(c->stream));  // (a launch that still reads the old table)
         if ((r = reserve(c, c->tasks_rel, sizeof(int2) * order.size()))) return r;
@@ -1120,7 +1121,9 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     HIPCHK(c, hipMemsetAsync(words + 4, 0, sizeof(unsigned) * (size_t)nb * kMaxDirs * kMaxBands, c->stream));
     {
         TimeScope t(c, "k_pass_rel");
-        HIPCHK(c, launch_pass_rel(p, c->ntasks_rel, fh, c->stream));
+        const long long wgs = tune_num("rel_wg", 0);  // (1 / 2: force one / two workgroups per CU)
+        const bool one_per_cu = wgs ? wgs == 1 : nb <= 1;  // (measured, Hirschmueller: x 1 7.5 against 9.6 ms, x 2 11.5 against 10.5, x 4 21.5 against 16.0)
+        HIPCHK(c, launch_pass_rel(p, c->ntasks_rel, fh, pube, one_per_cu, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->h_words + 1, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     c->pending_check = true;

@@ -1,0 +1,6 @@
+#!/bin/bash
+timeout 900 python -m pytest tests/test_gpu_rel.py -x -q 2>&1 | tail -3
+for cfg in "cfg3hr 1 2 1" "cfg3hr 1 2 2" "cfg3hr 2 2 1" "cfg3hr 2 2 2" "cfg3hr 4 2 1" "cfg3hr 4 2 2" "cfg3r 1 1 1" "cfg3r 1 1 2" "cfg3r 2 1 1" "cfg3r 2 1 2" "cfg3r 4 1 1" "cfg3r 4 1 2"; do
+  set -- $cfg
+  MGM_HIP_REL=$3 MGM_HIP_TUNE=rel_wg=$4 timeout 300 python bench.py --workload $1 --batch $2 --steps 5 --warmup 1 --repeats 0 --no-cpu-baseline --no-parity 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1 x$2 rel=$3 wg=$4', round(d['value'],1), {k:round(v,2) for k,v in d['kernel_ms_per_step'].items()})"
+done
