@@ -592,6 +592,10 @@ def roofline_of(w, B, avg, workload, step_ms=None, per_step=None):
         # pipelined steps: one pass launch serves D steps, so per-launch durations are not per-step figures; the aggregation
         # is priced against the WHOLE step's wall time instead -- an upper bound of its time (the step also holds K1 / K2)
         agg_ms = step_ms
+    rel = pass_name == "k_pass_rel"
+    hull_cells = cells
+    if rel:  # the range-proportional kernels walk only the labels each pixel OWNS: those are the cells 8(d)'s 12 B are due on
+        cells = float(nx) * ny * (2 * w["ragged"] + 1)
     alg_bytes = 12.0 * w["NDIR"] * cells * B
     achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
     cbytes = cost_bytes(w)
@@ -604,6 +608,10 @@ def roofline_of(w, B, avg, workload, step_ms=None, per_step=None):
     fmt = {pass_name: (cbytes + 4.0) * w["NDIR"] * cells * B,          # reads C once per direction, writes one Lr volume per direction
            "k_wta": (4.0 * w["NDIR"] + cbytes) * cells + 8.0 * nx * ny,  # reads NDIR Lr volumes + C, writes two W*H maps
            "k_cost": cbytes * cells}                                     # writes C (the images are negligible)
+    if rel:  # 64 one-byte cost slots and 64 fp32 Lr slots per pixel and direction, plus the 16-byte window record
+        slots = 64.0 * nx * ny
+        fmt = {pass_name: (1.0 + 4.0) * w["NDIR"] * slots * B + 16.0 * nx * ny * w["NDIR"] * B,
+               "k_wta": (4.0 * w["NDIR"] + 1.0) * slots + 24.0 * nx * ny, "k_cost": cbytes * hull_cells}
     per_kernel = {k: {"format_bytes": b, "GBps": b / (avg[k] * 1e-3) / 1e9, "frac": b / (avg[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                   for k, b in fmt.items() if k in avg}
     # How to READ the fraction: `frac` prices SURVEY 8(d)'s 12 B per cell and direction against the 8 TB/s spec
@@ -618,8 +626,11 @@ def roofline_of(w, B, avg, workload, step_ms=None, per_step=None):
     extra = {}
     if w.get("ragged"):  # what a range-proportional layout would be priced on: the labels that EXIST (mgm_costvolume.h:275-299)
         own = float(nx) * ny * (2 * w["ragged"] + 1)
-        extra = {"existing_cells_over_hull_cells": own / cells, "frac_range_proportional": 12.0 * w["NDIR"] * own * B / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "note": "frac prices the dense HULL (what the kernels walk); frac_range_proportional prices only the labels each pixel owns"}
+        extra = {"existing_cells_over_hull_cells": own / hull_cells, "frac_range_proportional": 12.0 * w["NDIR"] * own * B / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "frac_dense_hull_equivalent": 12.0 * w["NDIR"] * hull_cells * B / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "note": ("k_pass_rel walks only the labels each pixel owns: frac prices THOSE cells; frac_dense_hull_equivalent is what a dense-hull "
+                          "kernel would have to reach for the same time (may exceed 1)") if rel else
+                         "frac prices the dense HULL (what the kernels walk); frac_range_proportional prices only the labels each pixel owns"}
     return {**extra, "bound": "hbm", "kernel": "%s (one launch per batch of %d volumes) + k_wta (one launch per volume): the %d-direction aggregation" % (pass_name, B, w["NDIR"]),
             "moved_over_algorithmic": moved / alg_bytes, "moved_basis": "pmc counters" if traffic else "format bytes of the kernels' data layout",
             "frac_of_achievable": moved_gbs / HBM_ACHIEVABLE_GBS, "achievable_peak": HBM_ACHIEVABLE_GBS,

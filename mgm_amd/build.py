@@ -20,7 +20,8 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract
           "-Wall", "-Wno-unused-function"]
 # per-translation-unit extras (see the header comment of each file)
 # (source, object suffix, extra flags)
-UNITS = [("mgm_pass.hip", "", ["-fno-honor-nans"]), ("mgm_pass_rel.hip", "", ["-fno-honor-nans"])]
+REL_EXTRA = os.environ.get("MGM_REL_DEFINES", "").split()  # e.g. "-DMGM_REL_PHASES=1" (development build of the range-proportional kernels)
+UNITS = [("mgm_pass.hip", "", ["-fno-honor-nans"]), ("mgm_pass_rel.hip", "", ["-fno-honor-nans"] + REL_EXTRA)]
 P2_EXTRA = os.environ.get("MGM_P2_DEFINES", "").split()  # e.g. "-DMGM_P2_MAXD=3" (tuning experiments)
 UNITS += [("mgm_pass2.hip", "_lpl%d" % n, ["-fno-honor-nans", "-DMGM_P2_LPL=%d" % n] + P2_EXTRA) for n in (1, 2, 3, 4, 6, 8, 12, 16)]
 UNITS += [("mgm_pass2_dispatch.hip", "", P2_EXTRA), ("mgm_cost.hip", "", []), ("mgm_cost_fast.hip", "", []), ("mgm_wta.hip", "", []), ("mgm_post.hip", "", []),

@@ -123,13 +123,17 @@ struct RelParams {
     const int2 *tasks;  // ticket -> (volume*8 + pass, band)
     long long npix, nvol;
     int MGM, NDIR, pass0, LLmax, maxbands, weighted;
+    int pubq;           // the band's last line publishes its progress when (pixel & pubq) == 0: 0, 1, 3 (every, every second, every fourth pixel)
+    int ld, lead;       // steps of LDS-DMA the loader keeps in flight (2..5; every step of lead is a step of lag per band); pixels beyond the bare need its slow path waits for
     float P1, P2;
+    unsigned long long *tl;  // nullptr, or 8 words per work item (MGM_HIP_TIMELINE; tools/timeline.py): start, end, waited, slow paths, where, steps, polls
     PassGeom g[kMaxDirs];
 };
 hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi, long long npix, int L, int dmin, uint8_t *rel8, int *relb,
                              unsigned *flag, hipStream_t s);
-hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, bool one_per_cu, hipStream_t s);
+hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, int wg_per_cu, hipStream_t s);
 int pass_rel_lines();
+int pass_rel_phases();  // words per work item of phase clocks behind the timeline words (0: not a -DMGM_REL_PHASES=1 build)
 int pass_rel_hand_floats(bool one_slab);
 struct WtaRelParams {
     const uint8_t *c8;

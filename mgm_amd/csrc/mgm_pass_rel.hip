@@ -17,18 +17,54 @@
 // (mgm_core.cc:242-271: M[] is copied over [Lp.min, Lp.max]): combine_wfh masks to it.  Same neighbours, same operands,
 // same order as the dense kernels on the hull => the same bits on every label that exists.
 //
-// Structure: the first build's (mgm_pass.hip) -- one wavefront per scan line, 15 lines per workgroup in lock-step on the
-// slope-2 diagonal (+ a loader wave, see k_pass_rel), a 4-deep LDS ring per line (a slab is read by the next line at three consecutive steps, each time at
-// another shift), the band hand-off through global memory with progress words, work items by atomic ticket.  One label
-// slot per lane.  Not built here (the dense path keeps them): TSGM = 2 without weights (update_cost2 /
+// Structure: bands of 16 scan lines per workgroup in lock-step on the slope-2 diagonal -- 4 compute waves of FOUR lines each
+// (a pixel's 64 slots on a row of 16 lanes, 4 per lane: see k_pass_rel) + a loader wave that feeds LDS rings by LDS-DMA --, a
+// 4-deep LDS ring per line (a slab is read by the next line at three consecutive steps, each time at another shift), the band
+// hand-off through global memory with progress words, work items by atomic ticket.  Not built here (the dense path keeps them): TSGM = 2 without weights (update_cost2 /
 // update_cost2_trunclinear are other functions), windows wider than 62 labels, costs that are not bytes, P2 = +INF.
 #include "mgm_pass_common.h"
 
 namespace mgm {
 
-constexpr int RR = 15;   // lines per band = compute waves of a workgroup (+ 1 loader wave)
+#ifndef MGM_REL_PHASES
+#define MGM_REL_PHASES 0  // 1 (development build, MGM_REL_DEFINES=-DMGM_REL_PHASES=1): per work item, the clocks every wave spent computing /
+#endif                    // publishing / at the step barrier, and the loader issuing / waiting for its DMAs / at the barrier (with MGM_HIP_TIMELINE)
+constexpr int NW = 4;        // compute waves of a workgroup (+ 1 loader wave)
+constexpr int GL = 4;        // scan lines per wave: lane groups of 16 lanes, 4 label slots per lane
+constexpr int RR = NW * GL;  // lines per band
 constexpr int RD4 = 4;   // ring slots per line
-constexpr int LD = 4;    // steps of global loads the loader wave keeps in flight
+constexpr int SD = 8;    // slots of the rings the loader wave fills (costs, records, weights, the previous band's slabs)
+
+typedef __attribute__((address_space(3))) void *rel_lds_vptr;
+typedef const __attribute__((address_space(1))) void *rel_glb_vptr;
+// LDS-DMA: lane l moves 16 (4) bytes from its own source address to dst_base + 16 l (4 l): no VGPR round trip, so the
+// compiler has nothing to wait for, and the loader retires its loads with COUNTED waits (mgm_pass2.hip does the same)
+template <int AUX>
+__device__ __forceinline__ void rel_dma16(const void *src_lane, void *dst_base)
+{
+    __builtin_amdgcn_global_load_lds((rel_glb_vptr)src_lane, (rel_lds_vptr)dst_base, 16, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void rel_dma4(const void *src_lane, void *dst_base)
+{
+    __builtin_amdgcn_global_load_lds((rel_glb_vptr)src_lane, (rel_lds_vptr)dst_base, 4, 0, AUX);
+}
+constexpr int REL_SC1 = 16;  // agent-scope (L1-bypassing) cache policy bit
+template <int N>
+__device__ __forceinline__ void rel_wait_vmcnt()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// LDS read the compiler must not order against pending LDS-DMA itself (it would drain vmcnt): the counted wait has made
+// sure the word landed
+__device__ __forceinline__ unsigned rel_lds_read_opaque(const unsigned *p)
+{
+    unsigned v;
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned *)p;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
 
 // ---- the relative copy of a ragged volume ------------------------------------------------------------------------------
 // one thread per (pixel, slot): rel8[p][k] = byte code of C[p][base(p) + k - dmin] inside the pixel's window, 255 elsewhere;
@@ -83,36 +119,66 @@ __device__ __forceinline__ void rel_st_sc1_x2(float *p, relf2 v)
     asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
+// minimum over a row of 16 lanes, in every lane of the row (quad swaps, then the two mirrors: 4 DPP slots, no LDS crossbar)
+__device__ __forceinline__ float rel_row_min(float v)
+{
+    asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+    return v;
+}
+
 // ---- the kernel ----------------------------------------------------------------------------------------------------------
-// Memory side on a LOADER wave (the 16th of the workgroup), as in the second build: everything a step reads from memory --
-// the cost bytes and records of the band's 15 pixels (one 16-byte load per lane: lane 4 r + c fetches bytes 16 c .. of line
-// r's pixel), their edge weights, and the previous band's hand-off slab -- is requested LD steps ahead into registers and
-// written to LDS rings one step ahead; the compute waves touch only LDS and issue stores, so nothing makes them wait for
-// memory (the first version loaded in the compute waves and spent 4-9 us per step in vmcnt(0) drains: 19 ms for a
-// 1920x1080 volume of 49-label windows; the step is now what its arithmetic costs).
+// FOUR scan lines per wavefront: a pixel's 64 label slots sit on a ROW of 16 lanes (the unit of the DPP shifts), 4 slots per
+// lane, so one issue slot serves four pixels -- the first version of this file put one slot on a lane, one pixel on a wave,
+// and its step cost what a 256-label step of the dense kernels costs (min-convolutions: one per NEIGHBOUR here, the receiving
+// pixel's range shapes them) for a quarter of the labels: 14 ms per 1920x1080 volume of 55-label windows, VALU-bound.  The
+// lane groups of a wave are lines 4w .. 4w+3 of the band, each at its own pixel of the slope-2 diagonal; everything that
+// crosses lanes stays inside a row (rel_row_min, the scans with GROUPS = 4, neighbour_min with its edge flags), and lines
+// talk through the LDS rings exactly as before.
+// Memory side on a LOADER wave (the last of the workgroup), as in the second build: everything a step reads from memory --
+// the cost bytes and records of the band's 16 pixels, their edge weights, and the previous band's hand-off slot -- goes
+// straight into LDS rings by LDS-DMA, P.ld steps ahead, retired by COUNTED waits; the compute waves touch only LDS and
+// issue stores.  (With register loads the compiler drained vmcnt at every step: global_load .. s_waitcnt vmcnt(0).)
+// What bounds a step (profiles/r05_rel_phases.txt, a -DMGM_REL_PHASES=1 build): the compute waves' own instruction stream --
+// ~2000 clocks Hirschmueller, ~4300 FH, of which the loader needs 600; one wave per SIMD issues a wave64 instruction every
+// four clocks whatever their dependences (three min-convolutions side by side were no faster), so a single launch is bound
+// by instructions per step x steps of its chain of bands, a batch by VALU throughput.
 // PUBE (unit weights, Hirschmueller): the transform does not depend on the reader then, so the producer publishes
 // E[k] = fmin(fmin(L[k], N[k] + P1), m + P2) - m once (one slab; its "minimum" word carries FAR = (m + P2) - m, what the
 // expression gives for a disparity the neighbour does not have: L = N = +INF there) and the reader only adds -- the
 // terms of update_costW with DeltaI = 1 (mgm_core.cc:104-137; P1 * 1.0f is P1), in its order.
 template <bool FH, bool PUBE>
-__global__ void __launch_bounds__((RR + 1) * 64) k_pass_rel(const RelParams P)
+__global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
 {
     static_assert(!(FH && PUBE), "FH potentials convolve over the RECEIVING pixel's range: consumer side only");
     constexpr int NS = (FH || PUBE) ? 1 : 2;
     constexpr int HS = NS * 64 + 4;  // floats per hand-off slot: slab(s), minimum, base (+ 2 of padding: 16-byte pieces)
-    using NbT = Nb<1, NS>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *ring = smem;                                   // [RR + 1][RD4][NS][64]   (row RR: the previous band's last line)
-    float *ringm = ring + (RR + 1) * RD4 * NS * 64;       // [RR + 1][RD4]
-    int *ringb = reinterpret_cast<int *>(ringm + (RR + 1) * RD4);  // [RR + 1][RD4]
-    int *mring = ringb + (RR + 1) * RD4;                  // [4][RR][4]   records of the step's pixels: base, lo, hi
-    float *wring = reinterpret_cast<float *>(mring + 4 * RR * 4);  // [4][RR][4]   edge weights of the step's pixels
-    uint8_t *cring = reinterpret_cast<uint8_t *>(wring + 4 * RR * 4);  // [4][RR][64] cost bytes of the step's pixels
-    int *s_task = reinterpret_cast<int *>(cring + 4 * RR * 64);
+    // a ring entry = a hand-off slot: slab(s), then minimum, base, 2 words of padding -- HS floats, whole 16-byte pieces
+    float *ring = smem;                                    // [RR][RD4][HS]   what the lines of the band publish
+    float *hring = ring + RR * RD4 * HS;                   // [SD][HS]        the previous band's last line, by pixel & (SD - 1)
+    int *mring = reinterpret_cast<int *>(hring + SD * HS);  // [SD][RR][4]    records of the step's pixels: base, lo, hi
+    float *wring = reinterpret_cast<float *>(mring + SD * RR * 4);  // [SD][RR][4]   edge weights of the step's pixels
+    uint8_t *cring = reinterpret_cast<uint8_t *>(wring + SD * RR * 4);  // [SD][RR][64] cost bytes of the step's pixels
+    unsigned *hprog = reinterpret_cast<unsigned *>(cring + SD * RR * 64);  // [SD + 4]   the producer's progress word as the DMAs saw it
+    int *s_task = reinterpret_cast<int *>(hprog + SD + 4);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int r = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) *s_task = (int)atomicAdd(P.ticket, 1u);
+    if (tid == 0) {
+        *s_task = (int)atomicAdd(P.ticket, 1u);
+        if (P.tl) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            P.tl[(long long)*s_task * 8 + 0] = wall_clock64();
+            P.tl[(long long)*s_task * 8 + 4] = ((unsigned long long)(xcc & 15u) << 32) | hwid;
+        }
+    }
+    if (!P.weighted)  // unit weights: the ring holds ones, nothing is fetched
+        for (int k = tid; k < SD * RR * 4; k += (NW + 1) * 64) wring[k] = 1.0f;
     __syncthreads();
     const int2 tk = P.tasks[*s_task];
     const int vp = tk.x, band = tk.y;  // vp = volume*8 + pass
@@ -127,256 +193,314 @@ __global__ void __launch_bounds__((RR + 1) * 64) k_pass_rel(const RelParams P)
     float *hand_out = P.hand + ((long long)(vp * 2 + (band & 1)) * P.LLmax) * HS;
     const float *hand_in = P.hand + ((long long)(vp * 2 + ((band + 1) & 1)) * P.LLmax) * HS;
     unsigned *prog_out = P.prog + vp * P.maxbands + band;
-    const unsigned *prog_in = prog_out - 1;  // only dereferenced when band > 0
+    const unsigned *prog_in = band > 0 ? prog_out - 1 : prog_out;  // (band 0 issues the same DMAs, from its own words)
 
-    if (r == RR) {
+    if (r == NW) {
         // =========================== loader wave ===========================
+        // Step t reads: the cost bytes (one 16-byte piece per lane: lane 4 l + c has piece c of line l's pixel), the records
+        // (lane l < RR), the edge weights (lane 4 l + k: neighbour k of line l's pixel) of pixel t - 1 - 2 l of every line l,
+        // and pixel t of the previous band's last line.  All of it is requested LD steps ahead, straight into the rings'
+        // slot t & (SD - 1), every step the same number of DMA instructions (addresses clamped at the ends of a line: what
+        // lands for a pixel that does not exist is never looked at), retired by count: nothing here waits for a round trip
+        // except the slow path of the hand-off.
         const bool from_global = band > 0;
-        const int cl = lane >> 2, cpart = lane & 3;                 // cost bytes: line, 16-byte piece
-        const int cj = band * RR + (cl < RR ? cl : RR - 1);
-        const bool c_ok = cl < RR && cj < NL;
-        const long long cpix0 = g.base + (long long)(cj < NL ? cj : NL - 1) * g.jstep;
-        const int ml = lane < RR ? lane : RR - 1;                   // records: lane = line
-        const int mj = band * RR + ml;
-        const bool m_ok = lane < RR && mj < NL;
-        const long long mpix0 = g.base + (long long)(mj < NL ? mj : NL - 1) * g.jstep;
-        const int wk = lane & 3;                                    // weights: line lane / 4, neighbour lane % 4 (the cost lanes' split)
-        const long long wplane = (long long)g.wplane[wk] * P.npix;
-        uint4 Cst[LD];
-        int4 Mst[LD];
-        float Wst[LD], Hst[2][NS], Hx[2];  // (the hand-off slab is requested TWO steps ahead only: every step of lead is a step of lag per band)
-        // the producer's progress word, read WITHOUT waiting: requested every step, looked at two steps later -- in the steady state
-        // (this band a hand-off lag behind its predecessor) that value already covers what the step needs and the blocking poll
-        // below never runs (it did every fourth step -- the word moves in fours --, ~1.5 us of round trip each: a third of the step)
-        unsigned Pst[2] = {0u, 0u};
+        const bool weighted = P.weighted != 0;
+        const int cl = lane >> 2;
+        const int cj = min(band * RR + cl, NL - 1);
+        const long long cpix0 = g.base + (long long)cj * g.jstep;
+        const uint8_t *cptr = V.c8 + cpix0 * 64 + (lane & 3) * 16;
+        const float *wptr = weighted ? V.w8 + (long long)g.wplane[lane & 3] * P.npix + cpix0 : nullptr;
+        int ci = -1 - 2 * cl;
+        const int ml = lane < RR ? lane : RR - 1;
+        const int mj = min(band * RR + ml, NL - 1);
+        const int4 *mptr = reinterpret_cast<const int4 *>(V.base) + (g.base + (long long)mj * g.jstep);
+        int mi = -1 - 2 * ml;
+        const float *hptr = hand_in + lane * 4;
+        int ht = 0;
         unsigned known = 0;
         bool dead = false;
-        auto ensure = [&](unsigned need) {  // wait until the producer band has published slabs [0, need)
-            if (known >= need || dead) return;
-            unsigned spins = 0;
-            for (;;) {
-                known = __hip_atomic_load(prog_in, RLX_AGENT);
-                if (known >= need) break;
-                __builtin_amdgcn_s_sleep(4);
-                if (((++spins) & 1023u) == 0) {
-                    if (spins > SPIN_LIMIT || __hip_atomic_load(P.err, RLX_AGENT) != 0) {
-                        if (lane == 0) __hip_atomic_store(P.err, 1u, RLX_AGENT);
-                        dead = true;
-                        break;
+        unsigned long long tl_wait = 0, n_slow = 0, n_spin = 0;
+        auto issue = [&]() {  // everything step `ht` reads
+            const int slot = ht & (SD - 1);
+            rel_dma16<0>(cptr, cring + slot * RR * 64);
+            if (weighted) rel_dma4<0>(wptr, wring + slot * RR * 4);
+            {
+                const bool adv = ci >= 0 && ci < LL - 1;
+                cptr += adv ? istep * 64 : 0;
+                if (weighted) wptr += adv ? istep : 0;
+                ci++;
+            }
+            if (lane < RR) rel_dma16<0>(mptr, mring + slot * RR * 4);
+            {
+                const bool adv = mi >= 0 && mi < LL - 1;
+                mptr += adv ? istep : 0;
+                mi++;
+            }
+            const int h = ht < LL ? ht : LL - 1;
+            if (from_global && !dead && known < (unsigned)h + 1u) {
+                // slow path: the producer band is not far enough ahead.  Wait for a LEAD beyond the bare need: it publishes one
+                // pixel per step, so coming back at the first sufficient value would bring us here again at the next step.
+                const unsigned want = min((unsigned)h + 1u + (unsigned)P.lead, (unsigned)LL);
+                unsigned spins = 0;
+                const unsigned long long w0 = P.tl ? wall_clock64() : 0ull;
+                n_slow++;
+                for (;;) {
+                    n_spin++;
+                    if (lane == 0) rel_dma4<REL_SC1>(prog_in, hprog + SD);
+                    rel_wait_vmcnt<0>();
+                    known = (unsigned)__builtin_amdgcn_readfirstlane((int)rel_lds_read_opaque(hprog + SD));
+                    if (known >= want) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    if (((++spins) & 255u) == 0) {
+                        if (lane == 0) rel_dma4<REL_SC1>(P.err, hprog + SD + 1);
+                        rel_wait_vmcnt<0>();
+                        const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)rel_lds_read_opaque(hprog + SD + 1));
+                        if (spins > (SPIN_LIMIT >> 2) || e != 0) {
+                            if (lane == 0) __hip_atomic_store(P.err, 1u, RLX_AGENT);
+                            dead = true;
+                            break;
+                        }
                     }
                 }
+                if (P.tl) tl_wait += wall_clock64() - w0;
+            }
+            if (lane < 16 * NS + 1) rel_dma16<REL_SC1>(hptr, hring + slot * HS);
+            if (lane == 0) rel_dma4<REL_SC1>(prog_in, hprog + slot);
+            hptr += (ht < LL - 1) ? HS : 0;
+            ht++;
+        };
+        const int LD = P.ld;  // steps of DMA in flight (2 .. 5: the rings have SD = 8 slots, three of them being read)
+        auto retire = [&]() {  // all but the newest LD - 1 steps of DMA have landed
+            const int n = (weighted ? 5 : 4) * (LD - 1);
+            switch (n) {
+            case 4: rel_wait_vmcnt<4>(); break;
+            case 5: rel_wait_vmcnt<5>(); break;
+            case 8: rel_wait_vmcnt<8>(); break;
+            case 10: rel_wait_vmcnt<10>(); break;
+            case 12: rel_wait_vmcnt<12>(); break;
+            case 15: rel_wait_vmcnt<15>(); break;
+            case 16: rel_wait_vmcnt<16>(); break;
+            default: rel_wait_vmcnt<20>(); break;
             }
         };
-        auto issue = [&](int t, int u) {  // what step t reads, into register stage u
-            {
-                const int i = t - 1 - 2 * cl;
-                const bool ok = c_ok && i >= 0 && i < LL;
-                const long long pix = cpix0 + (long long)(ok ? i : 0) * istep;
-                Cst[u] = ok ? *reinterpret_cast<const uint4 *>(V.c8 + pix * 64 + cpart * 16) : make_uint4(~0u, ~0u, ~0u, ~0u);
-                Wst[u] = (ok && P.weighted) ? V.w8[wplane + pix] : 1.0f;
-            }
-            {
-                const int i = t - 1 - 2 * ml;
-                const bool ok = m_ok && i >= 0 && i < LL;
-                const long long pix = mpix0 + (long long)(ok ? i : 0) * istep;
-                Mst[u] = ok ? reinterpret_cast<const int4 *>(V.base)[pix] : make_int4(0, 0, 0, 0);
-            }
-        };
-        auto issue_hand = [&](int t, int u) {  // the previous band's slab that step t reads
-            if (from_global) {
-                const int h = t;  // the first line of the band is at pixel t - 1 and reads pixel t of the line before it
-                known = Pst[u] > known ? Pst[u] : known;  // (requested two steps ago)
-                Pst[u] = __hip_atomic_load(prog_in, RLX_AGENT);
-                if (h >= 0 && h < LL) {
-                    ensure((unsigned)h + 1u);
-                    const unsigned *src = reinterpret_cast<const unsigned *>(hand_in + (long long)h * HS);
-#pragma unroll
-                    for (int q = 0; q < NS; q++) Hst[u][q] = __builtin_bit_cast(float, __hip_atomic_load(src + q * 64 + lane, RLX_AGENT));
-                    Hx[u] = __builtin_bit_cast(float, __hip_atomic_load(src + NS * 64 + (lane & 1), RLX_AGENT));
-                }
-            }
-        };
-        auto commit = [&](int t, int u) {  // register stage u -> the rings, for step t
-            const int sl = t & 3;
-            if (cl < RR) {
-                *reinterpret_cast<uint4 *>(cring + ((sl * RR + cl) * 64 + cpart * 16)) = Cst[u];
-                wring[(sl * RR + cl) * 4 + wk] = Wst[u];
-            }
-            if (lane < RR) *reinterpret_cast<int4 *>(mring + (sl * RR + lane) * 4) = Mst[u];
-        };
-        auto commit_hand = [&](int t, int u) {
-            if (from_global && t >= 0 && t < LL) {
-                const int slot = t & (RD4 - 1);
-                float *dst = ring + ((RR * RD4 + slot) * NS) * 64 + lane;
-#pragma unroll
-                for (int q = 0; q < NS; q++) dst[q * 64] = Hst[u][q];
-                if (lane == 0) ringm[RR * RD4 + slot] = Hx[u];
-                if (lane == 1) ringb[RR * RD4 + slot] = __builtin_bit_cast(int, Hx[u]);
-            }
-        };
-#pragma unroll
-        for (int u = 0; u < LD; u++) issue(u, u);
-        issue_hand(0, 0);
-        issue_hand(1, 1);
-        commit(0, 0);
-        commit_hand(0, 0);
-        issue(LD, 0);
-        issue_hand(2, 0);
+#pragma unroll 1
+        for (int u = 0; u < LD; u++) issue();
+        retire();
         lds_barrier();  // B0
-        for (int s0 = 0; s0 < nsteps; s0 += LD) {
-#pragma unroll
-            for (int u = 0; u < LD; u++) {
-                const int s = s0 + u;
-                commit(s + 1, (u + 1) % LD);
-                commit_hand(s + 1, (u + 1) % 2);
-                issue(s + 1 + LD, (u + 1) % LD);
-                issue_hand(s + 3, (u + 1) % 2);
-                lds_barrier();
+        unsigned long long lph[3] = {0, 0, 0};
+        (void)lph;
+#pragma unroll 1
+        for (int s = 0; s < nsteps; s++) {
+            const unsigned long long l0 = MGM_REL_PHASES ? clock64() : 0;
+            issue();   // step s + LD
+            const unsigned long long l1 = MGM_REL_PHASES ? clock64() : 0;
+            retire();  // step s + 1 is in the rings -- and the progress word that travelled with it
+            if (from_global) {
+                const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)rel_lds_read_opaque(hprog + ((s + 1) & (SD - 1))));
+                known = v > known ? v : known;
             }
+            const unsigned long long l2 = MGM_REL_PHASES ? clock64() : 0;
+            lds_barrier();
+            if constexpr (MGM_REL_PHASES != 0) {
+                const unsigned long long l3 = clock64();
+                lph[0] += l1 - l0, lph[1] += l2 - l1, lph[2] += l3 - l2;
+            }
+        }
+        rel_wait_vmcnt<0>();  // (the DMAs beyond the last step)
+        if constexpr (MGM_REL_PHASES != 0)
+            if (P.tl && lane == 0) {
+                unsigned long long *w = P.tl + (long long)gridDim.x * 8 + (long long)*s_task * 16 + 12;
+                w[0] = lph[0], w[1] = lph[1], w[2] = lph[2];
+            }
+        if (P.tl && lane == 0) {
+            unsigned long long *w = P.tl + (long long)*s_task * 8;
+            w[1] = wall_clock64();
+            w[2] = tl_wait;
+            w[3] = n_slow;
+            w[5] = (unsigned long long)nsteps;
+            w[6] = n_spin;
         }
         return;
     }
 
     // ============================= compute waves =============================
-    const int j = band * RR + r;
+    const int grp = lane >> 4, li = lane & 15;  // the lane's line within the wave; its 4 label slots are 4 li .. 4 li + 3
+    const int ln = GL * r + grp;                // line within the band = ring row
+    const int j = band * RR + ln;
     const bool line_ok = j < NL;
     const bool has_prev = line_ok && (j >= 1);
-    const bool to_global = (r == RR - 1) && (band + 1 < g.nbands);
-    const int prow = r > 0 ? r - 1 : RR;  // ring row of the line before this one
+    const bool to_global = (r == NW - 1) && (band + 1 < g.nbands);  // (the wave that holds the band's last line)
+    const int prow = ln > 0 ? ln - 1 : RR;  // ring row of the line before this one
     float *__restrict__ Lrb = V.Lr + (long long)(pass - P.pass0) * P.nvol;
-    const long long pix0 = g.base + (long long)j * g.jstep;
+    const long long pix0 = g.base + (long long)(line_ok ? j : 0) * g.jstep;
+    const bool f0 = form == 0;
 
-    // neighbour `row`/`pixel n` of the pixel with base bp: the same disparities, +INF where n has no slot for them
-    auto fetch = [&](int row, int n, int bp, NbT &nb) {
-        const int slot = n & (RD4 - 1);
-        const int sh = bp - ringb[row * RD4 + slot];
-        const int idx = lane + sh;
-        const bool in = (unsigned)idx < 64u;
-        const float *src = ring + ((row * RD4 + slot) * NS) * 64;
-        nb.m = ringm[row * RD4 + slot];
-#pragma unroll
-        for (int q = 0; q < NS; q++) nb.w[q][0] = in ? src[q * 64 + (in ? idx : 0)] : (PUBE ? nb.m : f_inf());
+    // slab(s) `row`/`pixel n` as the pixel with base bp sees them: the same disparities, +INF (PUBE: FAR) where n has no slot
+    // for them.  ok = false (a pixel that takes no neighbours, a lane group without a pixel): nothing is believed of the ring.
+    auto entry = [&](int row, int n) -> const float * {
+        return row == RR ? hring + (n & (SD - 1)) * HS : ring + (row * RD4 + (n & (RD4 - 1))) * HS;
     };
 
     lds_barrier();  // B0: the loader's first step has landed
+    unsigned long long cph[3] = {0, 0, 0}, nsweeps = 0;
+    (void)cph;
+    (void)nsweeps;
     for (int s = 0; s < nsteps; s++) {
-        const int i = s - 1 - 2 * r;
-        if (line_ok && i >= 0 && i < LL) {
-            const long long pix = pix0 + (long long)i * istep;
-            const int sl = s & 3;
-            const int4 rec = *reinterpret_cast<const int4 *>(mring + (sl * RR + r) * 4);
+        const unsigned long long c0 = MGM_REL_PHASES ? clock64() : 0;
+        unsigned long long c1 = c0;
+        const int i = s - 1 - 2 * ln;
+        const bool act = line_ok && i >= 0 && i < LL;
+        if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+            const long long pix = pix0 + (long long)(act ? i : 0) * istep;
+            const int sl = s & (SD - 1);
+            const int4 rec = *reinterpret_cast<const int4 *>(mring + (sl * RR + ln) * 4);
             const int bp = rec.x;
-            float Cv[1], Lv[1];
-            Cv[0] = c8_decode((unsigned)cring[(sl * RR + r) * 64 + lane]);
-            const bool interior = has_prev && i >= 1 && i <= LL - 2;  // mgm_core.cc:538-541
-            if (interior) {
-                NbT nb_i, nb_s, nb_b, nb_f;
-                // (only the neighbours the update reads: MGM of them, in the pass's order)
-                const bool f0 = form == 0;
-                nb_i.w[0][0] = nb_s.w[0][0] = nb_b.w[0][0] = nb_f.w[0][0] = f_inf();
-                if constexpr (NS == 2) nb_i.w[1][0] = nb_s.w[1][0] = nb_b.w[1][0] = nb_f.w[1][0] = f_inf();
-                nb_i.m = nb_s.m = nb_b.m = nb_f.m = 0.0f;
-                if (f0 || MGM >= 4) fetch(r, i - 1, bp, nb_i);
-                if (f0 ? MGM >= 2 : MGM >= 3) fetch(prow, i, bp, nb_s);
-                if (f0 ? MGM >= 3 : MGM >= 2) fetch(prow, i - 1, bp, nb_b);
-                if (!f0 || MGM >= 4) fetch(prow, i + 1, bp, nb_f);
-                const float4 w4 = *reinterpret_cast<const float4 *>(wring + (sl * RR + r) * 4);
-                const float D[4] = {w4.x, w4.y, w4.z, w4.w};
-                if constexpr (PUBE) {
-                    // e = 0; e += t1 - m1; ... in the pass's order (0 + x is x: x >= +0); Lp = C + e / howmany
-                    const NbT &n1 = f0 ? nb_i : nb_f, &n2 = f0 ? nb_s : nb_b, &n3 = f0 ? nb_b : nb_s, &n4 = f0 ? nb_f : nb_i;
-                    float e = n1.w[0][0];
-                    if (MGM >= 2) e += n2.w[0][0];
-                    if (MGM >= 3) e += n3.w[0][0];
-                    if (MGM >= 4) e += n4.w[0][0];
-                    Lv[0] = Cv[0] + div_small_rt(e, MGM);
-                } else if constexpr (!FH) {
-                    if (f0) combine_whirsch<1>(Cv, nb_i, nb_s, nb_b, nb_f, D, P1, P2, MGM, Lv);
-                    else combine_whirsch<1>(Cv, nb_f, nb_b, nb_s, nb_i, D, P1, P2, MGM, Lv);
-                } else {
-                    const int rl = rec.y - bp, rh = rec.z - bp;  // the pixel's own range, in slots
-                    if (f0) combine_wfh<1>(Cv, nb_i, nb_s, nb_b, nb_f, D, P1, P2, MGM, lane, 64, Lv, rl, rh);
-                    else combine_wfh<1>(Cv, nb_f, nb_b, nb_s, nb_i, D, P1, P2, MGM, lane, 64, Lv, rl, rh);
+            const unsigned cw = *reinterpret_cast<const unsigned *>(cring + (sl * RR + ln) * 64 + 4 * li);
+            const float Cv[4] = {c8_decode(cw & 255u), c8_decode((cw >> 8) & 255u), c8_decode((cw >> 16) & 255u), c8_decode(cw >> 24)};
+            const bool interior = act && has_prev && i >= 1 && i <= LL - 2;  // mgm_core.cc:538-541
+            const float4 w4 = *reinterpret_cast<const float4 *>(wring + (sl * RR + ln) * 4);
+            const float D[4] = {w4.x, w4.y, w4.z, w4.w};
+            const int rl = rec.y - bp, rh = rec.z - bp;  // the pixel's own range, in slots
+            // the MGM neighbours the update reads, in the pass's order (form 0: the pixel before on this line, then the line
+            // before at i, i - 1, i + 1; the other form: the same four the other way round) -- mgm_core.cc:520-575
+            float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k < MGM) {
+                    const bool own = f0 ? k == 0 : k == 3;
+                    const int di = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
+                    const float *src = entry(own ? ln : prow, own ? i - 1 : i + di);
+                    const float m = interior ? src[NS * 64] : 0.0f;                                   // minimum (or FAR)
+                    const int sh = bp - reinterpret_cast<const int *>(src)[NS * 64 + 1];              // base
+                    const float far = PUBE ? m : f_inf();
+                    float w[NS][4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int idx = 4 * li + q + sh;
+                        const bool in = interior && (unsigned)idx < 64u;
+#pragma unroll
+                        for (int t = 0; t < NS; t++) w[t][q] = in ? src[t * 64 + (in ? idx : 0)] : far;
+                    }
+                    if constexpr (PUBE) {
+                        // e = 0; e += t1 - m1; ... (0 + x is x: x >= +0)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) e[q] = k == 0 ? w[0][q] : e[q] + w[0][q];
+                    } else if constexpr (!FH) {  // update_costW (mgm_core.cc:95-144): e = 0; e += fmin3(L, N + P1 D, m + P2 D) - m
+                        const float a = P1 * D[k], b = P2 * D[k];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) e[q] += fminf(fminf(w[0][q], w[NS - 1][q] + a), m + b) - m;
+                    } else {  // update_costW_trunclinear (229-281): the neighbour's values over THIS pixel's range, convolved there
+                        float M[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int o = 4 * li + q;
+                            M[q] = (o >= rl && o <= rh) ? w[0][q] : f_inf();
+                        }
+                        unsigned sw = 0;
+                        fh_minconv<4, false, GL>(M, m, P1 * D[k], P2 * D[k], lane, 64, sw);
+                        if constexpr (MGM_REL_PHASES != 0) nsweeps += sw;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) e[q] = k == 0 ? M[q] - m : e[q] + (M[q] - m);
+                    }
                 }
-            } else {
-                Lv[0] = Cv[0];
             }
-            Lrb[pix * 64 + lane] = Lv[0];
+            float Lv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) Lv[q] = interior ? Cv[q] + div_small_rt(e[q], MGM) : Cv[q];
+            if constexpr (MGM_REL_PHASES != 0) {
+                asm volatile("" : "+v"(Lv[0]), "+v"(Lv[1]), "+v"(Lv[2]), "+v"(Lv[3]));
+                c1 = clock64();
+            }
+            if (act) *reinterpret_cast<relf4 *>(Lrb + pix * 64 + 4 * li) = relf4{Lv[0], Lv[1], Lv[2], Lv[3]};
 
-            // what this pixel publishes: its raw slab (Hirschmueller: and the neighbour minima), minimum, base
-            const float m = slab_min<1>(Lv);
-            float N[1] = {f_inf()};
-            if constexpr (!FH) neighbour_min<1>(Lv, N);
-            float pub0 = Lv[0], pubm = m;  // what goes out: the raw slab and its minimum -- or (PUBE) E and FAR
+            // what this pixel publishes: its raw slab (Hirschmueller: and the neighbour minima), minimum, base -- or (PUBE) E and FAR
+            const float m = rel_row_min(fminf(fminf(Lv[0], Lv[1]), fminf(Lv[2], Lv[3])));
+            float N[4] = {f_inf(), f_inf(), f_inf(), f_inf()};
+            if constexpr (!FH) neighbour_min<4>(Lv, N, li == 0, li == 15);
+            relf4 pub = {Lv[0], Lv[1], Lv[2], Lv[3]};
+            float pubm = m;
             if constexpr (PUBE) {
                 const float cap = m + P2;
-                pub0 = fminf(fminf(Lv[0], N[0] + P1), cap) - m;
+#pragma unroll
+                for (int q = 0; q < 4; q++) pub[q] = fminf(fminf(Lv[q], N[q] + P1), cap) - m;
                 pubm = cap - m;
             }
-            {
-                const int slot = i & (RD4 - 1);
-                float *dst = ring + ((r * RD4 + slot) * NS) * 64 + lane;
-                dst[0] = pub0;
-                if constexpr (NS == 2) dst[64] = N[0];
-                if (lane == 0) {
-                    ringm[r * RD4 + slot] = pubm;
-                    ringb[r * RD4 + slot] = bp;
-                }
+            const relf4 pubN = {N[0], N[1], N[2], N[3]};
+            if (act) {
+                float *ent = ring + (ln * RD4 + (i & (RD4 - 1))) * HS;
+                *reinterpret_cast<relf4 *>(ent + 4 * li) = pub;
+                if constexpr (NS == 2) *reinterpret_cast<relf4 *>(ent + 64 + 4 * li) = pubN;
+                if (li == 0) *reinterpret_cast<relf2 *>(ent + NS * 64) = relf2{pubm, __builtin_bit_cast(float, bp)};
             }
             if (to_global) {
-                // the slab(s) just written to the ring, read back as 16-byte pieces by 16 lanes per slab (same wave: the LDS
-                // write has retired) and stored write-through; minimum and base as one 8-byte piece
-                float *dstg = hand_out + (long long)i * HS;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane < 16 * NS) {
-                    const float *srcl = ring + ((r * RD4 + (i & (RD4 - 1))) * NS) * 64 + lane * 4;
-                    const relf4 v = {srcl[0], srcl[1], srcl[2], srcl[3]};
-                    rel_st_sc1_x4(dstg + lane * 4, v);
-                }
-                if (lane == 0) {
-                    const relf2 v = {pubm, __builtin_bit_cast(float, bp)};
-                    rel_st_sc1_x2(dstg + NS * 64, v);
-                }
-                // Progress is published PL steps LATE, every fourth pixel: this wave only issues stores, they retire in order,
-                // so once at most PL steps' worth of them are outstanding every store of pixel i - PL has reached memory -- a
-                // counted wait instead of draining the queue (which stalled the whole band for a store round trip every eighth
-                // step, and the band behind it for up to eight pixels more)
-                constexpr int SPS = 1 + 1 + 1 + 1, PL = 3;  // store instructions per step (Lr, slab pieces, minimum + base; + the word itself)
-                if (i == LL - 1) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(prog_out, (unsigned)LL, RLX_AGENT);
-                } else if (i >= PL && ((i - PL + 1) & 3) == 0) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL * SPS) : "memory");
-                    if (lane == 0) __hip_atomic_store(prog_out, (unsigned)(i - PL + 1), RLX_AGENT);
+                const int iL = s - 1 - 2 * (RR - 1);  // the band's last line: lane group GL - 1 of this wave
+                if (iL >= 0 && iL < LL) {
+                    // the hand-off to the next band: write-through 16-byte stores straight from the registers
+                    float *dstg = hand_out + (long long)iL * HS;
+                    if (grp == GL - 1) {
+                        rel_st_sc1_x4(dstg + 4 * li, pub);
+                        if constexpr (NS == 2) rel_st_sc1_x4(dstg + 64 + 4 * li, pubN);
+                        if (li == 0) {
+                            const relf2 v = {pubm, __builtin_bit_cast(float, bp)};
+                            rel_st_sc1_x2(dstg + NS * 64, v);
+                        }
+                    }
+                    // Progress is published PL steps LATE, every fourth pixel: this wave only issues stores, they retire in order,
+                    // so once at most PL steps' worth of them are outstanding every store of pixel iL - PL has reached memory -- a
+                    // counted wait instead of draining the queue
+                    constexpr int SPS = 3 + NS, PL = 3;  // store instructions per step at most (Lr, slab pieces, minimum + base, the word itself)
+                    if (iL == LL - 1) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(prog_out, (unsigned)LL, RLX_AGENT);
+                    } else if (iL >= PL && ((iL - PL + 1) & P.pubq) == 0) {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL * SPS) : "memory");
+                        if (lane == 0) __hip_atomic_store(prog_out, (unsigned)(iL - PL + 1), RLX_AGENT);
+                    }
                 }
             }
         }
         // everybody's slab for this step is in LDS before anyone reads it
+        const unsigned long long c2 = MGM_REL_PHASES ? clock64() : 0;
         lds_barrier();
+        if constexpr (MGM_REL_PHASES != 0) {
+            const unsigned long long c3 = clock64();
+            cph[0] += c1 - c0, cph[1] += c2 - c1, cph[2] += c3 - c2;
+        }
     }
+    if constexpr (MGM_REL_PHASES != 0)
+        if (P.tl && lane == 0) {
+            unsigned long long *w = P.tl + (long long)gridDim.x * 8 + (long long)*s_task * 16 + r * 3;
+            w[0] = cph[0], w[1] = cph[1], w[2] = cph[2];
+            if (r == 0) w[15] = nsweeps;
+        }
 }
 
 template <bool FH, bool PUBE>
-static hipError_t launch_rel_one(const RelParams &p, int ntasks, bool one_per_cu, hipStream_t s)
+static hipError_t launch_rel_one(const RelParams &p, int ntasks, int wg_per_cu, hipStream_t s)
 {
     constexpr int NS = (FH || PUBE) ? 1 : 2;
-    size_t shmem = sizeof(float) * ((size_t)(RR + 1) * RD4 * NS * 64 + 2 * (RR + 1) * RD4 + 2 * 4 * RR * 4) + 4 * RR * 64 + 16;
-    // Occupancy through the LDS request, as for the second build: two of these workgroups fit a CU and each then steps ~1.7x
-    // slower -- right for a batch (throughput), wrong for a launch bound by its chains of bands (one or two volumes)
-    if (one_per_cu && shmem < 81 * 1024) shmem = 81 * 1024;
+    constexpr int HS = NS * 64 + 4;
+    size_t shmem = sizeof(float) * ((size_t)RR * RD4 * HS + (size_t)SD * HS + 2 * SD * RR * 4) + SD * RR * 64 + sizeof(unsigned) * (SD + 4) + 16;
+    // Occupancy through the LDS request, as for the second build: wg_per_cu workgroups (of 4 compute waves: one per SIMD) share a
+    // CU -- one for a launch bound by its chains of bands, more for a batch (throughput)
+    if (wg_per_cu >= 1) {
+        const size_t want = (size_t)(160 * 1024) / (size_t)(wg_per_cu + 1) + 1024;  // more than a (wg_per_cu + 1)-th of the LDS
+        if (shmem < want) shmem = want;
+    }
     auto kern = k_pass_rel<FH, PUBE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(ntasks), dim3((RR + 1) * 64), shmem, s, p);
+    hipLaunchKernelGGL(kern, dim3(ntasks), dim3((NW + 1) * 64), shmem, s, p);
     return hipGetLastError();
 }
-// pube: unit weights with Hirschmueller potentials (the producer publishes E)
-hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, bool one_per_cu, hipStream_t s)
+// pube: unit weights with Hirschmueller potentials (the producer publishes E); wg_per_cu: workgroups per CU (0: what fits)
+hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, int wg_per_cu, hipStream_t s)
 {
-    if (fh) return launch_rel_one<true, false>(p, ntasks, one_per_cu, s);
-    return pube ? launch_rel_one<false, true>(p, ntasks, one_per_cu, s) : launch_rel_one<false, false>(p, ntasks, one_per_cu, s);
+    if (fh) return launch_rel_one<true, false>(p, ntasks, wg_per_cu, s);
+    return pube ? launch_rel_one<false, true>(p, ntasks, wg_per_cu, s) : launch_rel_one<false, false>(p, ntasks, wg_per_cu, s);
 }
 int pass_rel_lines() { return RR; }
+int pass_rel_phases() { return MGM_REL_PHASES ? 16 : 0; }
 int pass_rel_hand_floats(bool one_slab) { return (one_slab ? 1 : 2) * 64 + 4; }
 
 }  // namespace mgm

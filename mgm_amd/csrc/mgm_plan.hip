@@ -1067,7 +1067,10 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     if ((r = reserve(c, c->hand_rel, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * HS))) return r;
     // the task table: the simulated list schedule of the launch (one ticket counter), cached per shape
     char key[96];
-    snprintf(key, sizeof key, "%d %d %d %d", nx, ny, NDIR, nb);
+    // workgroups (4 compute waves + the loader) per CU: tune rel_wg forces it
+    const long long wgs = tune_num("rel_wg", 0);
+    const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 2 ? 2 : 3);  // (measured: x 1 / x 2 / x 4 of 1920x1080, both potentials)
+    snprintf(key, sizeof key, "%d %d %d %d %d", nx, ny, NDIR, nb, rel_wg);
     if (c->tasks_rel_key != key) {
         std::vector<SimChain> ch;
         for (int v = 0; v < nb; v++)
@@ -1079,7 +1082,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
                 ch.push_back(k);
             }
         std::vector<int2> order;
-        (void)simulate_schedule(ch, 1, std::max(1, c->num_cu * (nb <= 1 ? 1 : 2)), 1 << 20, order);
+        (void)simulate_schedule(ch, 1, std::max(1, c->num_cu * rel_wg), 1 << 20, order);
         for (int2 &t : order) t.y &= 0xffff;
         HIPCHK(c, hipStreamSynchronize(c->stream));  // (a launch that still reads the old table)
         if ((r = reserve(c, c->tasks_rel, sizeof(int2) * order.size()))) return r;
@@ -1117,16 +1120,58 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     p.weighted = weighted ? 1 : 0;
     p.P1 = P1;
     p.P2 = P2;
+    // a launch bound by its chains of bands wants a short lead (lag per band); a batch has the slack and wants the loads covered
+    p.ld = (int)std::min(5LL, std::max(2LL, tune_num("rel_ld", nb <= 1 ? 2 : 3)));
+    p.lead = (int)std::min(32LL, std::max(0LL, tune_num("rel_lead", nb <= 1 ? 1 : 4)));
+    {
+        const long long q = tune_num("rel_pubq", 4);  // 1, 2 or 4
+        p.pubq = q >= 4 ? 3 : (q >= 2 ? 1 : 0);
+    }
+    p.tl = nullptr;
+    // MGM_HIP_TIMELINE=<file>: one line per work item (tools/timeline.py) -- where the compute units' time goes
+    const char *tl_file = getenv("MGM_HIP_TIMELINE");
+    if (tl_file && *tl_file) {
+        if ((r = reserve(c, c->dbg, sizeof(unsigned long long) * (8 + pass_rel_phases()) * (size_t)c->ntasks_rel))) return r;
+        HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, sizeof(unsigned long long) * (8 + pass_rel_phases()) * (size_t)c->ntasks_rel, c->stream));
+        p.tl = (unsigned long long *)c->dbg.p;
+    }
     HIPCHK(c, hipMemsetAsync(words, 0, sizeof(unsigned), c->stream));
     HIPCHK(c, hipMemsetAsync(words + 4, 0, sizeof(unsigned) * (size_t)nb * kMaxDirs * kMaxBands, c->stream));
     {
         TimeScope t(c, "k_pass_rel");
-        const long long wgs = tune_num("rel_wg", 0);  // (1 / 2: force one / two workgroups per CU)
-        const bool one_per_cu = wgs ? wgs == 1 : nb <= 1;  // (measured, Hirschmueller: x 1 7.5 against 9.6 ms, x 2 11.5 against 10.5, x 4 21.5 against 16.0)
-        HIPCHK(c, launch_pass_rel(p, c->ntasks_rel, fh, pube, one_per_cu, c->stream));
+        HIPCHK(c, launch_pass_rel(p, c->ntasks_rel, fh, pube, rel_wg, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->h_words + 1, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     c->pending_check = true;
+    if (p.tl) {
+        const int nph = pass_rel_phases();
+        std::vector<unsigned long long> d((size_t)c->ntasks_rel * (8 + nph));
+        std::vector<int2> tk((size_t)c->ntasks_rel);
+        HIPCHK(c, hipMemcpyAsync(d.data(), c->dbg.p, d.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(tk.data(), c->tasks_rel.p, tk.size() * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (FILE *f = fopen(tl_file, "a")) {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int i = 0; i < c->ntasks_rel; i++) {
+                if (d[(size_t)i * 8]) t0 = std::min(t0, d[(size_t)i * 8]);
+                t1 = std::max(t1, d[(size_t)i * 8 + 1]);
+            }
+            const double tick = 1e-2;  // wall_clock64: 100 MHz -> 0.01 us
+            fprintf(f, "launch %d %d %d %d %d %.1f volumes %d fh %d mgm %d rel 1\n", nx, ny, 64, c->ntasks_rel, rel_wg, (double)(t1 - t0) * tick, nb, fh ? 1 : 0, MGM);
+            for (int i = 0; i < c->ntasks_rel; i++) {
+                const unsigned long long *w = &d[(size_t)i * 8];
+                fprintf(f, "item %d %d %d %d %d %.2f %.2f %.2f %llu %llu %llu %llu %llu\n", i, tk[i].x, tk[i].y & 0xffff, 0, 0, (double)(w[0] - t0) * tick,
+                        (double)(w[1] - t0) * tick, (double)w[2] * tick, w[3], w[4] & 0xffffffffull, w[4] >> 32, w[5], w[6]);
+                if (nph) {  // (development build) clocks per wave: compute, publish, barrier x 4 waves; loader: issue, retire, barrier
+                    const unsigned long long *q = &d[(size_t)c->ntasks_rel * 8 + (size_t)i * nph];
+                    fprintf(f, "phases %d", i);
+                    for (int k = 0; k < 16; k++) fprintf(f, " %llu", q[k]);
+                    fprintf(f, "\n");
+                }
+            }
+            fclose(f);
+        }
+    }
     // what the context's last aggregation was: this one (the dense Lr workspace no longer belongs to these volumes)
     c->last_batch = 0;
     c->last_ndir = 0;

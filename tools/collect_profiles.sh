@@ -9,15 +9,16 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-PROFILED=${PROFILED:-"cfg3:12 cfg3:2 cfg3:1 cfg2:16 cfg2:2 cfg4:1 cfg5:16 cfg3w:12 cfg3hw:12 cfg3ad:12 cfg3ncc:12 cfg1s:16 cfg3L200:8 cfg3L768:4"}
-MATRIX=${MATRIX:-"cfg3h:12 cfg2:16 cfg5:16 cfg4:1 cfg4:2 cfg3:8 cfg3:4 cfg3:2 cfg3:1 cfg3h:2 cfg3h:1 cfg2:8 cfg2:4 cfg2:2 cfg2:1 cfg3w:12 cfg3w:1 cfg3hw:12 cfg3hw:1 cfg3ad:12 cfg3ad:1 cfg3ad1:12 cfg3ncc:12 cfg3ncc:1 cfg3bt:12 cfg3bt:1 cfg3c7:12 cfg3c7:1 cfg1s:16 cfg1s:1 cfg3L200:8 cfg3L200:1 cfg3L768:4 cfg3L768:1"}
+PROFILED=${PROFILED:-"cfg3:12 cfg3:2 cfg3:1 cfg2:16 cfg2:2 cfg2:1 cfg1s:2 cfg4:1 cfg3w:12 cfg3r:1 cfg3r:4"}
+MATRIX=${MATRIX:-"cfg3h:12 cfg2:16 cfg5:16 cfg4:1 cfg4:2 cfg3:8 cfg3:4 cfg3:2 cfg3:1 cfg3h:2 cfg3h:1 cfg2:8 cfg2:4 cfg2:2 cfg2:1 cfg3w:12 cfg3w:1 cfg3hw:12 cfg3hw:1 cfg3ad:12 cfg3ad:1 cfg3ad1:12 cfg3ncc:12 cfg3ncc:1 cfg3bt:12 cfg3c7:12 cfg1s:16 cfg1s:2 cfg1s:1 cfg3L200:8 cfg3L200:1 cfg3L768:4 cfg3L768:1 cfg3r:1 cfg3r:4 cfg3hr:1 cfg3hr:4 cfg3i2:1 cfg3w3:1 cfg3w3:4 cfg3hw3:1 cfg3L1536:1 cfg3L2048:1 cfg3neg:1 cfg3nan:1 cfg3rinf:1"}
 # a stream of single pairs / small batches through a pipelined context (mgm_ctx_set_pipeline): workload:batch:depth
 PIPED=${PIPED:-"cfg3:1:2 cfg3:1:4 cfg3:1:12 cfg3h:1:4 cfg2:1:4 cfg2:1:8 cfg3:2:2"}
 : > "$OUT/bench_lines.jsonl"
 timeout 900 python bench.py 2> "$OUT/bench_default.stderr" | tail -1 >> "$OUT/bench_lines.jsonl"
 for wb in $MATRIX; do
   w=${wb%%:*}; b=${wb##*:}
-  timeout 600 python bench.py --workload $w --batch $b --repeats 0 --no-cpu-baseline --no-parity 2>/dev/null | tail -1 >> "$OUT/bench_lines.jsonl"
+  st=20; case $w in cfg3nan|cfg3rinf|cfg3L1536|cfg3L2048) st=3;; esac   # (the slow fall-backs: 0.25-0.4 s per step)
+  timeout 600 python bench.py --workload $w --batch $b --steps $st --repeats 0 --no-cpu-baseline --no-parity 2>/dev/null | tail -1 >> "$OUT/bench_lines.jsonl"
 done
 for wbd in $PIPED; do
   w=${wbd%%:*}; rest=${wbd#*:}; b=${rest%%:*}; d=${rest##*:}
@@ -45,6 +46,7 @@ done
 # the single-GPU ingredients of DESIGN.md section 6's direction-sharding model, and the wall time of the whole command line
 timeout 600 python tools/time_passes.py cfg4 > "$OUT/cfg4_pass_blocks.txt" 2>&1
 for i in 1 2 3; do MGM_HIP_STATS=1 bash tools/cli_fullsize.sh 2>&1 | grep -v "^disp\|^cost"; sleep 2; done > "$OUT/cli_fullsize.txt" 2>&1
+bash tools/ragged_cli.sh > "$OUT/ragged_cli.txt" 2>&1
 ls -la "$OUT"
 for f in "$OUT"/*_kernel_stats.csv; do echo "== $f"; head -8 "$f" | cut -c1-200; done
 cat "$OUT"/*_hbm_counters.md 2>/dev/null | grep -E "^#|Aggregation|k_pass|k_wta"

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 mkdir -p mgm_amd/lib/variants
 while [ $# -gt 0 ]; do
   name="$1"; defs="$2"; shift 2
-  MGM_P2_DEFINES="$defs" python mgm_amd/build.py >/dev/null
+  MGM_P2_DEFINES="$defs" MGM_REL_DEFINES="${RELDEFS:-}" python mgm_amd/build.py >/dev/null
   mkdir -p mgm_amd/lib/variants/$name
   cp mgm_amd/lib/libmgm_hip.so mgm_amd/lib/variants/$name/
   echo "built $name: $defs"
