@@ -227,10 +227,44 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     // aggregation call would pad and encode again.  The flag word is read back at once; a volume that does not fit takes
     // the general kernel below, fp32 volume and all, and so do its refills.
     const int LP = (!c8_supported(p.L) && dev().c8 && dev().pad && dev().lazy_f32 && !p.rlo) ? padded_labels(p.L) : 0;
+    (*out)->rel_only = false;
     const bool census_fits = costfn == 2 && p.nch == 1 &&
                              (p.trunc == __builtin_huge_valf() || (p.trunc >= 0.0f && p.trunc <= 254.0f && p.trunc == rintf(p.trunc)));
     const bool diff_may_fit = (costfn == 0 || costfn == 1) && (pre == 0 || pre == 2) && p.trunc >= 0.0f && !std::signbit(p.trunc) &&
                               (long long)u->nx * u->ny < 0x7fffffffll;  // (what k_cost_diffx takes)
+    // A ragged single-word census volume: the RANGE-PROPORTIONAL copy alone, straight from the descriptor words (mgm_pass_rel.hip,
+    // k_cost_census_rel) -- neither the fp32 hull nor its compact twin is written; whoever wants the hull gets it from
+    // ensure_f32.  The flag word (a window wider than 62 labels) is read back at once: such a volume takes the general path.
+    if (p.rlo && census_fits && rel_enabled() && dev().lazy_f32 && tune_num("rel_direct", 1) != 0) {
+        const size_t npix = (size_t)u->nx * u->ny, need = npix * 64 + npix * 16 + 16;
+        if ((*out)->rel_cap < need) {
+            if ((*out)->relbuf) (void)hipFree((*out)->relbuf);
+            (*out)->relbuf = nullptr;
+            (*out)->rel_cap = 0;
+            if (dev_malloc((void **)&(*out)->relbuf, need) == hipSuccess) (*out)->rel_cap = need;
+        }
+        if ((*out)->relbuf) {
+            unsigned *flag = reinterpret_cast<unsigned *>((*out)->relbuf + npix * 64 + npix * 16);
+            HIPCHK(c, hipMemsetAsync(flag, 0, 4, c->stream));
+            {
+                TimeScope t(c, "k_cost");
+                HIPCHK(c, launch_cost_census_rel(p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, dmin, p.L, p.trunc, p.rlo, p.rhi, (*out)->relbuf,
+                                                 reinterpret_cast<int *>((*out)->relbuf + npix * 64), flag, c->stream));
+            }
+            if ((r = ensure_words(c))) return r;
+            HIPCHK(c, hipMemcpyAsync(c->h_words + 3, flag, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->h_words[3] == 0u) {
+                (*out)->rel_state = 2;
+                (*out)->rel_only = true;
+                (*out)->f32_state = 0;
+                (*out)->c8_state = 0;   // (no compact hull either: c8_resolve makes one from the expanded volume if a dense launch wants it)
+                (*out)->nan_state = 2;  // integer costs: NaN-free by construction
+                return MGM_OK;
+            }
+        }
+        (*out)->rel_state = 0;
+    }
     if (LP && (*out)->diff_fails < 2 && (census_fits || diff_may_fit)) {
         int pcb = (costfn == 2 || (costfn == 0 && u->nch == 1 && !(*out)->diff_wide) || LP > 512) ? 1 : 2;
         for (;;) {
@@ -457,7 +491,11 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
     // (round 5, later: unit-weight Hirschmueller volumes publish E on the producer side there, k_pass_rel PUBE: one volume 7.5 + 1.5 +
     // 0.45 ms against 4.6 + 3.9 -- still a tie --, two 10.5 + 2.9 + 0.9 against 9.2 + 7.7, four 16.0 + 5.9 + 1.7 against 15.2 + 14.8:
     // batches of them go)
-    const bool rel_pays = use_fh > 0 || (w8 && w8[0]) || n >= 2 || tune_num("rel", 1) >= 2;
+    // (round 5, last: four scan lines per wave -- two volumes 9.3 + 3.0, four 10.5 + 5.9 --, and census volumes whose ONLY copy is the
+    // range-proportional one: the hull would first have to be expanded and encoded again, 2.2 ms, so those go too: 8.1 + 1.5)
+    bool only_rel = true;
+    for (int v = 0; v < n; v++) only_rel = only_rel && C[v]->rel_only;
+    const bool rel_pays = use_fh > 0 || (w8 && w8[0]) || n >= 2 || only_rel || tune_num("rel", 1) >= 2;
     if (!S && MGM != 2 && P2 < __builtin_huge_valf() && rel_pays && rel_enabled()) {
         bool all = true;
         for (int v = 0; v < n && all; v++) {

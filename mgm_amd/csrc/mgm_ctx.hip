@@ -529,6 +529,14 @@ extern "C++" int ensure_f32(mgm_ctx *c, const mgm_cv *ccv)
 {
     mgm_cv *cv = const_cast<mgm_cv *>(ccv);
     if (cv->f32_state) return MGM_OK;
+    if (cv->rel_only && cv->rel_state == 2 && cv->relbuf) {  // K2 wrote the range-proportional copy alone (ragged census volume)
+        if (int r = cv_alloc_f32(c, cv)) return r;
+        const long long npix = (long long)cv->nx * cv->ny;
+        TimeScope t(c, "k_expand");
+        HIPCHK(c, launch_rel_expand(cv->relbuf, reinterpret_cast<const int *>(cv->relbuf + npix * 64), npix, cv->dmax - cv->dmin + 1, cv->dmin, cv->d, c->stream));
+        cv->f32_state = 1;
+        return MGM_OK;
+    }
     if (cv->p8_state == 2) {  // K2 wrote the padded compact copy alone
         if (int r = cv_alloc_f32(c, cv)) return r;
         TimeScope t(c, "k_expand");
@@ -569,6 +577,8 @@ void *mgm_cv_device_ptr(mgm_cv *cv)
     if (!cv) return nullptr;
     if (cv->owner && ensure_f32(cv->owner, cv)) return nullptr;
     cv->c8_state = 0;  // the caller may write through the pointer: re-derive the compact copy at the next use
+    cv->rel_only = false;  // (and the range-proportional copy no longer stands for the volume)
+    cv->rel_state = cv->rel_state == 2 || cv->rel_state == 1 ? 0 : cv->rel_state;
     cv->p8_state = 0;
     cv->nan_state = 0;
     cv->gen = next_cv_generation();
@@ -658,7 +668,9 @@ int c8_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *use)
     const long long n = (long long)cv->nx * cv->ny * L;
     bool launched = false;
     if (enabled && cv->c8_state == 0) {  // uploaded / externally written volume: make the compact copy now (one byte per cost)
-        int r = c8_alloc(c, cv, 1);
+        int r = ensure_f32(c, cv);  // (a ragged census volume that only has its range-proportional copy)
+        if (r) return r;
+        r = c8_alloc(c, cv, 1);
         if (r) return r;
         HIPCHK(c, hipMemsetAsync(cv->bad8, 0, 4, c->stream));
         TimeScope t(c, "k_compact");
@@ -668,6 +680,7 @@ int c8_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *use)
         launched = true;
     }
     if (cv->nan_state == 0) {
+        if (int r = ensure_f32(c, cv)) return r;
         if (!launched) HIPCHK(c, hipMemsetAsync(cv->bad8, 0, 4, c->stream));
         TimeScope t(c, "k_nanscan");
         HIPCHK(c, launch_nanscan(cv->d, n, cv->bad8, c->stream));

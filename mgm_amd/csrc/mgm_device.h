@@ -131,6 +131,9 @@ struct RelParams {
 };
 hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi, long long npix, int L, int dmin, uint8_t *rel8, int *relb,
                              unsigned *flag, hipStream_t s);
+hipError_t launch_cost_census_rel(const uint32_t *cu, const uint32_t *cv, int nx, int ny, int vnx, int vny, int dmin, int L, float trunc, const float *rlo,
+                                  const float *rhi, uint8_t *rel8, int *relb, unsigned *flag, hipStream_t s);
+hipError_t launch_rel_expand(const uint8_t *rel8, const int *relb, long long npix, int L, int dmin, float *C, hipStream_t s);
 hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, int wg_per_cu, hipStream_t s);
 int pass_rel_lines();
 int pass_rel_phases();  // words per work item of phase clocks behind the timeline words (0: not a -DMGM_REL_PHASES=1 build)

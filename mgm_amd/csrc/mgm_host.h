@@ -67,6 +67,9 @@ struct mgm_cv {
     uint8_t *relbuf = nullptr;
     size_t rel_cap = 0;
     int rel_state = 0;
+    // the relative copy is the ONLY copy (single-word census: K2 wrote it straight from the descriptors, f32_state 0);
+    // ensure_f32 expands it into the dense hull on demand
+    bool rel_only = false;
     // a caller-provided volume whose refill FAILED half-way holds neither its old costs nor new ones: mgm_aggregate*
     // refuses it (MGM_ERR_INVALID) until a later mgm_costvolume_build* has filled it
     bool unfilled = false;

@@ -22,6 +22,8 @@
 // 4-deep LDS ring per line (a slab is read by the next line at three consecutive steps, each time at another shift), the band
 // hand-off through global memory with progress words, work items by atomic ticket.  Not built here (the dense path keeps them): TSGM = 2 without weights (update_cost2 /
 // update_cost2_trunclinear are other functions), windows wider than 62 labels, costs that are not bytes, P2 = +INF.
+#include <algorithm>
+
 #include "mgm_pass_common.h"
 
 namespace mgm {
@@ -103,6 +105,63 @@ hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi,
 {
     const long long n = npix * 64;
     hipLaunchKernelGGL(k_rel_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C, rlo, rhi, npix, L, dmin, rel8, relb, flag);
+    return hipGetLastError();
+}
+
+// The relative copy of a single-word CENSUS volume straight from the descriptor words (integer costs, trunc = +INF or a whole
+// number up to 254: every cost is a byte and none is NaN by construction) -- no dense hull in between: a 1920x1080 volume of
+// 55-label windows in a hull of 256 cost 1.2 ms (general kernel, fp32 + compact hull) + 0.45 ms (k_rel_gather); this writes
+// its 133 MB alone.  One wave per pixel, lane = slot.  cost = min(popcount(cu ^ cv), trunc), trunc for a hypothesis outside
+// the right image (mgm_costvolume.h:65-78, 401-412); a pixel without a finite cost in its range is all zeros there (414-421).
+__global__ void __launch_bounds__(256) k_cost_census_rel(const uint32_t *__restrict__ cu, const uint32_t *__restrict__ cv, int nx, int ny, int vnx, int vny,
+                                                         int dmin, int L, unsigned tb, const float *__restrict__ rlo, const float *__restrict__ rhi,
+                                                         uint8_t *__restrict__ rel8, int *__restrict__ relb, unsigned *flag)
+{
+    const long long npix = (long long)nx * ny;
+    const int k = threadIdx.x & 63;
+    for (long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (long long)gridDim.x * 4) {
+        const int y = (int)(pix / nx), x = (int)(pix - (long long)y * nx);
+        const int lo = (int)rlo[pix], hi = (int)rhi[pix];
+        const int b = lo - 1, d = b + k;
+        const bool inw = d >= lo && d <= hi && d - dmin >= 0 && d - dmin < L;  // a label of this pixel
+        const bool yin = y < vny;
+        const int qx = x + d;
+        const bool in = yin && qx >= 0 && qx < vnx;
+        const unsigned pc = (unsigned)__builtin_popcount(cu[pix] ^ cv[(long long)(yin ? y : 0) * vnx + (in ? qx : 0)]);
+        unsigned code = inw ? (in ? (pc < tb ? pc : tb) : tb) : 255u;
+        if (__builtin_amdgcn_ballot_w64(inw && code != 255u) == 0ull) code = inw ? 0u : 255u;
+        rel8[pix * 64 + k] = (uint8_t)code;
+        if (k == 0) {
+            *reinterpret_cast<int4 *>(relb + pix * 4) = make_int4(b, lo, hi, 0);
+            const unsigned bad = (hi - lo + 1 > 62 || hi < lo) ? 1u : 0u;
+            if (bad && *flag != (*flag | bad)) atomicOr(flag, bad);
+        }
+    }
+}
+hipError_t launch_cost_census_rel(const uint32_t *cu, const uint32_t *cv, int nx, int ny, int vnx, int vny, int dmin, int L, float trunc, const float *rlo,
+                                  const float *rhi, uint8_t *rel8, int *relb, unsigned *flag, hipStream_t s)
+{
+    const unsigned tb = trunc == __builtin_huge_valf() ? 255u : (unsigned)trunc;
+    const long long npix = (long long)nx * ny;
+    const unsigned grid = (unsigned)std::min<long long>((npix + 3) / 4, 1 << 20);
+    hipLaunchKernelGGL(k_cost_census_rel, dim3(grid), dim3(256), 0, s, cu, cv, nx, ny, vnx, vny, dmin, L, tb, rlo, rhi, rel8, relb, flag);
+    return hipGetLastError();
+}
+// ... and the dense fp32 hull of such a volume, for whoever asks for it (ensure_f32): +INF wherever a pixel has no label
+__global__ void __launch_bounds__(256) k_rel_expand(const uint8_t *__restrict__ rel8, const int *__restrict__ relb, long long n, int L, int dmin,
+                                                    float *__restrict__ C)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const long long pix = t / L;
+    const int o = (int)(t - pix * L);
+    const int k = dmin + o - relb[pix * 4];
+    C[t] = (k >= 0 && k < 64) ? c8_decode((unsigned)rel8[pix * 64 + k]) : __builtin_huge_valf();
+}
+hipError_t launch_rel_expand(const uint8_t *rel8, const int *relb, long long npix, int L, int dmin, float *C, hipStream_t s)
+{
+    const long long n = npix * L;
+    hipLaunchKernelGGL(k_rel_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rel8, relb, n, L, dmin, C);
     return hipGetLastError();
 }
 

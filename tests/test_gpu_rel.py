@@ -93,9 +93,26 @@ def test_rel_is_not_taken_where_it_does_not_apply():
         ctx.aggregate_dev(cv2, 8.0, 32.0, 4, 2, 0, 1, None, "vfit")
         S, _, _ = ctx.aggregate_dev(cv2, 8.0, 32.0, 4, 3, 0, 1, None, "vfit", want_S=True)
         assert "k_pass_rel" not in [n for n, _ in ctx.timings()] and S is not None
+        # unit weights, Hirschmueller, ONE volume: a tie where the hull exists (absolute differences: K2 writes the hull and the
+        # relative copy is gathered from it) -> the hull's queue kernels ...
+        cv3 = ctx.costvolume(np.floor(u / 4), np.floor(v / 4), lo, hi, "none", "ad", float("inf"), 5)
         ctx.timing_reset()
-        ctx.aggregate_dev(cv2, 8.0, 32.0, 4, 3, 0, 1, None, "vfit")  # unit weights, Hirschmueller: a tie -> the hull's queue kernels
+        ctx.aggregate_dev(cv3, 8.0, 32.0, 4, 3, 0, 1, None, "vfit")
         assert "k_pass_rel" not in [n for n, _ in ctx.timings()]
+        ctx.timing_reset()
+        ctx.aggregate_dev(cv3, 2.0, 30.0, 4, 3, 1, 1, None, "vfit")  # (FH on the same volume: the gathered copy is used)
+        assert "k_pass_rel" in [n for n, _ in ctx.timings()]
+        # ... but a single-word census volume only HAS the relative copy (k_cost_census_rel): the hull would have to be expanded first
+        ctx.timing_reset()
+        ctx.aggregate_dev(cv2, 8.0, 32.0, 4, 3, 0, 1, None, "vfit")
+        assert "k_pass_rel" in [n for n, _ in ctx.timings()]
+        assert "k_expand" not in [n for n, _ in ctx.timings()]
+        # and whoever asks for that hull gets the one the general kernel writes
+        hull = cv2.download()
+        os.environ["MGM_HIP_REL"] = "0"
+        ref = ctx.costvolume(u, v, lo, hi, "none", "census", float("inf"), 5).download()
+        os.environ.pop("MGM_HIP_REL", None)
+        assert hull.shape == ref.shape and np.array_equal(hull, ref)
         ctx.timing_reset()
         ctx.aggregate_dev(cv2, 2.0, 30.0, 4, 3, 1, 1, None, "vfit")  # FH: the range-proportional kernels
         assert "k_pass_rel" in [n for n, _ in ctx.timings()]
