@@ -379,7 +379,10 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     // one other positive value.  Anything they do not cover -- fp32 costs, more than 256 labels, launches too small for the
     // queues, a partitioned device, FH on ragged volumes (which borrows the weighted kernels above) -- keeps the general
     // weighted kernels.
-    bool w2 = w2cand && dev().w2 && R2 && use_c8 && cb == 1 && lpl <= 4 && !ones8 && !pass2_devtools() && dev().xcdq != 0 && dev().deep != 0;
+    // (FH on a ragged volume WITH two-valued weights as well: the producer-side transforms of W2 convolve over the SENDING pixel's
+    // slab -- found by the long random campaign of tests/test_gpu_rel.py in round 5, where the range-proportional kernels and the
+    // reference agreed and this path did not)
+    bool w2 = w2cand && dev().w2 && R2 && use_c8 && cb == 1 && lpl <= 4 && !ones8 && !(fh && ragged) && !pass2_devtools() && dev().xcdq != 0 && dev().deep != 0;
     if (w2) {
         int items = 0;
         for (int q = first; q < PEND; q++) items += nb * p.g[q].nbands;

@@ -68,6 +68,9 @@ CASES = [
     ("ragged ranges (range-proportional kernels): census, FH, weights, TSGM=3, TSGM_ITER=2, parabola", 1,
      "-P1 2 -P2 9 -r -16 -R 8 -t census -O 8 -aP2 4 -aThresh 12 -s parabola -m {ranges}/lo.npy -M {ranges}/hi.npy",
      dict(TSGM="3", TSGM_ITER="2", CENSUS_NCC_WIN="5", USE_TRUNCATED_LINEAR_POTENTIALS="1")),
+    ("the same command line on the dense hull (MGM_HIP_REL=0): FH + weights on a ragged volume keeps the consumer-side kernels", 1,
+     "-P1 2 -P2 9 -r -16 -R 8 -t census -O 8 -aP2 4 -aThresh 12 -s parabola -m {ranges}/lo.npy -M {ranges}/hi.npy",
+     dict(TSGM="3", TSGM_ITER="2", CENSUS_NCC_WIN="5", USE_TRUNCATED_LINEAR_POTENTIALS="1", MGM_HIP_REL="0")),
     ("ragged ranges (range-proportional kernels): census, TSGM=1, O 2, no over-count fix, TSGM_ITER=3, parabolaOCV", 1,
      "-r -16 -R 8 -t census -O 2 -s parabolaOCV -m {ranges}/lo.npy -M {ranges}/hi.npy", dict(TSGM="1", TSGM_ITER="3", TSGM_FIX_OVERCOUNT="0", CENSUS_NCC_WIN="3")),
     ("ragged ranges (range-proportional kernels): grey ad (byte costs), FH TSGM=4, median, O 4", 1,
