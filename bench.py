@@ -1115,15 +1115,26 @@ def main():
                                   ("cfg3L768", 1, 1), ("cfg3", 1, 4), ("cfg2", 1, 8),
                                   # round 5: what had no number before -- range images (-m/-M) and TSGM_ITER, and the
                                   # fall-back kernels (free-form weights, 1536 labels, negative penalties, NaN costs)
-                                  ("cfg3r", 1, 1), ("cfg3hr", 1, 1), ("cfg3i2", 1, 1), ("cfg3w3", 1, 1), ("cfg3hw3", 1, 1), ("cfg3L1536", 1, 1),
+                                  ("cfg3r", 1, 1), ("cfg3r", 4, 1), ("cfg3hr", 1, 1), ("cfg3hr", 4, 1),
+                                  # ... and the same ragged volumes on the dense HULL (MGM_HIP_REL=0: no range-proportional copy), the run
+                                  # the range-proportional kernels are to be compared with (vd = -1 marks them)
+                                  ("cfg3r", 1, -1), ("cfg3r", 4, -1), ("cfg3hr", 4, -1),
+                                  ("cfg3i2", 1, 1), ("cfg3w3", 1, 1), ("cfg3hw3", 1, 1), ("cfg3L1536", 1, 1),
                                   ("cfg3neg", 1, 1), ("cfg3nan", 1, 1)):
                 vw = WORKLOADS[vname]
+                hull = vd < 0
+                vd = abs(vd)
                 vsteps = 8 if vd > 1 else (2 if vname in ("cfg3nan", "cfg3L1536") else 5)  # (the slow fall-backs: 0.25-0.4 s per step)
-                vm = pairs_leg(env, vw, vb, vsteps, 1, 0, pipeline=vd)
+                if hull:
+                    os.environ["MGM_HIP_REL"] = "0"
+                try:
+                    vm = pairs_leg(env, vw, vb, vsteps, 1, 0, pipeline=vd)
+                finally:
+                    os.environ.pop("MGM_HIP_REL", None)
                 if rank == 0:
                     vr = roofline_of(vw, vb, vm["avg"], vname, step_ms=(vm["dt"] / vsteps * 1e3) if vd > 1 else None, per_step=vm["per_step"])
                     pn = next((k for k in ("k_pass2", "k_pass", "k_pass_rel", "k_pass_exact") if k in vm["avg"]), "k_pass2")
-                    vres["%s x%d%s" % (vname, vb, (" pipeline %d" % vd) if vd > 1 else "")] = {
+                    vres["%s x%d%s%s" % (vname, vb, (" pipeline %d" % vd) if vd > 1 else "", " on the dense hull" if hull else "")] = {
                         "workload": vw["desc"], "value": shard.job_rate([vsteps * vb] * n_ranks, vm["dt"]), "unit": "disparity-volumes/s",
                         "roofline_frac": vr["frac"], "frac_of_achievable": vr["frac_of_achievable"], "saturated": vr["saturated"],
                         **({"frac_range_proportional": vr["frac_range_proportional"]} if "frac_range_proportional" in vr else {}),
@@ -1131,6 +1142,10 @@ def main():
                         "time_basis": vr["time_basis"], "k2_ms": vm["avg"].get("k_cost"), "k3_ms": vm["avg"].get(pn),
                         "wta_ms": vm["avg"].get("k_wta")}
                 ctx.trim()
+            if rank == 0:  # range-proportional over dense hull, same volumes, same box, same run
+                for k in ("cfg3r x1", "cfg3r x4", "cfg3hr x4"):
+                    if k in vres and k + " on the dense hull" in vres:
+                        vres[k]["over_dense_hull"] = vres[k]["value"] / vres[k + " on the dense hull"]["value"]
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 res.setdefault("variants", {})["error"] = repr(e)[:300]

@@ -117,14 +117,15 @@ struct RelVolume {
 };
 struct RelParams {
     RelVolume vol[kMaxBatch];
-    float *hand;        // hand-off slots [volume*8 + pass][2][LLmax][NS*64 + 2]: slab(s), minimum, base
-    unsigned *prog;     // progress words [volume*8 + pass][maxbands]
+    float *hand;        // self-validating hand-off slots [volume][pass: g.hand_base][band][LL][NS*64 + 4]: slab(s), minimum, base + bias, padding;
+                        // every word of a slot carries the launch's tag in its sign bit (mgm_pass_rel.hip)
+    long long hand_vstride;  // slots per volume
+    unsigned tag;       // 0 or 0x80000000
     unsigned *ticket, *err;
     const int2 *tasks;  // ticket -> (volume*8 + pass, band)
     long long npix, nvol;
     int MGM, NDIR, pass0, LLmax, maxbands, weighted;
-    int pubq;           // the band's last line publishes its progress when (pixel & pubq) == 0: 0, 1, 3 (every, every second, every fourth pixel)
-    int ld, lead;       // steps of LDS-DMA the loader keeps in flight (2..5; every step of lead is a step of lag per band); pixels beyond the bare need its slow path waits for
+    int ld;             // steps of LDS-DMA the loader keeps in flight (2..5; every step of lead is a step of lag per band)
     float P1, P2;
     unsigned long long *tl;  // nullptr, or 8 words per work item (MGM_HIP_TIMELINE; tools/timeline.py): start, end, waited, slow paths, where, steps, polls
     PassGeom g[kMaxDirs];

@@ -152,6 +152,8 @@ struct mgm_ctx {
     bool pending_check = false;
     // self-validating hand-off slabs (k_pass2, TAGS): what the region was last cleared for, and the tag of its last launch
     std::string hand_key;
+    std::string hand_rel_key;      // the range-proportional kernels' slots (same protocol): geometry they were last written for ...
+    unsigned hand_rel_tag = 0;     // ... and the tag they carry
     unsigned hand_tags[kMaxDirs] = {};  // per pass: the tag its slots carry after its last launch
     int num_cu = 256;  // hipDeviceProp_t::multiProcessorCount
     int xcc_mask = -1;  // XCC ids the workgroups of a launch see (k_xcc_census; -1: not looked yet)

@@ -20,7 +20,7 @@
 // Structure: bands of 16 scan lines per workgroup in lock-step on the slope-2 diagonal -- 4 compute waves of FOUR lines each
 // (a pixel's 64 slots on a row of 16 lanes, 4 per lane: see k_pass_rel) + a loader wave that feeds LDS rings by LDS-DMA --, a
 // 4-deep LDS ring per line (a slab is read by the next line at three consecutive steps, each time at another shift), the band
-// hand-off through global memory with progress words, work items by atomic ticket.  Not built here (the dense path keeps them): TSGM = 2 without weights (update_cost2 /
+// hand-off through global memory in self-validating slots (the launch's tag in every word's sign bit), work items by atomic ticket.  Not built here (the dense path keeps them): TSGM = 2 without weights (update_cost2 /
 // update_cost2_trunclinear are other functions), windows wider than 62 labels, costs that are not bytes, P2 = +INF.
 #include <algorithm>
 
@@ -67,6 +67,20 @@ __device__ __forceinline__ unsigned rel_lds_read_opaque(const unsigned *p)
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
     return v;
 }
+typedef unsigned rel_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rel_u4 rel_lds_read128_opaque(const float *p)
+{
+    rel_u4 v;
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float *)p;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void rel_lds_write128_opaque(float *p, rel_u4 v)
+{
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)p;
+    asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+constexpr int REL_BIAS = 1 << 24;  // a hand-off slot holds base + REL_BIAS: a positive word, its sign bit free for the tag
 
 // ---- the relative copy of a ragged volume ------------------------------------------------------------------------------
 // one thread per (pixel, slot): rel8[p][k] = byte code of C[p][base(p) + k - dmin] inside the pixel's window, 255 elsewhere;
@@ -111,31 +125,50 @@ hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi,
 // The relative copy of a single-word CENSUS volume straight from the descriptor words (integer costs, trunc = +INF or a whole
 // number up to 254: every cost is a byte and none is NaN by construction) -- no dense hull in between: a 1920x1080 volume of
 // 55-label windows in a hull of 256 cost 1.2 ms (general kernel, fp32 + compact hull) + 0.45 ms (k_rel_gather); this writes
-// its 133 MB alone.  One wave per pixel, lane = slot.  cost = min(popcount(cu ^ cv), trunc), trunc for a hypothesis outside
+// its 133 MB alone.  cost = min(popcount(cu ^ cv), trunc), trunc for a hypothesis outside
 // the right image (mgm_costvolume.h:65-78, 401-412); a pixel without a finite cost in its range is all zeros there (414-421).
 __global__ void __launch_bounds__(256) k_cost_census_rel(const uint32_t *__restrict__ cu, const uint32_t *__restrict__ cv, int nx, int ny, int vnx, int vny,
                                                          int dmin, int L, unsigned tb, const float *__restrict__ rlo, const float *__restrict__ rhi,
                                                          uint8_t *__restrict__ rel8, int *__restrict__ relb, unsigned *flag)
 {
+    // four pixels per wave: a row of 16 lanes per pixel, four slots (one 4-byte store) per lane
     const long long npix = (long long)nx * ny;
-    const int k = threadIdx.x & 63;
-    for (long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (long long)gridDim.x * 4) {
-        const int y = (int)(pix / nx), x = (int)(pix - (long long)y * nx);
-        const int lo = (int)rlo[pix], hi = (int)rhi[pix];
-        const int b = lo - 1, d = b + k;
+    const int li = threadIdx.x & 15;
+    const long long pix = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + ((threadIdx.x >> 4) & 3);
+    if (pix >= npix) return;
+    const int y = (int)(pix / nx), x = (int)(pix - (long long)y * nx);
+    const int lo = (int)rlo[pix], hi = (int)rhi[pix];
+    const int b = lo - 1;
+    const bool yin = y < vny;
+    const uint32_t wu = cu[pix];
+    const uint32_t *row = cv + (long long)(yin ? y : 0) * vnx;
+    unsigned code[4];
+    bool fin = false;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int d = b + 4 * li + q;
         const bool inw = d >= lo && d <= hi && d - dmin >= 0 && d - dmin < L;  // a label of this pixel
-        const bool yin = y < vny;
         const int qx = x + d;
         const bool in = yin && qx >= 0 && qx < vnx;
-        const unsigned pc = (unsigned)__builtin_popcount(cu[pix] ^ cv[(long long)(yin ? y : 0) * vnx + (in ? qx : 0)]);
-        unsigned code = inw ? (in ? (pc < tb ? pc : tb) : tb) : 255u;
-        if (__builtin_amdgcn_ballot_w64(inw && code != 255u) == 0ull) code = inw ? 0u : 255u;
-        rel8[pix * 64 + k] = (uint8_t)code;
-        if (k == 0) {
-            *reinterpret_cast<int4 *>(relb + pix * 4) = make_int4(b, lo, hi, 0);
-            const unsigned bad = (hi - lo + 1 > 62 || hi < lo) ? 1u : 0u;
-            if (bad && *flag != (*flag | bad)) atomicOr(flag, bad);
+        const unsigned pc = (unsigned)__builtin_popcount(wu ^ row[in ? qx : 0]);
+        code[q] = inw ? (in ? (pc < tb ? pc : tb) : tb) : 255u;
+        fin = fin || (inw && code[q] != 255u);
+    }
+    // no finite cost in the pixel's range (its row of 16 lanes): zeros there
+    const unsigned long long any = __builtin_amdgcn_ballot_w64(fin);
+    if (((any >> (threadIdx.x & 48)) & 0xffffull) == 0ull) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int d = b + 4 * li + q;
+            const bool inw = d >= lo && d <= hi && d - dmin >= 0 && d - dmin < L;
+            code[q] = inw ? 0u : 255u;
         }
+    }
+    reinterpret_cast<unsigned *>(rel8 + pix * 64)[li] = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+    if (li == 0) {
+        *reinterpret_cast<int4 *>(relb + pix * 4) = make_int4(b, lo, hi, 0);
+        const unsigned bad = (hi - lo + 1 > 62 || hi < lo) ? 1u : 0u;
+        if (bad && *flag != (*flag | bad)) atomicOr(flag, bad);
     }
 }
 hipError_t launch_cost_census_rel(const uint32_t *cu, const uint32_t *cv, int nx, int ny, int vnx, int vny, int dmin, int L, float trunc, const float *rlo,
@@ -143,7 +176,7 @@ hipError_t launch_cost_census_rel(const uint32_t *cu, const uint32_t *cv, int nx
 {
     const unsigned tb = trunc == __builtin_huge_valf() ? 255u : (unsigned)trunc;
     const long long npix = (long long)nx * ny;
-    const unsigned grid = (unsigned)std::min<long long>((npix + 3) / 4, 1 << 20);
+    const unsigned grid = (unsigned)((npix + 15) / 16);
     hipLaunchKernelGGL(k_cost_census_rel, dim3(grid), dim3(256), 0, s, cu, cv, nx, ny, vnx, vny, dmin, L, tb, rlo, rhi, rel8, relb, flag);
     return hipGetLastError();
 }
@@ -221,8 +254,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     int *mring = reinterpret_cast<int *>(hring + SD * HS);  // [SD][RR][4]    records of the step's pixels: base, lo, hi
     float *wring = reinterpret_cast<float *>(mring + SD * RR * 4);  // [SD][RR][4]   edge weights of the step's pixels
     uint8_t *cring = reinterpret_cast<uint8_t *>(wring + SD * RR * 4);  // [SD][RR][64] cost bytes of the step's pixels
-    unsigned *hprog = reinterpret_cast<unsigned *>(cring + SD * RR * 64);  // [SD + 4]   the producer's progress word as the DMAs saw it
-    int *s_task = reinterpret_cast<int *>(hprog + SD + 4);
+    unsigned *hprog = reinterpret_cast<unsigned *>(cring + SD * RR * 64);  // [4]   scratch of the loader's slow path (the error word)
+    int *s_task = reinterpret_cast<int *>(hprog + 4);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int r = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -249,10 +282,15 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     const long long istep = g.istep;
     const int nsteps = (LL + 1 + 2 * (RR - 1) + 3) / 4 * 4;
 
-    float *hand_out = P.hand + ((long long)(vp * 2 + (band & 1)) * P.LLmax) * HS;
-    const float *hand_in = P.hand + ((long long)(vp * 2 + ((band + 1) & 1)) * P.LLmax) * HS;
-    unsigned *prog_out = P.prog + vp * P.maxbands + band;
-    const unsigned *prog_in = band > 0 ? prog_out - 1 : prog_out;  // (band 0 issues the same DMAs, from its own words)
+    // SELF-VALIDATING hand-off slots, one per (volume, pass, band, pixel), written once per launch with the launch's tag in the
+    // sign bit of every word (values, minimum and biased base are non-negative; the padding words carry the tag alone): the
+    // reading band fetches a slot when it wants it and looks at the sign bits -- no progress words, no publication lag, no
+    // counted waits on the writing side (the second build's protocol, mgm_pass2.hip TAGS).  With progress words a band ran
+    // ~51 steps behind its predecessor where the geometry asks for 32: 120 bands x 19 steps of a 6600-step chain.
+    const long long hslot0 = (long long)(vp / kMaxDirs) * P.hand_vstride + g.hand_base;
+    float *hand_out = P.hand + (hslot0 + (long long)band * LL) * HS;
+    const float *hand_in = P.hand + (hslot0 + (long long)(band > 0 ? band - 1 : 0) * LL) * HS;  // (band 0 issues the same DMAs, from its own slots)
+    const unsigned tag = P.tag;
 
     if (r == NW) {
         // =========================== loader wave ===========================
@@ -276,7 +314,6 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         int mi = -1 - 2 * ml;
         const float *hptr = hand_in + lane * 4;
         int ht = 0;
-        unsigned known = 0;
         bool dead = false;
         unsigned long long tl_wait = 0, n_slow = 0, n_spin = 0;
         auto issue = [&]() {  // everything step `ht` reads
@@ -295,56 +332,71 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 mptr += adv ? istep : 0;
                 mi++;
             }
-            const int h = ht < LL ? ht : LL - 1;
-            if (from_global && !dead && known < (unsigned)h + 1u) {
-                // slow path: the producer band is not far enough ahead.  Wait for a LEAD beyond the bare need: it publishes one
-                // pixel per step, so coming back at the first sufficient value would bring us here again at the next step.
-                const unsigned want = min((unsigned)h + 1u + (unsigned)P.lead, (unsigned)LL);
-                unsigned spins = 0;
-                const unsigned long long w0 = P.tl ? wall_clock64() : 0ull;
-                n_slow++;
-                for (;;) {
-                    n_spin++;
-                    if (lane == 0) rel_dma4<REL_SC1>(prog_in, hprog + SD);
-                    rel_wait_vmcnt<0>();
-                    known = (unsigned)__builtin_amdgcn_readfirstlane((int)rel_lds_read_opaque(hprog + SD));
-                    if (known >= want) break;
-                    __builtin_amdgcn_s_sleep(4);
-                    if (((++spins) & 255u) == 0) {
-                        if (lane == 0) rel_dma4<REL_SC1>(P.err, hprog + SD + 1);
-                        rel_wait_vmcnt<0>();
-                        const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)rel_lds_read_opaque(hprog + SD + 1));
-                        if (spins > (SPIN_LIMIT >> 2) || e != 0) {
-                            if (lane == 0) __hip_atomic_store(P.err, 1u, RLX_AGENT);
-                            dead = true;
-                            break;
-                        }
-                    }
-                }
-                if (P.tl) tl_wait += wall_clock64() - w0;
-            }
+            // the previous band's slot of pixel ht, whatever it holds by now: validate() looks at it when its step comes
             if (lane < 16 * NS + 1) rel_dma16<REL_SC1>(hptr, hring + slot * HS);
-            if (lane == 0) rel_dma4<REL_SC1>(prog_in, hprog + slot);
             hptr += (ht < LL - 1) ? HS : 0;
             ht++;
         };
+        // The slot of pixel t has landed in the hand ring: make sure it is THIS launch's (every word's sign bit = the tag),
+        // fetching it again until it is; then take the tags off (and the bias off the base) so that the compute waves read it like
+        // any ring entry.
+        auto validate = [&](int t) {
+            if (!from_global || t >= LL || dead) return;
+            float *ent = hring + (t & (SD - 1)) * HS;
+            const bool mine = lane < 16 * NS + 1;
+            rel_u4 v = {0u, 0u, 0u, 0u};
+            unsigned spins = 0;
+            unsigned long long w0 = 0;
+            for (;;) {
+                bool ok = true;
+                if (mine) {
+                    v = rel_lds_read128_opaque(ent + lane * 4);
+                    ok = tag ? ((v.x & v.y & v.z & v.w) >> 31) != 0u : ((v.x | v.y | v.z | v.w) >> 31) == 0u;
+                }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                if (spins == 0) {
+                    n_slow++;
+                    if (P.tl) w0 = wall_clock64();
+                }
+                n_spin++;
+                __builtin_amdgcn_s_sleep(2);
+                if (mine) rel_dma16<REL_SC1>(hand_in + (long long)t * HS + lane * 4, ent);
+                rel_wait_vmcnt<0>();
+                if (((++spins) & 255u) == 0) {
+                    if (lane == 0) rel_dma4<REL_SC1>(P.err, hprog);
+                    rel_wait_vmcnt<0>();
+                    const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)rel_lds_read_opaque(hprog));
+                    if (spins > (SPIN_LIMIT >> 2) || e != 0) {
+                        if (lane == 0) __hip_atomic_store(P.err, 1u, RLX_AGENT);
+                        dead = true;
+                        break;
+                    }
+                }
+            }
+            if (P.tl && w0) tl_wait += wall_clock64() - w0;
+            if (mine) {
+                v.x &= 0x7fffffffu, v.y &= 0x7fffffffu, v.z &= 0x7fffffffu, v.w &= 0x7fffffffu;
+                if (lane == 16 * NS) v.y -= (unsigned)REL_BIAS;  // the piece (minimum, base + bias, padding, padding)
+                rel_lds_write128_opaque(ent + lane * 4, v);
+            }
+        };
         const int LD = P.ld;  // steps of DMA in flight (2 .. 5: the rings have SD = 8 slots, three of them being read)
         auto retire = [&]() {  // all but the newest LD - 1 steps of DMA have landed
-            const int n = (weighted ? 5 : 4) * (LD - 1);
+            const int n = (weighted ? 4 : 3) * (LD - 1);
             switch (n) {
+            case 3: rel_wait_vmcnt<3>(); break;
             case 4: rel_wait_vmcnt<4>(); break;
-            case 5: rel_wait_vmcnt<5>(); break;
+            case 6: rel_wait_vmcnt<6>(); break;
             case 8: rel_wait_vmcnt<8>(); break;
-            case 10: rel_wait_vmcnt<10>(); break;
+            case 9: rel_wait_vmcnt<9>(); break;
             case 12: rel_wait_vmcnt<12>(); break;
-            case 15: rel_wait_vmcnt<15>(); break;
-            case 16: rel_wait_vmcnt<16>(); break;
-            default: rel_wait_vmcnt<20>(); break;
+            default: rel_wait_vmcnt<16>(); break;
             }
         };
 #pragma unroll 1
         for (int u = 0; u < LD; u++) issue();
         retire();
+        validate(0);
         lds_barrier();  // B0
         unsigned long long lph[3] = {0, 0, 0};
         (void)lph;
@@ -353,11 +405,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             const unsigned long long l0 = MGM_REL_PHASES ? clock64() : 0;
             issue();   // step s + LD
             const unsigned long long l1 = MGM_REL_PHASES ? clock64() : 0;
-            retire();  // step s + 1 is in the rings -- and the progress word that travelled with it
-            if (from_global) {
-                const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)rel_lds_read_opaque(hprog + ((s + 1) & (SD - 1))));
-                known = v > known ? v : known;
-            }
+            retire();  // step s + 1 is in the rings
+            validate(s + 1);
             const unsigned long long l2 = MGM_REL_PHASES ? clock64() : 0;
             lds_barrier();
             if constexpr (MGM_REL_PHASES != 0) {
@@ -494,26 +543,20 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             if (to_global) {
                 const int iL = s - 1 - 2 * (RR - 1);  // the band's last line: lane group GL - 1 of this wave
                 if (iL >= 0 && iL < LL) {
-                    // the hand-off to the next band: write-through 16-byte stores straight from the registers
+                    // the hand-off to the next band: write-through 16-byte stores straight from the registers, every word tagged
                     float *dstg = hand_out + (long long)iL * HS;
                     if (grp == GL - 1) {
-                        rel_st_sc1_x4(dstg + 4 * li, pub);
-                        if constexpr (NS == 2) rel_st_sc1_x4(dstg + 64 + 4 * li, pubN);
+                        auto tagged = [&](relf4 x) {
+                            rel_u4 u = __builtin_bit_cast(rel_u4, x);
+                            u.x |= tag, u.y |= tag, u.z |= tag, u.w |= tag;
+                            return __builtin_bit_cast(relf4, u);
+                        };
+                        rel_st_sc1_x4(dstg + 4 * li, tagged(pub));
+                        if constexpr (NS == 2) rel_st_sc1_x4(dstg + 64 + 4 * li, tagged(pubN));
                         if (li == 0) {
-                            const relf2 v = {pubm, __builtin_bit_cast(float, bp)};
-                            rel_st_sc1_x2(dstg + NS * 64, v);
+                            const relf4 hd = {pubm, __builtin_bit_cast(float, bp + REL_BIAS), 0.0f, 0.0f};
+                            rel_st_sc1_x4(dstg + NS * 64, tagged(hd));
                         }
-                    }
-                    // Progress is published PL steps LATE, every fourth pixel: this wave only issues stores, they retire in order,
-                    // so once at most PL steps' worth of them are outstanding every store of pixel iL - PL has reached memory -- a
-                    // counted wait instead of draining the queue
-                    constexpr int SPS = 3 + NS, PL = 3;  // store instructions per step at most (Lr, slab pieces, minimum + base, the word itself)
-                    if (iL == LL - 1) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (lane == 0) __hip_atomic_store(prog_out, (unsigned)LL, RLX_AGENT);
-                    } else if (iL >= PL && ((iL - PL + 1) & P.pubq) == 0) {
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL * SPS) : "memory");
-                        if (lane == 0) __hip_atomic_store(prog_out, (unsigned)(iL - PL + 1), RLX_AGENT);
                     }
                 }
             }

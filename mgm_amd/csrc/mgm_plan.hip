@@ -1067,12 +1067,38 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     if (maxbands > kMaxBands) return fail(c, MGM_ERR_UNSUPPORTED, "image side exceeds 65536 pixels");
     const long long stride = npix * 64 + lr_pad_floats();
     if ((r = reserve(c, c->lr_rel, sizeof(float) * (size_t)stride * NDIR * nb))) return r;
-    if ((r = reserve(c, c->hand_rel, sizeof(float) * (size_t)nb * kMaxDirs * 2 * maxLL * HS))) return r;
+    // self-validating hand-off slots, one per (volume, pass, band, pixel): written once per launch with the launch's tag (see
+    // k_pass_rel); another geometry clears the region (all-ones words) and starts again with tag 0
+    long long per_vol = 0;
+    for (int q = 0; q < NDIR; q++) {
+        p.g[q].hand_base = per_vol;
+        per_vol += (long long)p.g[q].nbands * p.g[q].LL;
+    }
+    p.hand_vstride = per_vol;
+    std::string tag_key;
+    {
+        const size_t bytes = sizeof(float) * (size_t)nb * per_vol * HS;
+        const void *before = c->hand_rel.p;
+        if ((r = reserve(c, c->hand_rel, bytes))) return r;
+        char hk[128];
+        snprintf(hk, sizeof hk, "%d %d %d %d %d %d", nx, ny, NDIR, nb, HS, R);
+        if (c->hand_rel.p != before || c->hand_rel_key != hk) {
+            HIPCHK(c, hipMemsetAsync(c->hand_rel.p, 0xff, bytes, c->stream));
+            c->hand_rel_key = hk;
+            c->hand_rel_tag = 0x80000000u;  // (what the cleared words look like)
+        }
+        c->hand_rel_tag ^= 0x80000000u;
+        p.tag = c->hand_rel_tag;
+        // until the launch has been enqueued the region counts as unknown (an error return in between must not leave slots behind
+        // that carry the tag of the launch after next)
+        tag_key = c->hand_rel_key;
+        c->hand_rel_key.clear();
+    }
     // the task table: the simulated list schedule of the launch (one ticket counter), cached per shape
     char key[96];
     // workgroups (4 compute waves + the loader) per CU: tune rel_wg forces it
     const long long wgs = tune_num("rel_wg", 0);
-    const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 2 ? 2 : 3);  // (measured: x 1 / x 2 / x 4 of 1920x1080, both potentials)
+    const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 1 ? 2 : 3);  // (measured: x 1 / x 2 / x 4 of 1920x1080, both potentials)
     snprintf(key, sizeof key, "%d %d %d %d %d", nx, ny, NDIR, nb, rel_wg);
     if (c->tasks_rel_key != key) {
         std::vector<SimChain> ch;
@@ -1080,7 +1106,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
             for (int q = 0; q < NDIR; q++) {
                 SimChain k;
                 k.x = v * kMaxDirs + q, k.st = 0, k.nb = p.g[q].nbands, k.sib = -1, k.chain = v * NDIR + q;
-                k.skew = 2.0 * R + 14.0;  // (the lock-step diagonal has slope 2 for every pass here; progress words + loader lead: ~14 steps of lag)
+                k.skew = 2.0 * R + 4.0;  // (the lock-step diagonal has slope 2 for every pass here; loader lead + one fetch: ~4 steps of lag)
                 k.len = p.g[q].LL + 2.0 * (R - 1) + 1.0;
                 ch.push_back(k);
             }
@@ -1109,7 +1135,6 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
         for (int v = 0; v < nb; v++)
             if (!p.vol[v].w8) return fail(c, MGM_ERR_INVALID, "mgm_aggregate_batch: weights for all volumes or for none");
     p.hand = (float *)c->hand_rel.p;
-    p.prog = words + 4;
     p.ticket = words + 0;
     p.err = words + 1;
     p.tasks = (const int2 *)c->tasks_rel.p;
@@ -1125,11 +1150,6 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     p.P2 = P2;
     // a launch bound by its chains of bands wants a short lead (lag per band); a batch has the slack and wants the loads covered
     p.ld = (int)std::min(5LL, std::max(2LL, tune_num("rel_ld", nb <= 1 ? 2 : 3)));
-    p.lead = (int)std::min(32LL, std::max(0LL, tune_num("rel_lead", nb <= 1 ? 1 : 4)));
-    {
-        const long long q = tune_num("rel_pubq", 4);  // 1, 2 or 4
-        p.pubq = q >= 4 ? 3 : (q >= 2 ? 1 : 0);
-    }
     p.tl = nullptr;
     // MGM_HIP_TIMELINE=<file>: one line per work item (tools/timeline.py) -- where the compute units' time goes
     const char *tl_file = getenv("MGM_HIP_TIMELINE");
@@ -1139,11 +1159,11 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
         p.tl = (unsigned long long *)c->dbg.p;
     }
     HIPCHK(c, hipMemsetAsync(words, 0, sizeof(unsigned), c->stream));
-    HIPCHK(c, hipMemsetAsync(words + 4, 0, sizeof(unsigned) * (size_t)nb * kMaxDirs * kMaxBands, c->stream));
     {
         TimeScope t(c, "k_pass_rel");
         HIPCHK(c, launch_pass_rel(p, c->ntasks_rel, fh, pube, rel_wg, c->stream));
     }
+    c->hand_rel_key = tag_key;  // enqueued: every slot of the region will carry this launch's tag
     HIPCHK(c, hipMemcpyAsync(c->h_words + 1, words + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     c->pending_check = true;
     if (p.tl) {
