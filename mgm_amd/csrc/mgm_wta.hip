@@ -569,44 +569,65 @@ __device__ __forceinline__ void cubicfit(const float (&p)[4], float &out_pmin, f
 // reference's S holds there: 0 - (NDIR-1)*INF, or 0 without the over-count fix) instead of a stored value.
 __global__ void __launch_bounds__(256) k_wta_rel(const WtaRelParams P)
 {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // FOUR pixels per wave: a pixel's 64 slots on a row of 16 lanes, 4 per lane (16-byte loads; the first version had one slot per
+    // lane, one pixel per wave: 4-byte loads and six LDS-crossbar rounds per pixel, 1.5 ms per 1920x1080 volume where its 4.4 GB ask for 0.7)
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, grp = lane >> 4;
     const float f = (float)(P.NDIR - 1);
     float vout = 0.0f;
     if (P.FIX == 1) vout = vout - f * f_inf();
     const bool vfin = finite_bits(vout);
-    for (long long pix = (long long)blockIdx.x * 4 + wv; pix < P.npix; pix += (long long)gridDim.x * 4) {
+    const long long nquads = (P.npix + 3) / 4;
+    for (long long q4 = (long long)blockIdx.x * 4 + wv; q4 < nquads; q4 += (long long)gridDim.x * 4) {
+        const long long pix0 = q4 * 4 + grp;
+        const bool live = pix0 < P.npix;
+        const long long pix = live ? pix0 : P.npix - 1;
         const int4 rec = reinterpret_cast<const int4 *>(P.base)[pix];  // (the pixel's record: disparity of slot 0, its own range)
         const int b = rec.x, lo = rec.y, hi = rec.z;
         const bool windowed = P.wlo != nullptr;
         const int wl = windowed ? (int)P.wlo[pix] : lo, wh = windowed ? (int)P.whi[pix] : hi;
-        const int d = b + lane;
-        float a = 0.0f;
-        for (int p = 0; p < P.NDIR; p++) a = a + P.Lr[(long long)p * P.nvol + pix * 64 + lane];
-        if (P.FIX == 1) a = a - f * c8_decode(P.c8[pix * 64 + lane]);
-        const bool own = d >= lo && d <= hi;
-        const float val = own ? a : vout;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int p = 0; p < P.NDIR; p++) {
+            const f4 t = *reinterpret_cast<const f4 *>(P.Lr + (long long)p * P.nvol + pix * 64 + 4 * li);
+#pragma unroll
+            for (int q = 0; q < 4; q++) a[q] = a[q] + t[q];
+        }
+        if (P.FIX == 1) {
+            const unsigned cw = *reinterpret_cast<const unsigned *>(P.c8 + pix * 64 + 4 * li);
+#pragma unroll
+            for (int q = 0; q < 4; q++) a[q] = a[q] - f * c8_decode((cw >> (8 * q)) & 255u);
+        }
+        float val[4];
+        // (2) its own disparities inside the window: the first strict minimum by rising disparity = the smallest (value, disparity)
+        float cb = f_inf();
+        int ci = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int d = b + 4 * li + q;
+            const bool own = d >= lo && d <= hi;
+            val[q] = own ? a[q] : vout;
+            if (own && d >= wl && d <= wh && finite_bits(val[q]) && val[q] < cb) {
+                cb = val[q];
+                ci = d;
+            }
+        }
+        auto take = [&](float ov, int oi) {
+            if (ov < cb || (ov == cb && oi < ci)) {
+                cb = ov;
+                ci = oi;
+            }
+        };
+        // butterfly over the row of 16 lanes: quad swaps, then the two mirrors
+        take(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cb), 0xB1, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, ci, 0xB1, 0xf, 0xf, false));
+        take(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cb), 0x4E, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, ci, 0x4E, 0xf, 0xf, false));
+        take(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cb), 0x141, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, ci, 0x141, 0xf, 0xf, false));
+        take(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cb), 0x140, 0xf, 0xf, false)), __builtin_amdgcn_update_dpp(0, ci, 0x140, 0xf, 0xf, false));
         // (1) the window's disparities below the pixel's own range: all `vout`, the first of them is the candidate
         float best = f_inf();
         int bi = 0x7fffffff;
         if (wl < lo && wl <= wh && vfin) {
             best = vout;
             bi = wl;
-        }
-        // (2) its own disparities inside the window
-        float cb = f_inf();
-        int ci = 0x7fffffff;
-        if (own && d >= wl && d <= wh && finite_bits(val)) {
-            cb = val;
-            ci = d;
-        }
-#pragma unroll
-        for (int x = 32; x >= 1; x >>= 1) {
-            const float ov = __shfl_xor(cb, x);
-            const int oi = __shfl_xor(ci, x);
-            if (ov < cb || (ov == cb && oi < ci)) {
-                cb = ov;
-                ci = oi;
-            }
         }
         if (ci != 0x7fffffff && best > cb) {
             best = cb;
@@ -621,14 +642,18 @@ __global__ void __launch_bounds__(256) k_wta_rel(const WtaRelParams P)
         float outv, outc = best;
         if (bi == 0x7fffffff) outv = __builtin_nanf("");  // the reference leaves minP uninitialised here
         else outv = (float)bi;
-        if (P.refine >= 1 && bi != 0x7fffffff && bi - 1 >= wl && bi + 2 <= wh) {  // mgm_refine.h:58 (S allocated over the window)
-            float v[4];
+        // the four values around the minimum, from the lanes of the row that hold them (fetched whether or not they are used: every
+        // lane takes part in the crossbar reads)
+        float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int sl = bi - 1 + k - b;  // slot of that disparity
-                const float x = __shfl(val, sl & 63);
-                v[k] = (sl >= 0 && sl < 64) ? x : vout;
-            }
+        for (int k = 0; k < 4; k++) {
+            const int sl = (bi == 0x7fffffff ? b : bi) - 1 + k - b;  // slot of that disparity (row-uniform)
+            const int e = sl & 3;
+            const float mine = e == 0 ? val[0] : (e == 1 ? val[1] : (e == 2 ? val[2] : val[3]));
+            const float x = __shfl(mine, (lane & 48) | ((sl >> 2) & 15));
+            v[k] = (sl >= 0 && sl < 64) ? x : vout;
+        }
+        if (P.refine >= 1 && bi != 0x7fffffff && bi - 1 >= wl && bi + 2 <= wh) {  // mgm_refine.h:58 (S allocated over the window)
             float vmin = outc, dx = 0;
             if (P.refine == 1) vfit(v[0], v[1], v[2], vmin, dx);
             else if (P.refine == 2) parabolafit(v, vmin, dx);
@@ -637,7 +662,7 @@ __global__ void __launch_bounds__(256) k_wta_rel(const WtaRelParams P)
             outv = (float)bi + dx;
             outc = vmin;
         }
-        if (lane == 0) {
+        if (li == 0 && live) {
             P.out[pix] = outv;
             P.outcost[pix] = outc;
         }
@@ -645,7 +670,7 @@ __global__ void __launch_bounds__(256) k_wta_rel(const WtaRelParams P)
 }
 hipError_t launch_wta_rel(const WtaRelParams &p, hipStream_t s)
 {
-    const long long groups = (p.npix + 3) / 4;
+    const long long groups = (p.npix + 15) / 16;  // four waves of four pixels per block
     const long long cap = (long long)p.num_cu * 64;
     hipLaunchKernelGGL(k_wta_rel, dim3((unsigned)std::max(1ll, std::min(groups, cap))), dim3(256), 0, s, p);
     return hipGetLastError();
