@@ -125,15 +125,23 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     // 256, of a colour pair below 766, squared differences below 65026 per channel: two bytes (up to 512 labels: the pass
     // kernels that read them).  The flag word tells afterwards whether every cost really had the form.
     const int cb = (costfn == 2 || (costfn == 0 && u->nch == 1 && !(*out)->diff_wide) || dmax - dmin + 1 > 512) ? 1 : 2;
-    if (c8_supported(dmax - dmin + 1) && dev().c8) {
-        if (may_be_integer) {
-            if ((r = c8_alloc(c, *out, cb))) return r;
-            p.C8 = (*out)->d8;
-            p.cbytes = cb;
-            (*out)->c8_state = 1;
-        } else
-            (*out)->c8_state = -1;
-    }
+    // (a ragged single-word census volume first tries to be written as its range-proportional copy ALONE, below: no compact hull
+    // is allocated for it unless that fails)
+    const bool rel_direct_candidate = rloI && costfn == 2 && census_words == 1 && rel_enabled() && dev().lazy_f32 && tune_num("rel_direct", 1) != 0 &&
+                                      (truncDist == __builtin_huge_valf() || (truncDist >= 0.0f && truncDist <= 254.0f && truncDist == rintf(truncDist)));
+    auto setup_c8 = [&]() -> int {
+        if (c8_supported(dmax - dmin + 1) && dev().c8) {
+            if (may_be_integer) {
+                if (int rr = c8_alloc(c, *out, cb)) return rr;
+                p.C8 = (*out)->d8;
+                p.cbytes = cb;
+                (*out)->c8_state = 1;
+            } else
+                (*out)->c8_state = -1;
+        }
+        return MGM_OK;
+    };
+    if (!rel_direct_candidate && (r = setup_c8())) return r;
     (*out)->f32_state = 1;
     p.nx = u->nx;
     p.ny = u->ny;
@@ -235,7 +243,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     // A ragged single-word census volume: the RANGE-PROPORTIONAL copy alone, straight from the descriptor words (mgm_pass_rel.hip,
     // k_cost_census_rel) -- neither the fp32 hull nor its compact twin is written; whoever wants the hull gets it from
     // ensure_f32.  The flag word (a window wider than 62 labels) is read back at once: such a volume takes the general path.
-    if (p.rlo && census_fits && rel_enabled() && dev().lazy_f32 && tune_num("rel_direct", 1) != 0) {
+    if (rel_direct_candidate && p.rlo && census_fits) {
         const size_t npix = (size_t)u->nx * u->ny, need = npix * 64 + npix * 16 + 16;
         if ((*out)->rel_cap < need) {
             if ((*out)->relbuf) (void)hipFree((*out)->relbuf);
@@ -265,6 +273,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
         }
         (*out)->rel_state = 0;
     }
+    if (rel_direct_candidate && (r = setup_c8())) return r;  // (it did not work out: a window wider than 62 labels -- the general path)
     if (LP && (*out)->diff_fails < 2 && (census_fits || diff_may_fit)) {
         int pcb = (costfn == 2 || (costfn == 0 && u->nch == 1 && !(*out)->diff_wide) || LP > 512) ? 1 : 2;
         for (;;) {

@@ -256,7 +256,8 @@ int mgm_ctx_destroy(mgm_ctx *c)
     (void)hipSetDevice(c->device);
     (void)pipe_join(c);  // (deferred calls of a pipelined context still write the caller's images)
     (void)hipStreamSynchronize(c->stream);
-    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->exact_scratch, &c->words, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8};
+    std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->exact_scratch, &c->words, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8,
+                               &c->lr_rel, &c->hand_rel, &c->tasks_rel};  // (the range-proportional kernels' workspace: round 5 forgot it here)
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);
         bufs.push_back(&c->pad8[v]);
@@ -299,6 +300,7 @@ int mgm_ctx_trim(mgm_ctx *c)
     std::vector<Buf *> bufs = {&c->lr, &c->hand, &c->hand2, &c->handm, &c->exact_mins, &c->exact_scratch, &c->census_u, &c->census_v, &c->dbg, &c->stmp, &c->ones8,
                                &c->lr_rel, &c->hand_rel, &c->tasks_rel};
     c->tasks_rel_key.clear();
+    c->hand_rel_key.clear();
     c->rel_last_batch = 0;
     for (int v = 0; v < kMaxBatch; v++) {
         bufs.push_back(&c->padf[v]);

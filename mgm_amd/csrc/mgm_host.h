@@ -62,7 +62,7 @@ struct mgm_cv {
     // last aggregation, so a refilled volume, or a new one at a recycled address, is not mistaken for one of them
     unsigned long long gen = 0;
     // ragged volume, range-proportional copy (round 5; mgm_pass_rel.hip): 64 cost bytes per pixel placed at its own window +
-    // the disparity of slot 0 + a flag word, one allocation [npix*64 bytes][npix ints][flag]; rel_state 0 none, 1 written (flag
+    // a 16-byte record per pixel (disparity of slot 0, lo, hi) + a flag word, one allocation [npix*64 bytes][npix*16 bytes][flag]; rel_state 0 none, 1 written (flag
     // not read back yet), 2 usable, -1 not usable (a window wider than 62 labels, a cost that is not a byte)
     uint8_t *relbuf = nullptr;
     size_t rel_cap = 0;
