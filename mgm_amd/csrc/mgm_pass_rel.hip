@@ -246,9 +246,15 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
 {
     static_assert(!(FH && PUBE), "FH potentials convolve over the RECEIVING pixel's range: consumer side only");
     constexpr int NS = (FH || PUBE) ? 1 : 2;
-    constexpr int HS = NS * 64 + 4;  // floats per hand-off slot: slab(s), minimum, base (+ 2 of padding: 16-byte pieces)
+    // A ring entry = a hand-off slot, whole 16-byte pieces.  One slab (FH, PUBE): [4 guard words][64 values][4 guard words][minimum,
+    // base, 2 of padding] -- the guards hold what a disparity the pixel does not have reads as (+INF; PUBE: FAR), so a reader takes
+    // its four values at ONE clamped index, no comparison or selection per value (the 64 + 64 variant: [L][N][minimum, base, padding])
+    constexpr bool GUARD = NS == 1;
+    constexpr int GO = GUARD ? 4 : 0;                   // where the values start
+    constexpr int HOFF = GUARD ? 72 : NS * 64;          // where the header (minimum, base) sits
+    constexpr int HS = HOFF + 4;                        // floats per entry / hand-off slot
+    constexpr int NPIECE = HS / 4;                      // its 16-byte pieces
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // a ring entry = a hand-off slot: slab(s), then minimum, base, 2 words of padding -- HS floats, whole 16-byte pieces
     float *ring = smem;                                    // [RR][RD4][HS]   what the lines of the band publish
     float *hring = ring + RR * RD4 * HS;                   // [SD][HS]        the previous band's last line, by pixel & (SD - 1)
     int *mring = reinterpret_cast<int *>(hring + SD * HS);  // [SD][RR][4]    records of the step's pixels: base, lo, hi
@@ -271,6 +277,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     }
     if (!P.weighted)  // unit weights: the ring holds ones, nothing is fetched
         for (int k = tid; k < SD * RR * 4; k += (NW + 1) * 64) wring[k] = 1.0f;
+    if constexpr (GUARD)  // entries nobody has written yet read as "no such disparity" everywhere
+        for (int k = tid; k < (RR * RD4 + SD) * HS; k += (NW + 1) * 64) ring[k] = f_inf();
     __syncthreads();
     const int2 tk = P.tasks[*s_task];
     const int vp = tk.x, band = tk.y;  // vp = volume*8 + pass
@@ -333,7 +341,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 mi++;
             }
             // the previous band's slot of pixel ht, whatever it holds by now: validate() looks at it when its step comes
-            if (lane < 16 * NS + 1) rel_dma16<REL_SC1>(hptr, hring + slot * HS);
+            if (lane < NPIECE) rel_dma16<REL_SC1>(hptr, hring + slot * HS);
             hptr += (ht < LL - 1) ? HS : 0;
             ht++;
         };
@@ -343,7 +351,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         auto validate = [&](int t) {
             if (!from_global || t >= LL || dead) return;
             float *ent = hring + (t & (SD - 1)) * HS;
-            const bool mine = lane < 16 * NS + 1;
+            const bool mine = lane < NPIECE;
             rel_u4 v = {0u, 0u, 0u, 0u};
             unsigned spins = 0;
             unsigned long long w0 = 0;
@@ -376,7 +384,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             if (P.tl && w0) tl_wait += wall_clock64() - w0;
             if (mine) {
                 v.x &= 0x7fffffffu, v.y &= 0x7fffffffu, v.z &= 0x7fffffffu, v.w &= 0x7fffffffu;
-                if (lane == 16 * NS) v.y -= (unsigned)REL_BIAS;  // the piece (minimum, base + bias, padding, padding)
+                if (lane == HOFF / 4) v.y -= (unsigned)REL_BIAS;  // the piece (minimum, base + bias, padding, padding)
                 rel_lds_write128_opaque(ent + lane * 4, v);
             }
         };
@@ -478,16 +486,24 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                     const bool own = f0 ? k == 0 : k == 3;
                     const int di = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
                     const float *src = entry(own ? ln : prow, own ? i - 1 : i + di);
-                    const float m = interior ? src[NS * 64] : 0.0f;                                   // minimum (or FAR)
-                    const int sh = bp - reinterpret_cast<const int *>(src)[NS * 64 + 1];              // base
-                    const float far = PUBE ? m : f_inf();
+                    const float m = interior ? src[HOFF] : 0.0f;                                   // minimum (or FAR)
+                    const int sh = bp - reinterpret_cast<const int *>(src)[HOFF + 1];              // base
                     float w[NS][4];
+                    if constexpr (GUARD) {
+                        // the four values at one index clamped into [first guard, last guard]: whatever lies outside the neighbour's
+                        // 64 slots reads a guard word (a pixel that takes no neighbours reads guard words only)
+                        const int idx0 = interior ? min(max(4 * li + sh, -4), 64) + GO : 0;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int idx = 4 * li + q + sh;
-                        const bool in = interior && (unsigned)idx < 64u;
+                        for (int q = 0; q < 4; q++) w[0][q] = src[idx0 + q];
+                    } else {
+                        const float far = PUBE ? m : f_inf();
 #pragma unroll
-                        for (int t = 0; t < NS; t++) w[t][q] = in ? src[t * 64 + (in ? idx : 0)] : far;
+                        for (int q = 0; q < 4; q++) {
+                            const int idx = 4 * li + q + sh;
+                            const bool in = interior && (unsigned)idx < 64u;
+#pragma unroll
+                            for (int t = 0; t < NS; t++) w[t][q] = in ? src[t * 64 + (in ? idx : 0)] : far;
+                        }
                     }
                     if constexpr (PUBE) {
                         // e = 0; e += t1 - m1; ... (0 + x is x: x >= +0)
@@ -534,11 +550,18 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 pubm = cap - m;
             }
             const relf4 pubN = {N[0], N[1], N[2], N[3]};
+            const float farv = PUBE ? pubm : f_inf();  // what a disparity this pixel does not have reads as
+            const relf4 far4 = {farv, farv, farv, farv};
+            const relf4 hdr4 = {pubm, __builtin_bit_cast(float, bp), 0.0f, 0.0f};
             if (act) {
                 float *ent = ring + (ln * RD4 + (i & (RD4 - 1))) * HS;
-                *reinterpret_cast<relf4 *>(ent + 4 * li) = pub;
+                *reinterpret_cast<relf4 *>(ent + GO + 4 * li) = pub;
                 if constexpr (NS == 2) *reinterpret_cast<relf4 *>(ent + 64 + 4 * li) = pubN;
-                if (li == 0) *reinterpret_cast<relf2 *>(ent + NS * 64) = relf2{pubm, __builtin_bit_cast(float, bp)};
+                if constexpr (GUARD) {
+                    if (li < 3) *reinterpret_cast<relf4 *>(ent + (li == 0 ? 0 : (li == 1 ? GO + 64 : HOFF))) = li == 2 ? hdr4 : far4;
+                } else {
+                    if (li == 0) *reinterpret_cast<relf2 *>(ent + HOFF) = relf2{pubm, __builtin_bit_cast(float, bp)};
+                }
             }
             if (to_global) {
                 const int iL = s - 1 - 2 * (RR - 1);  // the band's last line: lane group GL - 1 of this wave
@@ -551,11 +574,13 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                             u.x |= tag, u.y |= tag, u.z |= tag, u.w |= tag;
                             return __builtin_bit_cast(relf4, u);
                         };
-                        rel_st_sc1_x4(dstg + 4 * li, tagged(pub));
+                        rel_st_sc1_x4(dstg + GO + 4 * li, tagged(pub));
                         if constexpr (NS == 2) rel_st_sc1_x4(dstg + 64 + 4 * li, tagged(pubN));
-                        if (li == 0) {
-                            const relf4 hd = {pubm, __builtin_bit_cast(float, bp + REL_BIAS), 0.0f, 0.0f};
-                            rel_st_sc1_x4(dstg + NS * 64, tagged(hd));
+                        const relf4 hd = {pubm, __builtin_bit_cast(float, bp + REL_BIAS), 0.0f, 0.0f};
+                        if constexpr (GUARD) {
+                            if (li < 3) rel_st_sc1_x4(dstg + (li == 0 ? 0 : (li == 1 ? GO + 64 : HOFF)), tagged(li == 2 ? hd : far4));
+                        } else {
+                            if (li == 0) rel_st_sc1_x4(dstg + HOFF, tagged(hd));
                         }
                     }
                 }
@@ -581,7 +606,7 @@ template <bool FH, bool PUBE>
 static hipError_t launch_rel_one(const RelParams &p, int ntasks, int wg_per_cu, hipStream_t s)
 {
     constexpr int NS = (FH || PUBE) ? 1 : 2;
-    constexpr int HS = NS * 64 + 4;
+    constexpr int HS = NS == 1 ? 76 : NS * 64 + 4;
     size_t shmem = sizeof(float) * ((size_t)RR * RD4 * HS + (size_t)SD * HS + 2 * SD * RR * 4) + SD * RR * 64 + sizeof(unsigned) * (SD + 4) + 16;
     // Occupancy through the LDS request, as for the second build: wg_per_cu workgroups (of 4 compute waves: one per SIMD) share a
     // CU -- one for a launch bound by its chains of bands, more for a batch (throughput)
@@ -603,6 +628,6 @@ hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, i
 }
 int pass_rel_lines() { return RR; }
 int pass_rel_phases() { return MGM_REL_PHASES ? 16 : 0; }
-int pass_rel_hand_floats(bool one_slab) { return (one_slab ? 1 : 2) * 64 + 4; }
+int pass_rel_hand_floats(bool one_slab) { return one_slab ? 76 : 2 * 64 + 4; }  // (one slab: 4 + 64 + 4 guard-framed values + the header's 4)
 
 }  // namespace mgm
