@@ -234,8 +234,8 @@ __device__ __forceinline__ float rel_row_min(float v)
 // straight into LDS rings by LDS-DMA, P.ld steps ahead, retired by COUNTED waits; the compute waves touch only LDS and
 // issue stores.  (With register loads the compiler drained vmcnt at every step: global_load .. s_waitcnt vmcnt(0).)
 // What bounds a step (profiles/r05_rel_phases.txt, a -DMGM_REL_PHASES=1 build): the compute waves' own instruction stream --
-// ~2000 clocks Hirschmueller, ~4300 FH, of which the loader needs 600; one wave per SIMD issues a wave64 instruction every
-// four clocks whatever their dependences (three min-convolutions side by side were no faster), so a single launch is bound
+// ~1800 clocks Hirschmueller, ~3900 FH (the loader issues its DMAs in 150 and waits for the predecessor band's slot for the rest);
+// one wave per SIMD issues a wave64 instruction every four clocks whatever their dependences (three min-convolutions side by side were no faster), so a single launch is bound
 // by instructions per step x steps of its chain of bands, a batch by VALU throughput.
 // PUBE (unit weights, Hirschmueller): the transform does not depend on the reader then, so the producer publishes
 // E[k] = fmin(fmin(L[k], N[k] + P1), m + P2) - m once (one slab; its "minimum" word carries FAR = (m + P2) - m, what the
