@@ -64,3 +64,19 @@ def test_kernel_hash_ignores_comments_only(tmp_path):
     assert bench.kernel_source_hash(str(d)) == h0
     (d / "k.hip").write_text("__global__ void k(int *p) { *p = 2; }\n")
     assert bench.kernel_source_hash(str(d)) != h0
+
+
+def test_roofline_of_range_proportional_launch_prices_owned_cells():
+    """bench.roofline_of: a k_pass_rel launch is priced on the labels the pixels OWN (55 of a hull of 256 for cfg3r), so its
+    fraction cannot pass 1 where the hull-priced figure would; a k_pass2 launch of the same workload is priced on the hull."""
+    import bench
+    w = bench.WORKLOADS["cfg3r"]
+    own = (2 * w["ragged"] + 1) / float(bench.labels_of(w))
+    rel = bench.roofline_of(w, 4, {"k_cost": 0.16, "k_pass_rel": 8.0, "k_wta": 0.76}, "cfg3r")
+    hull = bench.roofline_of(w, 4, {"k_cost": 1.2, "k_pass2": 8.0, "k_wta": 0.76}, "cfg3r")
+    assert abs(rel["existing_cells_over_hull_cells"] - own) < 1e-12
+    assert abs(rel["frac"] - rel["frac_range_proportional"]) < 1e-12
+    assert abs(rel["frac_dense_hull_equivalent"] * own - rel["frac"]) < 1e-9
+    assert rel["frac"] < 1.0 < rel["frac_dense_hull_equivalent"]
+    assert abs(hull["frac"] - hull["frac_dense_hull_equivalent"]) < 1e-12 and hull["frac_range_proportional"] < hull["frac"]
+    assert rel["algorithmic_bytes_per_launch"] == 12.0 * w["NDIR"] * w["nx"] * w["ny"] * (2 * w["ragged"] + 1) * 4
