@@ -667,6 +667,267 @@ int orc_mgm(const float *C, int nx, int ny, int L, int dmin, const float *w8, fl
 }
 
 /* ------------------------------------------------------------------------ */
+/* RAGGED ranges (round 6): the same path with a per-pixel Dvec range.        */
+/*                                                                          */
+/* Containers: the reference allocates one Dvec per pixel over [min(p),     */
+/* max(p)] = ((int)dminI[p], (int)dmaxI[p]) (mgm_costvolume.h:311-327,      */
+/* dvec.cc:55-64) and every read outside a Dvec's own range gives +INF      */
+/* (dvec.cc:129).  Here a volume is the dense HULL [ny][nx][L], label o <->  */
+/* disparity dmin + o, with integer images lo/hi (absolute disparities,      */
+/* dmin <= lo <= hi <= dmin+L-1): a pixel OWNS lo..hi, every other slot of    */
+/* its slab holds +INF -- which is what a neighbour reads there.             */
+/* ------------------------------------------------------------------------ */
+
+/* allocate_and_fill_sgm_costvolume (mgm_costvolume.h:337-424) with range images.  Slots a pixel does not own are
+ * written +INF and take no part in the "no finite hypothesis => zeros" rule (414-421 loops over the pixel's Dvec). */
+int orc_costvolume_ranged(const float *in_u, const float *in_v, int nx, int ny, int nch, int vnx, int vny, int dmin,
+                          int L, const int *lo, const int *hi, int prefilter, int distance, float truncDist,
+                          int census_win, float *C)
+{
+    /* A cost depends on (p, o) alone, so the uniform restatement over the hull gives every label's cost (steps 0-2 and
+     * 4.1-4.3); the per-pixel rule (414-421) is then applied to each pixel's OWN range.  The hull call has applied that rule
+     * hull-wide: a slab it zeroed had no finite cost anywhere, so the own range has none either and is zeroed too. */
+    int r = orc_costvolume(in_u, in_v, nx, ny, nch, vnx, vny, dmin, dmin + L - 1, prefilter, distance, truncDist,
+                           census_win, C);
+    if (r) return r;
+    for (int jj = 0; jj < ny; jj++)
+        for (int ii = 0; ii < nx; ii++) {
+            size_t p = (size_t)jj * nx + ii;
+            float *Cp = C + p * L;
+            int a = lo[p] - dmin, b = hi[p] - dmin;
+            if (a < 0 || b >= L || a > b) return -21;
+            int allinvalid = 1;
+            for (int o = a; o <= b; o++)
+                if (isfinite(Cp[o])) allinvalid = 0;
+            if (allinvalid)
+                for (int o = a; o <= b; o++) Cp[o] = 0;
+            for (int o = 0; o < a; o++) Cp[o] = INFINITY;
+            for (int o = b + 1; o < L; o++) Cp[o] = INFINITY;
+        }
+    return 0;
+}
+
+/* FixBounrady_for_minConvTruncatedLinear, mgm_core.cc:166-186.  Lq = the neighbour's hull slab (index = label - dmin),
+ * [imin, imax] its own range, M the receiver's working row over [mmin, mmax]; all as hull indices. */
+static void fix_boundary(const float *Lq, int imin, int imax, float *M, int mmin, int mmax, float P1)
+{
+    if (imin < mmin) {
+        float T = Lq[imin];
+        for (int o = imin + 1; o <= mmin; o++) {
+            float Inext = o <= imax ? Lq[o] : INFINITY;
+            T = MIN_(T + P1, Inext);
+        }
+        M[0] = MIN_(M[0], T);
+    }
+    if (imax > mmax) {
+        float T = Lq[imax];
+        for (int o = imax - 1; o >= mmax; o--) {
+            float Inext = o >= imin ? Lq[o] : INFINITY;
+            T = MIN_(T + P1, Inext);
+        }
+        M[mmax - mmin] = MIN_(M[mmax - mmin], T);
+    }
+}
+
+/* update_pixel for a receiver that owns [a, b] (hull indices); qa/qb = the neighbours' own ranges.  Neighbour slabs hold
+ * +INF outside their ranges, so Lq[o] and AT(Lq, o+-1) are Dvec::operator[] (dvec.cc:129). */
+static void update_pixel_r(float *Lp, const float *Cp, const float *const Ln[4], const float mn[4], const float D[4],
+                           float P1, float P2, int howmany, int mode, int L, int a, int b, const int qa[4],
+                           const int qb[4], float *scratch)
+{
+    int NN = b - a + 1;
+    if (mode == 0) { /* update_cost2, mgm_core.cc:66-90 */
+        const float *Lq = Ln[0], *Lr = Ln[1];
+        float min1 = mn[0], min2 = mn[1];
+        for (int o = a; o <= b; o++) {
+            float C = Cp[o];
+            float vL0 = Lq[o];
+            float vLP1 = MIN_(AT(Lq, o - 1, L), AT(Lq, o + 1, L)) + P1;
+            float vLP2 = min1 + P2;
+            float v2L0 = Lr[o];
+            float v2LP1 = MIN_(AT(Lr, o - 1, L), AT(Lr, o + 1, L)) + P1;
+            float v2LP2 = min2 + P2;
+            float e = 0;
+            e += (fmin3(vL0, vLP1, vLP2) - min1) / 2;
+            e += (fmin3(v2L0, v2LP1, v2LP2) - min2) / 2;
+            Lp[o] = C + e;
+        }
+    } else if (mode == 1) { /* update_costW, 95-144 */
+        for (int o = a; o <= b; o++) {
+            float C = Cp[o];
+            float e = 0;
+            for (int k = 0; k < howmany; k++) {
+                const float *Lq = Ln[k];
+                float vL0 = Lq[o];
+                float vLP1 = MIN_(AT(Lq, o - 1, L), AT(Lq, o + 1, L)) + P1 * D[k];
+                float vLP2 = mn[k] + P2 * D[k];
+                e += fmin3(vL0, vLP1, vLP2) - mn[k];
+            }
+            Lp[o] = C + e / howmany;
+        }
+    } else if (mode == 2) { /* update_cost2_trunclinear, 197-219: the only caller of the boundary fix-up */
+        float *M1 = scratch, *M2 = scratch + L;
+        memcpy(M1, Ln[0] + a, sizeof(float) * NN);
+        fix_boundary(Ln[0], qa[0], qb[0], M1, a, b, P1);
+        minconv(M1, NN, mn[0], P1, P2);
+        memcpy(M2, Ln[1] + a, sizeof(float) * NN);
+        fix_boundary(Ln[1], qa[1], qb[1], M2, a, b, P1);
+        minconv(M2, NN, mn[1], P1, P2);
+        for (int o = a; o <= b; o++) Lp[o] = Cp[o] + (M1[o - a] - mn[0] + M2[o - a] - mn[1]) / 2;
+    } else { /* update_costW_trunclinear, 229-281: convolution over the receiver's range, no fix-up */
+        for (int k = 0; k < howmany; k++) {
+            float *M = scratch + (size_t)k * L;
+            memcpy(M, Ln[k] + a, sizeof(float) * NN);
+            minconv(M, NN, mn[k], P1 * D[k], P2 * D[k]);
+        }
+        for (int o = a; o <= b; o++) {
+            float e = scratch[o - a] - mn[0];
+            for (int k = 1; k < howmany; k++) e += scratch[(size_t)k * L + (o - a)] - mn[k];
+            Lp[o] = Cp[o] + e / howmany;
+        }
+    }
+}
+
+/*
+ * mgm(), mgm_core.cc:408-613, with range images.
+ *   C        [ny][nx][L] hull; only the slots a pixel owns (lo..hi) are read
+ *   lo, hi   the ranges CC was allocated with (absolute disparities)
+ *   slo, shi NULL, or the range images mgm() itself is called with when they differ from CC's (main()'s TSGM_ITER loop,
+ *            mgm.cc:377-388: CC keeps its ranges, S is allocated from the narrowed images, mgm_core.cc:426); with
+ *            sdmin/sL = the hull S is returned on
+ *   S        NULL or [ny][nx][sL]: the corrected aggregated volume; slots outside a pixel's S-range hold +INF
+ *   out/outcost, Lr_dump as orc_mgm (Lr_dump on C's hull, +INF outside a pixel's range)
+ * S[i] accumulates Lr[i][o] for o in Lr[i]'s range that also lie in S[i]'s (increment_nolock drops the others,
+ * dvec.cc:117-125); the search runs over S[i]'s range with CC[i][o] = +INF where CC does not own o (592-609).
+ */
+int orc_mgm_ranged(const float *C, int nx, int ny, int L, int dmin, const int *lo, const int *hi, const int *slo,
+                   const int *shi, int sdmin, int sL, const float *w8, float P1, float P2, int NDIR, int MGM, int FH,
+                   int FIX, float *S, float *out, float *outcost, float *Lr_dump)
+{
+    if (NDIR < 1 || NDIR > 8 || MGM < 1 || MGM > 4) return -1;
+    if (!slo || !shi) {
+        slo = lo;
+        shi = hi;
+        sdmin = dmin;
+        sL = L;
+    }
+    size_t npix = (size_t)nx * ny;
+    size_t nvol = npix * L;
+    for (size_t i = 0; i < npix; i++) {
+        if (lo[i] < dmin || hi[i] > dmin + L - 1 || lo[i] > hi[i]) return -21;
+        if (slo[i] < sdmin || shi[i] > sdmin + sL - 1 || slo[i] > shi[i]) return -22;
+    }
+    int weighted = 0;
+    if (w8)
+        for (size_t i = 0; i < npix * 8; i++)
+            if (w8[i] != 1.0) weighted = 1; /* mgm_core.cc:420-422 */
+
+    int mode;
+    if (weighted) mode = FH ? 3 : 1;
+    else if (FH) mode = (MGM == 2) ? 2 : 3;
+    else mode = (MGM == 2) ? 0 : 1;
+
+    float *Cm = (float *)malloc(sizeof(float) * nvol); /* C with +INF where a pixel does not own the label */
+    float *Lr = (float *)malloc(sizeof(float) * nvol);
+    float *mins = (float *)malloc(sizeof(float) * npix);
+    float *Sx = (float *)malloc(sizeof(float) * npix * (size_t)sL);
+    if (!Cm || !Lr || !mins || !Sx) return -2;
+    for (size_t i = 0; i < npix; i++) {
+        int a = lo[i] - dmin, b = hi[i] - dmin;
+        for (int o = 0; o < L; o++) Cm[i * L + o] = (o >= a && o <= b) ? C[i * L + o] : INFINITY;
+    }
+    memset(Sx, 0, sizeof(float) * npix * (size_t)sL); /* allocate_costvolume zero-initialises (426) */
+
+    for (int pass = 0; pass < NDIR; pass++) {
+        pass_t dir = PASSES[pass];
+        memcpy(Lr, Cm, sizeof(float) * nvol); /* 495-498 */
+        int maxii = nx, maxjj = ny;
+        if (!dir.row_major) {
+            maxii = ny;
+            maxjj = nx;
+        }
+#pragma omp parallel
+        {
+            float *scratch = (float *)malloc(sizeof(float) * 4 * (size_t)L);
+            for (int ii = 0; ii < maxii + 2 * maxjj; ii++) {
+#pragma omp for schedule(static, 1)
+                for (int jj = 0; jj < maxjj; jj++) {
+                    int x = ii - 2 * jj, y = jj;
+                    if (x < 0 || x >= maxii) continue;
+                    int maxnx = maxii, maxny = maxjj;
+                    if (!dir.row_major) {
+                        int t = x;
+                        x = y;
+                        y = t;
+                        t = maxnx;
+                        maxnx = maxny;
+                        maxny = t;
+                    }
+                    if (dir.inc_x == 0) x = (maxnx - 1) - x;
+                    if (dir.inc_y == 0) y = (maxny - 1) - y;
+                    size_t pidx = (size_t)x + (size_t)y * nx;
+                    size_t nidx[4];
+                    int inside = 1;
+                    for (int k = 0; k < 4; k++) {
+                        int qx = x + dir.d[k][0], qy = y + dir.d[k][1];
+                        if (!(qx >= 0 && qy >= 0 && qx < nx && qy < ny)) inside = 0;
+                        nidx[k] = (size_t)qx + (size_t)qy * nx;
+                    }
+                    if (inside) { /* 538-541 */
+                        const float *Ln[4];
+                        float mn[4], D[4];
+                        int qa[4], qb[4];
+                        for (int k = 0; k < 4; k++) {
+                            Ln[k] = Lr + nidx[k] * L;
+                            mn[k] = (k < MGM) ? mins[nidx[k]] : INFINITY;
+                            D[k] = weighted ? w8[pidx + (size_t)P2C[k][pass] * npix] : 1.0f;
+                            qa[k] = lo[nidx[k]] - dmin;
+                            qb[k] = hi[nidx[k]] - dmin;
+                        }
+                        update_pixel_r(Lr + pidx * L, Cm + pidx * L, Ln, mn, D, P1, P2, MGM, mode, L, lo[pidx] - dmin,
+                                       hi[pidx] - dmin, qa, qb, scratch);
+                    }
+                    /* Dvec::get_minvalue over the pixel's own range (dvec.cc:81-88) */
+                    mins[pidx] = slab_min(Lr + pidx * L + (lo[pidx] - dmin), hi[pidx] - lo[pidx] + 1);
+                }
+            }
+            free(scratch);
+        }
+        if (Lr_dump) memcpy(Lr_dump + (size_t)pass * nvol, Lr, sizeof(float) * nvol);
+#pragma omp parallel for
+        for (size_t i = 0; i < npix; i++) /* 582-587 */
+            for (int d = lo[i]; d <= hi[i]; d++)
+                if (d >= slo[i] && d <= shi[i]) Sx[i * sL + (d - sdmin)] += Lr[i * L + (d - dmin)];
+    }
+
+#pragma omp parallel for
+    for (size_t i = 0; i < npix; i++) { /* 592-609 */
+        float minP = NAN;
+        float minL = INFINITY;
+        float *Si = Sx + i * sL;
+        for (int d = slo[i]; d <= shi[i]; d++) {
+            float Cd = (d >= lo[i] && d <= hi[i]) ? C[i * L + (d - dmin)] : INFINITY;
+            if (FIX == 1) Si[d - sdmin] = Si[d - sdmin] - (NDIR - 1) * Cd;
+            if (isfinite(Si[d - sdmin]))
+                if (minL > Si[d - sdmin]) {
+                    minL = Si[d - sdmin];
+                    minP = (float)d;
+                }
+        }
+        out[i] = minP;
+        outcost[i] = minL;
+        if (S)
+            for (int o = 0; o < sL; o++)
+                S[i * sL + o] = (o + sdmin >= slo[i] && o + sdmin <= shi[i]) ? Si[o] : INFINITY;
+    }
+    free(Cm);
+    free(Lr);
+    free(mins);
+    free(Sx);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* Sub-pixel refinement: mgm_refine.h:40-70 + refine.h.                      */
 /* ------------------------------------------------------------------------ */
 enum { REF_NONE = 0, REF_VFIT = 1, REF_PARABOLA = 2, REF_CUBIC = 3, REF_PARABOLA_OCV = 4 };
@@ -796,6 +1057,35 @@ int orc_refine(const float *S, int nx, int ny, int L, int dmin, int method, floa
         if (!(minP == minP)) continue; /* NaN label: UB in the reference */
         int o = (int)minP;
         if (o - 1 >= dmin && o + 2 <= dmin + L - 1) {
+            const float *Si = S + i * L + (o - dmin);
+            float v[4] = {Si[-1], Si[0], Si[1], Si[2]};
+            float dx = 0;
+            if (method == REF_VFIT) vfit(v, &minL, &dx);
+            else if (method == REF_PARABOLA) parabolafit(v, &minL, &dx);
+            else if (method == REF_CUBIC) cubicfit(v, &minL, &dx);
+            else parabolafit_ocv(v, &minL, &dx);
+            minP = o + dx;
+        }
+        out[i] = minP;
+        outcost[i] = minL;
+    }
+    return 0;
+}
+
+/* subpixel_refinement_sgm (mgm_refine.h:40-70) on a ragged S: the gate is the pixel's own S range (58). */
+int orc_refine_ranged(const float *S, int nx, int ny, int L, int dmin, const int *lo, const int *hi, int method,
+                      float *out, float *outcost)
+{
+    if (method == REF_NONE) return 0;
+    if (method < 0 || method > REF_PARABOLA_OCV) return -1;
+    size_t N = (size_t)nx * ny;
+#pragma omp parallel for
+    for (size_t i = 0; i < N; i++) {
+        float minP = out[i];
+        float minL = outcost[i];
+        if (!(minP == minP)) continue; /* NaN label: UB in the reference */
+        int o = (int)minP;
+        if (o - 1 >= lo[i] && o + 2 <= hi[i]) {
             const float *Si = S + i * L + (o - dmin);
             float v[4] = {Si[-1], Si[0], Si[1], Si[2]};
             float dx = 0;

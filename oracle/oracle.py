@@ -29,6 +29,15 @@ REF_MGM_O = os.path.join(HERE, "_ref", "mgm_o")
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def int_ranges(dminI, dmaxI):
+    """Range images -> the integer ranges the reference's Dvecs get: `init(int min, int max)` called with floats
+    (mgm_costvolume.h:323, dvec.cc:55) truncates toward zero."""
+    lo = np.trunc(np.asarray(dminI, np.float64)).astype(np.int32)
+    hi = np.trunc(np.asarray(dmaxI, np.float64)).astype(np.int32)
+    return np.ascontiguousarray(lo.reshape(lo.shape[-2:])), np.ascontiguousarray(hi.reshape(hi.shape[-2:]))
 
 
 def build(force=False):
@@ -90,6 +99,12 @@ class Oracle:
         L.orc_mgm.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float,
                               C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_void_p]
         L.orc_refine.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p]
+        L.orc_costvolume_ranged.argtypes = ([_f32p, _f32p] + [C.c_int] * 7 + [_i32p, _i32p, C.c_int, C.c_int, C.c_float,
+                                                                                 C.c_int, _f32p])
+        L.orc_mgm_ranged.argtypes = ([_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float] + [C.c_int] * 4
+                                     + [C.c_void_p, _f32p, _f32p, C.c_void_p])
+        L.orc_refine_ranged.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _f32p, _f32p]
 
     def set_threads(self, n):
         self.lib.orc_set_num_threads(int(n))
@@ -150,6 +165,61 @@ class Oracle:
         return out, outcost
 
 
+    # ---- ragged ranges (round 6): hull volumes (ny, nx, L) + integer range images (ny, nx) ----
+    def costvolume_ranged(self, u, v, lo, hi, hmin, hmax, prefilter="none", distance="ad", truncDist=np.inf, census_win=3):
+        """Cost volume on the hull [hmin, hmax]; +INF where a pixel does not own the label."""
+        u, v = _img(u), _img(v)
+        nch, ny, nx = u.shape
+        _, vny, vnx = v.shape
+        L = hmax - hmin + 1
+        Cv = np.empty((ny, nx, L), np.float32)
+        r = self.lib.orc_costvolume_ranged(u, v, nx, ny, nch, vnx, vny, hmin, L, np.ascontiguousarray(lo, np.int32),
+                                           np.ascontiguousarray(hi, np.int32),
+                                           self.lib.orc_prefilter_index(prefilter.encode()),
+                                           self.lib.orc_distance_index(distance.encode()), truncDist, census_win, Cv)
+        if r:
+            raise ValueError("orc_costvolume_ranged failed (%d)" % r)
+        return Cv
+
+    def mgm_ranged(self, Cv, hmin, lo, hi, P1, P2, NDIR, MGM, FH=0, FIX=1, w8=None, srange=None, want_S=True,
+                   dump_lr=False):
+        """mgm() with range images.  srange = (slo, shi, shmin, shmax): the (narrowed) ranges mgm() is CALLED with while
+        the cost volume keeps (lo, hi) -- main()'s TSGM_ITER loop.  Returns (S, out, outcost[, Lr])."""
+        Cv = np.ascontiguousarray(Cv, np.float32)
+        ny, nx, L = Cv.shape
+        lo, hi = np.ascontiguousarray(lo, np.int32), np.ascontiguousarray(hi, np.int32)
+        if srange is None:
+            slo = shi = None
+            shmin, sL = hmin, L
+        else:
+            slo, shi = np.ascontiguousarray(srange[0], np.int32), np.ascontiguousarray(srange[1], np.int32)
+            shmin, sL = srange[2], srange[3] - srange[2] + 1
+        S = np.empty((ny, nx, sL), np.float32) if want_S else None
+        out = np.empty((ny, nx), np.float32)
+        outc = np.empty((ny, nx), np.float32)
+        if w8 is not None:
+            w8 = np.ascontiguousarray(w8, np.float32)
+            assert w8.shape == (8, ny, nx)
+        lr = np.empty((NDIR, ny, nx, L), np.float32) if dump_lr else None
+        r = self.lib.orc_mgm_ranged(Cv, nx, ny, L, hmin, lo, hi, _optp(slo), _optp(shi), shmin, sL, _optp(w8), P1, P2,
+                                    NDIR, MGM, FH, FIX, _optp(S), out, outc, _optp(lr))
+        if r:
+            raise ValueError("orc_mgm_ranged failed (%d)" % r)
+        return (S, out, outc, lr) if dump_lr else (S, out, outc)
+
+    def refine_ranged(self, S, shmin, slo, shi, method, out, outcost):
+        S = np.ascontiguousarray(S, np.float32)
+        ny, nx, L = S.shape
+        out = np.array(out, np.float32, copy=True)
+        outcost = np.array(outcost, np.float32, copy=True)
+        r = self.lib.orc_refine_ranged(S, nx, ny, L, shmin, np.ascontiguousarray(slo, np.int32),
+                                       np.ascontiguousarray(shi, np.int32),
+                                       self.lib.orc_refinement_index(method.encode()), out, outcost)
+        if r < 0:
+            raise ValueError("orc_refine_ranged failed (%d)" % r)
+        return out, outcost
+
+
 class Reference:
     """The compiled reference itself (only where oracle/_ref was built)."""
 
@@ -170,6 +240,63 @@ class Reference:
         L.ref_refine.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _f32p, _f32p]
         if hasattr(L, "ref_seconds"):
             L.ref_seconds.restype = C.c_double
+        if hasattr(L, "ref_mgm_ranged"):
+            L.ref_costvolume_ranged.argtypes = ([_f32p, _f32p] + [C.c_int] * 5 + [_f32p, _f32p, C.c_int, C.c_int, C.c_char_p,
+                                                                                   C.c_char_p, C.c_float, C.c_float, _f32p])
+            L.ref_mgm_ranged.argtypes = ([_f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float] + [C.c_int] * 4
+                                         + [C.c_float, C.c_void_p, _f32p, _f32p])
+            L.ref_refine_ranged.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_char_p, _f32p, _f32p]
+
+    def has_ranged(self):
+        return hasattr(self.lib, "ref_mgm_ranged")
+
+    # ---- ragged ranges: the reference takes the float range IMAGES (its Dvec constructor truncates them) ----
+    def costvolume_ranged(self, u, v, dminI, dmaxI, hmin, hmax, prefilter="none", distance="ad", truncDist=np.inf,
+                          fill=np.inf):
+        u, v = _img(u), _img(v)
+        nch, ny, nx = u.shape
+        _, vny, vnx = v.shape
+        L = hmax - hmin + 1
+        Cv = np.empty((ny, nx, L), np.float32)
+        r = self.lib.ref_costvolume_ranged(u, v, nx, ny, nch, vnx, vny, np.ascontiguousarray(dminI, np.float32),
+                                           np.ascontiguousarray(dmaxI, np.float32), hmin, L, prefilter.encode(),
+                                           distance.encode(), truncDist, fill, Cv)
+        if r:
+            raise ValueError("ref_costvolume_ranged: a range leaves the hull (%d)" % r)
+        return Cv
+
+    def mgm_ranged(self, Cv, hmin, dminI, dmaxI, P1, P2, NDIR, MGM, FH=0, FIX=1, w8=None, srange=None, want_S=True,
+                   fill=np.inf):
+        Cv = np.ascontiguousarray(Cv, np.float32)
+        ny, nx, L = Cv.shape
+        dminI, dmaxI = np.ascontiguousarray(dminI, np.float32), np.ascontiguousarray(dmaxI, np.float32)
+        if srange is None:
+            smin = smax = None
+            shmin, sL = hmin, L
+        else:
+            smin, smax = np.ascontiguousarray(srange[0], np.float32), np.ascontiguousarray(srange[1], np.float32)
+            shmin, sL = srange[2], srange[3] - srange[2] + 1
+        S = np.empty((ny, nx, sL), np.float32) if want_S else None
+        out = np.empty((ny, nx), np.float32)
+        outc = np.empty((ny, nx), np.float32)
+        if w8 is not None:
+            w8 = np.ascontiguousarray(w8, np.float32)
+        with _quiet_stdout():
+            r = self.lib.ref_mgm_ranged(Cv, nx, ny, dminI, dmaxI, hmin, L, _optp(smin), _optp(smax), shmin, sL, _optp(w8),
+                                        P1, P2, NDIR, MGM, FH, FIX, fill, _optp(S), out, outc)
+        if r:
+            raise ValueError("ref_mgm_ranged: a range leaves the hull (%d)" % r)
+        return S, out, outc
+
+    def refine_ranged(self, S, shmin, sminI, smaxI, method, out, outcost):
+        S = np.ascontiguousarray(S, np.float32)
+        ny, nx, sL = S.shape
+        out = np.array(out, np.float32, copy=True)
+        outcost = np.array(outcost, np.float32, copy=True)
+        self.lib.ref_refine_ranged(S, nx, ny, np.ascontiguousarray(sminI, np.float32),
+                                   np.ascontiguousarray(smaxI, np.float32), shmin, sL, method.encode(), out, outcost)
+        return out, outcost
 
     def seconds(self):
         """Wall time of the reference function inside the last costvolume / mgm / refine call (not the container copies)."""

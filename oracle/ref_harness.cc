@@ -141,4 +141,75 @@ int ref_refine(const float *S, int nx, int ny, int dmin, int dmax, const char *m
     return 0;
 }
 
+/* ---- RAGGED ranges (round 6): the reference called with range IMAGES, as main() does for -m/-M files and inside its
+ * TSGM_ITER loop (mgm.cc:338-353, 377-388).  Dense side of the adapter: the hull [hmin, hmin+L-1] of all ranges, `fill`
+ * where a pixel's Dvec has no such label. ---- */
+
+/* allocate_and_fill_sgm_costvolume (mgm_costvolume.h:337-424) with per-pixel ranges */
+int ref_costvolume_ranged(const float *u, const float *v, int nx, int ny, int nch, int vnx, int vny, const float *dminI,
+                          const float *dmaxI, int hmin, int L, const char *prefilter, const char *distance,
+                          float truncDist, float fill, float *C)
+{
+    Img U = make_img(u, nx, ny, nch), V = make_img(v, vnx, vny, nch);
+    Img lo = make_img(dminI, nx, ny, 1), hi = make_img(dmaxI, nx, ny, 1);
+    RefTimer *tm = new RefTimer();
+    struct costvolume_t CC = allocate_and_fill_sgm_costvolume(U, V, lo, hi, (char *)prefilter, (char *)distance, truncDist);
+    delete tm;
+    for (int i = 0; i < nx * ny; i++) {
+        if (CC[i].min < hmin || CC[i].max > hmin + L - 1) return -1;
+        for (int o = 0; o < L; o++)
+            C[(size_t)i * L + o] = (o + hmin >= CC[i].min && o + hmin <= CC[i].max) ? CC[i][o + hmin] : fill;
+    }
+    return 0;
+}
+
+/* mgm() (mgm_core.cc:408-613): CC allocated from (dminI, dmaxI) and filled from the hull volume C; mgm() itself is called
+ * with (sminI, smaxI) -- the same images, or (TSGM_ITER > 1) the narrowed ones while CC keeps its ranges.  S (may be NULL)
+ * is returned on the hull [shmin, shmin+sL-1] with `fill` outside a pixel's S range. */
+int ref_mgm_ranged(const float *C, int nx, int ny, const float *dminI, const float *dmaxI, int hmin, int L,
+                   const float *sminI, const float *smaxI, int shmin, int sL, const float *w8, float P1, float P2,
+                   int NDIR, int MGM, int FH, int FIX, float fill, float *S, float *out, float *outcost)
+{
+    Img lo = make_img(dminI, nx, ny, 1), hi = make_img(dmaxI, nx, ny, 1);
+    Img slo = make_img(sminI ? sminI : dminI, nx, ny, 1), shi = make_img(smaxI ? smaxI : dmaxI, nx, ny, 1);
+    if (!sminI) { shmin = hmin; sL = L; }
+    struct costvolume_t CC = allocate_costvolume(lo, hi);
+    for (int i = 0; i < nx * ny; i++) {
+        if (CC[i].min < hmin || CC[i].max > hmin + L - 1) return -1;
+        for (int d = CC[i].min; d <= CC[i].max; d++) CC[i].set_nolock(d, C[(size_t)i * L + (d - hmin)]);
+    }
+    Img W(nx, ny, 8);
+    for (int i = 0; i < nx * ny * 8; i++) W[i] = w8 ? w8[i] : 1.0f;
+    Img O(nx, ny), OC(nx, ny);
+    RefTimer *tm = new RefTimer();
+    struct costvolume_t SS = mgm(CC, W, slo, shi, &O, &OC, P1, P2, NDIR, MGM, FH, FIX);
+    delete tm;
+    if (S)
+        for (int i = 0; i < nx * ny; i++) {
+            if (SS[i].min < shmin || SS[i].max > shmin + sL - 1) return -2;
+            for (int o = 0; o < sL; o++)
+                S[(size_t)i * sL + o] = (o + shmin >= SS[i].min && o + shmin <= SS[i].max) ? SS[i][o + shmin] : fill;
+        }
+    memcpy(out, &O.data[0], sizeof(float) * (size_t)nx * ny);
+    memcpy(outcost, &OC.data[0], sizeof(float) * (size_t)nx * ny);
+    return 0;
+}
+
+/* subpixel_refinement_sgm (mgm_refine.h:40-70) on a ragged corrected S given on its hull */
+int ref_refine_ranged(const float *S, int nx, int ny, const float *sminI, const float *smaxI, int shmin, int sL,
+                      const char *method, float *out, float *outcost)
+{
+    Img slo = make_img(sminI, nx, ny, 1), shi = make_img(smaxI, nx, ny, 1);
+    struct costvolume_t SS = allocate_costvolume(slo, shi);
+    for (int i = 0; i < nx * ny; i++)
+        for (int d = SS[i].min; d <= SS[i].max; d++) SS[i].set_nolock(d, S[(size_t)i * sL + (d - shmin)]);
+    std::vector<float> O(out, out + (size_t)nx * ny), OC(outcost, outcost + (size_t)nx * ny);
+    RefTimer *tm = new RefTimer();
+    subpixel_refinement_sgm(SS, O, OC, (char *)method);
+    delete tm;
+    memcpy(out, &O[0], sizeof(float) * (size_t)nx * ny);
+    memcpy(outcost, &OC[0], sizeof(float) * (size_t)nx * ny);
+    return 0;
+}
+
 } /* extern "C" */
