@@ -505,7 +505,16 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
     bool only_rel = true;
     for (int v = 0; v < n; v++) only_rel = only_rel && C[v]->rel_only;
     const bool rel_pays = use_fh > 0 || (w8 && w8[0]) || n >= 2 || only_rel || tune_num("rel", 1) >= 2;
-    if (!S && MGM != 2 && P2 < __builtin_huge_valf() && rel_pays && rel_enabled()) {
+    //  the hand-off of k_pass_rel keeps the launch's tag in the sign bit of every published word, so every L / E / minimum
+    // must be >= +0: non-negative penalties (the dense path's own gate, run_passes `first_build`) and, for weighted launches,
+    // positive finite weights (a negative or NaN weight makes N + P1 D - m negative or NaN): those take the dense kernels.
+    bool rel_sign_ok = P1 >= 0.0f && P2 >= 0.0f;
+    if (rel_sign_ok && w8 && w8[0] && !S && MGM != 2 && P2 < __builtin_huge_valf() && rel_pays && rel_enabled()) {
+        bool odd = false;
+        if ((r = weights_have_odd_values(c, w8, n, npix, &odd))) return r;
+        rel_sign_ok = !odd;
+    }
+    if (!S && MGM != 2 && P2 < __builtin_huge_valf() && rel_pays && rel_sign_ok && rel_enabled()) {
         bool all = true;
         for (int v = 0; v < n && all; v++) {
             bool u = false;
@@ -533,23 +542,29 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
         // placements and keep the fastest (the launch is idempotent: same inputs, same Lr volumes, whichever allocation)
         if (r == MGM_OK && c->place_tries >= 2 && c->lr.p && (c->lr.p != c->placed_ptr || c->lr.cap != c->placed_cap) && c->lr.cap >= (1ull << 28)) {
             auto timed = [&](float *ms) -> int {
-                hipEvent_t a, b;
-                HIPCHK(c, hipEventCreate(&a));
-                HIPCHK(c, hipEventCreate(&b));
-                HIPCHK(c, hipEventRecord(a, c->stream));
+                struct Ev {  // (destroyed on every exit path)
+                    hipEvent_t e = nullptr;
+                    ~Ev() { if (e) (void)hipEventDestroy(e); }
+                } a, b;
+                HIPCHK(c, hipEventCreate(&a.e));
+                HIPCHK(c, hipEventCreate(&b.e));
+                HIPCHK(c, hipEventRecord(a.e, c->stream));
                 int rr = run_passes(c, C + v0, (w8 && w8[0]) ? w8 + v0 : nullptr, m, P1, P2, MGM, use_fh, 0, NDIR, true);
                 if (rr == MGM_OK) {
-                    HIPCHK(c, hipEventRecord(b, c->stream));
+                    HIPCHK(c, hipEventRecord(b.e, c->stream));
                     HIPCHK(c, hipStreamSynchronize(c->stream));
-                    HIPCHK(c, hipEventElapsedTime(ms, a, b));
+                    HIPCHK(c, hipEventElapsedTime(ms, a.e, b.e));
                 }
-                (void)hipEventDestroy(a);
-                (void)hipEventDestroy(b);
                 return rr;
             };
             float best = 0;
             if ((r = timed(&best))) break;  // (the first run above was the warm-up)
-            std::vector<Buf> held;
+            struct Held {  // the allocations that are only held so that the next try lands elsewhere: freed on every exit path
+                std::vector<Buf> v;
+                void release() { for (Buf &h : v) if (h.p) (void)hipFree(h.p); v.clear(); }
+                ~Held() { release(); }
+                void push_back(const Buf &b) { v.push_back(b); }
+            } held;
             for (int t = 1; t < c->place_tries && r == MGM_OK; t++) {
                 size_t fr = 0, tot = 0;
                 if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < c->lr.cap + (1ull << 30)) break;  // no room for a second workspace
@@ -577,8 +592,7 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
                 }
             }
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            for (Buf &h : held)
-                if (h.p) (void)hipFree(h.p);
+            held.release();
             c->placed_ptr = c->lr.p;
             c->placed_cap = c->lr.cap;
         }
@@ -771,6 +785,29 @@ int mgm_aggregate(mgm_ctx *c, const mgm_cv *C, const float *w8, float P1, float 
 int mgm_debug_download_lr(mgm_ctx *c, int pass, float *dense)
 {
     if (int jr = pipe_join(c)) return jr;  // (pipelined context: run what has been deferred first)
+    if (c && dense && c->rel_last_batch > 0 && c->last_ndir == 0 && c->rel_last_cvs[0] && c->lr_rel.p) {
+        // the last aggregation ran on the range-proportional copy (k_pass_rel): volume 0's pass, expanded on the host to the dense
+        // hull -- label o <-> slot o + dmin - base(p) of the pixel's 64, +INF where the pixel has no such label (test aid only)
+        if (pass < 0 || pass >= c->rel_last_ndir) return fail(c, MGM_ERR_INVALID, "mgm_debug_download_lr: no such pass");
+        const mgm_cv *C = c->rel_last_cvs[0];
+        const size_t npix = (size_t)C->nx * C->ny;
+        const int L = C->dmax - C->dmin + 1;
+        HIPCHK(c, hipSetDevice(c->device));
+        std::vector<float> slabs(npix * 64);
+        std::vector<int> rec(npix * 4);
+        HIPCHK(c, hipMemcpyAsync(slabs.data(), (const float *)c->lr_rel.p + (size_t)pass * c->rel_last_stride, sizeof(float) * npix * 64,
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(rec.data(), C->relbuf + npix * 64, sizeof(int) * npix * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (size_t p = 0; p < npix; p++) {
+            const int b = rec[p * 4], lo = rec[p * 4 + 1], hi = rec[p * 4 + 2];
+            for (int o = 0; o < L; o++) {
+                const int d = C->dmin + o;
+                dense[p * L + o] = (d >= lo && d <= hi) ? slabs[p * 64 + (d - b)] : __builtin_huge_valf();
+            }
+        }
+        return MGM_OK;
+    }
     if (!c || !dense || pass < 0 || pass >= c->last_ndir || !c->lr.p)
         return fail(c, MGM_ERR_INVALID, "mgm_debug_download_lr: nothing to download");
     HIPCHK(c, hipSetDevice(c->device));

@@ -85,6 +85,25 @@ static int run_passes_exact(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *
         c->last_cvs[v] = v < nb ? Cs[v] : nullptr;
         c->last_gens[v] = v < nb ? Cs[v]->gen : 0;
     }
+    c->rel_last_batch = 0;  // (an earlier range-proportional aggregation of the same volume is no longer the context's last)
+    return MGM_OK;
+}
+
+// Weighted launches of the range-proportional kernels: does any weight image hold a value that is not positive and finite
+// (<= 0, NaN, INF)?  One small scan + read-back per call, the same kernel run_passes uses to recognise two-valued weights.
+int weights_have_odd_values(mgm_ctx *c, const mgm_img *const *w8s, int nb, long long npix, bool *odd)
+{
+    *odd = false;
+    int r;
+    if ((r = reserve(c, c->wvals, sizeof(unsigned) * 4 * kMaxBatch))) return r;
+    unsigned init[4 * kMaxBatch], got[4 * kMaxBatch];
+    for (int v = 0; v < nb; v++) init[4 * v] = 0u, init[4 * v + 1] = 0xffffffffu, init[4 * v + 2] = 0u, init[4 * v + 3] = 0u;
+    HIPCHK(c, hipMemcpyAsync(c->wvals.p, init, sizeof(unsigned) * 4 * nb, hipMemcpyHostToDevice, c->stream));
+    for (int v = 0; v < nb; v++)
+        if (w8s[v]) HIPCHK(c, launch_weight_values(w8s[v]->d, npix * 8, (unsigned *)c->wvals.p + 4 * v, c->stream));
+    HIPCHK(c, hipMemcpyAsync(got, c->wvals.p, sizeof(unsigned) * 4 * nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int v = 0; v < nb; v++) *odd = *odd || (w8s[v] && got[4 * v + 3] != 0);
     return MGM_OK;
 }
 
@@ -214,7 +233,7 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
 
     // weighted? (mgm_core.cc:420-423: any value != 1.0 switches every update) -- and what values do the weights take: the
     // planes compute_mgm_weights makes hold 1 and ONE other value, which the pass kernel exploits (k_pass2, W2)
-    bool weighted = false, w2cand = false;
+    bool weighted = false, w2cand = false, wodd = false;  // wodd: a weight that is not positive and finite (<= 0, NaN, INF)
     float w2a[kMaxBatch] = {};
     if (w8s && w8s[0]) {
         if ((r = reserve(c, c->wvals, sizeof(unsigned) * 4 * kMaxBatch))) return r;
@@ -234,6 +253,7 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
             if (v && wv != weighted && (MGM == 2 || !w8s[v]))
                 return fail(c, MGM_ERR_UNSUPPORTED, "batched volumes must be all weighted or all unweighted");
             weighted = weighted || wv;
+            wodd = wodd || (wv && got[4 * v + 3] != 0);
             w2cand = w2cand && (!wv || (got[4 * v + 3] == 0 && got[4 * v + 1] == got[4 * v + 2]));
             if (wv) memcpy(&w2a[v], &got[4 * v + 1], 4);
             else w2a[v] = 1.0f;  // (planes of ones in a weighted launch: no selector bit is set, the other value is never used)
@@ -257,7 +277,11 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     //     an all-INF slab and the next one INF - INF = NaN;
     //   * (found below, by the scan of an uploaded volume) NaN costs.
     //   * more than 2048 labels: no fast kernel is built that wide (the reference's Dvec has no label limit, dvec.cc:60).
-    bool exact = (ragged && !(P2 < __builtin_huge_valf())) || Lreal > kMaxLPL * 64;
+    //   * (round 6, found by tests/test_gpu_ragged_oracle.py) FH potentials on a ragged volume with a NEGATIVE slope -- P1 < 0, or a
+    //     weight <= 0 / NaN scaling it: the fast kernels mask the neighbour's slab to the receiving pixel's range and convolve
+    //     over the whole hull, which equals the reference's convolution over the range (mgm_core.cc:242-271) only while the
+    //     ramp the forward pass leaves ABOVE the range cannot flow back into it (M[rh] + 2 P1 >= M[rh]).
+    bool exact = (ragged && !(P2 < __builtin_huge_valf())) || Lreal > kMaxLPL * 64 || (ragged && use_fh > 0 && (!(P1 >= 0.0f) || wodd));
     for (int v = 0; v < nb; v++) exact |= Cs[v]->nan_words;
     if (exact) return run_passes_exact(c, Cs, w8s, nb, P1, P2, MGM, fh, weighted_given, first, count, slot0, nslots);
     const float *ones8 = nullptr;

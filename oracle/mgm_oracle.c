@@ -796,15 +796,17 @@ static void update_pixel_r(float *Lp, const float *Cp, const float *const Ln[4],
  *            mgm.cc:377-388: CC keeps its ranges, S is allocated from the narrowed images, mgm_core.cc:426); with
  *            sdmin/sL = the hull S is returned on
  *   S        NULL or [ny][nx][sL]: the corrected aggregated volume; slots outside a pixel's S-range hold +INF
- *   out/outcost, Lr_dump as orc_mgm (Lr_dump on C's hull, +INF outside a pixel's range)
+ *   out/outcost as orc_mgm; Lr_dump NULL, or one hull volume (+INF outside a pixel's range) per pass whose bit is set in
+ *            dump_mask, in pass order (a full-size test keeps two of the eight)
  * S[i] accumulates Lr[i][o] for o in Lr[i]'s range that also lie in S[i]'s (increment_nolock drops the others,
  * dvec.cc:117-125); the search runs over S[i]'s range with CC[i][o] = +INF where CC does not own o (592-609).
  */
 int orc_mgm_ranged(const float *C, int nx, int ny, int L, int dmin, const int *lo, const int *hi, const int *slo,
                    const int *shi, int sdmin, int sL, const float *w8, float P1, float P2, int NDIR, int MGM, int FH,
-                   int FIX, float *S, float *out, float *outcost, float *Lr_dump)
+                   int FIX, float *S, float *out, float *outcost, float *Lr_dump, unsigned dump_mask)
 {
     if (NDIR < 1 || NDIR > 8 || MGM < 1 || MGM > 4) return -1;
+    int ndumped = 0;
     if (!slo || !shi) {
         slo = lo;
         shi = hi;
@@ -893,7 +895,7 @@ int orc_mgm_ranged(const float *C, int nx, int ny, int L, int dmin, const int *l
             }
             free(scratch);
         }
-        if (Lr_dump) memcpy(Lr_dump + (size_t)pass * nvol, Lr, sizeof(float) * nvol);
+        if (Lr_dump && ((dump_mask >> pass) & 1u)) memcpy(Lr_dump + (size_t)(ndumped++) * nvol, Lr, sizeof(float) * nvol);
 #pragma omp parallel for
         for (size_t i = 0; i < npix; i++) /* 582-587 */
             for (int d = lo[i]; d <= hi[i]; d++)

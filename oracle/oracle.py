@@ -103,7 +103,7 @@ class Oracle:
                                                                                  C.c_int, _f32p])
         L.orc_mgm_ranged.argtypes = ([_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float] + [C.c_int] * 4
-                                     + [C.c_void_p, _f32p, _f32p, C.c_void_p])
+                                     + [C.c_void_p, _f32p, _f32p, C.c_void_p, C.c_uint])
         L.orc_refine_ranged.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _f32p, _f32p]
 
     def set_threads(self, n):
@@ -184,7 +184,8 @@ class Oracle:
     def mgm_ranged(self, Cv, hmin, lo, hi, P1, P2, NDIR, MGM, FH=0, FIX=1, w8=None, srange=None, want_S=True,
                    dump_lr=False):
         """mgm() with range images.  srange = (slo, shi, shmin, shmax): the (narrowed) ranges mgm() is CALLED with while
-        the cost volume keeps (lo, hi) -- main()'s TSGM_ITER loop.  Returns (S, out, outcost[, Lr])."""
+        the cost volume keeps (lo, hi) -- main()'s TSGM_ITER loop.  dump_lr: True (every pass) or a tuple of pass numbers.
+        Returns (S, out, outcost[, Lr])."""
         Cv = np.ascontiguousarray(Cv, np.float32)
         ny, nx, L = Cv.shape
         lo, hi = np.ascontiguousarray(lo, np.int32), np.ascontiguousarray(hi, np.int32)
@@ -200,9 +201,10 @@ class Oracle:
         if w8 is not None:
             w8 = np.ascontiguousarray(w8, np.float32)
             assert w8.shape == (8, ny, nx)
-        lr = np.empty((NDIR, ny, nx, L), np.float32) if dump_lr else None
+        passes = tuple(range(NDIR)) if dump_lr is True else tuple(dump_lr or ())
+        lr = np.empty((len(passes), ny, nx, L), np.float32) if passes else None
         r = self.lib.orc_mgm_ranged(Cv, nx, ny, L, hmin, lo, hi, _optp(slo), _optp(shi), shmin, sL, _optp(w8), P1, P2,
-                                    NDIR, MGM, FH, FIX, _optp(S), out, outc, _optp(lr))
+                                    NDIR, MGM, FH, FIX, _optp(S), out, outc, _optp(lr), sum(1 << q for q in passes))
         if r:
             raise ValueError("orc_mgm_ranged failed (%d)" % r)
         return (S, out, outc, lr) if dump_lr else (S, out, outc)
