@@ -212,17 +212,66 @@ def cost_bytes(w):
 
 
 # ---- the CPU legs (rank 0 only; never inside a timed GPU region) --------------------------------------------------------
+def special_inputs(w, pair):
+    """What pairs_leg feeds the device beside the pair, rebuilt on the host for the CPU legs (rank 0: seed offsets = pair):
+    range images (ragged), free-form weight planes (w8), the uploaded volume with its NaN (nan)."""
+    from mgm_amd import synth
+    u, v, gt = pair_of(w, pair)
+    x = {"u": u, "v": v, "dminI": None, "dmaxI": None, "w8": None, "vol": None}
+    if w.get("ragged"):
+        g = gt.astype(np.float32)
+        x["dminI"], x["dmaxI"] = np.clip(g - w["ragged"], w["dmin"], w["dmax"]), np.clip(g + w["ragged"], w["dmin"], w["dmax"])
+    if w.get("w8") == "three":
+        rng = np.random.default_rng(77 + pair)
+        x["w8"] = rng.choice(np.array([1.0, 2.5, 4.0], np.float32), size=(8, w["ny"], w["nx"]), p=[0.7, 0.2, 0.1])
+    if w.get("nan"):
+        vol = synth.raw_volume(w["nx"], w["ny"], labels_of(w), seed=5 + pair)
+        vol[vol.shape[0] // 2, vol.shape[1] // 2, 7] = np.nan
+        x["vol"] = vol
+    return x
+
+
+def iter_ranges(w, disp):
+    """main()'s update_dmin_dmax + remove_nonfinite (mgm.cc:386-388) on flat range images, by the compiled reference's own
+    function (oracle/_ref/libmgm_refpost.so); None where that library did not travel."""
+    from oracle.oracle import RefPost
+    if not RefPost.available():
+        return None
+    lo = np.full((w["ny"], w["nx"]), w["dmin"], np.float32)
+    hi = np.full((w["ny"], w["nx"]), w["dmax"], np.float32)
+    return RefPost().update_ranges(disp, lo, hi, 3, 2)
+
+
 def oracle_whole_volume(w, threads, pair=0):
     """Pair `pair` through the CPU oracle (oracle/mgm_oracle.c), whole volume, `threads` OpenMP threads (the reference
-    parallelises each diagonal of a pass the same way, mgm_core.cc:505-579).  Returns (disp, cost, seconds)."""
-    from oracle.oracle import Oracle
+    parallelises each diagonal of a pass the same way, mgm_core.cc:505-579).  Returns (disp, cost, seconds).  Round 6: also the
+    workloads with range images (orc_mgm_ranged, pinned on the reference's mgm() with range images), free-form weights, an
+    uploaded volume holding a NaN, and TSGM_ITER = 2 (the second call of mgm() with narrowed S ranges)."""
+    from oracle.oracle import Oracle, int_ranges
     orc = Oracle(threads=threads)
-    u, v, _ = pair_of(w, pair)
+    x = special_inputs(w, pair)
+    u, v = x["u"], x["v"]
     t0 = time.perf_counter()
-    C = orc.costvolume(u, v, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w), w["win"])
-    w8 = orc.weights(u, w["aP2"], w["aThresh"]) if weighted(w) else None
+    if x["dminI"] is not None:
+        lo, hi = int_ranges(x["dminI"], x["dmaxI"])
+        C = orc.costvolume_ranged(u, v, lo, hi, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w), w["win"])
+        S, o, c = orc.mgm_ranged(C, w["dmin"], lo, hi, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, x["w8"])
+        ro, rc = orc.refine_ranged(S, w["dmin"], lo, hi, "vfit", o, c)
+        return ro, rc, time.perf_counter() - t0
+    C = x["vol"] if x["vol"] is not None else orc.costvolume(u, v, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w), w["win"])
+    w8 = orc.weights(u, w["aP2"], w["aThresh"]) if weighted(w) else x["w8"]
     S, o, c = orc.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, w8)
     ro, rc = orc.refine(S, w["dmin"], "vfit", o, c)
+    for _ in range(1, int(w.get("iter", 1))):  # mgm.cc:377-388: CC keeps its ranges, mgm() is called with the narrowed images
+        r = iter_ranges(w, ro)
+        if r is None:
+            raise RuntimeError("TSGM_ITER > 1 needs oracle/_ref/libmgm_refpost.so (update_dmin_dmax)")
+        slo, shi = int_ranges(*r)
+        ny, nx = slo.shape
+        flo, fhi = np.full((ny, nx), w["dmin"], np.int32), np.full((ny, nx), w["dmax"], np.int32)
+        shmin, shmax = int(slo.min()), int(shi.max())
+        S, o, c = orc.mgm_ranged(C, w["dmin"], flo, fhi, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, w8, (slo, shi, shmin, shmax))
+        ro, rc = orc.refine_ranged(S, shmin, slo, shi, "vfit", o, c)
     return ro, rc, time.perf_counter() - t0
 
 
@@ -230,24 +279,40 @@ def reference_whole_volume(w, threads, want=None, pair=0):
     """The REAL reference (oracle/_ref/libmgm_ref.so: gfacciol/mgm compiled from its own sources behind
     oracle/ref_harness.cc) on pair 0: allocate_and_fill_sgm_costvolume + mgm() + subpixel_refinement_sgm, timed INSIDE
     the harness around those three calls (the dense <-> Dvec container copies of the harness are not the reference's
-    work).  Returns seconds, or None where the library is not there / the census window cannot be set."""
+    work).  Returns seconds, or None where the library is not there / the census window cannot be set.  Round 6: with range
+    images too (the reference on the SAME -m/-M images: what a ragged workload's CPU baseline is)."""
     from oracle.oracle import Oracle, Reference
     if not Reference.available():
         return None
+    if w.get("iter", 1) > 1 or w.get("nan"):
+        return None  # (TSGM_ITER lives in main(); a NaN cost leaves the reference's labels undefined)
     os.environ["CENSUS_NCC_WIN"] = str(w["win"])  # a smart parameter of the reference, cached on first use per process
     ref = Reference()
     if ref.census_win() != w["win"] or not hasattr(ref.lib, "ref_seconds"):
         return None
     Oracle(threads=threads)  # (sets the OpenMP thread count of the process: both libraries share libgomp)
-    u, v, _ = pair_of(w, pair)
+    x = special_inputs(w, pair)
+    u, v = x["u"], x["v"]
     os.environ["USE_TRUNCATED_LINEAR_POTENTIALS"] = "1" if w["FH"] else "0"
-    C = ref.costvolume(u, v, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w))
-    t = ref.seconds()
-    w8 = ref.weights(u, w["aP2"], w["aThresh"]) if weighted(w) else None  # (compute_mgm_weights: negligible, not timed)
-    S, o, c = ref.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, w8)
-    t += ref.seconds()
-    ro, rc = ref.refine(S, w["dmin"], "vfit", o, c)
-    t += ref.seconds()
+    if x["dminI"] is not None:
+        if not ref.has_ranged():
+            return None
+        C = ref.costvolume_ranged(u, v, x["dminI"], x["dmaxI"], w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w))
+        t = ref.seconds()
+        S, o, c = ref.mgm_ranged(C, w["dmin"], x["dminI"], x["dmaxI"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, x["w8"])
+        t += ref.seconds()
+        o = np.where(np.isfinite(c), o, x["dminI"]).astype(np.float32)  # (a pixel without a finite S: the reference's label is uninitialised)
+        ro, rc = ref.refine_ranged(S, w["dmin"], x["dminI"], x["dmaxI"], "vfit", o, c)
+        t += ref.seconds()
+        ro = np.where(np.isfinite(c), ro, np.nan).astype(np.float32)
+    else:
+        C = ref.costvolume(u, v, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w))
+        t = ref.seconds()
+        w8 = ref.weights(u, w["aP2"], w["aThresh"]) if weighted(w) else x["w8"]  # (compute_mgm_weights: negligible, not timed)
+        S, o, c = ref.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, w8)
+        t += ref.seconds()
+        ro, rc = ref.refine(S, w["dmin"], "vfit", o, c)
+        t += ref.seconds()
     if want is not None:
         want["o"], want["c"] = ro, rc
     return t
@@ -278,20 +343,29 @@ def cpu_baseline(w, whole_first, threads, seconds_target=12.0, pair=0):
     orc = Oracle(threads=1)
 
     def band(rows):
-        u, v, _ = synth.stereo_pair(nx, rows, w["dmin"] * 3 // 4, max(0, w["dmax"] * 3 // 4), nch=w.get("nch", 1))
+        from oracle.oracle import int_ranges
+        u, v, gt = synth.stereo_pair(nx, rows, w["dmin"] * 3 // 4, max(0, w["dmax"] * 3 // 4), nch=w.get("nch", 1))
         t0 = time.perf_counter()
+        if w.get("ragged"):
+            g = gt.astype(np.float32)
+            lo, hi = int_ranges(np.clip(g - w["ragged"], w["dmin"], w["dmax"]), np.clip(g + w["ragged"], w["dmin"], w["dmax"]))
+            C = orc.costvolume_ranged(u, v, lo, hi, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w), w["win"])
+            S, o, c = orc.mgm_ranged(C, w["dmin"], lo, hi, w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, None)
+            orc.refine_ranged(S, w["dmin"], lo, hi, "vfit", o, c)
+            return time.perf_counter() - t0
         C = orc.costvolume(u, v, w["dmin"], w["dmax"], "none", cost_of(w), trunc_of(w), w["win"])
         w8 = orc.weights(u, w["aP2"], w["aThresh"]) if weighted(w) else None
         S, o, c = orc.mgm(C, w["dmin"], w["P1"], w["P2"], w["NDIR"], w["MGM"], w["FH"], 1, w8)
         orc.refine(S, w["dmin"], "vfit", o, c)
         return time.perf_counter() - t0
 
-    per_row = band(8) / 8  # calibrate on a thin band, then size the sample
-    rows = int(max(16, min(w["ny"], seconds_target / per_row)))
-    dt = band(rows)
-    port["one_thread"] = {"value": (rows / w["ny"]) / dt, "cores": 1,
-                          "sample": "%dx%dx%d band (%d of %d rows), %.1f s, extrapolated linearly in rows" % (nx, rows, L, rows, w["ny"], dt),
-                          "mcell_updates_per_s": nx * rows * L * w["NDIR"] / dt / 1e6}
+    if not any(w.get(k) for k in ("iter", "w8", "nan")):  # (those inputs are not a function of a row band alone)
+        per_row = band(8) / 8  # calibrate on a thin band, then size the sample
+        rows = int(max(16, min(w["ny"], seconds_target / per_row)))
+        dt = band(rows)
+        port["one_thread"] = {"value": (rows / w["ny"]) / dt, "cores": 1,
+                              "sample": "%dx%dx%d band (%d of %d rows), %.1f s, extrapolated linearly in rows" % (nx, rows, L, rows, w["ny"], dt),
+                              "mcell_updates_per_s": nx * rows * L * w["NDIR"] / dt / 1e6}
     res["port"] = port
     # -- the reference itself
     ref_runs, ref_out = [], {}
@@ -1069,11 +1143,7 @@ def main():
         from oracle.oracle import usable_cpus
         T = min(32, usable_cpus())
         if not args.no_parity:
-            special = [k for k in ("ragged", "iter", "w8", "nan") if w.get(k)]
-            if special:
-                parity = {"status": "skipped", "why": "workload keys %s: beyond the in-run dense oracle (compared with the reference binary / the oracle in "
-                                                      "tests/test_gpu_cli.py, test_gpu_windowed.py, test_gpu_parity.py, test_gpu_fuzz.py)" % special}
-            elif cells > PARITY_MAX_CELLS:
+            if cells > PARITY_MAX_CELLS:
                 parity = {"status": "skipped", "why": "%.1f G cells: beyond the in-run oracle (covered by tests/test_gpu_fullsize.py)" % (cells / 1e9)}
             else:
                 got_o, got_c = m["outs"][gate].download()[0], m["outcs"][gate].download()[0]
@@ -1085,7 +1155,7 @@ def main():
                 if bad:
                     line.code = 3
             res["parity"] = parity
-        if n_ranks == 1 and not args.no_cpu_baseline and cells <= PARITY_MAX_CELLS and not any(w.get(k) for k in ("ragged", "iter", "w8", "nan")):
+        if n_ranks == 1 and not args.no_cpu_baseline and cells <= PARITY_MAX_CELLS:
             res["cpu_baseline"], ref_out = cpu_baseline(w, whole_s, T, pair=gate)
             if ref_out and parity is not None and parity.get("status") != "skipped":  # the reference's own maps, while we have them
                 got_o, got_c = m["outs"][gate].download()[0], m["outcs"][gate].download()[0]
@@ -1125,12 +1195,46 @@ def main():
                 hull = vd < 0
                 vd = abs(vd)
                 vsteps = 8 if vd > 1 else (2 if vname in ("cfg3nan", "cfg3L1536") else 5)  # (the slow fall-backs: 0.25-0.4 s per step)
+                # round 6: the ragged / TSGM_ITER / free-form-weight legs are gated on the CPU oracle too --
+                # one pair of the leg's last step against oracle/mgm_oracle.c (orc_mgm_ranged for range images) -- and the ragged
+                # ones carry the REFERENCE on the same range images as their CPU baseline (one run, timed inside the harness)
+                gated = (not stub and not hull and vd == 1 and not args.no_parity and n_ranks == 1
+                         and (vw.get("ragged") or vname in ("cfg3i2", "cfg3w3")))
                 if hull:
                     os.environ["MGM_HIP_REL"] = "0"
                 try:
-                    vm = pairs_leg(env, vw, vb, vsteps, 1, 0, pipeline=vd)
+                    vm = pairs_leg(env, vw, vb, vsteps, 1, 0, keep=gated, pipeline=vd)
                 finally:
                     os.environ.pop("MGM_HIP_REL", None)
+                vpar, vcpu = None, None
+                if gated and rank == 0:
+                    try:
+                        vg = (vsteps + 1) % vb
+                        got_o, got_c = vm["outs"][vg].download()[0], vm["outcs"][vg].download()[0]
+                        ref_o, ref_c, osec = oracle_whole_volume(vw, T, vg)
+                        bad = nd(ref_o, got_o.reshape(ref_o.shape)) + nd(ref_c, got_c.reshape(ref_c.shape))
+                        vpar = {"status": "bit-exact" if bad == 0 else "FAILED", "differing_words": bad, "pair": vg,
+                                "what": "refined disparity and cost maps of pair %d of %d vs oracle/mgm_oracle.c (%d threads, %.1f s)" % (vg, vb, T, osec)}
+                        if bad:
+                            line.code = 3
+                        if vw.get("ragged") and not args.no_cpu_baseline:
+                            rout = {}
+                            rsec = reference_whole_volume(vw, T, rout, vg)
+                            if rsec is not None:
+                                vcpu = {"value": 1.0 / rsec, "unit": "disparity-volumes/s", "cores": T, "kind": "reference",
+                                        "sample": "one whole %dx%d volume on the same range images: the reference's allocate_and_fill_sgm_costvolume + "
+                                                  "mgm() + subpixel_refinement_sgm (oracle/_ref/libmgm_ref.so) on %d OpenMP threads, one run, timed around "
+                                                  "the three calls" % (vw["nx"], vw["ny"], T)}
+                                fin = np.isfinite(rout["c"])
+                                vpar["vs_reference_differing_words"] = nd(np.where(fin, rout["o"], 0), np.where(fin, got_o.reshape(rout["o"].shape), 0)) + \
+                                    nd(rout["c"], got_c.reshape(rout["c"].shape))
+                                if vpar["vs_reference_differing_words"]:
+                                    vpar["status"], line.code = "FAILED", 3
+                    except Exception as e:  # noqa: BLE001
+                        vpar = {"status": "error", "why": repr(e)[:300]}
+                if gated:
+                    for h in vm.get("outs", []) + vm.get("outcs", []):
+                        h.free()
                 if rank == 0:
                     vr = roofline_of(vw, vb, vm["avg"], vname, step_ms=(vm["dt"] / vsteps * 1e3) if vd > 1 else None, per_step=vm["per_step"])
                     pn = next((k for k in ("k_pass2", "k_pass", "k_pass_rel", "k_pass_exact") if k in vm["avg"]), "k_pass2")
@@ -1140,7 +1244,8 @@ def main():
                         **({"frac_range_proportional": vr["frac_range_proportional"]} if "frac_range_proportional" in vr else {}),
                         "pass_kernel": pn,
                         "time_basis": vr["time_basis"], "k2_ms": vm["avg"].get("k_cost"), "k3_ms": vm["avg"].get(pn),
-                        "wta_ms": vm["avg"].get("k_wta")}
+                        "wta_ms": vm["avg"].get("k_wta"),
+                        **({"parity": vpar} if vpar is not None else {}), **({"cpu_baseline": vcpu} if vcpu is not None else {})}
                 ctx.trim()
             if rank == 0:  # range-proportional over dense hull, same volumes, same box, same run
                 for k in ("cfg3r x1", "cfg3r x4", "cfg3hr x4"):

@@ -126,6 +126,7 @@ struct RelParams {
     long long npix, nvol;
     int MGM, NDIR, pass0, LLmax, maxbands, weighted;
     int ld;             // steps of LDS-DMA the loader keeps in flight (2..5; every step of lead is a step of lag per band)
+    int fh_multi;       // FH: the pixel's TSGM min-convolutions side by side (k_pass_rel<true, false, TSGM>) instead of one after the other
     float P1, P2;
     unsigned long long *tl;  // nullptr, or 8 words per work item (MGM_HIP_TIMELINE; tools/timeline.py): start, end, waited, slow paths, where, steps, polls
     PassGeom g[kMaxDirs];

@@ -380,6 +380,88 @@ __device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, f
         for (int k = 0; k < LPL; k++) M[k] = fminf(M[k], cap);
     }
 }
+// ---- NK min-convolutions SIDE BY SIDE (round 6; the range-proportional kernels' three-or-four neighbours of a pixel) ----------
+// fh_scan is one dependent chain from its first instruction to its last (origin -> log-step guess -> sweep), ending in a
+// wave-wide vote and a branch: a wave that runs three of them one after the other issues a VALU instruction every ~10 clocks
+// (profiles/r05_rel_phases.txt: 3900 clocks per step for ~400 instructions), and the compiler cannot interleave them across
+// their loops.  Here the NK guesses and the NK first sweeps are ONE straight-line block (independent chains the scheduler
+// interleaves) with ONE vote; a rejected guess anywhere (rare) sends every array through fh_scan from scratch -- the fixed point
+// of the sweeps is unique and equals the sequential recurrence whatever the starting carries, so the result is fh_scan's bit
+// for bit.  (fh_scan itself is left untouched: the dense kernels' hot loops are built on it.)
+template <int LPL, bool FWD, int GROUPS>
+__device__ __forceinline__ float fh_guess(const float (&M)[LPL], float P1, int lane)
+{
+    static_assert(GROUPS == 4, "rows of 16 lanes: the only user is the range-proportional pass kernel");
+    constexpr int K0 = FWD ? 0 : LPL - 1;
+    constexpr int DK = FWD ? 1 : -1;
+    const float rampP = (float)LPL * P1;
+    float a = M[K0];
+#pragma unroll
+    for (int q = 1; q < LPL; q++) a = fminf(M[K0 + q * DK], a + P1);
+    const float r1 = rampP, r2 = 2.0f * rampP, r4 = 4.0f * rampP, r8 = 8.0f * rampP;
+    float c = a;
+    if constexpr (FWD) {
+        c = dpp_min_row_shr1(c, c + r1);
+        c = dpp_min_row_shr2(c, c + r2);
+        c = dpp_min_row_shr4(c, c + r4);
+        c = dpp_min_row_shr8(c, c + r8);
+    } else {
+        c = dpp_min_row_shl1(c, c + r1);
+        c = dpp_min_row_shl2(c, c + r2);
+        c = dpp_min_row_shl4(c, c + r4);
+        c = dpp_min_row_shl8(c, c + r8);
+    }
+    (void)lane;
+    return c;
+}
+template <int LPL, bool FWD, int GROUPS, int NK>
+__device__ __forceinline__ void fh_scan_multi(float (&M)[NK][LPL], const float (&P1)[NK], int lane, unsigned &sweeps)
+{
+    constexpr int GL = 64 / GROUPS;
+    constexpr int K0 = FWD ? 0 : LPL - 1;
+    constexpr int K1 = FWD ? LPL - 1 : 0;
+    constexpr int DK = FWD ? 1 : -1;
+    const bool edge = FWD ? lane % GL == 0 : lane % GL == GL - 1;  // no carry into the first lane of a label range
+    float c[NK], f[NK][LPL];
+#pragma unroll
+    for (int k = 0; k < NK; k++) c[k] = fh_guess<LPL, FWD, GROUPS>(M[k], P1[k], lane);
+    bool same = true;
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const float p1edge = edge ? f_inf() : P1[k];
+        const float cin = FWD ? dpp_add_wave_shr1(c[k], p1edge) : dpp_add_wave_shl1(c[k], p1edge);
+        f[k][K0] = fminf(M[k][K0], cin);
+#pragma unroll
+        for (int q = 1; q < LPL; q++) f[k][K0 + q * DK] = fminf(M[k][K0 + q * DK], f[k][K0 + (q - 1) * DK] + P1[k]);
+        same = same && (f[k][K1] == c[k]);
+    }
+    sweeps += NK;
+    if (__builtin_amdgcn_ballot_w64(!same) == 0ull) {
+#pragma unroll
+        for (int k = 0; k < NK; k++)
+#pragma unroll
+            for (int q = 0; q < LPL; q++) M[k][q] = f[k][q];
+    } else {  // (cold) some guess was rejected: every array settles by itself
+#pragma unroll
+        for (int k = 0; k < NK; k++) fh_scan<LPL, FWD, GROUPS>(M[k], P1[k], lane, sweeps);
+    }
+}
+// minConvTruncatedLinear of NK arrays whose label slots all exist (64 slots per row of 16 lanes: no padding to restore between
+// the two passes); m, P1, P2 per array
+template <int LPL, int GROUPS, int NK>
+__device__ __forceinline__ void fh_minconv_multi(float (&M)[NK][LPL], const float (&m)[NK], const float (&P1)[NK], const float (&P2)[NK], int lane,
+                                                 unsigned &sweeps)
+{
+    fh_scan_multi<LPL, true, GROUPS, NK>(M, P1, lane, sweeps);
+    fh_scan_multi<LPL, false, GROUPS, NK>(M, P1, lane, sweeps);
+#pragma unroll
+    for (int k = 0; k < NK; k++)
+        if (P2[k] < f_inf()) {
+            const float cap = m[k] + P2[k];
+#pragma unroll
+            for (int q = 0; q < LPL; q++) M[k][q] = fminf(M[k][q], cap);
+        }
+}
 template <int LPL, bool FULL = false>
 __device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, float P2, int lane, int L)
 {

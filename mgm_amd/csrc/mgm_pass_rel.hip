@@ -241,10 +241,17 @@ __device__ __forceinline__ float rel_row_min(float v)
 // E[k] = fmin(fmin(L[k], N[k] + P1), m + P2) - m once (one slab; its "minimum" word carries FAR = (m + P2) - m, what the
 // expression gives for a disparity the neighbour does not have: L = N = +INF there) and the reader only adds -- the
 // terms of update_costW with DeltaI = 1 (mgm_core.cc:104-137; P1 * 1.0f is P1), in its order.
-template <bool FH, bool PUBE>
+// NK (round 6; FH only): the neighbour count TSGM as a compile-time constant -- the pixel's NK min-convolutions then run SIDE BY
+// SIDE in one instruction stream (fh_minconv_multi: independent dependency chains, one vote per direction instead of one per
+// array and direction); 0: the run-time loop over the neighbours, one convolution after the other.
+// Slope (round 6): form-0 passes with TSGM <= 3 never read the fwd neighbour (i + 1, j - 1), so a line only has to stay ONE pixel
+// behind the line before it (g.slope, as in the second build, mgm_pass2.hip): a band then hands over R + lag steps after it
+// started instead of 2 R + lag -- the chain of a 1920-column pass of 120 bands drops from 120 x 36 + 1110 to 120 x 20 + 1095.
+template <bool FH, bool PUBE, int NK = 0>
 __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
 {
     static_assert(!(FH && PUBE), "FH potentials convolve over the RECEIVING pixel's range: consumer side only");
+    static_assert(NK == 0 || FH, "side-by-side convolutions: FH only");
     constexpr int NS = (FH || PUBE) ? 1 : 2;
     // A ring entry = a hand-off slot, whole 16-byte pieces.  One slab (FH, PUBE): [4 guard words][64 values][4 guard words][minimum,
     // base, 2 of padding] -- the guards hold what a disparity the pixel does not have reads as (+INF; PUBE: FAR), so a reader takes
@@ -288,7 +295,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     const int NL = g.NL, LL = g.LL, MGM = P.MGM, form = g.form;
     const float P1 = P.P1, P2 = P.P2;
     const long long istep = g.istep;
-    const int nsteps = (LL + 1 + 2 * (RR - 1) + 3) / 4 * 4;
+    const int SL = g.slope;  // line l of the band is at pixel s - 1 - SL l at step s
+    const int nsteps = (LL + 1 + SL * (RR - 1) + 3) / 4 * 4;
 
     // SELF-VALIDATING hand-off slots, one per (volume, pass, band, pixel), written once per launch with the launch's tag in the
     // sign bit of every word (values, minimum and biased base are non-negative; the padding words carry the tag alone): the
@@ -315,11 +323,11 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         const long long cpix0 = g.base + (long long)cj * g.jstep;
         const uint8_t *cptr = V.c8 + cpix0 * 64 + (lane & 3) * 16;
         const float *wptr = weighted ? V.w8 + (long long)g.wplane[lane & 3] * P.npix + cpix0 : nullptr;
-        int ci = -1 - 2 * cl;
+        int ci = -1 - SL * cl;
         const int ml = lane < RR ? lane : RR - 1;
         const int mj = min(band * RR + ml, NL - 1);
         const int4 *mptr = reinterpret_cast<const int4 *>(V.base) + (g.base + (long long)mj * g.jstep);
-        int mi = -1 - 2 * ml;
+        int mi = -1 - SL * ml;
         const float *hptr = hand_in + lane * 4;
         int ht = 0;
         bool dead = false;
@@ -464,7 +472,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     for (int s = 0; s < nsteps; s++) {
         const unsigned long long c0 = MGM_REL_PHASES ? clock64() : 0;
         unsigned long long c1 = c0;
-        const int i = s - 1 - 2 * ln;
+        const int i = s - 1 - SL * ln;
         const bool act = line_ok && i >= 0 && i < LL;
         if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
             const long long pix = pix0 + (long long)(act ? i : 0) * istep;
@@ -480,6 +488,33 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             // the MGM neighbours the update reads, in the pass's order (form 0: the pixel before on this line, then the line
             // before at i, i - 1, i + 1; the other form: the same four the other way round) -- mgm_core.cc:520-575
             float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (NK > 0) {
+                // the NK neighbours' slabs over this pixel's range, convolved side by side, summed in the pass's order
+                float Mk[NK][4], mk[NK], p1k[NK], p2k[NK];
+#pragma unroll
+                for (int k = 0; k < NK; k++) {
+                    const bool own = f0 ? k == 0 : k == 3;
+                    const int di = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
+                    const float *src = entry(own ? ln : prow, own ? i - 1 : i + di);
+                    mk[k] = interior ? src[HOFF] : 0.0f;
+                    const int sh = bp - reinterpret_cast<const int *>(src)[HOFF + 1];
+                    const int idx0 = interior ? min(max(4 * li + sh, -4), 64) + GO : 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int o = 4 * li + q;
+                        Mk[k][q] = (o >= rl && o <= rh) ? src[idx0 + q] : f_inf();
+                    }
+                    p1k[k] = P1 * D[k];
+                    p2k[k] = P2 * D[k];
+                }
+                unsigned sw = 0;
+                fh_minconv_multi<4, GL, NK>(Mk, mk, p1k, p2k, lane, sw);
+                if constexpr (MGM_REL_PHASES != 0) nsweeps += sw;
+#pragma unroll
+                for (int k = 0; k < NK; k++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) e[q] = k == 0 ? Mk[k][q] - mk[k] : e[q] + (Mk[k][q] - mk[k]);
+            } else
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (k < MGM) {
@@ -564,7 +599,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 }
             }
             if (to_global) {
-                const int iL = s - 1 - 2 * (RR - 1);  // the band's last line: lane group GL - 1 of this wave
+                const int iL = s - 1 - SL * (RR - 1);  // the band's last line: lane group GL - 1 of this wave
                 if (iL >= 0 && iL < LL) {
                     // the hand-off to the next band: write-through 16-byte stores straight from the registers, every word tagged
                     float *dstg = hand_out + (long long)iL * HS;
@@ -602,7 +637,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         }
 }
 
-template <bool FH, bool PUBE>
+template <bool FH, bool PUBE, int NK = 0>
 static hipError_t launch_rel_one(const RelParams &p, int ntasks, int wg_per_cu, hipStream_t s)
 {
     constexpr int NS = (FH || PUBE) ? 1 : 2;
@@ -614,7 +649,7 @@ static hipError_t launch_rel_one(const RelParams &p, int ntasks, int wg_per_cu, 
         const size_t want = (size_t)(160 * 1024) / (size_t)(wg_per_cu + 1) + 1024;  // more than a (wg_per_cu + 1)-th of the LDS
         if (shmem < want) shmem = want;
     }
-    auto kern = k_pass_rel<FH, PUBE>;
+    auto kern = k_pass_rel<FH, PUBE, NK>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(ntasks), dim3((NW + 1) * 64), shmem, s, p);
@@ -623,7 +658,15 @@ static hipError_t launch_rel_one(const RelParams &p, int ntasks, int wg_per_cu, 
 // pube: unit weights with Hirschmueller potentials (the producer publishes E); wg_per_cu: workgroups per CU (0: what fits)
 hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, int wg_per_cu, hipStream_t s)
 {
-    if (fh) return launch_rel_one<true, false>(p, ntasks, wg_per_cu, s);
+    if (fh) {
+        if (!p.fh_multi) return launch_rel_one<true, false>(p, ntasks, wg_per_cu, s);
+        switch (p.MGM) {
+        case 1: return launch_rel_one<true, false, 1>(p, ntasks, wg_per_cu, s);
+        case 2: return launch_rel_one<true, false, 2>(p, ntasks, wg_per_cu, s);
+        case 3: return launch_rel_one<true, false, 3>(p, ntasks, wg_per_cu, s);
+        default: return launch_rel_one<true, false, 4>(p, ntasks, wg_per_cu, s);
+        }
+    }
     return pube ? launch_rel_one<false, true>(p, ntasks, wg_per_cu, s) : launch_rel_one<false, false>(p, ntasks, wg_per_cu, s);
 }
 int pass_rel_lines() { return RR; }

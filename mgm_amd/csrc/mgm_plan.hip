@@ -1084,7 +1084,8 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     RelParams p{};
     int maxLL = 0, maxbands = 0;
     for (int q = 0; q < NDIR; q++) {
-        if (!make_geom(q, nx, ny, R, 4, false, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
+        // (round 6) form-0 passes with TSGM <= 3 walk slope 1 (make_geom decides; tune rel_slope1=0: slope 2 everywhere, as in round 5)
+        if (!make_geom(q, nx, ny, R, MGM, tune_num("rel_slope1", 1) != 0, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
         maxLL = std::max(maxLL, p.g[q].LL);
         maxbands = std::max(maxbands, p.g[q].nbands);
     }
@@ -1123,15 +1124,15 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     // workgroups (4 compute waves + the loader) per CU: tune rel_wg forces it
     const long long wgs = tune_num("rel_wg", 0);
     const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 1 ? 2 : 3);  // (measured: x 1 / x 2 / x 4 of 1920x1080, both potentials)
-    snprintf(key, sizeof key, "%d %d %d %d %d", nx, ny, NDIR, nb, rel_wg);
+    snprintf(key, sizeof key, "%d %d %d %d %d %d", nx, ny, NDIR, nb, rel_wg, p.g[0].slope);
     if (c->tasks_rel_key != key) {
         std::vector<SimChain> ch;
         for (int v = 0; v < nb; v++)
             for (int q = 0; q < NDIR; q++) {
                 SimChain k;
                 k.x = v * kMaxDirs + q, k.st = 0, k.nb = p.g[q].nbands, k.sib = -1, k.chain = v * NDIR + q;
-                k.skew = 2.0 * R + 4.0;  // (the lock-step diagonal has slope 2 for every pass here; loader lead + one fetch: ~4 steps of lag)
-                k.len = p.g[q].LL + 2.0 * (R - 1) + 1.0;
+                k.skew = (double)p.g[q].slope * R + 4.0;  // (slope of the lock-step diagonal x lines; loader lead + one fetch: ~4 steps of lag)
+                k.len = p.g[q].LL + (double)p.g[q].slope * (R - 1) + 1.0;
                 ch.push_back(k);
             }
         std::vector<int2> order;
@@ -1174,6 +1175,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     p.P2 = P2;
     // a launch bound by its chains of bands wants a short lead (lag per band); a batch has the slack and wants the loads covered
     p.ld = (int)std::min(5LL, std::max(2LL, tune_num("rel_ld", nb <= 1 ? 2 : 3)));
+    p.fh_multi = tune_num("rel_multi", 1) != 0 ? 1 : 0;
     p.tl = nullptr;
     // MGM_HIP_TIMELINE=<file>: one line per work item (tools/timeline.py) -- where the compute units' time goes
     const char *tl_file = getenv("MGM_HIP_TIMELINE");

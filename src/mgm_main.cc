@@ -18,7 +18,7 @@
 //     device stage, a writer thread behind it -- and the device objects of a pair (images, volumes, maps) are kept and
 //     refilled by the next pair of the same geometry instead of being freed and allocated again.  A failing job (bad
 //     option, unreadable file, device-side refusal) fails alone: every device-side error is an exception caught per job.
-// MGM_HIP_STATS=1 prints the wall-time breakdown on stderr.
+// MGM_HIP_STATS=1 prints the wall-time breakdown on stderr; MGM_HIP_KERNELS=1 the names of the kernels a job launched.
 //
 // WITH_MGM2=1 (mgm_naive_parallelism, mgm_core.cc:632-831): every pass on its own private Lr volume, all passes in
 // flight at once, then the volumes accumulated into S -- which is how the device path is organised anyway
@@ -490,6 +490,7 @@ static void bring_up(Session &S, int ITER, bool ranged)
         // MGM_PLACE_TRIES=n: a context that stays may try n physical placements of its workspace and keep the fastest (off by default: three
         // more allocations of a 34 GB workspace cost ~2 s, what 100 further pairs gain back)
         if (S.rc_ctx == 0 && S.resident) (void)mgm_ctx_set_placement_tries(S.ctx, (int)env_param("MGM_PLACE_TRIES", 0));
+        if (S.rc_ctx == 0 && getenv("MGM_HIP_KERNELS") && atoi(getenv("MGM_HIP_KERNELS")) != 0) (void)mgm_timing_enable(S.ctx, 1);
     }
 }
 
@@ -629,6 +630,18 @@ static int device_job(Session &S, Job &j, const std::function<void()> &decoded, 
             mgm_img_free(ctx, dsyn);
         }
         sw.mark("download(rest)");
+        // MGM_HIP_KERNELS=1: which kernels the job ran, in launch order, on stderr (tests assert which pass kernel a command line took)
+        if (getenv("MGM_HIP_KERNELS") && atoi(getenv("MGM_HIP_KERNELS")) != 0 && !multi) {
+            const int n = mgm_timing_count(ctx);
+            fprintf(stderr, "[mgm kernels]");
+            for (int k = 0; k < n; k++) {
+                const char *name = nullptr;
+                float ms = 0;
+                if (mgm_timing_get(ctx, k, &name, &ms) == 0 && name) fprintf(stderr, " %s", name);
+            }
+            fprintf(stderr, "\n");
+            (void)mgm_timing_reset(ctx);
+        }
     } catch (const DeviceError &e) {
         fprintf(stderr, "mgm: %s\n", e.what());
         // whatever the failed job left half-made goes; the context stays (resident mode: the next job starts clean)

@@ -171,10 +171,20 @@ def test_cli_matches_reference(case, tmp_path):
         a = args.format(tmp=d, ranges=tmp_path).split()
         cmd = [exe] + a + [str(tmp_path / "u.npy"), str(tmp_path / "v.npy"), str(d / "disp.npy"), str(d / "cost.npy"),
                            str(d / "back.npy")]
-        e = dict(os.environ, **dict(dict(OMP_NUM_THREADS="4"), **env))
+        e = dict(os.environ, **dict(dict(OMP_NUM_THREADS="4", MGM_HIP_KERNELS="1"), **env))
         r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (tag, r.stderr)
         outs[tag] = (r.stdout, {f: np.load(d / f) for f in sorted(os.listdir(d))})
+        if tag == "ours":  # which pass kernel did the command line take? (the ragged cases must say so)
+            kernels = [ln for ln in r.stderr.splitlines() if ln.startswith("[mgm kernels]")]
+            assert kernels, r.stderr
+            ran = set(" ".join(kernels).split()[2:])
+            if "(range-proportional kernels)" in name:
+                assert "k_pass_rel" in ran, (name, sorted(ran))
+            if env.get("MGM_HIP_REL") == "0" or "P2 = inf" in name:
+                assert "k_pass_rel" not in ran, (name, sorted(ran))
+            if "P2 = inf" in name or name.startswith("-p census"):
+                assert "k_pass_exact" in ran, (name, sorted(ran))
     # NaN costs: pixels without a finite S exist, whose label is the reference's uninitialised `float minP` (these cases run
     # with TESTLRRL=0: the left-right check would carry that garbage into its neighbours' verdicts)
     if "P2 = inf" in name or name.startswith("-p census"):
