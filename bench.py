@@ -719,6 +719,29 @@ def roofline_of(w, B, avg, workload, step_ms=None, per_step=None):
             "avg_launch_ms": {k: avg[k] for k in sorted(avg)}, "per_kernel": per_kernel}
 
 
+def roofline_digest(res, vres, wname):
+    """the driver's record keeps `roofline` but drops `variants` -- so the figures north_star's target sentence is
+    about (ONE volume; a pair = two volumes, what `mgm u v out` launches) and the weakest legs go INTO `roofline`."""
+    rf = res.get("roofline")
+    if not isinstance(rf, dict):
+        return
+
+    def pick(key):
+        v = vres.get(key)
+        if not isinstance(v, dict) or "roofline_frac" not in v:
+            return None
+        return {"volumes_per_s": v["value"], "frac": v["roofline_frac"], "frac_counter": v.get("roofline_frac_counter"),
+                "frac_of_achievable": v.get("frac_of_achievable"), "k3_ms": v.get("k3_ms"), "wta_ms": v.get("wta_ms"), "pass_kernel": v.get("pass_kernel"),
+                **({"parity": v["parity"].get("status")} if isinstance(v.get("parity"), dict) else {})}
+
+    rf["single_volume"] = pick("%s x1" % wname)  # (the same workload as the headline, ONE volume per launch)
+    rf["pair"] = pick("%s x2" % wname)
+    ranked = sorted(((k, v) for k, v in vres.items() if isinstance(v, dict) and isinstance(v.get("roofline_frac"), float)
+                     and "on the dense hull" not in k and "pipeline" not in k), key=lambda kv: kv[1]["roofline_frac"])
+    rf["worst_variants"] = [{"variant": k, **pick(k)} for k, _ in ranked[:3]]
+    rf["ragged_variants"] = {k: pick(k) for k in ("cfg3r x1", "cfg3r x2", "cfg3r x4", "cfg3hr x1", "cfg3hr x4") if pick(k)}
+
+
 def replicas_leg(env, name, steps, warmup):
     """BASELINE config 5: replicas only -- 16 independent pairs per step and GPU, no communication."""
     w = WORKLOADS[name]
@@ -896,6 +919,10 @@ def directions_legs(env, name, steps, warmup, timeout_s, transports=("single", "
         res["model"] = {"what": "DESIGN.md section 6: K2 + K3(passes per rank) + exchange over one link + k_wta on 1/n of the rows",
                         "link_gbps_used": link, "link_rate_source": "measured (probe)" if (lp.get("min") or link != 153.0) else "assumed",
                         "prediction": mdist.sharding_model(world, NDIR, 4.0 * nx * ny * L / 1e9, k3_one, sg.get("wta_ms") or 17.3, sg.get("k2_ms") or 1.25, link)}
+        # ... and for the node sizes the driver's scaling run uses, whatever this run's world is (single-GPU terms of THIS run)
+        res["model"]["by_world"] = {str(n): {k: v for k, v in mdist.sharding_model(n, NDIR, 4.0 * nx * ny * L / 1e9, k3_one, sg.get("wta_ms") or 17.3,
+                                                                                    sg.get("k2_ms") or 1.25, link).items()
+                                             if k in ("passes_per_rank", "gb_per_link", "exchange_ms", "total_ms")} for n in (2, 4, 8)}
         for k in ("rccl", "rccl_overlap", "peer"):
             if isinstance(res.get(k), dict) and "ms_per_volume" in res[k] and res["model"]["prediction"].get("total_ms"):
                 res[k]["vs_model"] = res[k]["ms_per_volume"] / res["model"]["prediction"]["total_ms"]
@@ -1017,6 +1044,8 @@ def stub_directions(env, res, steps):
         vols = torch.rand((NDIR, ny, nx, L), generator=gen)  # (every rank can regenerate every pass: the check below)
         if not mdist.agree(True, dist, None, env.ctrl, "cpu"):
             raise RuntimeError("stub agreement failed")
+        if os.environ.get("MGM_STUB_DIE_AT") == "exchange" and rank == world - 1 and s == 0:
+            os.kill(os.getpid(), signal.SIGKILL)  # test hook: a rank dies between the agreement and its first transfer
         recv = mdist.exchange_lr([vols[p] for p in range(first, first + count)], NDIR, ny, dist, like=vols[0, :0], timeout_s=60.0)
         r0, nr = mdist.row_slabs(ny, world)[rank]
         bad += int((recv != vols[:, r0:r0 + nr]).sum())
@@ -1109,6 +1138,11 @@ def main():
     B = args.batch
     m = pairs_leg(env, w, B, args.steps, args.warmup, args.repeats, keep=True, pipeline=args.pipeline)
     dt = m["dt"]
+    try:  # device memory the headline launch leaves in use: the context's grow-only workspace (NDIR fp32 Lr volumes per batched volume) + the kept maps
+        free_b, total_b = ctx.mem_info()
+        mem_in_use_gb = (total_b - free_b) / 1e9
+    except Exception:  # noqa: BLE001
+        mem_in_use_gb = None
     if rank == 0:
         from mgm_amd import shard
         vols_per_block = args.steps * n_ranks * B
@@ -1124,13 +1158,18 @@ def main():
                        "edge_weights": ("-aP2 %g -aThresh %g" % (w["aP2"], w["aThresh"])) if weighted(w) else None,
                        "pipeline_depth": args.pipeline,
                        "parallelism": ("independent pairs, %d per step and GPU, no data-path collective" % B) if n_ranks > 1 else "1 GPU"},
-            "roofline": roofline_of(w, B, m["avg"], wname, step_ms=(dt / args.steps * 1e3) if args.pipeline > 1 else None, per_step=m["per_step"]),
+            "roofline": {**roofline_of(w, B, m["avg"], wname, step_ms=(dt / args.steps * 1e3) if args.pipeline > 1 else None, per_step=m["per_step"]),
+                         "workspace_gb": {"lr_volumes": B * max(1, args.pipeline) * w["NDIR"] * (64.0 * nx * ny if w.get("ragged") else cells) * 4.0 / 1e9,
+                                          "device_memory_in_use_after_the_timed_steps": mem_in_use_gb,
+                                          "note": "NDIR fp32 Lr volumes per batched volume, all passes concurrent (DESIGN.md 3); "
+                                                  "mgm_ctx_set_workspace_limit cuts a batch into sub-batches"}},
             # (say it HERE, not only in DESIGN.md) what scales on a node and what does not
             "multi_gpu_note": ("`value` is the weak-scaling mode: every rank aggregates its own pairs, no data-path collective (replicas). "
                                "Sharding ONE volume by direction (`directions`, cfg4) is link-bound by construction -- fp32 Lr row slabs, summed in pass "
                                "order, not all-reduced -- and DESIGN.md section 6's model puts it at 0.24x / 0.81x / 2.1x of one GPU on 2 / 4 / 8 GPUs at "
-                               "153 GB/s per link; the strong-scaling mode to prefer below 8 GPUs is `cfg4_pairs2` (one mgm() run of the pair per GPU).")
-                              if n_ranks > 1 else None,
+                               "153 GB/s per link; the strong-scaling mode to prefer below 8 GPUs is `cfg4_pairs2` (one mgm() run of the pair per GPU)."
+                               + ("" if n_ranks > 1 else "  (This line is the N = 1 leg: the very code path every rank of an N-rank run takes, minus the "
+                                                         "barrier's peers; `directions.model` holds the model's prediction for 2 / 4 / 8 GPUs.)")),
             "kernel_ms_per_step": m["per_step"],
             "repeat_values": [vols_per_block / t for t in m["rep_dt"]],
             "parity": None,
@@ -1185,7 +1224,7 @@ def main():
                                   ("cfg3L768", 1, 1), ("cfg3", 1, 4), ("cfg2", 1, 8),
                                   # round 5: what had no number before -- range images (-m/-M) and TSGM_ITER, and the
                                   # fall-back kernels (free-form weights, 1536 labels, negative penalties, NaN costs)
-                                  ("cfg3r", 1, 1), ("cfg3r", 4, 1), ("cfg3hr", 1, 1), ("cfg3hr", 4, 1),
+                                  ("cfg3r", 1, 1), ("cfg3r", 2, 1), ("cfg3r", 4, 1), ("cfg3hr", 1, 1), ("cfg3hr", 4, 1),
                                   # ... and the same ragged volumes on the dense HULL (MGM_HIP_REL=0: no range-proportional copy), the run
                                   # the range-proportional kernels are to be compared with (vd = -1 marks them)
                                   ("cfg3r", 1, -1), ("cfg3r", 4, -1), ("cfg3hr", 4, -1),
@@ -1217,7 +1256,7 @@ def main():
                                 "what": "refined disparity and cost maps of pair %d of %d vs oracle/mgm_oracle.c (%d threads, %.1f s)" % (vg, vb, T, osec)}
                         if bad:
                             line.code = 3
-                        if vw.get("ragged") and not args.no_cpu_baseline:
+                        if vw.get("ragged") and not args.no_cpu_baseline and vb == 1:
                             rout = {}
                             rsec = reference_whole_volume(vw, T, rout, vg)
                             if rsec is not None:
@@ -1240,7 +1279,8 @@ def main():
                     pn = next((k for k in ("k_pass2", "k_pass", "k_pass_rel", "k_pass_exact") if k in vm["avg"]), "k_pass2")
                     vres["%s x%d%s%s" % (vname, vb, (" pipeline %d" % vd) if vd > 1 else "", " on the dense hull" if hull else "")] = {
                         "workload": vw["desc"], "value": shard.job_rate([vsteps * vb] * n_ranks, vm["dt"]), "unit": "disparity-volumes/s",
-                        "roofline_frac": vr["frac"], "frac_of_achievable": vr["frac_of_achievable"], "saturated": vr["saturated"],
+                        "roofline_frac": vr["frac"], "roofline_frac_counter": vr["frac_counter"], "frac_of_achievable": vr["frac_of_achievable"],
+                        "saturated": vr["saturated"],
                         **({"frac_range_proportional": vr["frac_range_proportional"]} if "frac_range_proportional" in vr else {}),
                         "pass_kernel": pn,
                         "time_basis": vr["time_basis"], "k2_ms": vm["avg"].get("k_cost"), "k3_ms": vm["avg"].get(pn),
@@ -1251,6 +1291,7 @@ def main():
                 for k in ("cfg3r x1", "cfg3r x4", "cfg3hr x4"):
                     if k in vres and k + " on the dense hull" in vres:
                         vres[k]["over_dense_hull"] = vres[k]["value"] / vres[k + " on the dense hull"]["value"]
+                roofline_digest(res, vres, wname)
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 res.setdefault("variants", {})["error"] = repr(e)[:300]

@@ -508,20 +508,27 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
     //  the hand-off of k_pass_rel keeps the launch's tag in the sign bit of every published word, so every L / E / minimum
     // must be >= +0: non-negative penalties (the dense path's own gate, run_passes `first_build`) and, for weighted launches,
     // positive finite weights (a negative or NaN weight makes N + P1 D - m negative or NaN): those take the dense kernels.
+    // (round 6) TSGM = 2: with weights it is update_costW[_trunclinear] like every other TSGM; without -- weight images of ones
+    // count as none, mgm_core.cc:420-423 -- Hirschmueller is update_cost2 (built: PUBE with halved terms), FH is
+    // update_cost2_trunclinear with its boundary fix-up (not built here: the dense hull has it).
     bool rel_sign_ok = P1 >= 0.0f && P2 >= 0.0f;
-    if (rel_sign_ok && w8 && w8[0] && !S && MGM != 2 && P2 < __builtin_huge_valf() && rel_pays && rel_enabled()) {
-        bool odd = false;
-        if ((r = weights_have_odd_values(c, w8, n, npix, &odd))) return r;
+    bool rel_weighted = w8 && w8[0];
+    const bool rel_candidate = !S && P2 < __builtin_huge_valf() && rel_pays && rel_sign_ok && rel_enabled();
+    if (rel_candidate && rel_weighted) {
+        bool odd = false, any = false;
+        if ((r = weights_have_odd_values(c, w8, n, npix, &odd, &any))) return r;
         rel_sign_ok = !odd;
+        if (MGM == 2 && !any) rel_weighted = false;  // planes of ones: the reference runs unweighted
     }
-    if (!S && MGM != 2 && P2 < __builtin_huge_valf() && rel_pays && rel_sign_ok && rel_enabled()) {
+    const bool rel_fn_ok = MGM != 2 || rel_weighted || use_fh <= 0;
+    if (rel_candidate && rel_sign_ok && rel_fn_ok) {
         bool all = true;
         for (int v = 0; v < n && all; v++) {
             bool u = false;
             if ((r = rel_resolve(c, C[v], &u))) return r;
             all = u;
         }
-        if (all) return run_rel(c, C, (w8 && w8[0]) ? w8 : nullptr, n, P1, P2, MGM, use_fh, NDIR, fix_overcount, ridx, out, outcost);
+        if (all) return run_rel(c, C, rel_weighted ? w8 : nullptr, n, P1, P2, MGM, use_fh, NDIR, fix_overcount, ridx, out, outcost);
     }
     // The Lr volumes of a launch take NDIR x W x H x L floats per volume.  A batch that does not fit the caller's
     // workspace limit (mgm_ctx_set_workspace_limit), or the device (hipMalloc fails), is run as several launches over

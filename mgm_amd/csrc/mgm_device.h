@@ -126,6 +126,7 @@ struct RelParams {
     long long npix, nvol;
     int MGM, NDIR, pass0, LLmax, maxbands, weighted;
     int ld;             // steps of LDS-DMA the loader keeps in flight (2..5; every step of lead is a step of lag per band)
+    int cost2;          // TSGM = 2 without weights, Hirschmueller: update_cost2's association (every term halved before the sum)
     int fh_multi;       // FH: the pixel's TSGM min-convolutions side by side (k_pass_rel<true, false, TSGM>) instead of one after the other
     float P1, P2;
     unsigned long long *tl;  // nullptr, or 8 words per work item (MGM_HIP_TIMELINE; tools/timeline.py): start, end, waited, slow paths, where, steps, polls
@@ -335,6 +336,68 @@ MGM_DPP_ADD(dpp_add_wave_shr1, "wave_shr:1 row_mask:0xf")
 MGM_DPP_ADD(dpp_add_wave_shl1, "wave_shl:1 row_mask:0xf")
 #undef MGM_DPP_MIN
 #undef MGM_DPP_ADD
+// The same on NK independent values in ONE block (round 6, fh_scan_multi): one s_nop for the block, the NK DPP instructions back to
+// back -- the chains of NK side-by-side scans interleave at every stage instead of running one after the other (the compiler keeps
+// inline-assembly blocks in source order).
+#define MGM_DPP_MIN_N(name, ctrl)                                                                                                     \
+    template <int NK>                                                                                                                 \
+    __device__ __forceinline__ void name(float (&c)[NK], const float (&t)[NK])                                                        \
+    {                                                                                                                                 \
+        static_assert(NK >= 1 && NK <= 4, "one to four chains");                                                                      \
+        if constexpr (NK == 1)                                                                                                        \
+            asm("s_nop 1\n\tv_min_f32_dpp %0, %1, %0 " ctrl " bank_mask:0xf" : "+v"(c[0]) : "v"(t[0]));                               \
+        else if constexpr (NK == 2)                                                                                                   \
+            asm("s_nop 1\n\tv_min_f32_dpp %0, %2, %0 " ctrl " bank_mask:0xf\n\tv_min_f32_dpp %1, %3, %1 " ctrl " bank_mask:0xf"      \
+                : "+v"(c[0]), "+v"(c[1])                                                                                              \
+                : "v"(t[0]), "v"(t[1]));                                                                                              \
+        else if constexpr (NK == 3)                                                                                                   \
+            asm("s_nop 1\n\tv_min_f32_dpp %0, %3, %0 " ctrl " bank_mask:0xf\n\tv_min_f32_dpp %1, %4, %1 " ctrl                       \
+                " bank_mask:0xf\n\tv_min_f32_dpp %2, %5, %2 " ctrl " bank_mask:0xf"                                                   \
+                : "+v"(c[0]), "+v"(c[1]), "+v"(c[2])                                                                                  \
+                : "v"(t[0]), "v"(t[1]), "v"(t[2]));                                                                                   \
+        else                                                                                                                          \
+            asm("s_nop 1\n\tv_min_f32_dpp %0, %4, %0 " ctrl " bank_mask:0xf\n\tv_min_f32_dpp %1, %5, %1 " ctrl                       \
+                " bank_mask:0xf\n\tv_min_f32_dpp %2, %6, %2 " ctrl " bank_mask:0xf\n\tv_min_f32_dpp %3, %7, %3 " ctrl                \
+                " bank_mask:0xf"                                                                                                      \
+                : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])                                                                      \
+                : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));                                                                        \
+    }
+#define MGM_DPP_ADD_N(name, ctrl)                                                                                                     \
+    template <int NK>                                                                                                                 \
+    __device__ __forceinline__ void name(float (&t)[NK], const float (&c)[NK], const float (&a)[NK])                                  \
+    {                                                                                                                                 \
+        static_assert(NK >= 1 && NK <= 4, "one to four chains");                                                                      \
+        if constexpr (NK == 1)                                                                                                        \
+            asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 " ctrl " bank_mask:0xf bound_ctrl:0" : "=&v"(t[0]) : "v"(c[0]), "v"(a[0]));      \
+        else if constexpr (NK == 2)                                                                                                   \
+            asm("s_nop 1\n\tv_add_f32_dpp %0, %2, %4 " ctrl " bank_mask:0xf bound_ctrl:0\n\tv_add_f32_dpp %1, %3, %5 " ctrl          \
+                " bank_mask:0xf bound_ctrl:0"                                                                                         \
+                : "=&v"(t[0]), "=&v"(t[1])                                                                                            \
+                : "v"(c[0]), "v"(c[1]), "v"(a[0]), "v"(a[1]));                                                                        \
+        else if constexpr (NK == 3)                                                                                                   \
+            asm("s_nop 1\n\tv_add_f32_dpp %0, %3, %6 " ctrl " bank_mask:0xf bound_ctrl:0\n\tv_add_f32_dpp %1, %4, %7 " ctrl          \
+                " bank_mask:0xf bound_ctrl:0\n\tv_add_f32_dpp %2, %5, %8 " ctrl " bank_mask:0xf bound_ctrl:0"                         \
+                : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2])                                                                               \
+                : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(a[0]), "v"(a[1]), "v"(a[2]));                                                  \
+        else                                                                                                                          \
+            asm("s_nop 1\n\tv_add_f32_dpp %0, %4, %8 " ctrl " bank_mask:0xf bound_ctrl:0\n\tv_add_f32_dpp %1, %5, %9 " ctrl          \
+                " bank_mask:0xf bound_ctrl:0\n\tv_add_f32_dpp %2, %6, %10 " ctrl                                                     \
+                " bank_mask:0xf bound_ctrl:0\n\tv_add_f32_dpp %3, %7, %11 " ctrl " bank_mask:0xf bound_ctrl:0"                        \
+                : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])                                                                  \
+                : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));                            \
+    }
+MGM_DPP_MIN_N(dpp_min_row_shr1_n, "row_shr:1 row_mask:0xf")
+MGM_DPP_MIN_N(dpp_min_row_shr2_n, "row_shr:2 row_mask:0xf")
+MGM_DPP_MIN_N(dpp_min_row_shr4_n, "row_shr:4 row_mask:0xf")
+MGM_DPP_MIN_N(dpp_min_row_shr8_n, "row_shr:8 row_mask:0xf")
+MGM_DPP_MIN_N(dpp_min_row_shl1_n, "row_shl:1 row_mask:0xf")
+MGM_DPP_MIN_N(dpp_min_row_shl2_n, "row_shl:2 row_mask:0xf")
+MGM_DPP_MIN_N(dpp_min_row_shl4_n, "row_shl:4 row_mask:0xf")
+MGM_DPP_MIN_N(dpp_min_row_shl8_n, "row_shl:8 row_mask:0xf")
+MGM_DPP_ADD_N(dpp_add_wave_shr1_n, "wave_shr:1 row_mask:0xf")
+MGM_DPP_ADD_N(dpp_add_wave_shl1_n, "wave_shl:1 row_mask:0xf")
+#undef MGM_DPP_MIN_N
+#undef MGM_DPP_ADD_N
 
 // wave-wide minimum, result uniform (SGPR).  NaN-free inputs only.
 __device__ __forceinline__ float wave_min(float v)

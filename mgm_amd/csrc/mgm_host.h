@@ -267,7 +267,7 @@ int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const f
 // the range-proportional path of ragged volumes (mgm_plan.hip): is this call one it takes?  then the passes + the winner search
 bool rel_enabled();
 int rel_resolve(mgm_ctx *c, const mgm_cv *cv, bool *usable);
-int weights_have_odd_values(mgm_ctx *c, const mgm_img *const *w8s, int nb, long long npix, bool *odd);
+int weights_have_odd_values(mgm_ctx *c, const mgm_img *const *w8s, int nb, long long npix, bool *odd, bool *any = nullptr);
 int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int nb, float P1, float P2, int MGM, int use_fh, int NDIR,
             int fix_overcount, int ridx, mgm_img *const *outs, mgm_img *const *outcosts);
 int run_wta_rel(mgm_ctx *c, const mgm_cv *C, int slot, int NDIR, int fix_overcount, int ridx, const float *wlo, const float *whi, float *out,

@@ -388,53 +388,58 @@ __device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, f
 // interleaves) with ONE vote; a rejected guess anywhere (rare) sends every array through fh_scan from scratch -- the fixed point
 // of the sweeps is unique and equals the sequential recurrence whatever the starting carries, so the result is fh_scan's bit
 // for bit.  (fh_scan itself is left untouched: the dense kernels' hot loops are built on it.)
-template <int LPL, bool FWD, int GROUPS>
-__device__ __forceinline__ float fh_guess(const float (&M)[LPL], float P1, int lane)
-{
-    static_assert(GROUPS == 4, "rows of 16 lanes: the only user is the range-proportional pass kernel");
-    constexpr int K0 = FWD ? 0 : LPL - 1;
-    constexpr int DK = FWD ? 1 : -1;
-    const float rampP = (float)LPL * P1;
-    float a = M[K0];
-#pragma unroll
-    for (int q = 1; q < LPL; q++) a = fminf(M[K0 + q * DK], a + P1);
-    const float r1 = rampP, r2 = 2.0f * rampP, r4 = 4.0f * rampP, r8 = 8.0f * rampP;
-    float c = a;
-    if constexpr (FWD) {
-        c = dpp_min_row_shr1(c, c + r1);
-        c = dpp_min_row_shr2(c, c + r2);
-        c = dpp_min_row_shr4(c, c + r4);
-        c = dpp_min_row_shr8(c, c + r8);
-    } else {
-        c = dpp_min_row_shl1(c, c + r1);
-        c = dpp_min_row_shl2(c, c + r2);
-        c = dpp_min_row_shl4(c, c + r4);
-        c = dpp_min_row_shl8(c, c + r8);
-    }
-    (void)lane;
-    return c;
-}
 template <int LPL, bool FWD, int GROUPS, int NK>
 __device__ __forceinline__ void fh_scan_multi(float (&M)[NK][LPL], const float (&P1)[NK], int lane, unsigned &sweeps)
 {
+    static_assert(GROUPS == 4, "rows of 16 lanes: the only user is the range-proportional pass kernel");
     constexpr int GL = 64 / GROUPS;
     constexpr int K0 = FWD ? 0 : LPL - 1;
     constexpr int K1 = FWD ? LPL - 1 : 0;
     constexpr int DK = FWD ? 1 : -1;
-    const bool edge = FWD ? lane % GL == 0 : lane % GL == GL - 1;  // no carry into the first lane of a label range
-    float c[NK], f[NK][LPL];
+    // every stage is written ACROSS the NK arrays (k innermost): NK independent chains per stage
+    // carry-out of every lane ignoring its carry-in (fh_scan's `origin`)
+    float c[NK], t[NK], rp[NK];
 #pragma unroll
-    for (int k = 0; k < NK; k++) c[k] = fh_guess<LPL, FWD, GROUPS>(M[k], P1[k], lane);
+    for (int k = 0; k < NK; k++) c[k] = M[k][K0];
+#pragma unroll
+    for (int q = 1; q < LPL; q++)
+#pragma unroll
+        for (int k = 0; k < NK; k++) c[k] = fminf(M[k][K0 + q * DK], c[k] + P1[k]);
+    // the guess: min-plus scan with single-rounded ramps inside each row of 16 lanes (fh_scan with GROUPS = 4)
+#pragma unroll
+    for (int k = 0; k < NK; k++) rp[k] = (float)LPL * P1[k];
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+#pragma unroll
+        for (int k = 0; k < NK; k++) t[k] = c[k] + (float)(1 << st) * rp[k];
+        if constexpr (FWD) {
+            if (st == 0) dpp_min_row_shr1_n<NK>(c, t);
+            else if (st == 1) dpp_min_row_shr2_n<NK>(c, t);
+            else if (st == 2) dpp_min_row_shr4_n<NK>(c, t);
+            else dpp_min_row_shr8_n<NK>(c, t);
+        } else {
+            if (st == 0) dpp_min_row_shl1_n<NK>(c, t);
+            else if (st == 1) dpp_min_row_shl2_n<NK>(c, t);
+            else if (st == 2) dpp_min_row_shl4_n<NK>(c, t);
+            else dpp_min_row_shl8_n<NK>(c, t);
+        }
+    }
+    // one sweep: the exact in-lane recurrence given the neighbour lane's carry; the guess holds iff the carries reproduce
+    const bool edge = FWD ? lane % GL == 0 : lane % GL == GL - 1;  // no carry into the first lane of a label range
+    float pe[NK], cin[NK], f[NK][LPL];
+#pragma unroll
+    for (int k = 0; k < NK; k++) pe[k] = edge ? f_inf() : P1[k];
+    if constexpr (FWD) dpp_add_wave_shr1_n<NK>(cin, c, pe);
+    else dpp_add_wave_shl1_n<NK>(cin, c, pe);
+#pragma unroll
+    for (int k = 0; k < NK; k++) f[k][K0] = fminf(M[k][K0], cin[k]);
+#pragma unroll
+    for (int q = 1; q < LPL; q++)
+#pragma unroll
+        for (int k = 0; k < NK; k++) f[k][K0 + q * DK] = fminf(M[k][K0 + q * DK], f[k][K0 + (q - 1) * DK] + P1[k]);
     bool same = true;
 #pragma unroll
-    for (int k = 0; k < NK; k++) {
-        const float p1edge = edge ? f_inf() : P1[k];
-        const float cin = FWD ? dpp_add_wave_shr1(c[k], p1edge) : dpp_add_wave_shl1(c[k], p1edge);
-        f[k][K0] = fminf(M[k][K0], cin);
-#pragma unroll
-        for (int q = 1; q < LPL; q++) f[k][K0 + q * DK] = fminf(M[k][K0 + q * DK], f[k][K0 + (q - 1) * DK] + P1[k]);
-        same = same && (f[k][K1] == c[k]);
-    }
+    for (int k = 0; k < NK; k++) same = same && (f[k][K1] == c[k]);
     sweeps += NK;
     if (__builtin_amdgcn_ballot_w64(!same) == 0ull) {
 #pragma unroll
@@ -454,13 +459,13 @@ __device__ __forceinline__ void fh_minconv_multi(float (&M)[NK][LPL], const floa
 {
     fh_scan_multi<LPL, true, GROUPS, NK>(M, P1, lane, sweeps);
     fh_scan_multi<LPL, false, GROUPS, NK>(M, P1, lane, sweeps);
+    // the cap, unconditionally: with P2 = +INF it is min(M, +INF) = M (no NaNs here: the caller's volumes have none and its P2 is finite)
 #pragma unroll
-    for (int k = 0; k < NK; k++)
-        if (P2[k] < f_inf()) {
-            const float cap = m[k] + P2[k];
+    for (int k = 0; k < NK; k++) {
+        const float cap = m[k] + P2[k];
 #pragma unroll
-            for (int q = 0; q < LPL; q++) M[k][q] = fminf(M[k][q], cap);
-        }
+        for (int q = 0; q < LPL; q++) M[k][q] = fminf(M[k][q], cap);
+    }
 }
 template <int LPL, bool FULL = false>
 __device__ __forceinline__ void fh_minconv(float (&M)[LPL], float m, float P1, float P2, int lane, int L)

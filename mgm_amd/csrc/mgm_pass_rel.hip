@@ -20,8 +20,9 @@
 // Structure: bands of 16 scan lines per workgroup in lock-step on the slope-2 diagonal -- 4 compute waves of FOUR lines each
 // (a pixel's 64 slots on a row of 16 lanes, 4 per lane: see k_pass_rel) + a loader wave that feeds LDS rings by LDS-DMA --, a
 // 4-deep LDS ring per line (a slab is read by the next line at three consecutive steps, each time at another shift), the band
-// hand-off through global memory in self-validating slots (the launch's tag in every word's sign bit), work items by atomic ticket.  Not built here (the dense path keeps them): TSGM = 2 without weights (update_cost2 /
-// update_cost2_trunclinear are other functions), windows wider than 62 labels, costs that are not bytes, P2 = +INF.
+// hand-off through global memory in self-validating slots (the launch's tag in every word's sign bit), work items by atomic ticket.  Not built here (the dense path keeps them): FH with TSGM = 2 without weights
+// (update_cost2_trunclinear and its boundary fix-up), windows wider than 62 labels, costs that are not bytes, P2 = +INF, negative
+// penalties or weights (the tags).  (Round 6: TSGM = 2 without weights, Hirschmueller -- update_cost2 -- runs here, PUBE with halved terms.)
 #include <algorithm>
 
 #include "mgm_pass_common.h"
@@ -496,13 +497,18 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                     const bool own = f0 ? k == 0 : k == 3;
                     const int di = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
                     const float *src = entry(own ? ln : prow, own ? i - 1 : i + di);
-                    mk[k] = interior ? src[HOFF] : 0.0f;
-                    const int sh = bp - reinterpret_cast<const int *>(src)[HOFF + 1];
+                    const relf2 hdr = *reinterpret_cast<const relf2 *>(src + HOFF);  // (minimum, base): one unconditional 8-byte read
+                    const float hmin = hdr.x, hbase = hdr.y;  // (scalars first: __builtin_bit_cast of the vector ELEMENT hdr[1] read element 0)
+                    mk[k] = interior ? hmin : 0.0f;
+                    const int sh = bp - __builtin_bit_cast(int, hbase);
                     const int idx0 = interior ? min(max(4 * li + sh, -4), 64) + GO : 0;
+                    float wv[4];  // (read first, unconditionally: a select per value, not an exec-masked LDS read per value)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) wv[q] = src[idx0 + q];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const int o = 4 * li + q;
-                        Mk[k][q] = (o >= rl && o <= rh) ? src[idx0 + q] : f_inf();
+                        Mk[k][q] = (o >= rl && o <= rh) ? wv[q] : f_inf();
                     }
                     p1k[k] = P1 * D[k];
                     p2k[k] = P2 * D[k];
@@ -541,9 +547,11 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                         }
                     }
                     if constexpr (PUBE) {
-                        // e = 0; e += t1 - m1; ... (0 + x is x: x >= +0)
+                        // e = 0; e += t1 - m1; ... (0 + x is x: x >= +0); update_cost2 (TSGM = 2 without weights, mgm_core.cc:66-90)
+                        // halves every term before it is added: e += (t1 - m1) / 2; e += (t2 - m2) / 2; L = C + e
+                        const float hf = P.cost2 ? 0.5f : 1.0f;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) e[q] = k == 0 ? w[0][q] : e[q] + w[0][q];
+                        for (int q = 0; q < 4; q++) e[q] = k == 0 ? w[0][q] * hf : e[q] + w[0][q] * hf;
                     } else if constexpr (!FH) {  // update_costW (mgm_core.cc:95-144): e = 0; e += fmin3(L, N + P1 D, m + P2 D) - m
                         const float a = P1 * D[k], b = P2 * D[k];
 #pragma unroll
@@ -565,7 +573,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             }
             float Lv[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) Lv[q] = interior ? Cv[q] + div_small_rt(e[q], MGM) : Cv[q];
+            for (int q = 0; q < 4; q++)  // (NK: the divisor folds at compile time; update_cost2 has divided already)
+                Lv[q] = interior ? Cv[q] + ((PUBE && P.cost2) ? e[q] : div_small_rt(e[q], NK > 0 ? NK : MGM)) : Cv[q];
             if constexpr (MGM_REL_PHASES != 0) {
                 asm volatile("" : "+v"(Lv[0]), "+v"(Lv[1]), "+v"(Lv[2]), "+v"(Lv[3]));
                 c1 = clock64();

@@ -91,9 +91,10 @@ static int run_passes_exact(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *
 
 // Weighted launches of the range-proportional kernels: does any weight image hold a value that is not positive and finite
 // (<= 0, NaN, INF)?  One small scan + read-back per call, the same kernel run_passes uses to recognise two-valued weights.
-int weights_have_odd_values(mgm_ctx *c, const mgm_img *const *w8s, int nb, long long npix, bool *odd)
+int weights_have_odd_values(mgm_ctx *c, const mgm_img *const *w8s, int nb, long long npix, bool *odd, bool *any)
 {
     *odd = false;
+    if (any) *any = false;
     int r;
     if ((r = reserve(c, c->wvals, sizeof(unsigned) * 4 * kMaxBatch))) return r;
     unsigned init[4 * kMaxBatch], got[4 * kMaxBatch];
@@ -103,7 +104,10 @@ int weights_have_odd_values(mgm_ctx *c, const mgm_img *const *w8s, int nb, long 
         if (w8s[v]) HIPCHK(c, launch_weight_values(w8s[v]->d, npix * 8, (unsigned *)c->wvals.p + 4 * v, c->stream));
     HIPCHK(c, hipMemcpyAsync(got, c->wvals.p, sizeof(unsigned) * 4 * nb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int v = 0; v < nb; v++) *odd = *odd || (w8s[v] && got[4 * v + 3] != 0);
+    for (int v = 0; v < nb; v++) {
+        *odd = *odd || (w8s[v] && got[4 * v + 3] != 0);
+        if (any) *any = *any || (w8s[v] && got[4 * v] != 0);  // a value != 1.0: the run is a weighted one (mgm_core.cc:420-423)
+    }
     return MGM_OK;
 }
 
@@ -1176,6 +1180,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     // a launch bound by its chains of bands wants a short lead (lag per band); a batch has the slack and wants the loads covered
     p.ld = (int)std::min(5LL, std::max(2LL, tune_num("rel_ld", nb <= 1 ? 2 : 3)));
     p.fh_multi = tune_num("rel_multi", 1) != 0 ? 1 : 0;
+    p.cost2 = (pube && MGM == 2) ? 1 : 0;
     p.tl = nullptr;
     // MGM_HIP_TIMELINE=<file>: one line per work item (tools/timeline.py) -- where the compute units' time goes
     const char *tl_file = getenv("MGM_HIP_TIMELINE");

@@ -330,3 +330,18 @@ def test_transport_fallbacks_keep_the_line_valid():
     dr = d["directions"]
     assert dr["transport"] == "replicas" and dr["value"] is None and dr["ranks"] == 2 and d["value"] > 0
     assert dr["fallback_chain"][-1].startswith("replicas:") and dr["differs_from_single"] == {}
+
+
+def test_a_rank_killed_mid_exchange_leaves_a_valid_line():
+    """the first node run will be the RCCL exchange's first execution with n > 1 -- a rank that DIES between the
+    agreement and its first transfer (SIGKILL: no Python teardown, its sockets just close) must not take the line with it.  The
+    survivors' exchange fails or times out, torch.distributed.run terminates them (SIGTERM), and rank 0 still prints the ONE json
+    line with the headline and everything measured before the leg; the exit code says a rank failed."""
+    r, d, lines = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "0", "--extras-timeout", "120"],
+                             {"MGM_STUB_DIE_AT": "exchange"}, timeout=600)
+    assert len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert d["value"] > 0 and d["n_gpus"] == 2 and d["config"]["workload"].startswith("cfg3") and d["cfg5_replicas"]["value"] > 0
+    dr = d.get("directions", {})
+    assert "value" not in dr or dr.get("transport") in (None, "replicas", "peer"), dr  # (no figure from the leg that lost a rank)
+    assert "extras_note" in d or "error" in dr or "error" in dr.get("rccl", {}), d.keys()
+    assert r.returncode != 0  # the launcher reports the dead rank

@@ -88,9 +88,13 @@ SMALL = [
     ("jumps_fh", 71, 52, -200, 20, ("jumpy", 9), 1, 3, 8, 2.0, 20000.0, None, "vfit", 1, True),
     ("jumps_hirsch", 71, 52, -200, 20, ("jumpy", 14), 0, 4, 8, 8.0, 32.0, None, None, 0, True),
     ("jumps_t1_o4", 83, 40, -120, 0, ("jumpy", 30), 1, 1, 4, 2.0, 30.0, None, "vfit", 1, True),
-    ("t2_hirsch", 90, 41, -60, 0, ("win", 10, 12, 3), 0, 2, 8, 8.0, 32.0, None, "vfit", 1, None),   # update_cost2
-    ("t2_fh_boundary_fix", 90, 41, -60, 0, ("win", 10, 12, 3), 1, 2, 8, 2.0, 30.0, None, "vfit", 1, None),  # update_cost2_trunclinear + fix-up
-    ("t2_fh_jumps", 61, 44, -100, 0, ("jumpy", 11), 1, 2, 4, 2.0, 30.0, None, "cubic", 0, None),
+    ("t2_hirsch", 90, 41, -60, 0, ("win", 10, 12, 3), 0, 2, 8, 8.0, 32.0, None, "vfit", 1, True),   # update_cost2 (round 6: on the range-proportional kernels)
+    ("t2_hirsch_jumps_o4", 75, 38, -150, 0, ("jumpy", 20), 0, 2, 4, 8.0, 32.0, None, "cubic", 0, True),
+    ("t2_hirsch_ones_as_weights", 64, 33, -60, 0, ("win", 10, 12, 3), 0, 2, 8, 8.0, 32.0, "ones", "vfit", 1, True),  # planes of ones: the reference runs UNWEIGHTED (update_cost2)
+    ("t2_hirsch_image_weights", 64, 33, -60, 0, ("win", 10, 12, 3), 0, 2, 8, 8.0, 32.0, "image", None, 1, True),     # update_costW with two neighbours
+    ("t2_fh_boundary_fix", 90, 41, -60, 0, ("win", 10, 12, 3), 1, 2, 8, 2.0, 30.0, None, "vfit", 1, False),  # update_cost2_trunclinear + fix-up
+    ("t2_fh_jumps", 61, 44, -100, 0, ("jumpy", 11), 1, 2, 4, 2.0, 30.0, None, "cubic", 0, False),
+    ("t2_fh_image_weights", 61, 44, -100, 0, ("jumpy", 11), 1, 2, 4, 2.0, 30.0, "image", "vfit", 1, True),  # update_costW_trunclinear, two neighbours
 ]
 
 
@@ -122,6 +126,9 @@ def test_ragged_small_vs_oracle(oracle, case):
         elif wkind == "image":
             w8 = ctx.weights_dev(ctx.upload_image(u), 4.0, 12.0)
             w8h = w8.download()
+        elif wkind == "ones":
+            w8h = np.ones((8, ny, nx), np.float32)
+            w8 = ctx.upload_image(w8h)
         try:
             Sa, oa, ca, lra = oracle.mgm_ranged(Ca, hmin, lo, hi, P1, P2, NDIR, MGM, FH, fix, w8h, dump_lr=True)
         finally:

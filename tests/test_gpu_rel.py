@@ -93,11 +93,12 @@ def test_rel_is_not_taken_where_it_does_not_apply():
         ctx.timing(True)
         ctx.aggregate_dev(cv, 8.0, 32.0, 8, 3, 0, 1, None, "vfit")
         assert "k_pass_rel" not in [n for n, _ in ctx.timings()]
-        # TSGM = 2 without weights is another update function -> the dense hull; S wanted -> the dense hull
+        # FH with TSGM = 2 without weights is update_cost2_trunclinear with its boundary fix-up -> the dense hull (round 6: the
+        # Hirschmueller TSGM = 2 function, update_cost2, runs on the range-proportional kernels); S wanted -> the dense hull
         lo, hi = ranges(gt, dmin, dmax, 8, 9)
         cv2 = ctx.costvolume(u, v, lo, hi, "none", "census", float("inf"), 5)
         ctx.timing_reset()
-        ctx.aggregate_dev(cv2, 8.0, 32.0, 4, 2, 0, 1, None, "vfit")
+        ctx.aggregate_dev(cv2, 2.0, 30.0, 4, 2, 1, 1, None, "vfit")
         S, _, _ = ctx.aggregate_dev(cv2, 8.0, 32.0, 4, 3, 0, 1, None, "vfit", want_S=True)
         assert "k_pass_rel" not in [n for n, _ in ctx.timings()] and S is not None
         # unit weights, Hirschmueller, ONE volume: a tie where the hull exists (absolute differences: K2 writes the hull and the
