@@ -289,15 +289,29 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         for (int k = tid; k < (RR * RD4 + SD) * HS; k += (NW + 1) * 64) ring[k] = f_inf();
     __syncthreads();
     const int2 tk = P.tasks[*s_task];
-    const int vp = tk.x, band = tk.y;  // vp = volume*8 + pass
+    const int vp = tk.x, band = tk.y & 0xffff, strip = (tk.y >> 16) & 0xff;  // vp = volume*8 + pass
     const int pass = vp & (kMaxDirs - 1);
     const RelVolume &V = P.vol[vp / kMaxDirs];
     const PassGeom &g = P.g[pass];
     const int NL = g.NL, LL = g.LL, MGM = P.MGM, form = g.form;
     const float P1 = P.P1, P2 = P.P2;
-    const long long istep = g.istep;
     const int SL = g.slope;  // line l of the band is at pixel s - 1 - SL l at step s
-    const int nsteps = (LL + 1 + SL * (RR - 1) + 3) / 4 * 4;
+    // TWO STRIPS per line (round 6; form 1 with TSGM <= 3: a pixel depends on the line before only, never on its own line -- the
+    // second build's `strips`, mgm_pass2.hip): this work item walks strip `strip` of its band's lines, strip 0 = [0, split) upwards
+    // from pixel 0, strip 1 = [split, LL) downwards from pixel LL - 1 -- in MIRRORED coordinates i' = LL - 1 - i, in which it is
+    // again a walk upwards from 0 with the fwd and back neighbours at i' - 1 and i' + 1.  So that neither strip ever needs the
+    // other's lines of the SAME band, line l of the band is walked over [0, W - l), W = strip length + lines - 1: the band's last
+    // line covers exactly the strip, the lines above it a little more (the pixels both items compute get the same values twice).
+    // What a strip needs from the other comes through the previous band's hand-off slots, which are indexed by ABSOLUTE pixel and
+    // validate themselves.  The chain of a pass is then 2 steps per line + HALF a line.  Everything below runs in LOCAL
+    // coordinates (rings, steps); only addresses and hand-off slots are absolute.
+    const bool strips = g.nstrips == 2;
+    const bool mirror = strips && strip == 1;
+    const int slen = !strips ? LL : (strip == 0 ? g.split : LL - g.split);
+    const int W = !strips ? LL : min(LL, slen + RR - 1);  // pixels of the band's first line
+    const long long istep = mirror ? -g.istep : g.istep;
+    const long long gbase = mirror ? g.base + (long long)(LL - 1) * g.istep : g.base;
+    const int nsteps = (W + 1 + SL * (RR - 1) + 3) / 4 * 4;
 
     // SELF-VALIDATING hand-off slots, one per (volume, pass, band, pixel), written once per launch with the launch's tag in the
     // sign bit of every word (values, minimum and biased base are non-negative; the padding words carry the tag alone): the
@@ -321,15 +335,16 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         const bool weighted = P.weighted != 0;
         const int cl = lane >> 2;
         const int cj = min(band * RR + cl, NL - 1);
-        const long long cpix0 = g.base + (long long)cj * g.jstep;
+        const long long cpix0 = gbase + (long long)cj * g.jstep;
         const uint8_t *cptr = V.c8 + cpix0 * 64 + (lane & 3) * 16;
         const float *wptr = weighted ? V.w8 + (long long)g.wplane[lane & 3] * P.npix + cpix0 : nullptr;
         int ci = -1 - SL * cl;
         const int ml = lane < RR ? lane : RR - 1;
         const int mj = min(band * RR + ml, NL - 1);
-        const int4 *mptr = reinterpret_cast<const int4 *>(V.base) + (g.base + (long long)mj * g.jstep);
+        const int4 *mptr = reinterpret_cast<const int4 *>(V.base) + (gbase + (long long)mj * g.jstep);
         int mi = -1 - SL * ml;
-        const float *hptr = hand_in + lane * 4;
+        const float *hptr = hand_in + (mirror ? (long long)(LL - 1) * HS : 0) + lane * 4;  // (local pixel 0)
+        const long long hstep = mirror ? -(long long)HS : (long long)HS;
         int ht = 0;
         bool dead = false;
         unsigned long long tl_wait = 0, n_slow = 0, n_spin = 0;
@@ -338,27 +353,27 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             rel_dma16<0>(cptr, cring + slot * RR * 64);
             if (weighted) rel_dma4<0>(wptr, wring + slot * RR * 4);
             {
-                const bool adv = ci >= 0 && ci < LL - 1;
+                const bool adv = ci >= 0 && ci < W - 1;
                 cptr += adv ? istep * 64 : 0;
                 if (weighted) wptr += adv ? istep : 0;
                 ci++;
             }
             if (lane < RR) rel_dma16<0>(mptr, mring + slot * RR * 4);
             {
-                const bool adv = mi >= 0 && mi < LL - 1;
+                const bool adv = mi >= 0 && mi < W - 1;
                 mptr += adv ? istep : 0;
                 mi++;
             }
             // the previous band's slot of pixel ht, whatever it holds by now: validate() looks at it when its step comes
             if (lane < NPIECE) rel_dma16<REL_SC1>(hptr, hring + slot * HS);
-            hptr += (ht < LL - 1) ? HS : 0;
+            hptr += (ht < LL - 1) ? hstep : 0;
             ht++;
         };
         // The slot of pixel t has landed in the hand ring: make sure it is THIS launch's (every word's sign bit = the tag),
         // fetching it again until it is; then take the tags off (and the bias off the base) so that the compute waves read it like
         // any ring entry.
         auto validate = [&](int t) {
-            if (!from_global || t >= LL || dead) return;
+            if (!from_global || t >= LL || t > W || dead) return;  // (beyond local pixel W nobody of this item reads: the other strip's business)
             float *ent = hring + (t & (SD - 1)) * HS;
             const bool mine = lane < NPIECE;
             rel_u4 v = {0u, 0u, 0u, 0u};
@@ -377,7 +392,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 }
                 n_spin++;
                 __builtin_amdgcn_s_sleep(2);
-                if (mine) rel_dma16<REL_SC1>(hand_in + (long long)t * HS + lane * 4, ent);
+                if (mine) rel_dma16<REL_SC1>(hand_in + (long long)(mirror ? LL - 1 - t : t) * HS + lane * 4, ent);
                 rel_wait_vmcnt<0>();
                 if (((++spins) & 255u) == 0) {
                     if (lane == 0) rel_dma4<REL_SC1>(P.err, hprog);
@@ -457,7 +472,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     const bool to_global = (r == NW - 1) && (band + 1 < g.nbands);  // (the wave that holds the band's last line)
     const int prow = ln > 0 ? ln - 1 : RR;  // ring row of the line before this one
     float *__restrict__ Lrb = V.Lr + (long long)(pass - P.pass0) * P.nvol;
-    const long long pix0 = g.base + (long long)(line_ok ? j : 0) * g.jstep;
+    const long long pix0 = gbase + (long long)(line_ok ? j : 0) * g.jstep;
+    const int Wl = !strips ? LL : min(LL, slen + RR - 1 - ln);  // this line is walked over [0, Wl)
     const bool f0 = form == 0;
 
     // slab(s) `row`/`pixel n` as the pixel with base bp sees them: the same disparities, +INF (PUBE: FAR) where n has no slot
@@ -474,7 +490,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         const unsigned long long c0 = MGM_REL_PHASES ? clock64() : 0;
         unsigned long long c1 = c0;
         const int i = s - 1 - SL * ln;
-        const bool act = line_ok && i >= 0 && i < LL;
+        const bool act = line_ok && i >= 0 && i < Wl;
         if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
             const long long pix = pix0 + (long long)(act ? i : 0) * istep;
             const int sl = s & (SD - 1);
@@ -495,7 +511,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
 #pragma unroll
                 for (int k = 0; k < NK; k++) {
                     const bool own = f0 ? k == 0 : k == 3;
-                    const int di = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
+                    const int di0 = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
+                    const int di = mirror ? -di0 : di0;  // (mirrored strip: the fwd neighbour i + 1 is local i' - 1)
                     const float *src = entry(own ? ln : prow, own ? i - 1 : i + di);
                     const relf2 hdr = *reinterpret_cast<const relf2 *>(src + HOFF);  // (minimum, base): one unconditional 8-byte read
                     const float hmin = hdr.x, hbase = hdr.y;  // (scalars first: __builtin_bit_cast of the vector ELEMENT hdr[1] read element 0)
@@ -525,7 +542,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             for (int k = 0; k < 4; k++) {
                 if (k < MGM) {
                     const bool own = f0 ? k == 0 : k == 3;
-                    const int di = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
+                    const int di0 = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
+                    const int di = mirror ? -di0 : di0;
                     const float *src = entry(own ? ln : prow, own ? i - 1 : i + di);
                     const float m = interior ? src[HOFF] : 0.0f;                                   // minimum (or FAR)
                     const int sh = bp - reinterpret_cast<const int *>(src)[HOFF + 1];              // base
@@ -609,9 +627,9 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             }
             if (to_global) {
                 const int iL = s - 1 - SL * (RR - 1);  // the band's last line: lane group GL - 1 of this wave
-                if (iL >= 0 && iL < LL) {
+                if (iL >= 0 && iL < min(LL, slen)) {  // (strips: the band's last line covers exactly its strip -- no slot is written twice)
                     // the hand-off to the next band: write-through 16-byte stores straight from the registers, every word tagged
-                    float *dstg = hand_out + (long long)iL * HS;
+                    float *dstg = hand_out + (long long)(mirror ? LL - 1 - iL : iL) * HS;
                     if (grp == GL - 1) {
                         auto tagged = [&](relf4 x) {
                             rel_u4 u = __builtin_bit_cast(rel_u4, x);

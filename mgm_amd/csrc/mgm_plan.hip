@@ -1092,6 +1092,13 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
         if (!make_geom(q, nx, ny, R, MGM, tune_num("rel_slope1", 1) != 0, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
         maxLL = std::max(maxLL, p.g[q].LL);
         maxbands = std::max(maxbands, p.g[q].nbands);
+        // (round 6) two strips per line for the form-1 passes: no pixel of those passes depends on its own line with TSGM <= 3, so the
+        // two halves of a band's lines are two work items (k_pass_rel).  Measured, 1920x1080, windows of 49 labels: FH x 1 8.91 -> 8.12 ms,
+        // x 4 13.33 -> 12.89; Hirschmueller x 1 6.13 -> 5.53 (tune rel_strips=0: none)
+        if (tune_num("rel_strips", 1) != 0 && p.g[q].form == 1 && MGM <= 3 && p.g[q].LL >= 8 * R) {
+            p.g[q].nstrips = 2;
+            p.g[q].split = p.g[q].LL / 2;
+        }
     }
     if (maxbands > kMaxBands) return fail(c, MGM_ERR_UNSUPPORTED, "image side exceeds 65536 pixels");
     const long long stride = npix * 64 + lr_pad_floats();
@@ -1128,20 +1135,22 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     // workgroups (4 compute waves + the loader) per CU: tune rel_wg forces it
     const long long wgs = tune_num("rel_wg", 0);
     const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 1 ? 2 : 3);  // (measured: x 1 / x 2 / x 4 of 1920x1080, both potentials)
-    snprintf(key, sizeof key, "%d %d %d %d %d %d", nx, ny, NDIR, nb, rel_wg, p.g[0].slope);
+    snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d", nx, ny, NDIR, nb, rel_wg, p.g[0].slope, MGM, p.g[NDIR - 1].nstrips);
     if (c->tasks_rel_key != key) {
         std::vector<SimChain> ch;
         for (int v = 0; v < nb; v++)
-            for (int q = 0; q < NDIR; q++) {
-                SimChain k;
-                k.x = v * kMaxDirs + q, k.st = 0, k.nb = p.g[q].nbands, k.sib = -1, k.chain = v * NDIR + q;
-                k.skew = (double)p.g[q].slope * R + 4.0;  // (slope of the lock-step diagonal x lines; loader lead + one fetch: ~4 steps of lag)
-                k.len = p.g[q].LL + (double)p.g[q].slope * (R - 1) + 1.0;
-                ch.push_back(k);
-            }
+            for (int q = 0; q < NDIR; q++)
+                for (int st = 0; st < p.g[q].nstrips; st++) {
+                    const PassGeom &g = p.g[q];
+                    SimChain k;
+                    k.x = v * kMaxDirs + q, k.st = st, k.nb = g.nbands, k.chain = v * NDIR + q;
+                    k.sib = g.nstrips == 2 ? (int)ch.size() + (st == 0 ? 1 : -1) : -1;  // (a band waits for BOTH strips of the band before it)
+                    k.skew = (double)g.slope * R + 4.0;  // (slope of the lock-step diagonal x lines; loader lead + one fetch: ~4 steps of lag)
+                    k.len = (g.nstrips == 2 ? (st == 0 ? g.split : g.LL - g.split) + R - 1 : g.LL) + (double)g.slope * (R - 1) + 1.0;
+                    ch.push_back(k);
+                }
         std::vector<int2> order;
         (void)simulate_schedule(ch, 1, std::max(1, c->num_cu * rel_wg), 1 << 20, order);
-        for (int2 &t : order) t.y &= 0xffff;
         HIPCHK(c, hipStreamSynchronize(c->stream));  // (a launch that still reads the old table)
         if ((r = reserve(c, c->tasks_rel, sizeof(int2) * order.size()))) return r;
         HIPCHK(c, hipMemcpyAsync(c->tasks_rel.p, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice, c->stream));
