@@ -155,21 +155,26 @@ struct WtaRelParams {
 hipError_t launch_wta_rel(const WtaRelParams &p, hipStream_t s);
 
 // the slow, operand-order-faithful pass kernel (mgm_pass_exact.hip): one pass of one volume
+struct ExactPass {       // one pass of the reference's table (mgm_core.cc:463-471, 481-484)
+    float *Lr;           // this pass's volume [npix][L]: written whole by the launch (a pixel that is not updated keeps C, 495-498)
+    int d[4][2];         // neighbour offsets
+    int wplane[4];       // weight plane of neighbour k
+    int inc_x, inc_y, row_major;
+    int jj0, njj;        // this launch: first jj of the diagonal that lies inside the image, and how many
+};
 struct ExactParams {
     const float *C;      // [npix][L]
-    float *Lr;           // this pass's volume [npix][L], initialised to C by the caller
-    float *mins;         // [npix] slab minima of the pixels visited so far
-    float *fhscratch;    // FH potentials with more than 8192 labels: max(nx, ny) x 4 x L floats (the convolution arrays of a
+    float *mins;         // [npass][npix] slab minima of the pixels visited so far
+    float *fhscratch;    // FH potentials with more than 8192 labels: npass x max(nx, ny) x 4 x L floats (the convolution arrays of a
                          // diagonal's pixels, which fit the LDS up to 8192 labels), else unused
     const float *w8;     // 8 planes or nullptr
     const float *rlo, *rhi;  // ragged volume: per-pixel range images, or nullptr
     int nx, ny, L, dmin;
     float P1, P2;
     int MGM, mode;       // mode: 0 update_cost2, 1 update_costW, 2 update_cost2_trunclinear, 3 update_costW_trunclinear
-    int d[4][2];         // the pass's neighbour offsets (mgm_core.cc:463-471)
-    int inc_x, inc_y, row_major;
-    int wplane[4];       // weight plane of neighbour k (481-484)
-    int ii, jj0;         // diagonal; first jj of it that lies inside the image
+    int npass;           // passes of this launch: blockIdx.y (round 6: the passes are independent -- one launch per DIAGONAL serves them all)
+    int ii;              // diagonal
+    ExactPass pass[kMaxDirs];
 };
 hipError_t launch_pass_exact(const ExactParams &p, hipStream_t s);
 

@@ -11,12 +11,17 @@
 //     INF - INF = NaN (mgm_core.cc:242-271 on Dvec::operator[]'s +INF, dvec.cc:129).
 //
 // Shape: the reference's own schedule (mgm_core.cc:505-579) -- one launch per diagonal ii of the slope-2 sweep, one
-// wavefront per pixel of it, the labels strided over the lanes; Lr starts as a copy of C (495-498), every visited pixel
-// leaves its slab minimum (577) in `mins`.  Ragged volumes keep the dense hull layout of the fast path (foreign labels
+// wavefront per pixel of it, the labels strided over the lanes; Lr starts as a copy of C (495-498: here every pixel writes its
+// WHOLE slab when its diagonal comes -- each pixel lies on exactly one -- so no copy is made first), every visited pixel
+// leaves its slab minimum (577) in `mins`.  Round 6: the passes of a volume are independent of each other (their sum is taken
+// later, in order), so ONE launch per diagonal serves all of them (blockIdx.y = pass): 8 x fewer launches of 8 x the waves --
+// the kernel is bound by its launches (one per diagonal: ~4900 for a 1920x1080 image), not by its arithmetic.  Ragged volumes keep the dense hull layout of the fast path (foreign labels
 // hold +INF = what Dvec::operator[] returns for them), a pixel only writes the labels of its own range (Dvec::set_nolock,
 // dvec.cc:111-118), and the FH functions convolve over the RECEIVING pixel's range with
 // FixBounrady_for_minConvTruncatedLinear (166-186) where the reference applies it (update_cost2_trunclinear only).
 // Nothing here is tuned: a 1920x1080x256 volume takes on the order of a second.
+#include <algorithm>
+
 #include "mgm_device.h"
 
 namespace mgm {
@@ -49,20 +54,24 @@ extern __shared__ float exact_smem[];
 __global__ void __launch_bounds__(64) k_pass_exact(const ExactParams P)
 {
     const int lane = threadIdx.x;
-    const int jj = P.jj0 + blockIdx.x;
-    const int maxii = P.row_major ? P.nx : P.ny, maxjj = P.row_major ? P.ny : P.nx;
+    const ExactPass &G = P.pass[blockIdx.y];
+    if ((int)blockIdx.x >= G.njj) return;
+    const int jj = G.jj0 + blockIdx.x;
+    const int maxii = G.row_major ? P.nx : P.ny, maxjj = G.row_major ? P.ny : P.nx;
     int x = P.ii - 2 * jj, y = jj;
     if (x < 0 || x >= maxii || jj >= maxjj) return;
-    if (!P.row_major) {
+    if (!G.row_major) {
         const int t = x;
         x = y;
         y = t;
     }
-    if (P.inc_x == 0) x = (P.nx - 1) - x;
-    if (P.inc_y == 0) y = (P.ny - 1) - y;
+    if (G.inc_x == 0) x = (P.nx - 1) - x;
+    if (G.inc_y == 0) y = (P.ny - 1) - y;
     const long long npix = (long long)P.nx * P.ny, pidx = (long long)x + (long long)y * P.nx;
     const int L = P.L;
-    float *Lp = P.Lr + pidx * L;
+    float *const Lr = G.Lr;
+    float *const mins = P.mins + (long long)blockIdx.y * npix;
+    float *Lp = Lr + pidx * L;
     const float *Cp = P.C + pidx * L;
     int rl = 0, rh = L - 1;  // the pixel's own labels (dense indices)
     if (P.rlo) {
@@ -72,7 +81,7 @@ __global__ void __launch_bounds__(64) k_pass_exact(const ExactParams P)
     long long nidx[4];
     bool inside = true;
     for (int k = 0; k < 4; k++) {
-        const int qx = x + P.d[k][0], qy = y + P.d[k][1];
+        const int qx = x + G.d[k][0], qy = y + G.d[k][1];
         if (!(qx >= 0 && qy >= 0 && qx < P.nx && qy < P.ny)) inside = false;
         nidx[k] = (long long)qx + (long long)qy * P.nx;
     }
@@ -82,9 +91,9 @@ __global__ void __launch_bounds__(64) k_pass_exact(const ExactParams P)
         float mn[4], D[4];
         int nl[4], nh[4];  // the neighbours' own ranges (FixBoundary)
         for (int k = 0; k < 4; k++) {
-            Ln[k] = P.Lr + nidx[k] * L;
-            mn[k] = (k < hm) ? P.mins[nidx[k]] : __builtin_huge_valf();
-            D[k] = P.w8 ? P.w8[pidx + (long long)P.wplane[k] * npix] : 1.0f;
+            Ln[k] = Lr + nidx[k] * L;
+            mn[k] = (k < hm) ? mins[nidx[k]] : __builtin_huge_valf();
+            D[k] = P.w8 ? P.w8[pidx + (long long)G.wplane[k] * npix] : 1.0f;
             nl[k] = 0;
             nh[k] = L - 1;
             if (P.rlo) {
@@ -93,6 +102,9 @@ __global__ void __launch_bounds__(64) k_pass_exact(const ExactParams P)
             }
         }
         auto at = [&](const float *a, int o) { return (o >= 0 && o < L) ? a[o] : __builtin_huge_valf(); };  // Dvec::operator[]
+        // the labels of the hull this pixel does not own keep what C holds there (+INF): Lr = CC (495-498), set_nolock drops them
+        for (int o = lane; o < L; o += 64)
+            if (o < rl || o > rh) Lp[o] = Cp[o];
         if (P.mode == 0) {
             for (int o = rl + lane; o <= rh; o += 64) {
                 float e = 0;
@@ -121,7 +133,7 @@ __global__ void __launch_bounds__(64) k_pass_exact(const ExactParams P)
             const int nk = P.mode == 2 ? 2 : hm;
             // the convolution arrays: in LDS up to 8192 labels, beyond that in a slice of global scratch of this workgroup's
             // own (one wave per workgroup; the block barriers below order its stores and loads)
-            float *const conv = P.fhscratch ? P.fhscratch + (size_t)blockIdx.x * 4 * (size_t)L : exact_smem;
+            float *const conv = P.fhscratch ? P.fhscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 * (size_t)L : exact_smem;
             if (NN > 0) {
                 for (int k = 0; k < nk; k++)
                     for (int o = lane; o < NN; o += 64) conv[(size_t)k * NN + o] = Ln[k][rl + o];
@@ -172,6 +184,9 @@ __global__ void __launch_bounds__(64) k_pass_exact(const ExactParams P)
             }
         }
         __syncthreads();  // (the slab is complete before its minimum is taken; one wave per block)
+    } else {  // a pixel of the frame: never updated, its Lr is its cost slab (495-498)
+        for (int o = lane; o < L; o += 64) Lp[o] = Cp[o];
+        __syncthreads();
     }
     // Dvec::get_minvalue (dvec.cc:81-88): strict `<` scan in label order from +INF -- NaNs never enter, and of several
     // equal minima (+0 and -0) the FIRST is kept.  Lane l scans the labels l*chunk .. in order, then the lanes combine in
@@ -190,13 +205,12 @@ __global__ void __launch_bounds__(64) k_pass_exact(const ExactParams P)
         const float hi = __shfl_down(m, off);
         if (lane + off < 64 && hi < m) m = hi;
     }
-    if (lane == 0) P.mins[pidx] = m;
+    if (lane == 0) mins[pidx] = m;
 }
 
 hipError_t launch_pass_exact(const ExactParams &base, hipStream_t s)
 {
     ExactParams p = base;
-    const int maxii = p.row_major ? p.nx : p.ny, maxjj = p.row_major ? p.ny : p.nx;
     size_t shmem = (p.mode >= 2) ? sizeof(float) * 4 * (size_t)p.L : 0;
     if (shmem > 128 * 1024) {  // (more than 8192 labels: the caller provides global scratch, mgm_plan.hip)
         if (!p.fhscratch) return hipErrorInvalidValue;
@@ -207,16 +221,24 @@ hipError_t launch_pass_exact(const ExactParams &base, hipStream_t s)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pass_exact), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    for (int ii = 0; ii < maxii + 2 * maxjj; ii++) {  // mgm_core.cc:505: for (ii = 0; ii < maxii + 2*maxjj; ii++)
-        // jj with 0 <= ii - 2*jj < maxii
-        int jlo = ii - (maxii - 1);
-        jlo = jlo <= 0 ? 0 : (jlo + 1) / 2;
-        int jhi = ii / 2;
-        if (jhi > maxjj - 1) jhi = maxjj - 1;
-        if (jhi < jlo) continue;
+    int last = 0;
+    for (int q = 0; q < p.npass; q++) last = std::max(last, p.pass[q].row_major ? p.nx + 2 * p.ny : p.ny + 2 * p.nx);
+    for (int ii = 0; ii < last; ii++) {  // mgm_core.cc:505: for (ii = 0; ii < maxii + 2*maxjj; ii++), every pass of the launch at once
+        int most = 0;
+        for (int q = 0; q < p.npass; q++) {
+            const int maxii = p.pass[q].row_major ? p.nx : p.ny, maxjj = p.pass[q].row_major ? p.ny : p.nx;
+            // jj with 0 <= ii - 2*jj < maxii
+            int jlo = ii - (maxii - 1);
+            jlo = jlo <= 0 ? 0 : (jlo + 1) / 2;
+            int jhi = ii / 2;
+            if (jhi > maxjj - 1) jhi = maxjj - 1;
+            p.pass[q].jj0 = jlo;
+            p.pass[q].njj = jhi < jlo ? 0 : jhi - jlo + 1;
+            most = std::max(most, p.pass[q].njj);
+        }
+        if (most == 0) continue;
         p.ii = ii;
-        p.jj0 = jlo;
-        hipLaunchKernelGGL(k_pass_exact, dim3((unsigned)(jhi - jlo + 1)), dim3(64), shmem, s, p);
+        hipLaunchKernelGGL(k_pass_exact, dim3((unsigned)most, (unsigned)p.npass), dim3(64), shmem, s, p);
     }
     return hipGetLastError();
 }

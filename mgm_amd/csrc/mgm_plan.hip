@@ -37,9 +37,9 @@ static int run_passes_exact(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *
     const long long lr_stride = nvol + lr_pad_floats();
     int r;
     if ((r = reserve(c, c->lr, sizeof(float) * (size_t)lr_stride * nslots * nb))) return r;
-    if ((r = reserve(c, c->exact_mins, sizeof(float) * (size_t)npix))) return r;
+    if ((r = reserve(c, c->exact_mins, sizeof(float) * (size_t)npix * count))) return r;
     const bool big_fh = fh && (size_t)L * 16 > 128 * 1024;  // the four convolution arrays of a pixel do not fit the LDS
-    if (big_fh && (r = reserve(c, c->exact_scratch, sizeof(float) * (size_t)std::max(nx, ny) * 4 * (size_t)L))) return r;
+    if (big_fh && (r = reserve(c, c->exact_scratch, sizeof(float) * (size_t)count * std::max(nx, ny) * 4 * (size_t)L))) return r;
     ExactParams p{};
     p.nx = nx;
     p.ny = ny;
@@ -58,21 +58,24 @@ static int run_passes_exact(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *
         p.w8 = weighted ? w8s[v]->d : nullptr;
         p.rlo = Cs[v]->rlo;
         p.rhi = Cs[v]->rhi;
+        // (round 6) all passes of the volume in ONE sweep of launches, one per diagonal (they are independent: blockIdx.y = pass);
+        // every pixel writes its whole slab when its diagonal comes, so Lr = CC (495-498) needs no copy
+        p.npass = count;
         for (int q = first; q < first + count; q++) {
             const RefPass &rp = kPasses[q];
+            ExactPass &g = p.pass[q - first];
             for (int k = 0; k < 4; k++) {
-                p.d[k][0] = rp.d[k][0];
-                p.d[k][1] = rp.d[k][1];
-                p.wplane[k] = kPassToChannel[k][q];
+                g.d[k][0] = rp.d[k][0];
+                g.d[k][1] = rp.d[k][1];
+                g.wplane[k] = kPassToChannel[k][q];
             }
-            p.inc_x = rp.inc_x;
-            p.inc_y = rp.inc_y;
-            p.row_major = rp.row_major;
-            p.Lr = (float *)c->lr.p + ((size_t)v * nslots + slot0 + (q - first)) * lr_stride;
-            HIPCHK(c, hipMemcpyAsync(p.Lr, p.C, sizeof(float) * (size_t)nvol, hipMemcpyDeviceToDevice, c->stream));  // Lr = CC (495-498)
-            TimeScope t(c, "k_pass_exact");
-            HIPCHK(c, launch_pass_exact(p, c->stream));
+            g.inc_x = rp.inc_x;
+            g.inc_y = rp.inc_y;
+            g.row_major = rp.row_major;
+            g.Lr = (float *)c->lr.p + ((size_t)v * nslots + slot0 + (q - first)) * lr_stride;
         }
+        TimeScope t(c, "k_pass_exact");
+        HIPCHK(c, launch_pass_exact(p, c->stream));
     }
     c->last_nvol = nvol;
     c->last_stride = lr_stride;
