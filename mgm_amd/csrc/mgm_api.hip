@@ -244,20 +244,15 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     // k_cost_census_rel) -- neither the fp32 hull nor its compact twin is written; whoever wants the hull gets it from
     // ensure_f32.  The flag word (a window wider than 62 labels) is read back at once: such a volume takes the general path.
     if (rel_direct_candidate && p.rlo && census_fits) {
-        const size_t npix = (size_t)u->nx * u->ny, need = npix * 64 + npix * 16 + 16;
-        if ((*out)->rel_cap < need) {
-            if ((*out)->relbuf) (void)hipFree((*out)->relbuf);
-            (*out)->relbuf = nullptr;
-            (*out)->rel_cap = 0;
-            if (dev_malloc((void **)&(*out)->relbuf, need) == hipSuccess) (*out)->rel_cap = need;
-        }
-        if ((*out)->relbuf) {
-            unsigned *flag = reinterpret_cast<unsigned *>((*out)->relbuf + npix * 64 + npix * 16);
+        for (int slots = 64; slots <= 128; slots *= 2) {  // (round 6: windows of up to 62 labels in 64 slots per pixel, else up to 126 in 128)
+            if ((r = rel_alloc(c, *out, slots, 1))) return r;
+            if (!(*out)->relbuf) break;
+            unsigned *flag = (*out)->rel_flag();
             HIPCHK(c, hipMemsetAsync(flag, 0, 4, c->stream));
             {
                 TimeScope t(c, "k_cost");
-                HIPCHK(c, launch_cost_census_rel(p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, dmin, p.L, p.trunc, p.rlo, p.rhi, (*out)->relbuf,
-                                                 reinterpret_cast<int *>((*out)->relbuf + npix * 64), flag, c->stream));
+                HIPCHK(c, launch_cost_census_rel(p.cu, p.cv, p.nx, p.ny, p.vnx, p.vny, dmin, p.L, p.trunc, p.rlo, p.rhi, slots, (*out)->relbuf, (*out)->rel_records(),
+                                                 flag, c->stream));
             }
             if ((r = ensure_words(c))) return r;
             HIPCHK(c, hipMemcpyAsync(c->h_words + 3, flag, 4, hipMemcpyDeviceToHost, c->stream));
@@ -270,6 +265,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
                 (*out)->nan_state = 2;  // integer costs: NaN-free by construction
                 return MGM_OK;
             }
+            if (tune_num("rel_wide", 1) == 0) break;
         }
         (*out)->rel_state = 0;
     }
@@ -373,18 +369,14 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     // cost a byte (the flag word is read back by the first aggregation).
     (*out)->rel_state = 0;
     if (p.rlo && p.C && rel_enabled()) {
-        const size_t npix = (size_t)u->nx * u->ny, need = npix * 64 + npix * 16 + 16;
-        if ((*out)->rel_cap < need) {
-            if ((*out)->relbuf) (void)hipFree((*out)->relbuf);
-            (*out)->relbuf = nullptr;
-            (*out)->rel_cap = 0;
-            if (dev_malloc((void **)&(*out)->relbuf, need) == hipSuccess) (*out)->rel_cap = need;
-        }
+        // the narrowest form the cost function can have: one byte for single-word census and grey-level absolute differences, two for
+        // the other absolute / squared differences; the flag word (read back by the first aggregation, rel_resolve) widens it
+        const int rcb = (costfn == 2 || (costfn == 0 && u->nch == 1)) ? 1 : 2;
+        if ((r = rel_alloc(c, *out, 64, rcb))) return r;
         if ((*out)->relbuf) {
-            unsigned *flag = reinterpret_cast<unsigned *>((*out)->relbuf + npix * 64 + npix * 16);
-            HIPCHK(c, hipMemsetAsync(flag, 0, 4, c->stream));
+            HIPCHK(c, hipMemsetAsync((*out)->rel_flag(), 0, 4, c->stream));
             TimeScope t(c, "k_rel_gather");
-            HIPCHK(c, launch_rel_gather(p.C, p.rlo, p.rhi, (long long)npix, p.L, dmin, (*out)->relbuf, reinterpret_cast<int *>((*out)->relbuf + npix * 64), flag,
+            HIPCHK(c, launch_rel_gather(p.C, p.rlo, p.rhi, (long long)u->nx * u->ny, p.L, dmin, 64, rcb, (*out)->relbuf, (*out)->rel_records(), (*out)->rel_flag(),
                                         c->stream));
             (*out)->rel_state = 1;
         }
@@ -526,7 +518,7 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
         for (int v = 0; v < n && all; v++) {
             bool u = false;
             if ((r = rel_resolve(c, C[v], &u))) return r;
-            all = u;
+            all = u && C[v]->rel_slots == C[0]->rel_slots && C[v]->rel_cb == C[0]->rel_cb;  // (one format per launch)
         }
         if (all) return run_rel(c, C, rel_weighted ? w8 : nullptr, n, P1, P2, MGM, use_fh, NDIR, fix_overcount, ridx, out, outcost);
     }
@@ -800,17 +792,18 @@ int mgm_debug_download_lr(mgm_ctx *c, int pass, float *dense)
         const size_t npix = (size_t)C->nx * C->ny;
         const int L = C->dmax - C->dmin + 1;
         HIPCHK(c, hipSetDevice(c->device));
-        std::vector<float> slabs(npix * 64);
+        const size_t slots = (size_t)C->rel_slots;
+        std::vector<float> slabs(npix * slots);
         std::vector<int> rec(npix * 4);
-        HIPCHK(c, hipMemcpyAsync(slabs.data(), (const float *)c->lr_rel.p + (size_t)pass * c->rel_last_stride, sizeof(float) * npix * 64,
+        HIPCHK(c, hipMemcpyAsync(slabs.data(), (const float *)c->lr_rel.p + (size_t)pass * c->rel_last_stride, sizeof(float) * npix * slots,
                                  hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(rec.data(), C->relbuf + npix * 64, sizeof(int) * npix * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(rec.data(), C->rel_records(), sizeof(int) * npix * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (size_t p = 0; p < npix; p++) {
             const int b = rec[p * 4], lo = rec[p * 4 + 1], hi = rec[p * 4 + 2];
             for (int o = 0; o < L; o++) {
                 const int d = C->dmin + o;
-                dense[p * L + o] = (d >= lo && d <= hi) ? slabs[p * 64 + (d - b)] : __builtin_huge_valf();
+                dense[p * L + o] = (d >= lo && d <= hi) ? slabs[p * slots + (d - b)] : __builtin_huge_valf();
             }
         }
         return MGM_OK;

@@ -535,7 +535,7 @@ extern "C++" int ensure_f32(mgm_ctx *c, const mgm_cv *ccv)
         if (int r = cv_alloc_f32(c, cv)) return r;
         const long long npix = (long long)cv->nx * cv->ny;
         TimeScope t(c, "k_expand");
-        HIPCHK(c, launch_rel_expand(cv->relbuf, reinterpret_cast<const int *>(cv->relbuf + npix * 64), npix, cv->dmax - cv->dmin + 1, cv->dmin, cv->d, c->stream));
+        HIPCHK(c, launch_rel_expand(cv->relbuf, cv->rel_records(), npix, cv->dmax - cv->dmin + 1, cv->dmin, cv->rel_slots, cv->rel_cb, cv->d, c->stream));
         cv->f32_state = 1;
         return MGM_OK;
     }

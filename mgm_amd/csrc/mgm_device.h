@@ -109,10 +109,10 @@ struct WtaParams {
 // ---- ragged volumes in the range-proportional layout (mgm_pass_rel.hip, k_wta_rel): 64 label slots per pixel placed at the
 // pixel's own window, slot k <-> disparity base + k
 struct RelVolume {
-    const uint8_t *c8;       // [npix][64] cost bytes (255 = +INF: the slot is not a disparity of the pixel, or its cost is +INF)
+    const uint8_t *c8;       // [npix][slots] cost codes of cb bytes (all ones = +INF: the slot is not a disparity of the pixel, or its cost is +INF)
     const int *base;         // [npix][4] the pixel's record: disparity of slot 0 (= its lowest disparity - 1), lowest, highest, 0
     const float *rlo, *rhi;  // [npix] the pixel's own range (the volume's range images)
-    float *Lr;               // NDIR volumes [npix][64], pass p at Lr + (p - pass0)*nvol
+    float *Lr;               // NDIR volumes [npix][slots], pass p at Lr + (p - pass0)*nvol
     const float *w8;         // 8 planes [npix] or nullptr
 };
 struct RelParams {
@@ -126,21 +126,22 @@ struct RelParams {
     long long npix, nvol;
     int MGM, NDIR, pass0, LLmax, maxbands, weighted;
     int ld;             // steps of LDS-DMA the loader keeps in flight (2..5; every step of lead is a step of lag per band)
+    int slots, cb;      // the volumes' range-proportional format: 64 or 128 label slots per pixel, 1 or 2 bytes per cost (round 6)
     int cost2;          // TSGM = 2 without weights, Hirschmueller: update_cost2's association (every term halved before the sum)
     int fh_multi;       // FH: the pixel's TSGM min-convolutions side by side (k_pass_rel<true, false, TSGM>) instead of one after the other
     float P1, P2;
     unsigned long long *tl;  // nullptr, or 8 words per work item (MGM_HIP_TIMELINE; tools/timeline.py): start, end, waited, slow paths, where, steps, polls
     PassGeom g[kMaxDirs];
 };
-hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi, long long npix, int L, int dmin, uint8_t *rel8, int *relb,
+hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi, long long npix, int L, int dmin, int slots, int cb, uint8_t *rel8, int *relb,
                              unsigned *flag, hipStream_t s);
 hipError_t launch_cost_census_rel(const uint32_t *cu, const uint32_t *cv, int nx, int ny, int vnx, int vny, int dmin, int L, float trunc, const float *rlo,
-                                  const float *rhi, uint8_t *rel8, int *relb, unsigned *flag, hipStream_t s);
-hipError_t launch_rel_expand(const uint8_t *rel8, const int *relb, long long npix, int L, int dmin, float *C, hipStream_t s);
+                                  const float *rhi, int slots, uint8_t *rel8, int *relb, unsigned *flag, hipStream_t s);
+hipError_t launch_rel_expand(const uint8_t *rel8, const int *relb, long long npix, int L, int dmin, int slots, int cb, float *C, hipStream_t s);
 hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, int wg_per_cu, hipStream_t s);
 int pass_rel_lines();
 int pass_rel_phases();  // words per work item of phase clocks behind the timeline words (0: not a -DMGM_REL_PHASES=1 build)
-int pass_rel_hand_floats(bool one_slab);
+int pass_rel_hand_floats(bool one_slab, int slots);
 struct WtaRelParams {
     const uint8_t *c8;
     const int *base;
@@ -151,6 +152,7 @@ struct WtaRelParams {
     long long npix, nvol;
     int NDIR, FIX, refine;   // refine: index into the reference's table (0 none, 1 vfit, 2 parabola, 3 cubic, 4 parabolaOCV)
     int num_cu;
+    int slots, cb;           // the volume's range-proportional format
 };
 hipError_t launch_wta_rel(const WtaRelParams &p, hipStream_t s);
 

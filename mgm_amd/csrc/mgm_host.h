@@ -64,9 +64,16 @@ struct mgm_cv {
     // ragged volume, range-proportional copy (round 5; mgm_pass_rel.hip): 64 cost bytes per pixel placed at its own window +
     // a 16-byte record per pixel (disparity of slot 0, lo, hi) + a flag word, one allocation [npix*64 bytes][npix*16 bytes][flag]; rel_state 0 none, 1 written (flag
     // not read back yet), 2 usable, -1 not usable (a window wider than 62 labels, a cost that is not a byte)
+    // (round 6) the copy's FORMAT: rel_slots = 64 or 128 label slots per pixel (windows of up to 62 / 126 labels), rel_cb = 1 or 2 bytes
+    // per cost code; [npix * rel_slots * rel_cb bytes of costs][npix * 16 bytes of records][flag word].  A gathered copy starts in the
+    // narrowest form its cost function allows and is gathered again wider if the flag word asks for it (rel_resolve).
     uint8_t *relbuf = nullptr;
     size_t rel_cap = 0;
     int rel_state = 0;
+    int rel_slots = 64, rel_cb = 1;
+    size_t rel_cost_bytes() const { return (size_t)nx * ny * (size_t)rel_slots * (size_t)rel_cb; }
+    int *rel_records() const { return reinterpret_cast<int *>(relbuf + rel_cost_bytes()); }
+    unsigned *rel_flag() const { return reinterpret_cast<unsigned *>(relbuf + rel_cost_bytes() + (size_t)nx * ny * 16); }
     // the relative copy is the ONLY copy (single-word census: K2 wrote it straight from the descriptors, f32_state 0);
     // ensure_f32 expands it into the dense hull on demand
     bool rel_only = false;
@@ -267,6 +274,7 @@ int run_wta(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const f
 // the range-proportional path of ragged volumes (mgm_plan.hip): is this call one it takes?  then the passes + the winner search
 bool rel_enabled();
 int rel_resolve(mgm_ctx *c, const mgm_cv *cv, bool *usable);
+int rel_alloc(mgm_ctx *c, mgm_cv *cv, int slots, int cb);  // (re)allocates relbuf for the format and sets rel_slots / rel_cb; MGM_OK also when the device has no room (relbuf stays null)
 int weights_have_odd_values(mgm_ctx *c, const mgm_img *const *w8s, int nb, long long npix, bool *odd, bool *any = nullptr);
 int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int nb, float P1, float P2, int MGM, int use_fh, int NDIR,
             int fix_overcount, int ridx, mgm_img *const *outs, mgm_img *const *outcosts);

@@ -84,14 +84,19 @@ __device__ __forceinline__ void rel_lds_write128_opaque(float *p, rel_u4 v)
 constexpr int REL_BIAS = 1 << 24;  // a hand-off slot holds base + REL_BIAS: a positive word, its sign bit free for the tag
 
 // ---- the relative copy of a ragged volume ------------------------------------------------------------------------------
-// one thread per (pixel, slot): rel8[p][k] = byte code of C[p][base(p) + k - dmin] inside the pixel's window, 255 elsewhere;
-// flag |= 1 if a window is wider than 62 labels, |= 2 if a cost has no byte form
+// Round 6: the layout comes in two widths and two cost sizes -- SLOTS = 64 or 128 label slots per pixel (windows of up to 62 /
+// 126 labels: 4 or 8 slots per lane on the pixel's row of 16 lanes), costs as one byte (255 = +INF) or two (65535 = +INF:
+// absolute differences of colour pairs, squared differences).  The host tries the narrowest form first and widens by what
+// the flag word says (mgm_api.hip, rel_fill).
+// one thread per (pixel, slot): rel[p][k] = code of C[p][base(p) + k - dmin] inside the pixel's window, all-ones elsewhere;
+// flag |= 1 if a window is wider than SLOTS - 2 labels, |= 2 if a cost does not have the form
 __global__ void __launch_bounds__(256) k_rel_gather(const float *__restrict__ C, const float *__restrict__ rlo, const float *__restrict__ rhi, long long npix,
-                                                    int L, int dmin, uint8_t *__restrict__ rel8, int *__restrict__ relb, unsigned *flag)
+                                                    int L, int dmin, int lgslots, int cb, uint8_t *__restrict__ rel8, int *__restrict__ relb, unsigned *flag)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long p = t >> 6;
-    const int k = (int)(t & 63);
+    const long long p = t >> lgslots;
+    const int slots = 1 << lgslots;
+    const int k = (int)(t & (slots - 1));
     if (p >= npix) return;
     const int lo = (int)rlo[p], hi = (int)rhi[p];
     const int b = lo - 1;
@@ -102,24 +107,26 @@ __global__ void __launch_bounds__(256) k_rel_gather(const float *__restrict__ C,
         relb[p * 4 + 3] = 0;
     }
     unsigned bad = 0;
-    if (hi - lo + 1 > 62 || hi < lo) bad |= 1u;
+    if (hi - lo + 1 > slots - 2 || hi < lo) bad |= 1u;
     const int d = b + k;  // disparity of this slot
-    unsigned code = 255u;
+    const unsigned none = cb == 1 ? 255u : 65535u;
+    unsigned code = none;
     if (d >= lo && d <= hi && d - dmin >= 0 && d - dmin < L) {
-        code = c8_encode(C[p * L + (d - dmin)]);
-        if (code > 255u) {
+        code = cb == 1 ? c8_encode(C[p * L + (d - dmin)]) : c16_encode(C[p * L + (d - dmin)]);
+        if (code > none) {
             bad |= 2u;
-            code = 255u;
+            code = none;
         }
     }
-    rel8[p * 64 + k] = (uint8_t)code;
+    if (cb == 1) rel8[p * slots + k] = (uint8_t)code;
+    else reinterpret_cast<uint16_t *>(rel8)[p * slots + k] = (uint16_t)code;
     if (bad && *flag != (*flag | bad)) atomicOr(flag, bad);  // (look before raising: one word for everybody)
 }
-hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi, long long npix, int L, int dmin, uint8_t *rel8, int *relb,
+hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi, long long npix, int L, int dmin, int slots, int cb, uint8_t *rel8, int *relb,
                              unsigned *flag, hipStream_t s)
 {
-    const long long n = npix * 64;
-    hipLaunchKernelGGL(k_rel_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C, rlo, rhi, npix, L, dmin, rel8, relb, flag);
+    const long long n = npix * slots;
+    hipLaunchKernelGGL(k_rel_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C, rlo, rhi, npix, L, dmin, slots == 128 ? 7 : 6, cb, rel8, relb, flag);
     return hipGetLastError();
 }
 
@@ -128,11 +135,13 @@ hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi,
 // 55-label windows in a hull of 256 cost 1.2 ms (general kernel, fp32 + compact hull) + 0.45 ms (k_rel_gather); this writes
 // its 133 MB alone.  cost = min(popcount(cu ^ cv), trunc), trunc for a hypothesis outside
 // the right image (mgm_costvolume.h:65-78, 401-412); a pixel without a finite cost in its range is all zeros there (414-421).
+template <int SPL>
 __global__ void __launch_bounds__(256) k_cost_census_rel(const uint32_t *__restrict__ cu, const uint32_t *__restrict__ cv, int nx, int ny, int vnx, int vny,
                                                          int dmin, int L, unsigned tb, const float *__restrict__ rlo, const float *__restrict__ rhi,
                                                          uint8_t *__restrict__ rel8, int *__restrict__ relb, unsigned *flag)
 {
-    // four pixels per wave: a row of 16 lanes per pixel, four slots (one 4-byte store) per lane
+    constexpr int SLOTS = 16 * SPL;
+    // four pixels per wave: a row of 16 lanes per pixel, SPL slots (4-byte stores) per lane
     const long long npix = (long long)nx * ny;
     const int li = threadIdx.x & 15;
     const long long pix = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + ((threadIdx.x >> 4) & 3);
@@ -143,11 +152,11 @@ __global__ void __launch_bounds__(256) k_cost_census_rel(const uint32_t *__restr
     const bool yin = y < vny;
     const uint32_t wu = cu[pix];
     const uint32_t *row = cv + (long long)(yin ? y : 0) * vnx;
-    unsigned code[4];
+    unsigned code[SPL];
     bool fin = false;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int d = b + 4 * li + q;
+    for (int q = 0; q < SPL; q++) {
+        const int d = b + SPL * li + q;
         const bool inw = d >= lo && d <= hi && d - dmin >= 0 && d - dmin < L;  // a label of this pixel
         const int qx = x + d;
         const bool in = yin && qx >= 0 && qx < vnx;
@@ -159,43 +168,48 @@ __global__ void __launch_bounds__(256) k_cost_census_rel(const uint32_t *__restr
     const unsigned long long any = __builtin_amdgcn_ballot_w64(fin);
     if (((any >> (threadIdx.x & 48)) & 0xffffull) == 0ull) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int d = b + 4 * li + q;
+        for (int q = 0; q < SPL; q++) {
+            const int d = b + SPL * li + q;
             const bool inw = d >= lo && d <= hi && d - dmin >= 0 && d - dmin < L;
             code[q] = inw ? 0u : 255u;
         }
     }
-    reinterpret_cast<unsigned *>(rel8 + pix * 64)[li] = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+#pragma unroll
+    for (int w = 0; w < SPL / 4; w++)
+        reinterpret_cast<unsigned *>(rel8 + pix * SLOTS)[li * (SPL / 4) + w] = code[4 * w] | (code[4 * w + 1] << 8) | (code[4 * w + 2] << 16) | (code[4 * w + 3] << 24);
     if (li == 0) {
         *reinterpret_cast<int4 *>(relb + pix * 4) = make_int4(b, lo, hi, 0);
-        const unsigned bad = (hi - lo + 1 > 62 || hi < lo) ? 1u : 0u;
+        const unsigned bad = (hi - lo + 1 > SLOTS - 2 || hi < lo) ? 1u : 0u;
         if (bad && *flag != (*flag | bad)) atomicOr(flag, bad);
     }
 }
 hipError_t launch_cost_census_rel(const uint32_t *cu, const uint32_t *cv, int nx, int ny, int vnx, int vny, int dmin, int L, float trunc, const float *rlo,
-                                  const float *rhi, uint8_t *rel8, int *relb, unsigned *flag, hipStream_t s)
+                                  const float *rhi, int slots, uint8_t *rel8, int *relb, unsigned *flag, hipStream_t s)
 {
     const unsigned tb = trunc == __builtin_huge_valf() ? 255u : (unsigned)trunc;
     const long long npix = (long long)nx * ny;
     const unsigned grid = (unsigned)((npix + 15) / 16);
-    hipLaunchKernelGGL(k_cost_census_rel, dim3(grid), dim3(256), 0, s, cu, cv, nx, ny, vnx, vny, dmin, L, tb, rlo, rhi, rel8, relb, flag);
+    if (slots == 128) hipLaunchKernelGGL(k_cost_census_rel<8>, dim3(grid), dim3(256), 0, s, cu, cv, nx, ny, vnx, vny, dmin, L, tb, rlo, rhi, rel8, relb, flag);
+    else hipLaunchKernelGGL(k_cost_census_rel<4>, dim3(grid), dim3(256), 0, s, cu, cv, nx, ny, vnx, vny, dmin, L, tb, rlo, rhi, rel8, relb, flag);
     return hipGetLastError();
 }
 // ... and the dense fp32 hull of such a volume, for whoever asks for it (ensure_f32): +INF wherever a pixel has no label
 __global__ void __launch_bounds__(256) k_rel_expand(const uint8_t *__restrict__ rel8, const int *__restrict__ relb, long long n, int L, int dmin,
-                                                    float *__restrict__ C)
+                                                    int slots, int cb, float *__restrict__ C)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const long long pix = t / L;
     const int o = (int)(t - pix * L);
     const int k = dmin + o - relb[pix * 4];
-    C[t] = (k >= 0 && k < 64) ? c8_decode((unsigned)rel8[pix * 64 + k]) : __builtin_huge_valf();
+    float v = __builtin_huge_valf();
+    if (k >= 0 && k < slots) v = cb == 1 ? c8_decode((unsigned)rel8[pix * slots + k]) : c16_decode((unsigned)reinterpret_cast<const uint16_t *>(rel8)[pix * slots + k]);
+    C[t] = v;
 }
-hipError_t launch_rel_expand(const uint8_t *rel8, const int *relb, long long npix, int L, int dmin, float *C, hipStream_t s)
+hipError_t launch_rel_expand(const uint8_t *rel8, const int *relb, long long npix, int L, int dmin, int slots, int cb, float *C, hipStream_t s)
 {
     const long long n = npix * L;
-    hipLaunchKernelGGL(k_rel_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rel8, relb, n, L, dmin, C);
+    hipLaunchKernelGGL(k_rel_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rel8, relb, n, L, dmin, slots, cb, C);
     return hipGetLastError();
 }
 
@@ -248,27 +262,35 @@ __device__ __forceinline__ float rel_row_min(float v)
 // Slope (round 6): form-0 passes with TSGM <= 3 never read the fwd neighbour (i + 1, j - 1), so a line only has to stay ONE pixel
 // behind the line before it (g.slope, as in the second build, mgm_pass2.hip): a band then hands over R + lag steps after it
 // started instead of 2 R + lag -- the chain of a 1920-column pass of 120 bands drops from 120 x 36 + 1110 to 120 x 20 + 1095.
-template <bool FH, bool PUBE, int NK = 0>
+// SPL, CB (round 6): label slots per lane (4: 64 slots per pixel, windows of up to 62 labels; 8: 128 slots, up to 126) and bytes per
+// cost (1, or 2: colour AD / SD).  Everything below is written for SPL values per lane; the loader's DMA counts follow.
+template <bool FH, bool PUBE, int NK = 0, int SPL = 4, int CB = 1>
 __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
 {
     static_assert(!(FH && PUBE), "FH potentials convolve over the RECEIVING pixel's range: consumer side only");
     static_assert(NK == 0 || FH, "side-by-side convolutions: FH only");
+    static_assert((SPL == 4 || SPL == 8) && (CB == 1 || CB == 2), "64 or 128 slots, one or two bytes per cost");
+    constexpr int SLOTS = 16 * SPL;          // label slots per pixel
+    constexpr int CBY = SLOTS * CB;          // cost bytes per pixel
+    constexpr int CPP = CBY / 16;            // ... in 16-byte pieces
+    constexpr int CI = RR * CPP / 64;        // DMA instructions that fetch the cost pieces of the band's RR pixels (1, 2 or 4)
     constexpr int NS = (FH || PUBE) ? 1 : 2;
     // A ring entry = a hand-off slot, whole 16-byte pieces.  One slab (FH, PUBE): [4 guard words][64 values][4 guard words][minimum,
     // base, 2 of padding] -- the guards hold what a disparity the pixel does not have reads as (+INF; PUBE: FAR), so a reader takes
     // its four values at ONE clamped index, no comparison or selection per value (the 64 + 64 variant: [L][N][minimum, base, padding])
     constexpr bool GUARD = NS == 1;
-    constexpr int GO = GUARD ? 4 : 0;                   // where the values start
-    constexpr int HOFF = GUARD ? 72 : NS * 64;          // where the header (minimum, base) sits
+    constexpr int GO = GUARD ? SPL : 0;                 // where the values start (a lane's worth of guard words before and after them)
+    constexpr int HOFF = GUARD ? SLOTS + 2 * SPL : NS * SLOTS;  // where the header (minimum, base) sits
     constexpr int HS = HOFF + 4;                        // floats per entry / hand-off slot
     constexpr int NPIECE = HS / 4;                      // its 16-byte pieces
+    constexpr int HI = (NPIECE + 63) / 64;              // DMA instructions per hand-off slot (2 only for two slabs of 128)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *ring = smem;                                    // [RR][RD4][HS]   what the lines of the band publish
     float *hring = ring + RR * RD4 * HS;                   // [SD][HS]        the previous band's last line, by pixel & (SD - 1)
     int *mring = reinterpret_cast<int *>(hring + SD * HS);  // [SD][RR][4]    records of the step's pixels: base, lo, hi
     float *wring = reinterpret_cast<float *>(mring + SD * RR * 4);  // [SD][RR][4]   edge weights of the step's pixels
-    uint8_t *cring = reinterpret_cast<uint8_t *>(wring + SD * RR * 4);  // [SD][RR][64] cost bytes of the step's pixels
-    unsigned *hprog = reinterpret_cast<unsigned *>(cring + SD * RR * 64);  // [4]   scratch of the loader's slow path (the error word)
+    uint8_t *cring = reinterpret_cast<uint8_t *>(wring + SD * RR * 4);  // [SD][RR][CBY] cost bytes of the step's pixels
+    unsigned *hprog = reinterpret_cast<unsigned *>(cring + SD * RR * CBY);  // [4]   scratch of the loader's slow path (the error word)
     int *s_task = reinterpret_cast<int *>(hprog + 4);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -333,12 +355,20 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         // except the slow path of the hand-off.
         const bool from_global = band > 0;
         const bool weighted = P.weighted != 0;
-        const int cl = lane >> 2;
-        const int cj = min(band * RR + cl, NL - 1);
-        const long long cpix0 = gbase + (long long)cj * g.jstep;
-        const uint8_t *cptr = V.c8 + cpix0 * 64 + (lane & 3) * 16;
-        const float *wptr = weighted ? V.w8 + (long long)g.wplane[lane & 3] * P.npix + cpix0 : nullptr;
-        int ci = -1 - SL * cl;
+        // cost pieces: instruction n moves piece (lane + 64 n) % CPP of line (lane + 64 n) / CPP -- [line][piece] order in the ring
+        const uint8_t *cptr[CI];
+        int ci[CI];
+#pragma unroll
+        for (int n = 0; n < CI; n++) {
+            const int cl = (lane + 64 * n) / CPP;
+            const int cj = min(band * RR + cl, NL - 1);
+            cptr[n] = V.c8 + (gbase + (long long)cj * g.jstep) * CBY + ((lane + 64 * n) % CPP) * 16;
+            ci[n] = -1 - SL * cl;
+        }
+        const int wl = lane >> 2;  // edge weights: lane 4 l + k has neighbour k of line l's pixel
+        const long long wpix0 = gbase + (long long)min(band * RR + wl, NL - 1) * g.jstep;
+        const float *wptr = weighted ? V.w8 + (long long)g.wplane[lane & 3] * P.npix + wpix0 : nullptr;
+        int wi = -1 - SL * wl;
         const int ml = lane < RR ? lane : RR - 1;
         const int mj = min(band * RR + ml, NL - 1);
         const int4 *mptr = reinterpret_cast<const int4 *>(V.base) + (gbase + (long long)mj * g.jstep);
@@ -350,13 +380,18 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         unsigned long long tl_wait = 0, n_slow = 0, n_spin = 0;
         auto issue = [&]() {  // everything step `ht` reads
             const int slot = ht & (SD - 1);
-            rel_dma16<0>(cptr, cring + slot * RR * 64);
-            if (weighted) rel_dma4<0>(wptr, wring + slot * RR * 4);
-            {
-                const bool adv = ci >= 0 && ci < W - 1;
-                cptr += adv ? istep * 64 : 0;
-                if (weighted) wptr += adv ? istep : 0;
-                ci++;
+#pragma unroll
+            for (int n = 0; n < CI; n++) {
+                rel_dma16<0>(cptr[n], cring + slot * RR * CBY + n * 1024);
+                const bool adv = ci[n] >= 0 && ci[n] < W - 1;
+                cptr[n] += adv ? istep * CBY : 0;
+                ci[n]++;
+            }
+            if (weighted) {
+                rel_dma4<0>(wptr, wring + slot * RR * 4);
+                const bool adv = wi >= 0 && wi < W - 1;
+                wptr += adv ? istep : 0;
+                wi++;
             }
             if (lane < RR) rel_dma16<0>(mptr, mring + slot * RR * 4);
             {
@@ -365,7 +400,9 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 mi++;
             }
             // the previous band's slot of pixel ht, whatever it holds by now: validate() looks at it when its step comes
-            if (lane < NPIECE) rel_dma16<REL_SC1>(hptr, hring + slot * HS);
+#pragma unroll
+            for (int n = 0; n < HI; n++)
+                if (lane + 64 * n < NPIECE) rel_dma16<REL_SC1>(hptr + 256 * n, hring + slot * HS + 256 * n);
             hptr += (ht < LL - 1) ? hstep : 0;
             ht++;
         };
@@ -375,16 +412,17 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         auto validate = [&](int t) {
             if (!from_global || t >= LL || t > W || dead) return;  // (beyond local pixel W nobody of this item reads: the other strip's business)
             float *ent = hring + (t & (SD - 1)) * HS;
-            const bool mine = lane < NPIECE;
-            rel_u4 v = {0u, 0u, 0u, 0u};
+            rel_u4 v[HI];
             unsigned spins = 0;
             unsigned long long w0 = 0;
             for (;;) {
                 bool ok = true;
-                if (mine) {
-                    v = rel_lds_read128_opaque(ent + lane * 4);
-                    ok = tag ? ((v.x & v.y & v.z & v.w) >> 31) != 0u : ((v.x | v.y | v.z | v.w) >> 31) == 0u;
-                }
+#pragma unroll
+                for (int n = 0; n < HI; n++)
+                    if (lane + 64 * n < NPIECE) {
+                        v[n] = rel_lds_read128_opaque(ent + (lane + 64 * n) * 4);
+                        ok = ok && (tag ? ((v[n].x & v[n].y & v[n].z & v[n].w) >> 31) != 0u : ((v[n].x | v[n].y | v[n].z | v[n].w) >> 31) == 0u);
+                    }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                 if (spins == 0) {
                     n_slow++;
@@ -392,7 +430,9 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 }
                 n_spin++;
                 __builtin_amdgcn_s_sleep(2);
-                if (mine) rel_dma16<REL_SC1>(hand_in + (long long)(mirror ? LL - 1 - t : t) * HS + lane * 4, ent);
+#pragma unroll
+                for (int n = 0; n < HI; n++)
+                    if (lane + 64 * n < NPIECE) rel_dma16<REL_SC1>(hand_in + (long long)(mirror ? LL - 1 - t : t) * HS + (lane + 64 * n) * 4, ent + 256 * n);
                 rel_wait_vmcnt<0>();
                 if (((++spins) & 255u) == 0) {
                     if (lane == 0) rel_dma4<REL_SC1>(P.err, hprog);
@@ -406,23 +446,23 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 }
             }
             if (P.tl && w0) tl_wait += wall_clock64() - w0;
-            if (mine) {
-                v.x &= 0x7fffffffu, v.y &= 0x7fffffffu, v.z &= 0x7fffffffu, v.w &= 0x7fffffffu;
-                if (lane == HOFF / 4) v.y -= (unsigned)REL_BIAS;  // the piece (minimum, base + bias, padding, padding)
-                rel_lds_write128_opaque(ent + lane * 4, v);
-            }
+#pragma unroll
+            for (int n = 0; n < HI; n++)
+                if (lane + 64 * n < NPIECE) {
+                    v[n].x &= 0x7fffffffu, v[n].y &= 0x7fffffffu, v[n].z &= 0x7fffffffu, v[n].w &= 0x7fffffffu;
+                    if (lane + 64 * n == HOFF / 4) v[n].y -= (unsigned)REL_BIAS;  // the piece (minimum, base + bias, padding, padding)
+                    rel_lds_write128_opaque(ent + (lane + 64 * n) * 4, v[n]);
+                }
         };
         const int LD = P.ld;  // steps of DMA in flight (2 .. 5: the rings have SD = 8 slots, three of them being read)
         auto retire = [&]() {  // all but the newest LD - 1 steps of DMA have landed
-            const int n = (weighted ? 4 : 3) * (LD - 1);
+            const int n = (CI + 1 + HI + (weighted ? 1 : 0)) * (LD - 1);  // (3 .. 8 instructions per step, 1 .. 4 steps)
             switch (n) {
-            case 3: rel_wait_vmcnt<3>(); break;
-            case 4: rel_wait_vmcnt<4>(); break;
-            case 6: rel_wait_vmcnt<6>(); break;
-            case 8: rel_wait_vmcnt<8>(); break;
-            case 9: rel_wait_vmcnt<9>(); break;
-            case 12: rel_wait_vmcnt<12>(); break;
-            default: rel_wait_vmcnt<16>(); break;
+#define MGM_REL_W(k) case k: rel_wait_vmcnt<k>(); break;
+                MGM_REL_W(3) MGM_REL_W(4) MGM_REL_W(5) MGM_REL_W(6) MGM_REL_W(7) MGM_REL_W(8) MGM_REL_W(9) MGM_REL_W(10) MGM_REL_W(12) MGM_REL_W(14)
+                MGM_REL_W(15) MGM_REL_W(16) MGM_REL_W(18) MGM_REL_W(20) MGM_REL_W(21) MGM_REL_W(24) MGM_REL_W(28) MGM_REL_W(32)
+#undef MGM_REL_W
+            default: rel_wait_vmcnt<0>(); break;  // (a count not listed: wait for everything -- correct, only slower)
             }
         };
 #pragma unroll 1
@@ -464,7 +504,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     }
 
     // ============================= compute waves =============================
-    const int grp = lane >> 4, li = lane & 15;  // the lane's line within the wave; its 4 label slots are 4 li .. 4 li + 3
+    const int grp = lane >> 4, li = lane & 15;  // the lane's line within the wave; its label slots are SPL li .. SPL li + SPL - 1
     const int ln = GL * r + grp;                // line within the band = ring row
     const int j = band * RR + ln;
     const bool line_ok = j < NL;
@@ -496,18 +536,28 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             const int sl = s & (SD - 1);
             const int4 rec = *reinterpret_cast<const int4 *>(mring + (sl * RR + ln) * 4);
             const int bp = rec.x;
-            const unsigned cw = *reinterpret_cast<const unsigned *>(cring + (sl * RR + ln) * 64 + 4 * li);
-            const float Cv[4] = {c8_decode(cw & 255u), c8_decode((cw >> 8) & 255u), c8_decode((cw >> 16) & 255u), c8_decode(cw >> 24)};
+            float Cv[SPL];
+            {
+                constexpr int NWORD = SPL * CB / 4;  // the lane's cost codes as 32-bit words
+                unsigned cw[NWORD];
+#pragma unroll
+                for (int w = 0; w < NWORD; w++) cw[w] = reinterpret_cast<const unsigned *>(cring + (sl * RR + ln) * CBY + SPL * CB * li)[w];
+#pragma unroll
+                for (int q = 0; q < SPL; q++)
+                    Cv[q] = CB == 1 ? c8_decode((cw[q / 4] >> (8 * (q % 4))) & 255u) : c16_decode((cw[q / 2] >> (16 * (q % 2))) & 65535u);
+            }
             const bool interior = act && has_prev && i >= 1 && i <= LL - 2;  // mgm_core.cc:538-541
             const float4 w4 = *reinterpret_cast<const float4 *>(wring + (sl * RR + ln) * 4);
             const float D[4] = {w4.x, w4.y, w4.z, w4.w};
             const int rl = rec.y - bp, rh = rec.z - bp;  // the pixel's own range, in slots
             // the MGM neighbours the update reads, in the pass's order (form 0: the pixel before on this line, then the line
             // before at i, i - 1, i + 1; the other form: the same four the other way round) -- mgm_core.cc:520-575
-            float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float e[SPL];
+#pragma unroll
+            for (int q = 0; q < SPL; q++) e[q] = 0.0f;
             if constexpr (NK > 0) {
                 // the NK neighbours' slabs over this pixel's range, convolved side by side, summed in the pass's order
-                float Mk[NK][4], mk[NK], p1k[NK], p2k[NK];
+                float Mk[NK][SPL], mk[NK], p1k[NK], p2k[NK];
 #pragma unroll
                 for (int k = 0; k < NK; k++) {
                     const bool own = f0 ? k == 0 : k == 3;
@@ -518,25 +568,25 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                     const float hmin = hdr.x, hbase = hdr.y;  // (scalars first: __builtin_bit_cast of the vector ELEMENT hdr[1] read element 0)
                     mk[k] = interior ? hmin : 0.0f;
                     const int sh = bp - __builtin_bit_cast(int, hbase);
-                    const int idx0 = interior ? min(max(4 * li + sh, -4), 64) + GO : 0;
-                    float wv[4];  // (read first, unconditionally: a select per value, not an exec-masked LDS read per value)
+                    const int idx0 = interior ? min(max(SPL * li + sh, -SPL), SLOTS) + GO : 0;
+                    float wv[SPL];  // (read first, unconditionally: a select per value, not an exec-masked LDS read per value)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) wv[q] = src[idx0 + q];
+                    for (int q = 0; q < SPL; q++) wv[q] = src[idx0 + q];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int o = 4 * li + q;
+                    for (int q = 0; q < SPL; q++) {
+                        const int o = SPL * li + q;
                         Mk[k][q] = (o >= rl && o <= rh) ? wv[q] : f_inf();
                     }
                     p1k[k] = P1 * D[k];
                     p2k[k] = P2 * D[k];
                 }
                 unsigned sw = 0;
-                fh_minconv_multi<4, GL, NK>(Mk, mk, p1k, p2k, lane, sw);
+                fh_minconv_multi<SPL, GL, NK>(Mk, mk, p1k, p2k, lane, sw);
                 if constexpr (MGM_REL_PHASES != 0) nsweeps += sw;
 #pragma unroll
                 for (int k = 0; k < NK; k++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) e[q] = k == 0 ? Mk[k][q] - mk[k] : e[q] + (Mk[k][q] - mk[k]);
+                    for (int q = 0; q < SPL; q++) e[q] = k == 0 ? Mk[k][q] - mk[k] : e[q] + (Mk[k][q] - mk[k]);
             } else
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -547,21 +597,21 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                     const float *src = entry(own ? ln : prow, own ? i - 1 : i + di);
                     const float m = interior ? src[HOFF] : 0.0f;                                   // minimum (or FAR)
                     const int sh = bp - reinterpret_cast<const int *>(src)[HOFF + 1];              // base
-                    float w[NS][4];
+                    float w[NS][SPL];
                     if constexpr (GUARD) {
-                        // the four values at one index clamped into [first guard, last guard]: whatever lies outside the neighbour's
-                        // 64 slots reads a guard word (a pixel that takes no neighbours reads guard words only)
-                        const int idx0 = interior ? min(max(4 * li + sh, -4), 64) + GO : 0;
+                        // the lane's values at one index clamped into [first guard, last guard]: whatever lies outside the neighbour's
+                        // slots reads a guard word (a pixel that takes no neighbours reads guard words only)
+                        const int idx0 = interior ? min(max(SPL * li + sh, -SPL), SLOTS) + GO : 0;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) w[0][q] = src[idx0 + q];
+                        for (int q = 0; q < SPL; q++) w[0][q] = src[idx0 + q];
                     } else {
                         const float far = PUBE ? m : f_inf();
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int idx = 4 * li + q + sh;
-                            const bool in = interior && (unsigned)idx < 64u;
+                        for (int q = 0; q < SPL; q++) {
+                            const int idx = SPL * li + q + sh;
+                            const bool in = interior && (unsigned)idx < (unsigned)SLOTS;
 #pragma unroll
-                            for (int t = 0; t < NS; t++) w[t][q] = in ? src[t * 64 + (in ? idx : 0)] : far;
+                            for (int t = 0; t < NS; t++) w[t][q] = in ? src[t * SLOTS + (in ? idx : 0)] : far;
                         }
                     }
                     if constexpr (PUBE) {
@@ -569,58 +619,72 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                         // halves every term before it is added: e += (t1 - m1) / 2; e += (t2 - m2) / 2; L = C + e
                         const float hf = P.cost2 ? 0.5f : 1.0f;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) e[q] = k == 0 ? w[0][q] * hf : e[q] + w[0][q] * hf;
+                        for (int q = 0; q < SPL; q++) e[q] = k == 0 ? w[0][q] * hf : e[q] + w[0][q] * hf;
                     } else if constexpr (!FH) {  // update_costW (mgm_core.cc:95-144): e = 0; e += fmin3(L, N + P1 D, m + P2 D) - m
                         const float a = P1 * D[k], b = P2 * D[k];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) e[q] += fminf(fminf(w[0][q], w[NS - 1][q] + a), m + b) - m;
+                        for (int q = 0; q < SPL; q++) e[q] += fminf(fminf(w[0][q], w[NS - 1][q] + a), m + b) - m;
                     } else {  // update_costW_trunclinear (229-281): the neighbour's values over THIS pixel's range, convolved there
-                        float M[4];
+                        float M[SPL];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int o = 4 * li + q;
+                        for (int q = 0; q < SPL; q++) {
+                            const int o = SPL * li + q;
                             M[q] = (o >= rl && o <= rh) ? w[0][q] : f_inf();
                         }
                         unsigned sw = 0;
-                        fh_minconv<4, false, GL>(M, m, P1 * D[k], P2 * D[k], lane, 64, sw);
+                        fh_minconv<SPL, false, GL>(M, m, P1 * D[k], P2 * D[k], lane, SLOTS, sw);
                         if constexpr (MGM_REL_PHASES != 0) nsweeps += sw;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) e[q] = k == 0 ? M[q] - m : e[q] + (M[q] - m);
+                        for (int q = 0; q < SPL; q++) e[q] = k == 0 ? M[q] - m : e[q] + (M[q] - m);
                     }
                 }
             }
-            float Lv[4];
+            float Lv[SPL];
 #pragma unroll
-            for (int q = 0; q < 4; q++)  // (NK: the divisor folds at compile time; update_cost2 has divided already)
+            for (int q = 0; q < SPL; q++)  // (NK: the divisor folds at compile time; update_cost2 has divided already)
                 Lv[q] = interior ? Cv[q] + ((PUBE && P.cost2) ? e[q] : div_small_rt(e[q], NK > 0 ? NK : MGM)) : Cv[q];
             if constexpr (MGM_REL_PHASES != 0) {
                 asm volatile("" : "+v"(Lv[0]), "+v"(Lv[1]), "+v"(Lv[2]), "+v"(Lv[3]));
                 c1 = clock64();
             }
-            if (act) *reinterpret_cast<relf4 *>(Lrb + pix * 64 + 4 * li) = relf4{Lv[0], Lv[1], Lv[2], Lv[3]};
+            if (act)
+#pragma unroll
+                for (int h = 0; h < SPL / 4; h++)
+                    reinterpret_cast<relf4 *>(Lrb + pix * SLOTS + SPL * li)[h] = relf4{Lv[4 * h], Lv[4 * h + 1], Lv[4 * h + 2], Lv[4 * h + 3]};
 
             // what this pixel publishes: its raw slab (Hirschmueller: and the neighbour minima), minimum, base -- or (PUBE) E and FAR
-            const float m = rel_row_min(fminf(fminf(Lv[0], Lv[1]), fminf(Lv[2], Lv[3])));
-            float N[4] = {f_inf(), f_inf(), f_inf(), f_inf()};
-            if constexpr (!FH) neighbour_min<4>(Lv, N, li == 0, li == 15);
-            relf4 pub = {Lv[0], Lv[1], Lv[2], Lv[3]};
+            float lmin = Lv[0];
+#pragma unroll
+            for (int q = 1; q < SPL; q++) lmin = fminf(lmin, Lv[q]);
+            const float m = rel_row_min(lmin);
+            float N[SPL];
+#pragma unroll
+            for (int q = 0; q < SPL; q++) N[q] = f_inf();
+            if constexpr (!FH) neighbour_min<SPL>(Lv, N, li == 0, li == 15);
+            float pubv[SPL];
+#pragma unroll
+            for (int q = 0; q < SPL; q++) pubv[q] = Lv[q];
             float pubm = m;
             if constexpr (PUBE) {
                 const float cap = m + P2;
 #pragma unroll
-                for (int q = 0; q < 4; q++) pub[q] = fminf(fminf(Lv[q], N[q] + P1), cap) - m;
+                for (int q = 0; q < SPL; q++) pubv[q] = fminf(fminf(Lv[q], N[q] + P1), cap) - m;
                 pubm = cap - m;
             }
-            const relf4 pubN = {N[0], N[1], N[2], N[3]};
             const float farv = PUBE ? pubm : f_inf();  // what a disparity this pixel does not have reads as
             const relf4 far4 = {farv, farv, farv, farv};
             const relf4 hdr4 = {pubm, __builtin_bit_cast(float, bp), 0.0f, 0.0f};
+            constexpr int GP = SPL / 4;  // 16-byte pieces of a guard (a lane's worth of words) and of a lane's values
             if (act) {
                 float *ent = ring + (ln * RD4 + (i & (RD4 - 1))) * HS;
-                *reinterpret_cast<relf4 *>(ent + GO + 4 * li) = pub;
-                if constexpr (NS == 2) *reinterpret_cast<relf4 *>(ent + 64 + 4 * li) = pubN;
-                if constexpr (GUARD) {
-                    if (li < 3) *reinterpret_cast<relf4 *>(ent + (li == 0 ? 0 : (li == 1 ? GO + 64 : HOFF))) = li == 2 ? hdr4 : far4;
+#pragma unroll
+                for (int h = 0; h < GP; h++) {
+                    reinterpret_cast<relf4 *>(ent + GO + SPL * li)[h] = relf4{pubv[4 * h], pubv[4 * h + 1], pubv[4 * h + 2], pubv[4 * h + 3]};
+                    if constexpr (NS == 2) reinterpret_cast<relf4 *>(ent + SLOTS + SPL * li)[h] = relf4{N[4 * h], N[4 * h + 1], N[4 * h + 2], N[4 * h + 3]};
+                }
+                if constexpr (GUARD) {  // lanes 0 .. GP-1: the guard before the values, GP .. 2 GP - 1: the one after, 2 GP: the header
+                    if (li < 2 * GP + 1)
+                        *reinterpret_cast<relf4 *>(ent + (li < GP ? 4 * li : (li < 2 * GP ? GO + SLOTS + 4 * (li - GP) : HOFF))) = li == 2 * GP ? hdr4 : far4;
                 } else {
                     if (li == 0) *reinterpret_cast<relf2 *>(ent + HOFF) = relf2{pubm, __builtin_bit_cast(float, bp)};
                 }
@@ -636,11 +700,15 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                             u.x |= tag, u.y |= tag, u.z |= tag, u.w |= tag;
                             return __builtin_bit_cast(relf4, u);
                         };
-                        rel_st_sc1_x4(dstg + GO + 4 * li, tagged(pub));
-                        if constexpr (NS == 2) rel_st_sc1_x4(dstg + 64 + 4 * li, tagged(pubN));
+#pragma unroll
+                        for (int h = 0; h < GP; h++) {
+                            rel_st_sc1_x4(dstg + GO + SPL * li + 4 * h, tagged(relf4{pubv[4 * h], pubv[4 * h + 1], pubv[4 * h + 2], pubv[4 * h + 3]}));
+                            if constexpr (NS == 2) rel_st_sc1_x4(dstg + SLOTS + SPL * li + 4 * h, tagged(relf4{N[4 * h], N[4 * h + 1], N[4 * h + 2], N[4 * h + 3]}));
+                        }
                         const relf4 hd = {pubm, __builtin_bit_cast(float, bp + REL_BIAS), 0.0f, 0.0f};
                         if constexpr (GUARD) {
-                            if (li < 3) rel_st_sc1_x4(dstg + (li == 0 ? 0 : (li == 1 ? GO + 64 : HOFF)), tagged(li == 2 ? hd : far4));
+                            if (li < 2 * GP + 1)
+                                rel_st_sc1_x4(dstg + (li < GP ? 4 * li : (li < 2 * GP ? GO + SLOTS + 4 * (li - GP) : HOFF)), tagged(li == 2 * GP ? hd : far4));
                         } else {
                             if (li == 0) rel_st_sc1_x4(dstg + HOFF, tagged(hd));
                         }
@@ -664,40 +732,52 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         }
 }
 
-template <bool FH, bool PUBE, int NK = 0>
+template <bool FH, bool PUBE, int NK, int SPL, int CB>
 static hipError_t launch_rel_one(const RelParams &p, int ntasks, int wg_per_cu, hipStream_t s)
 {
     constexpr int NS = (FH || PUBE) ? 1 : 2;
-    constexpr int HS = NS == 1 ? 76 : NS * 64 + 4;
-    size_t shmem = sizeof(float) * ((size_t)RR * RD4 * HS + (size_t)SD * HS + 2 * SD * RR * 4) + SD * RR * 64 + sizeof(unsigned) * (SD + 4) + 16;
+    constexpr int SLOTS = 16 * SPL;
+    constexpr int HS = (NS == 1 ? SLOTS + 2 * SPL : NS * SLOTS) + 4;
+    size_t shmem = sizeof(float) * ((size_t)RR * RD4 * HS + (size_t)SD * HS + 2 * SD * RR * 4) + (size_t)SD * RR * SLOTS * CB + sizeof(unsigned) * (SD + 4) + 16;
     // Occupancy through the LDS request, as for the second build: wg_per_cu workgroups (of 4 compute waves: one per SIMD) share a
     // CU -- one for a launch bound by its chains of bands, more for a batch (throughput)
     if (wg_per_cu >= 1) {
         const size_t want = (size_t)(160 * 1024) / (size_t)(wg_per_cu + 1) + 1024;  // more than a (wg_per_cu + 1)-th of the LDS
         if (shmem < want) shmem = want;
     }
-    auto kern = k_pass_rel<FH, PUBE, NK>;
+    auto kern = k_pass_rel<FH, PUBE, NK, SPL, CB>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(ntasks), dim3((NW + 1) * 64), shmem, s, p);
     return hipGetLastError();
 }
-// pube: unit weights with Hirschmueller potentials (the producer publishes E); wg_per_cu: workgroups per CU (0: what fits)
-hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, int wg_per_cu, hipStream_t s)
+template <int SPL, int CB>
+static hipError_t launch_rel_fmt(const RelParams &p, int ntasks, bool fh, bool pube, int wg_per_cu, hipStream_t s)
 {
     if (fh) {
-        if (!p.fh_multi) return launch_rel_one<true, false>(p, ntasks, wg_per_cu, s);
+        if constexpr (SPL == 4 && CB == 1)  // (the one-after-the-other build is kept for the form round 5 measured, as an A/B switch)
+            if (!p.fh_multi) return launch_rel_one<true, false, 0, SPL, CB>(p, ntasks, wg_per_cu, s);
         switch (p.MGM) {
-        case 1: return launch_rel_one<true, false, 1>(p, ntasks, wg_per_cu, s);
-        case 2: return launch_rel_one<true, false, 2>(p, ntasks, wg_per_cu, s);
-        case 3: return launch_rel_one<true, false, 3>(p, ntasks, wg_per_cu, s);
-        default: return launch_rel_one<true, false, 4>(p, ntasks, wg_per_cu, s);
+        case 1: return launch_rel_one<true, false, 1, SPL, CB>(p, ntasks, wg_per_cu, s);
+        case 2: return launch_rel_one<true, false, 2, SPL, CB>(p, ntasks, wg_per_cu, s);
+        case 3: return launch_rel_one<true, false, 3, SPL, CB>(p, ntasks, wg_per_cu, s);
+        default: return launch_rel_one<true, false, 4, SPL, CB>(p, ntasks, wg_per_cu, s);
         }
     }
-    return pube ? launch_rel_one<false, true>(p, ntasks, wg_per_cu, s) : launch_rel_one<false, false>(p, ntasks, wg_per_cu, s);
+    return pube ? launch_rel_one<false, true, 0, SPL, CB>(p, ntasks, wg_per_cu, s) : launch_rel_one<false, false, 0, SPL, CB>(p, ntasks, wg_per_cu, s);
+}
+// pube: unit weights with Hirschmueller potentials (the producer publishes E); wg_per_cu: workgroups per CU (0: what fits);
+// p.slots (64 / 128) and p.cb (1 / 2): the volumes' range-proportional format
+hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, int wg_per_cu, hipStream_t s)
+{
+    if (p.slots == 128) return p.cb == 2 ? launch_rel_fmt<8, 2>(p, ntasks, fh, pube, wg_per_cu, s) : launch_rel_fmt<8, 1>(p, ntasks, fh, pube, wg_per_cu, s);
+    return p.cb == 2 ? launch_rel_fmt<4, 2>(p, ntasks, fh, pube, wg_per_cu, s) : launch_rel_fmt<4, 1>(p, ntasks, fh, pube, wg_per_cu, s);
 }
 int pass_rel_lines() { return RR; }
 int pass_rel_phases() { return MGM_REL_PHASES ? 16 : 0; }
-int pass_rel_hand_floats(bool one_slab) { return one_slab ? 76 : 2 * 64 + 4; }  // (one slab: 4 + 64 + 4 guard-framed values + the header's 4)
+int pass_rel_hand_floats(bool one_slab, int slots)  // (one slab: a lane's worth of guard words + the values + another guard + the header's 4)
+{
+    return (one_slab ? slots + 2 * (slots / 16) : 2 * slots) + 4;
+}
 
 }  // namespace mgm

@@ -1032,18 +1032,60 @@ bool rel_enabled()
     return !(e && atoi(e) == 0) && tune_num("rel", 1) != 0;
 }
 
+int rel_alloc(mgm_ctx *c, mgm_cv *cv, int slots, int cb)
+{
+    const size_t npix = (size_t)cv->nx * cv->ny, need = npix * (size_t)slots * (size_t)cb + npix * 16 + 16;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (cv->rel_cap < need) {
+        if (cv->relbuf) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));  // (a kernel may still be reading the old copy)
+            (void)hipFree(cv->relbuf);
+        }
+        cv->relbuf = nullptr;
+        cv->rel_cap = 0;
+        if (dev_malloc((void **)&cv->relbuf, need) == hipSuccess) cv->rel_cap = need;
+        else (void)hipGetLastError();
+    }
+    cv->rel_slots = slots;
+    cv->rel_cb = cb;
+    return MGM_OK;
+}
+
 int rel_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *usable)
 {
     mgm_cv *cv = const_cast<mgm_cv *>(ccv);
     *usable = false;
     if (!cv->rlo || !cv->relbuf || cv->rel_state == 0 || cv->rel_state == -1) return MGM_OK;
     if (cv->rel_state == 1) {
-        const size_t npix = (size_t)cv->nx * cv->ny;
         HIPCHK(c, hipSetDevice(c->device));
         if (int r = ensure_words(c)) return r;
-        HIPCHK(c, hipMemcpyAsync(c->h_words + 3, cv->relbuf + npix * 64 + npix * 16, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        cv->rel_state = c->h_words[3] == 0u ? 2 : -1;
+        // the flag word of the gathered copy: bit 0 = a window wider than the format's slots - 2, bit 1 = a cost without the format's
+        // code.  (round 6) The copy is then gathered again one step wider -- 64 -> 128 slots, one -> two bytes per cost -- while the
+        // fp32 hull it is gathered from is current; what fits neither keeps the dense hull.
+        for (int round = 0; round < 3; round++) {
+            HIPCHK(c, hipMemcpyAsync(c->h_words + 3, cv->rel_flag(), 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const unsigned f = c->h_words[3];
+            if (f == 0u) {
+                cv->rel_state = 2;
+                break;
+            }
+            const int slots = (f & 1u) ? cv->rel_slots * 2 : cv->rel_slots, cb = (f & 2u) ? cv->rel_cb * 2 : cv->rel_cb;
+            if (slots > 128 || cb > 2 || !cv->f32_state || !cv->d || tune_num("rel_wide", 1) == 0) {
+                cv->rel_state = -1;
+                break;
+            }
+            if (int r = rel_alloc(c, cv, slots, cb)) return r;
+            if (!cv->relbuf) {
+                cv->rel_state = -1;
+                break;
+            }
+            HIPCHK(c, hipMemsetAsync(cv->rel_flag(), 0, 4, c->stream));
+            TimeScope t(c, "k_rel_gather");
+            HIPCHK(c, launch_rel_gather(cv->d, cv->rlo, cv->rhi, (long long)cv->nx * cv->ny, cv->dmax - cv->dmin + 1, cv->dmin, slots, cb, cv->relbuf,
+                                        cv->rel_records(), cv->rel_flag(), c->stream));
+        }
+        if (cv->rel_state == 1) cv->rel_state = -1;
     }
     *usable = cv->rel_state == 2;
     return MGM_OK;
@@ -1055,7 +1097,9 @@ int run_wta_rel(mgm_ctx *c, const mgm_cv *C, int slot, int NDIR, int fix_overcou
     const size_t npix = (size_t)C->nx * C->ny;
     WtaRelParams w{};
     w.c8 = C->relbuf;
-    w.base = reinterpret_cast<const int *>(C->relbuf + npix * 64);
+    w.base = C->rel_records();
+    w.slots = C->rel_slots;
+    w.cb = C->rel_cb;
     w.rlo = C->rlo;
     w.rhi = C->rhi;
     w.Lr = (const float *)c->lr_rel.p + (size_t)slot * NDIR * c->rel_last_stride;
@@ -1082,7 +1126,8 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     const long long npix = (long long)nx * ny;
     const bool fh = use_fh > 0;
     const bool pube = !fh && !(w8s && w8s[0]);  // unit weights, Hirschmueller: the producer publishes E (k_pass_rel, PUBE)
-    const int R = pass_rel_lines(), HS = pass_rel_hand_floats(fh || pube);
+    const int slots = C->rel_slots, rcb = C->rel_cb;  // (every volume of the launch has this format: aggregate_batch_now)
+    const int R = pass_rel_lines(), HS = pass_rel_hand_floats(fh || pube, slots);
     int r;
     HIPCHK(c, hipSetDevice(c->device));
     if (int r0 = check_watchdog(c, false)) return r0;
@@ -1104,7 +1149,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
         }
     }
     if (maxbands > kMaxBands) return fail(c, MGM_ERR_UNSUPPORTED, "image side exceeds 65536 pixels");
-    const long long stride = npix * 64 + lr_pad_floats();
+    const long long stride = npix * slots + lr_pad_floats();
     if ((r = reserve(c, c->lr_rel, sizeof(float) * (size_t)stride * NDIR * nb))) return r;
     // self-validating hand-off slots, one per (volume, pass, band, pixel): written once per launch with the launch's tag (see
     // k_pass_rel); another geometry clears the region (all-ones words) and starts again with tag 0
@@ -1120,7 +1165,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
         const void *before = c->hand_rel.p;
         if ((r = reserve(c, c->hand_rel, bytes))) return r;
         char hk[128];
-        snprintf(hk, sizeof hk, "%d %d %d %d %d %d", nx, ny, NDIR, nb, HS, R);
+        snprintf(hk, sizeof hk, "%d %d %d %d %d %d %d", nx, ny, NDIR, nb, HS, R, slots);
         if (c->hand_rel.p != before || c->hand_rel_key != hk) {
             HIPCHK(c, hipMemsetAsync(c->hand_rel.p, 0xff, bytes, c->stream));
             c->hand_rel_key = hk;
@@ -1163,9 +1208,8 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     }
     bool weighted = false;
     for (int v = 0; v < nb; v++) {
-        const size_t np = (size_t)npix;
         p.vol[v].c8 = Cs[v]->relbuf;
-        p.vol[v].base = reinterpret_cast<const int *>(Cs[v]->relbuf + np * 64);
+        p.vol[v].base = Cs[v]->rel_records();
         p.vol[v].rlo = Cs[v]->rlo;
         p.vol[v].rhi = Cs[v]->rhi;
         p.vol[v].Lr = (float *)c->lr_rel.p + (size_t)v * NDIR * stride;
@@ -1193,6 +1237,8 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     p.ld = (int)std::min(5LL, std::max(2LL, tune_num("rel_ld", nb <= 1 ? 2 : 3)));
     p.fh_multi = tune_num("rel_multi", 1) != 0 ? 1 : 0;
     p.cost2 = (pube && MGM == 2) ? 1 : 0;
+    p.slots = slots;
+    p.cb = rcb;
     p.tl = nullptr;
     // MGM_HIP_TIMELINE=<file>: one line per work item (tools/timeline.py) -- where the compute units' time goes
     const char *tl_file = getenv("MGM_HIP_TIMELINE");

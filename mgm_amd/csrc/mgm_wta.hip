@@ -567,8 +567,11 @@ __device__ __forceinline__ void cubicfit(const float (&p)[4], float &out_pmin, f
 // over-count term, the first strict minimum among the finite entries of the pixel's window scanned by rising disparity,
 // the refinement gate of mgm_refine.h:58 on the window -- with "a disparity the pixel does not own" = `vout` (what the
 // reference's S holds there: 0 - (NDIR-1)*INF, or 0 without the over-count fix) instead of a stored value.
+// SPL, CB (round 6): label slots per lane (4 / 8: 64 / 128 slots per pixel) and bytes per cost code (1 / 2), as in k_pass_rel.
+template <int SPL, int CB>
 __global__ void __launch_bounds__(256) k_wta_rel(const WtaRelParams P)
 {
+    constexpr int SLOTS = 16 * SPL;
     // FOUR pixels per wave: a pixel's 64 slots on a row of 16 lanes, 4 per lane (16-byte loads; the first version had one slot per
     // lane, one pixel per wave: 4-byte loads and six LDS-crossbar rounds per pixel, 1.5 ms per 1920x1080 volume where its 4.4 GB ask for 0.7)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, grp = lane >> 4;
@@ -586,24 +589,33 @@ __global__ void __launch_bounds__(256) k_wta_rel(const WtaRelParams P)
         const bool windowed = P.wlo != nullptr;
         const int wl = windowed ? (int)P.wlo[pix] : lo, wh = windowed ? (int)P.whi[pix] : hi;
         typedef float f4 __attribute__((ext_vector_type(4)));
-        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int p = 0; p < P.NDIR; p++) {
-            const f4 t = *reinterpret_cast<const f4 *>(P.Lr + (long long)p * P.nvol + pix * 64 + 4 * li);
+        float a[SPL];
 #pragma unroll
-            for (int q = 0; q < 4; q++) a[q] = a[q] + t[q];
+        for (int q = 0; q < SPL; q++) a[q] = 0.0f;
+        for (int p = 0; p < P.NDIR; p++) {
+#pragma unroll
+            for (int h = 0; h < SPL / 4; h++) {
+                const f4 t = reinterpret_cast<const f4 *>(P.Lr + (long long)p * P.nvol + pix * SLOTS + SPL * li)[h];
+#pragma unroll
+                for (int q = 0; q < 4; q++) a[4 * h + q] = a[4 * h + q] + t[q];
+            }
         }
         if (P.FIX == 1) {
-            const unsigned cw = *reinterpret_cast<const unsigned *>(P.c8 + pix * 64 + 4 * li);
+            constexpr int NWORD = SPL * CB / 4;
+            unsigned cw[NWORD];
 #pragma unroll
-            for (int q = 0; q < 4; q++) a[q] = a[q] - f * c8_decode((cw >> (8 * q)) & 255u);
+            for (int w = 0; w < NWORD; w++) cw[w] = reinterpret_cast<const unsigned *>(P.c8 + (pix * SLOTS + SPL * li) * CB)[w];
+#pragma unroll
+            for (int q = 0; q < SPL; q++)
+                a[q] = a[q] - f * (CB == 1 ? c8_decode((cw[q / 4] >> (8 * (q % 4))) & 255u) : c16_decode((cw[q / 2] >> (16 * (q % 2))) & 65535u));
         }
-        float val[4];
+        float val[SPL];
         // (2) its own disparities inside the window: the first strict minimum by rising disparity = the smallest (value, disparity)
         float cb = f_inf();
         int ci = 0x7fffffff;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int d = b + 4 * li + q;
+        for (int q = 0; q < SPL; q++) {
+            const int d = b + SPL * li + q;
             const bool own = d >= lo && d <= hi;
             val[q] = own ? a[q] : vout;
             if (own && d >= wl && d <= wh && finite_bits(val[q]) && val[q] < cb) {
@@ -648,10 +660,12 @@ __global__ void __launch_bounds__(256) k_wta_rel(const WtaRelParams P)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int sl = (bi == 0x7fffffff ? b : bi) - 1 + k - b;  // slot of that disparity (row-uniform)
-            const int e = sl & 3;
-            const float mine = e == 0 ? val[0] : (e == 1 ? val[1] : (e == 2 ? val[2] : val[3]));
-            const float x = __shfl(mine, (lane & 48) | ((sl >> 2) & 15));
-            v[k] = (sl >= 0 && sl < 64) ? x : vout;
+            const int e = sl & (SPL - 1);
+            float mine = val[0];
+#pragma unroll
+            for (int q = 1; q < SPL; q++) mine = e == q ? val[q] : mine;
+            const float x = __shfl(mine, (lane & 48) | ((sl / SPL) & 15));
+            v[k] = (sl >= 0 && sl < SLOTS) ? x : vout;
         }
         if (P.refine >= 1 && bi != 0x7fffffff && bi - 1 >= wl && bi + 2 <= wh) {  // mgm_refine.h:58 (S allocated over the window)
             float vmin = outc, dx = 0;
@@ -672,7 +686,14 @@ hipError_t launch_wta_rel(const WtaRelParams &p, hipStream_t s)
 {
     const long long groups = (p.npix + 15) / 16;  // four waves of four pixels per block
     const long long cap = (long long)p.num_cu * 64;
-    hipLaunchKernelGGL(k_wta_rel, dim3((unsigned)std::max(1ll, std::min(groups, cap))), dim3(256), 0, s, p);
+    const dim3 grid((unsigned)std::max(1ll, std::min(groups, cap)));
+    if (p.slots == 128) {
+        if (p.cb == 2) hipLaunchKernelGGL((k_wta_rel<8, 2>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_wta_rel<8, 1>), grid, dim3(256), 0, s, p);
+    } else {
+        if (p.cb == 2) hipLaunchKernelGGL((k_wta_rel<4, 2>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_wta_rel<4, 1>), grid, dim3(256), 0, s, p);
+    }
     return hipGetLastError();
 }
 

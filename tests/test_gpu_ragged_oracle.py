@@ -81,7 +81,20 @@ SMALL = [
     ("w62", 97, 45, -90, 10, ("exact", 62), 1, 3, 8, 2.0, 20000.0, None, "vfit", 1, True),
     ("w61", 97, 45, -90, 10, ("exact", 61), 0, 3, 8, 8.0, 32.0, None, "cubic", 1, True),
     ("w60_t4", 80, 37, -90, 10, ("exact", 60), 1, 4, 8, 1.5, 9.0, None, "parabola", 0, True),
-    ("w63_past_the_limit", 97, 45, -90, 10, ("exact", 63), 1, 3, 8, 2.0, 20000.0, None, "vfit", 1, False),
+    # round 6: 128 slots per pixel take windows of up to 126 labels; two-byte cost codes take colour AD and SD
+    ("w63_in_128_slots", 97, 45, -90, 10, ("exact", 63), 1, 3, 8, 2.0, 20000.0, None, "vfit", 1, True),
+    ("w100_hirsch_t4", 80, 37, -160, 10, ("exact", 100), 0, 4, 8, 8.0, 32.0, None, "cubic", 1, True),
+    ("w125_fh", 70, 35, -200, 10, ("exact", 125), 1, 3, 8, 2.0, 30.0, None, "parabola", 0, True),
+    ("w126_fh_weights", 66, 35, -200, 10, ("exact", 126), 1, 3, 8, 2.0, 20000.0, "image", "vfit", 1, True),
+    ("w126_hirsch_three_weights", 66, 35, -200, 10, ("exact", 126), 0, 3, 4, 8.0, 32.0, "three", None, 1, True),
+    ("w126_t2_hirsch", 66, 35, -200, 10, ("exact", 126), 0, 2, 8, 8.0, 32.0, None, "vfit", 1, True),
+    ("w127_past_the_limit", 66, 35, -200, 10, ("exact", 127), 1, 3, 8, 2.0, 20000.0, None, "vfit", 1, False),
+    ("wide_jumps_fh", 71, 52, -300, 20, ("jumpy", 90), 1, 3, 8, 2.0, 20000.0, None, "vfit", 1, True),
+    ("ad_colour_two_bytes_fh", 90, 40, -60, 0, ("win", 12, 14, 3), 1, 3, 8, 6.0, 60.0, None, "vfit", 1, True, "ad", 3),
+    ("ad_colour_two_bytes_hirsch_weights", 90, 40, -60, 0, ("win", 12, 14, 3), 0, 4, 8, 24.0, 96.0, "image", "cubic", 1, True, "ad", 3),
+    ("ad_colour_t2_wide", 70, 36, -150, 0, ("exact", 101), 0, 2, 4, 24.0, 96.0, None, None, 1, True, "ad", 3),
+    ("sd_grey_two_bytes_wide_fh", 70, 36, -150, 0, ("exact", 90), 1, 3, 8, 40.0, 4000.0, None, "vfit", 0, True, "sd", 1),
+    ("ad_grey_one_byte", 90, 40, -60, 0, ("win", 12, 14, 3), 1, 3, 8, 2.0, 30.0, None, "vfit", 1, True, "ad", 1),
     ("h17", 64, 17, -60, 0, ("win", 20, 22, 3), 1, 3, 8, 2.0, 20000.0, None, "vfit", 1, True),
     ("h33_w3", 50, 33, -60, 0, ("win", 20, 22, 3), 0, 3, 8, 8.0, 32.0, "three", "parabolaOCV", 1, True),
     ("h47_image_weights", 120, 47, -60, 0, ("win", 12, 17, 2), 1, 4, 8, 2.0, 40.0, "image", "vfit", 1, True),
@@ -100,8 +113,9 @@ SMALL = [
 
 @pytest.mark.parametrize("case", SMALL, ids=lambda c: c[0])
 def test_ragged_small_vs_oracle(oracle, case):
-    name, nx, ny, dmin, dmax, rk, FH, MGM, NDIR, P1, P2, wkind, refine, fix, expect_rel = case
-    u, v, gt = synth.stereo_pair(nx, ny, dmin * 3 // 4, min(0, dmax), seed=101 + nx + ny)
+    name, nx, ny, dmin, dmax, rk, FH, MGM, NDIR, P1, P2, wkind, refine, fix, expect_rel = case[:15]
+    cost, nch = (case[15], case[16]) if len(case) > 15 else ("census", 1)
+    u, v, gt = synth.stereo_pair(nx, ny, dmin * 3 // 4, min(0, dmax), seed=101 + nx + ny, nch=nch)
     if rk[0] == "exact":
         dminI, dmaxI = exact_width_ranges(gt, dmin, dmax, rk[1], 7 + ny)
     elif rk[0] == "win":
@@ -112,11 +126,11 @@ def test_ragged_small_vs_oracle(oracle, case):
     hmin, hmax = int(lo.min()), int(hi.max())
     L = hmax - hmin + 1
     own = own_mask(lo, hi, hmin, L)
-    Ca = oracle.costvolume_ranged(u, v, lo, hi, hmin, hmax, "none", "census", np.inf, 5)
+    Ca = oracle.costvolume_ranged(u, v, lo, hi, hmin, hmax, "none", cost, np.inf, 5)
     oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
     with mgm_amd.Context(0) as ctx:
         os.environ["MGM_HIP_REL"] = "2"
-        cv = ctx.costvolume(u, v, dminI, dmaxI, "none", "census", float("inf"), 5)
+        cv = ctx.costvolume(u, v, dminI, dmaxI, "none", cost, float("inf"), 5)
         os.environ.pop("MGM_HIP_REL")
         assert cv.dims == (nx, ny, hmin, hmax)
         w8 = w8h = None
@@ -126,6 +140,7 @@ def test_ragged_small_vs_oracle(oracle, case):
         elif wkind == "image":
             w8 = ctx.weights_dev(ctx.upload_image(u), 4.0, 12.0)
             w8h = w8.download()
+            assert ndiff(w8h, oracle.weights(u, 4.0, 12.0)) == 0
         elif wkind == "ones":
             w8h = np.ones((8, ny, nx), np.float32)
             w8 = ctx.upload_image(w8h)

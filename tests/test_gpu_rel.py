@@ -87,8 +87,10 @@ def test_rel_is_not_taken_where_it_does_not_apply():
     u, v, gt = synth.stereo_pair(nx, ny, -60, 0, seed=3)
     os.environ.pop("MGM_HIP_REL", None)
     with mgm_amd.Context(0) as ctx:
-        # windows wider than 62 labels -> the dense hull
-        lo, hi = ranges(gt, dmin, dmax, 40, 9)
+        # windows wider than 126 labels -> the dense hull (round 6: up to 126 labels fit the 128-slot form)
+        lo = np.full(gt.shape, -200.0, np.float32)
+        hi = np.full(gt.shape, -65.0, np.float32)  # 136 labels per pixel ...
+        hi[3, 5] = -80.0                           # ... and one pixel with another range: a ragged volume
         cv = ctx.costvolume(u, v, lo, hi, "none", "census", float("inf"), 5)
         ctx.timing(True)
         ctx.aggregate_dev(cv, 8.0, 32.0, 8, 3, 0, 1, None, "vfit")
@@ -170,6 +172,6 @@ def test_rel_random_cases_match_dense_hull(seed):
         os.environ.pop("MGM_HIP_REL", None)
     what = (seed, nx, ny, dmin, dmax, half, FH, MGM, NDIR, P1, P2, wkind, refine, fix, win, trunc)
     is_ragged = bool((lo != lo.flat[0]).any() or (hi != hi.flat[0]).any())  # (windows that cover a small hull everywhere: a uniform volume)
-    fits = int((hi - lo).max()) + 1 <= 62
+    fits = int((hi - lo).max()) + 1 <= 126
     assert ("k_pass_rel" in res["2"][2]) == (is_ragged and fits) and "k_pass_rel" not in res["0"][2], what
     assert ndiff(res["2"][0], res["0"][0]) == 0 and ndiff(res["2"][1], res["0"][1]) == 0, what
