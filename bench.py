@@ -99,6 +99,12 @@ WORKLOADS = {
                   desc="cfg3 with range images: per-pixel windows of +-24 labels inside the 256-label hull (-m/-M; 49 of 256 labels exist per pixel)"),
     "cfg3hr": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=0, P1=8.0, P2=32.0, ragged=24,
                    desc="cfg3h with range images: per-pixel windows of +-24 labels inside the 256-label hull"),
+    # round 6: what the widened range-proportional layout takes -- windows of 101 labels (128 slots per pixel), and BASELINE config 1's
+    # cost (absolute differences of a colour pair: two-byte codes) and update function (TSGM = 2: update_cost2) with range images
+    "cfg3r50": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, ragged=50,
+                    desc="cfg3 with range images: per-pixel windows of +-50 labels (101 of 256 labels exist per pixel; 128 slots per pixel)"),
+    "cfg1sr": dict(nx=700, ny=500, dmin=-120, dmax=30, win=3, NDIR=4, MGM=2, FH=0, P1=24.0, P2=96.0, cost="ad", nch=3, ragged=20,
+                   desc="BASELINE config 1's shape and cost with range images: 700x500 RGB, -t ad, -O 4 TSGM=2, windows of +-20 labels inside -120..30"),
     "cfg3i2": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, iter=2,
                    desc="cfg3 with TSGM_ITER=2: a second winner search in ranges narrowed around the first solution (mgm.cc:377-388)"),
     "cfg3w3": dict(nx=1920, ny=1080, dmin=-255, dmax=0, win=5, NDIR=8, MGM=3, FH=1, P1=2.0, P2=20000.0, w8="three",
@@ -682,10 +688,11 @@ def roofline_of(w, B, avg, workload, step_ms=None, per_step=None):
     fmt = {pass_name: (cbytes + 4.0) * w["NDIR"] * cells * B,          # reads C once per direction, writes one Lr volume per direction
            "k_wta": (4.0 * w["NDIR"] + cbytes) * cells + 8.0 * nx * ny,  # reads NDIR Lr volumes + C, writes two W*H maps
            "k_cost": cbytes * cells}                                     # writes C (the images are negligible)
-    if rel:  # 64 one-byte cost slots and 64 fp32 Lr slots per pixel and direction, plus the 16-byte window record
-        slots = 64.0 * nx * ny
-        fmt = {pass_name: (1.0 + 4.0) * w["NDIR"] * slots * B + 16.0 * nx * ny * w["NDIR"] * B,
-               "k_wta": (4.0 * w["NDIR"] + 1.0) * slots + 24.0 * nx * ny, "k_cost": cbytes * hull_cells}
+    if rel:  # 64 / 128 cost slots of one / two bytes and as many fp32 Lr slots per pixel and direction, plus the 16-byte window record
+        slots = (64.0 if 2 * w["ragged"] + 1 <= 62 else 128.0) * nx * ny
+        rcb = 1.0 if (cost_of(w) == "census" or (cost_of(w) == "ad" and w.get("nch", 1) == 1)) else 2.0
+        fmt = {pass_name: (rcb + 4.0) * w["NDIR"] * slots * B + 16.0 * nx * ny * w["NDIR"] * B,
+               "k_wta": (4.0 * w["NDIR"] + rcb) * slots + 24.0 * nx * ny, "k_cost": cbytes * hull_cells}
     per_kernel = {k: {"format_bytes": b, "GBps": b / (avg[k] * 1e-3) / 1e9, "frac": b / (avg[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                   for k, b in fmt.items() if k in avg}
     # How to READ the fraction: `frac` prices SURVEY 8(d)'s 12 B per cell and direction against the 8 TB/s spec
@@ -739,7 +746,7 @@ def roofline_digest(res, vres, wname):
     ranked = sorted(((k, v) for k, v in vres.items() if isinstance(v, dict) and isinstance(v.get("roofline_frac"), float)
                      and "on the dense hull" not in k and "pipeline" not in k), key=lambda kv: kv[1]["roofline_frac"])
     rf["worst_variants"] = [{"variant": k, **pick(k)} for k, _ in ranked[:3]]
-    rf["ragged_variants"] = {k: pick(k) for k in ("cfg3r x1", "cfg3r x2", "cfg3r x4", "cfg3hr x1", "cfg3hr x4") if pick(k)}
+    rf["ragged_variants"] = {k: pick(k) for k in ("cfg3r x1", "cfg3r x2", "cfg3r x4", "cfg3hr x1", "cfg3hr x4", "cfg3r50 x1", "cfg1sr x2") if pick(k)}
 
 
 def replicas_leg(env, name, steps, warmup):
@@ -1225,6 +1232,7 @@ def main():
                                   # round 5: what had no number before -- range images (-m/-M) and TSGM_ITER, and the
                                   # fall-back kernels (free-form weights, 1536 labels, negative penalties, NaN costs)
                                   ("cfg3r", 1, 1), ("cfg3r", 2, 1), ("cfg3r", 4, 1), ("cfg3hr", 1, 1), ("cfg3hr", 4, 1),
+                                  ("cfg3r50", 1, 1), ("cfg1sr", 2, 1),
                                   # ... and the same ragged volumes on the dense HULL (MGM_HIP_REL=0: no range-proportional copy), the run
                                   # the range-proportional kernels are to be compared with (vd = -1 marks them)
                                   ("cfg3r", 1, -1), ("cfg3r", 4, -1), ("cfg3hr", 4, -1),

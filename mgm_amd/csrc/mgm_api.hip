@@ -244,7 +244,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     // k_cost_census_rel) -- neither the fp32 hull nor its compact twin is written; whoever wants the hull gets it from
     // ensure_f32.  The flag word (a window wider than 62 labels) is read back at once: such a volume takes the general path.
     if (rel_direct_candidate && p.rlo && census_fits) {
-        for (int slots = 64; slots <= 128; slots *= 2) {  // (round 6: windows of up to 62 labels in 64 slots per pixel, else up to 126 in 128)
+        for (int slots = (*out)->rel_hint_slots == 128 ? 128 : 64; slots <= 128; slots *= 2) {  // (round 6: windows of up to 62 labels in 64 slots per pixel, else up to 126 in 128)
             if ((r = rel_alloc(c, *out, slots, 1))) return r;
             if (!(*out)->relbuf) break;
             unsigned *flag = (*out)->rel_flag();
@@ -258,6 +258,7 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
             HIPCHK(c, hipMemcpyAsync(c->h_words + 3, flag, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (c->h_words[3] == 0u) {
+                (*out)->rel_hint_slots = slots;
                 (*out)->rel_state = 2;
                 (*out)->rel_only = true;
                 (*out)->f32_state = 0;

@@ -71,6 +71,7 @@ struct mgm_cv {
     size_t rel_cap = 0;
     int rel_state = 0;
     int rel_slots = 64, rel_cb = 1;
+    int rel_hint_slots = 64;  // the width the last direct filling of this volume needed: a refill starts there (a failed attempt costs ~2.5 ms of flag traffic)
     size_t rel_cost_bytes() const { return (size_t)nx * ny * (size_t)rel_slots * (size_t)rel_cb; }
     int *rel_records() const { return reinterpret_cast<int *>(relbuf + rel_cost_bytes()); }
     unsigned *rel_flag() const { return reinterpret_cast<unsigned *>(relbuf + rel_cost_bytes() + (size_t)nx * ny * 16); }
