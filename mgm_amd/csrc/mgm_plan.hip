@@ -1182,7 +1182,9 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     char key[96];
     // workgroups (4 compute waves + the loader) per CU: tune rel_wg forces it
     const long long wgs = tune_num("rel_wg", 0);
-    const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 1 ? 2 : 3);  // (measured: x 1 / x 2 / x 4 of 1920x1080, both potentials)
+    // (measured, round 6, 1920x1080 windows of 49 labels, FH with the side-by-side convolutions: x 1 7.87 / 8.20 / 8.53 ms at 1 / 2 / 3 per CU,
+    // x 2 13.0 / 8.6 / 9.6, x 4 24.3 / 14.1 / 12.9; Hirschmueller the same order)
+    const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 1 ? (fh ? 1 : 2) : (nb <= 2 ? 2 : 3));
     snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d", nx, ny, NDIR, nb, rel_wg, p.g[0].slope, MGM, p.g[NDIR - 1].nstrips);
     if (c->tasks_rel_key != key) {
         std::vector<SimChain> ch;
