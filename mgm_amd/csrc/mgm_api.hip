@@ -521,7 +521,27 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
             if ((r = rel_resolve(c, C[v], &u))) return r;
             all = u && C[v]->rel_slots == C[0]->rel_slots && C[v]->rel_cb == C[0]->rel_cb;  // (one format per launch)
         }
-        if (all) return run_rel(c, C, rel_weighted ? w8 : nullptr, n, P1, P2, MGM, use_fh, NDIR, fix_overcount, ridx, out, outcost);
+        if (all) {
+            //  the range-proportional launch honours the workspace limit too, and a batch the device cannot hold is run
+            // in halves instead of failing: NDIR x npix x slots floats per volume (+ ~8 % of hand-off slots)
+            int chunk = n;
+            const double per_vol = 4.0 * ((double)npix * C[0]->rel_slots + (double)lr_pad_floats()) * NDIR * 1.08;
+            if (c->ws_limit)
+                while (chunk > 1 && per_vol * chunk > (double)c->ws_limit) chunk--;
+            for (int v0 = 0; v0 < n;) {
+                const int m = std::min(chunk, n - v0);
+                r = run_rel(c, C + v0, rel_weighted ? w8 + v0 : nullptr, m, P1, P2, MGM, use_fh, NDIR, fix_overcount, ridx, out + v0, outcost + v0);
+                if (r == MGM_ERR_NOMEM && m > 1) {
+                    chunk = std::max(1, m / 2);
+                    (void)hipGetLastError();
+                    c->err.clear();
+                    continue;
+                }
+                if (r) return r;
+                v0 += m;
+            }
+            return MGM_OK;
+        }
     }
     // The Lr volumes of a launch take NDIR x W x H x L floats per volume.  A batch that does not fit the caller's
     // workspace limit (mgm_ctx_set_workspace_limit), or the device (hipMalloc fails), is run as several launches over

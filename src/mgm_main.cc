@@ -18,6 +18,8 @@
 //     device stage, a writer thread behind it -- and the device objects of a pair (images, volumes, maps) are kept and
 //     refilled by the next pair of the same geometry instead of being freed and allocated again.  A failing job (bad
 //     option, unreadable file, device-side refusal) fails alone: every device-side error is an exception caught per job.
+//     A line whose input file is an earlier line's OUTPUT (a coarse-to-fine chain: -m/-M written by the line before) is
+//     decoded only once that output has been written: lines behave as if run one after the other.
 // MGM_HIP_STATS=1 prints the wall-time breakdown on stderr; MGM_HIP_KERNELS=1 the names of the kernels a job launched.
 //
 // WITH_MGM2=1 (mgm_naive_parallelism, mgm_core.cc:632-831): every pass on its own private Lr volume, all passes in
@@ -762,12 +764,24 @@ static int run_batch(const char *file)
     constexpr size_t AHEAD = 2;
     std::mutex mu;
     std::condition_variable cv;
-    size_t decoded = 0, on_device = 0, to_write = 0;  // jobs [0, decoded) are decoded; the device stage is at job on_device; [0, to_write) may be written
+    size_t decoded = 0, on_device = 0, to_write = 0, written = 0;  // jobs [0, decoded) are decoded; the device stage is at job on_device; [0, to_write) may be written; [0, written) are
+    //  a line may consume what an earlier line produces (coarse-to-fine: the -m/-M range images of line k written by line k - 1):
+    // the decoder then waits for the writer -- needs[k] = how many jobs must have been WRITTEN before job k's inputs are read
+    std::vector<size_t> needs(N, 0);
+    for (size_t k = 0; k < N; k++) {
+        const Job &j = *jobs[k];
+        for (size_t m = 0; m < k; m++) {
+            const Job &e = *jobs[m];
+            for (const std::string *in : {&j.f_u, &j.f_v, &j.min_file, &j.max_file})
+                for (const std::string *out : {&e.f_out, &e.f_cost, &e.f_back, &e.nolr_file})
+                    if (!in->empty() && *in == *out) needs[k] = m + 1;
+        }
+    }
     std::thread decoder([&] {
         for (size_t k = 0; k < N; k++) {
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return k < on_device + 1 + AHEAD; });
+                cv.wait(lk, [&] { return k < on_device + 1 + AHEAD && written >= needs[k]; });
             }
             decode_job(*jobs[k]);
             {
@@ -793,6 +807,11 @@ static int run_batch(const char *file)
             }
             // the job is done: its images go
             j.u = j.v = j.rlo = j.rhi = j.outoff = j.outcost = j.syn = j.nolr = HostImg();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                written = k + 1;
+            }
+            cv.notify_all();
         }
     });
     Session S;

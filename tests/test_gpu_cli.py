@@ -375,3 +375,36 @@ def test_resident_batch_mode_matches_reference_pair_by_pair(tmp_path):
     r = subprocess.run([OURS, "--batch", str(tmp_path / "list2.txt")], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 1 and "line 2 failed" in r.stderr
     assert ndiff(np.load(tmp_path / "ours_e_disp.npy"), np.load(tmp_path / "ref_e_disp.npy")) == 0
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference CLI (oracle/_ref/mgm) was not built")
+def test_resident_batch_lines_may_consume_earlier_outputs(tmp_path):
+    """in `mgm --batch` the decoder works ahead of the device stage -- a line whose -m/-M files are an EARLIER line's
+    outputs (a coarse-to-fine chain) must see them complete: per line, the same files as the reference binary run line by line."""
+    u, v, _ = synth.stereo_pair(112, 72, -16, 8, seed=61)
+    np.save(tmp_path / "u.npy", u[0])
+    np.save(tmp_path / "v.npy", v[0])
+    env = dict(TSGM="3", CENSUS_NCC_WIN="5", TESTLRRL="0")
+    # line 1 writes a disparity map and a cost map; lines 2 and 3 use those two FILES as their range images (any float image
+    # will do for the purpose: main() repairs empty ranges and non-finite bounds, mgm.cc:342-353)
+    def lines_for(who):
+        d1, c1 = str(tmp_path / (who + "_d1.npy")), str(tmp_path / (who + "_c1.npy"))
+        base = [str(tmp_path / "u.npy"), str(tmp_path / "v.npy")]
+        return [["-r", "-16", "-R", "8", "-t", "census", "-O", "4"] + base + [d1, c1],
+                ["-r", "-16", "-R", "8", "-t", "census", "-O", "8", "-s", "vfit", "-m", d1, "-M", c1] + base + [str(tmp_path / (who + "_d2.npy"))],
+                ["-r", "-16", "-R", "8", "-t", "census", "-O", "4", "-P1", "2", "-P2", "30", "-m", d1, "-M", c1] + base + [str(tmp_path / (who + "_d3.npy"))]]
+    ref_stdout = ""
+    for a in lines_for("ref"):
+        r = subprocess.run([REF] + a, env=dict(os.environ, OMP_NUM_THREADS="4", **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        ref_stdout += r.stdout
+    (tmp_path / "chain.txt").write_text("\n".join(" ".join(a) for a in lines_for("ours")) + "\n")
+    for _ in range(3):  # (a race shows up some of the time: run it a few times)
+        r = subprocess.run([OURS, "--batch", str(tmp_path / "chain.txt")], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == ref_stdout
+        for k in ("d1", "c1", "d2", "d3"):
+            a, b = np.load(tmp_path / ("ref_%s.npy" % k)), np.load(tmp_path / ("ours_%s.npy" % k))
+            assert a.shape == b.shape and ndiff(a, b) == 0, k
+        for k in ("d1", "c1", "d2", "d3"):
+            os.remove(tmp_path / ("ours_%s.npy" % k))

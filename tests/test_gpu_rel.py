@@ -175,3 +175,34 @@ def test_rel_random_cases_match_dense_hull(seed):
     fits = int((hi - lo).max()) + 1 <= 126
     assert ("k_pass_rel" in res["2"][2]) == (is_ragged and fits) and "k_pass_rel" not in res["0"][2], what
     assert ndiff(res["2"][0], res["0"][0]) == 0 and ndiff(res["2"][1], res["0"][1]) == 0, what
+
+
+def test_rel_batch_honours_the_workspace_limit():
+    """a batch of ragged volumes whose range-proportional Lr volumes exceed mgm_ctx_set_workspace_limit runs as several
+    launches of k_pass_rel (as the dense path does) -- same maps as the unlimited launch."""
+    nx, ny, dmin, dmax = 120, 70, -60, 0
+    pairs = [synth.stereo_pair(nx, ny, -45, 0, seed=70 + k) for k in range(4)]
+    os.environ["MGM_HIP_REL"] = "1"
+    try:
+        with mgm_amd.Context(0) as ctx:
+            cvs = []
+            for k, (u, v, gt) in enumerate(pairs):
+                lo, hi = ranges(gt, dmin, dmax, 10, 30 + k)
+                lo[0, 0], hi[0, 1] = dmin, dmax  # (batched volumes share their hull)
+                cvs.append(ctx.costvolume(u, v, lo, hi, "none", "census", float("inf"), 5))
+            res = []
+            for limit in (0, int(1.3 * 4 * 8 * nx * ny * 64 * 1.08)):  # (room for one volume's eight Lr volumes, not for two)
+                ctx.set_workspace_limit(limit)
+                ctx.trim()
+                ctx.timing(True)
+                ctx.timing_reset()
+                _, outs, outcs = ctx.aggregate_batch_dev(cvs, 2.0, 30.0, 8, 3, 1, 1, None, "vfit")
+                names = [n for n, _ in ctx.timings()]
+                ctx.timing(False)
+                res.append(([o.download() for o in outs], [c.download() for c in outcs], names.count("k_pass_rel")))
+            ctx.set_workspace_limit(0)
+    finally:
+        os.environ.pop("MGM_HIP_REL", None)
+    assert res[0][2] == 1 and res[1][2] == 4, (res[0][2], res[1][2])
+    for k in range(4):
+        assert ndiff(res[0][0][k], res[1][0][k]) == 0 and ndiff(res[0][1][k], res[1][1][k]) == 0, k
