@@ -44,7 +44,10 @@ inline HostImg read(const std::string &path)
     std::string descr = field("'descr'");
     descr = descr.substr(descr.find('\'') + 1);
     descr = descr.substr(0, descr.find('\''));
-    if (field("'fortran_order'").find("True") < 8) { fclose(f); throw std::runtime_error(path + ": fortran order unsupported"); }
+    // fortran_order: True -- iio swaps the two image sides, reads, and transposes (iio.c:3209-3252): for a 2-D array exactly numpy's
+    // column-major layout (np.save of an F-contiguous array, e.g. a transposed view); with a third axis iio still treats it as
+    // the interleaved pixel dimension, and so does this reader (same bytes, same image)
+    const bool fortran = field("'fortran_order'").find("True") < 8;
     std::string sh = field("'shape'");
     sh = sh.substr(sh.find('(') + 1);
     sh = sh.substr(0, sh.find(')'));
@@ -56,6 +59,7 @@ inline HostImg read(const std::string &path)
         while (p < sh.size() && sh[p] != ',') p++;
     }
     if (dims.size() < 2 || dims.size() > 3) { fclose(f); throw std::runtime_error(path + ": expected (h,w) or (h,w,c)"); }
+    if (dims.size() == 3 && dims[0] == 1 && dims[1] > 1 && dims[2] > 1) dims = {dims[1], dims[2]};  // iio's "squeeze" (iio.c:3202-3207)
     HostImg im;
     im.ny = (int)dims[0];
     im.nx = (int)dims[1];
@@ -89,6 +93,12 @@ inline HostImg read(const std::string &path)
     // interleaved (h,w,c) -> planar, as iio_read_image_float_split does
     im.data.resize(n);
     const size_t np = (size_t)im.nx * im.ny;
+    if (fortran) {  // the file holds the transposed image: pixel (x, y) sits at (x * ny + y)
+        for (int y = 0; y < im.ny; y++)
+            for (int x = 0; x < im.nx; x++)
+                for (int c = 0; c < im.nch; c++) im.data[(size_t)y * im.nx + x + c * np] = inter[((size_t)x * im.ny + y) * im.nch + c];
+        return im;
+    }
     for (size_t p = 0; p < np; p++)
         for (int c = 0; c < im.nch; c++) im.data[p + c * np] = inter[p * im.nch + c];
     return im;

@@ -408,3 +408,32 @@ def test_resident_batch_lines_may_consume_earlier_outputs(tmp_path):
             assert a.shape == b.shape and ndiff(a, b) == 0, k
         for k in ("d1", "c1", "d2", "d3"):
             os.remove(tmp_path / ("ours_%s.npy" % k))
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference CLI (oracle/_ref/mgm) was not built")
+@pytest.mark.parametrize("half", [24, 50], ids=["windows_of_49", "windows_of_101"])
+def test_full_size_ragged_command_line_matches_reference(half, tmp_path):
+    """tools/ragged_cli.sh as a test: the whole command line on a 1920x1080 pair with -m/-M range images (per-pixel
+    windows inside a 256-label hull; FH, TSGM 3, 8 directions, vfit, median, left-right check) against the reference binary on
+    the same files -- and the left-to-right run must have taken the range-proportional kernels (64 / 128 slots per pixel)."""
+    u, v, gt = synth.stereo_pair(1920, 1080, -191, 0, seed=20150907)
+    np.save(tmp_path / "u.npy", u[0])
+    np.save(tmp_path / "v.npy", v[0])
+    np.save(tmp_path / "lo.npy", np.clip(gt - half, -255, 0).astype(np.float32))
+    np.save(tmp_path / "hi.npy", np.clip(gt + half, -255, 0).astype(np.float32))
+    args = "-r -255 -R 0 -t census -s vfit -O 8 -P1 2 -P2 20000 -m {t}/lo.npy -M {t}/hi.npy".format(t=tmp_path).split()
+    env = dict(CENSUS_NCC_WIN="5", TSGM="3", USE_TRUNCATED_LINEAR_POTENTIALS="1", MEDIAN="1", MGM_HIP_KERNELS="1")
+    outs = {}
+    for tag, exe in (("ref", REF), ("ours", OURS)):
+        d = tmp_path / tag
+        d.mkdir()
+        cmd = [exe] + args + [str(tmp_path / "u.npy"), str(tmp_path / "v.npy"), str(d / "disp.npy"), str(d / "cost.npy")]
+        r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS=str(min(32, len(os.sched_getaffinity(0)))), **env),
+                           capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        outs[tag] = (r.stdout, {f: np.load(d / f) for f in sorted(os.listdir(d))}, r.stderr)
+    assert outs["ref"][0] == outs["ours"][0], "stdout differs"
+    kernels = " ".join(ln for ln in outs["ours"][2].splitlines() if ln.startswith("[mgm kernels]")).split()
+    assert "k_pass_rel" in kernels, kernels
+    for f in ("disp.npy", "cost.npy"):
+        assert ndiff(outs["ref"][1][f], outs["ours"][1][f]) == 0, f

@@ -558,3 +558,33 @@ def test_tiffs_written_here_are_read_by_iio(tmp_path):
     _ref_run([tmp_path / "u.npy", tmp_path / "v.npy", tmp_path / "o2.npy"])
     r1, r2 = np.load(tmp_path / "o1.npy"), np.load(tmp_path / "o2.npy")
     assert np.isfinite(r1).any() and np.array_equal(r1.view(np.uint32), r2.view(np.uint32))
+
+
+def test_npy_fortran_order_and_squeeze(tmp_path):
+    """np.save of an F-contiguous array writes 'fortran_order': True (a transposed view, or what fancy indexing leaves behind): iio
+    reads it (iio.c:3209-3252: swap the sides, read, transpose), and so does src/npyio.h -- the image, not its transpose."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 255, size=(23, 31)).astype(np.float32)
+    f = np.asfortranarray(a)
+    assert f.flags.f_contiguous and not f.flags.c_contiguous
+    np.save(tmp_path / "f.npy", f)
+    assert b"'fortran_order': True" in open(tmp_path / "f.npy", "rb").read(200)
+    same(decode(tmp_path / "f.npy", tmp_path), a)
+    np.save(tmp_path / "s.npy", a[None])  # shape (1, 23, 31): iio squeezes the leading one away (iio.c:3202-3207)
+    same(decode(tmp_path / "s.npy", tmp_path), a)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_IMG), reason="oracle/_ref/mgm_img was not built (needs libpng/libtiff headers)")
+def test_npy_fortran_order_decodes_as_iio_decodes_it(tmp_path):
+    rng = np.random.default_rng(22)
+    for c in (None, 3):  # (with a third axis iio keeps treating it as the interleaved pixel dimension: same bytes, same image here)
+        u, v = _pair(rng, c=c)
+        np.save(tmp_path / "fu.npy", np.asfortranarray(u.astype(np.float32)))
+        np.save(tmp_path / "fv.npy", np.asfortranarray(v.astype(np.float32)))
+        np.save(tmp_path / "du.npy", decode(tmp_path / "fu.npy", tmp_path))
+        np.save(tmp_path / "dv.npy", decode(tmp_path / "fv.npy", tmp_path))
+        _ref_run([tmp_path / "fu.npy", tmp_path / "fv.npy", tmp_path / "o1.npy", tmp_path / "c1.npy"])
+        _ref_run([tmp_path / "du.npy", tmp_path / "dv.npy", tmp_path / "o2.npy", tmp_path / "c2.npy"])
+        for x in ("o", "c"):
+            r1, r2 = np.load(tmp_path / (x + "1.npy")), np.load(tmp_path / (x + "2.npy"))
+            assert r1.shape == r2.shape and np.array_equal(r1.view(np.uint32), r2.view(np.uint32)), (c, x)
