@@ -9,8 +9,8 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-PROFILED=${PROFILED:-"cfg3:12 cfg3:2 cfg3:1 cfg2:16 cfg2:2 cfg2:1 cfg1s:2 cfg4:1 cfg3w:12 cfg3r:1 cfg3r:4"}
-MATRIX=${MATRIX:-"cfg3h:12 cfg2:16 cfg5:16 cfg4:1 cfg4:2 cfg3:8 cfg3:4 cfg3:2 cfg3:1 cfg3h:2 cfg3h:1 cfg2:8 cfg2:4 cfg2:2 cfg2:1 cfg3w:12 cfg3w:1 cfg3hw:12 cfg3hw:1 cfg3ad:12 cfg3ad:1 cfg3ad1:12 cfg3ncc:12 cfg3ncc:1 cfg3bt:12 cfg3c7:12 cfg1s:16 cfg1s:2 cfg1s:1 cfg3L200:8 cfg3L200:1 cfg3L768:4 cfg3L768:1 cfg3r:1 cfg3r:4 cfg3hr:1 cfg3hr:4 cfg3i2:1 cfg3w3:1 cfg3w3:4 cfg3hw3:1 cfg3L1536:1 cfg3L2048:1 cfg3neg:1 cfg3nan:1 cfg3rinf:1"}
+PROFILED=${PROFILED:-"cfg3:12 cfg3:2 cfg3:1 cfg2:16 cfg2:2 cfg2:1 cfg1s:2 cfg4:1 cfg3w:12 cfg3r:1 cfg3r:2 cfg3r:4 cfg3hr:1 cfg3r50:1 cfg1sr:2"}
+MATRIX=${MATRIX:-"cfg3h:12 cfg2:16 cfg5:16 cfg4:1 cfg4:2 cfg3:8 cfg3:4 cfg3:2 cfg3:1 cfg3h:2 cfg3h:1 cfg2:8 cfg2:4 cfg2:2 cfg2:1 cfg3w:12 cfg3w:1 cfg3hw:12 cfg3hw:1 cfg3ad:12 cfg3ad:1 cfg3ad1:12 cfg3ncc:12 cfg3ncc:1 cfg3bt:12 cfg3c7:12 cfg1s:16 cfg1s:2 cfg1s:1 cfg3L200:8 cfg3L200:1 cfg3L768:4 cfg3L768:1 cfg3r:1 cfg3r:2 cfg3r:4 cfg3hr:1 cfg3hr:2 cfg3hr:4 cfg3r50:1 cfg3r50:4 cfg1sr:2 cfg1sr:4 cfg3i2:1 cfg3w3:1 cfg3w3:4 cfg3hw3:1 cfg3L1536:1 cfg3L2048:1 cfg3neg:1 cfg3nan:1 cfg3rinf:1"}
 # a stream of single pairs / small batches through a pipelined context (mgm_ctx_set_pipeline): workload:batch:depth
 PIPED=${PIPED:-"cfg3:1:2 cfg3:1:4 cfg3:1:12 cfg3h:1:4 cfg2:1:4 cfg2:1:8 cfg3:2:2"}
 : > "$OUT/bench_lines.jsonl"
