@@ -513,7 +513,7 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
         rel_sign_ok = !odd;
         if (MGM == 2 && !any) rel_weighted = false;  // planes of ones: the reference runs unweighted
     }
-    const bool rel_fn_ok = MGM != 2 || rel_weighted || use_fh <= 0;
+    const bool rel_fn_ok = MGM != 2 || rel_weighted || use_fh <= 0 || tune_num("rel_fh2", 1) != 0;  // (round 6, last: update_cost2_trunclinear is built too, k_pass_rel FH2)
     if (rel_candidate && rel_sign_ok && rel_fn_ok) {
         bool all = true;
         for (int v = 0; v < n && all; v++) {

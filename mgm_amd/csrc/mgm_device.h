@@ -127,6 +127,7 @@ struct RelParams {
     int MGM, NDIR, pass0, LLmax, maxbands, weighted;
     int ld;             // steps of LDS-DMA the loader keeps in flight (2..5; every step of lead is a step of lag per band)
     int slots, cb;      // the volumes' range-proportional format: 64 or 128 label slots per pixel, 1 or 2 bytes per cost (round 6)
+    int fh2;            // FH potentials, TSGM = 2, no weights: update_cost2_trunclinear with its boundary fix-up (k_pass_rel, FH2)
     int cost2;          // TSGM = 2 without weights, Hirschmueller: update_cost2's association (every term halved before the sum)
     int fh_multi;       // FH: the pixel's TSGM min-convolutions side by side (k_pass_rel<true, false, TSGM>) instead of one after the other
     float P1, P2;
@@ -141,7 +142,7 @@ hipError_t launch_rel_expand(const uint8_t *rel8, const int *relb, long long npi
 hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, int wg_per_cu, hipStream_t s);
 int pass_rel_lines();
 int pass_rel_phases();  // words per work item of phase clocks behind the timeline words (0: not a -DMGM_REL_PHASES=1 build)
-int pass_rel_hand_floats(bool one_slab, int slots);
+int pass_rel_hand_floats(bool one_slab, int slots, bool fh2);
 struct WtaRelParams {
     const uint8_t *c8;
     const int *base;

@@ -264,9 +264,18 @@ __device__ __forceinline__ float rel_row_min(float v)
 // started instead of 2 R + lag -- the chain of a 1920-column pass of 120 bands drops from 120 x 36 + 1110 to 120 x 20 + 1095.
 // SPL, CB (round 6): label slots per lane (4: 64 slots per pixel, windows of up to 62 labels; 8: 128 slots, up to 126) and bytes per
 // cost (1, or 2: colour AD / SD).  Everything below is written for SPL values per lane; the loader's DMA counts follow.
-template <bool FH, bool PUBE, int NK = 0, int SPL = 4, int CB = 1>
+// FH2 (round 6): update_cost2_trunclinear (mgm_core.cc:197-219) -- FH potentials with TSGM = 2 and NO weights, the one update function
+// with FixBounrady_for_minConvTruncatedLinear (166-186): before the receiving pixel convolves a neighbour's values over its own range
+// [pa, pb], what lies OUTSIDE that range in the neighbour's range [qa, qb] is folded into the two end labels -- T_left = the forward
+// recurrence over the neighbour's labels from qa up to pa, T_right = the backward one from qb down to pb, each continued as a plain
+// ramp where it leaves the neighbour's range.  Those recurrences run over labels the receiving pixel's 64 / 128 slots may not even
+// hold, so the PRODUCER computes them once, in its own frame -- F = the forward pass of its raw slab, B = the backward pass --
+// and publishes [L][F][B]; a reader picks F at pa (or at qb and ramps on), B at pb (or at qa), and min()s them into its two end
+// labels before the convolution.  Then e = (M1 - m1 + M2 - m2) / 2 in the reference's association.
+template <bool FH, bool PUBE, int NK = 0, int SPL = 4, int CB = 1, bool FH2 = false>
 __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
 {
+    static_assert(!FH2 || (FH && NK == 2), "update_cost2_trunclinear: FH, two neighbours, side by side");
     static_assert(!(FH && PUBE), "FH potentials convolve over the RECEIVING pixel's range: consumer side only");
     static_assert(NK == 0 || FH, "side-by-side convolutions: FH only");
     static_assert((SPL == 4 || SPL == 8) && (CB == 1 || CB == 2), "64 or 128 slots, one or two bytes per cost");
@@ -280,7 +289,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     // its four values at ONE clamped index, no comparison or selection per value (the 64 + 64 variant: [L][N][minimum, base, padding])
     constexpr bool GUARD = NS == 1;
     constexpr int GO = GUARD ? SPL : 0;                 // where the values start (a lane's worth of guard words before and after them)
-    constexpr int HOFF = GUARD ? SLOTS + 2 * SPL : NS * SLOTS;  // where the header (minimum, base) sits
+    constexpr int FOFF = SLOTS + 2 * SPL, BOFF = FOFF + SLOTS;  // FH2: the forward and backward passes of the raw slab, behind the guard-framed values
+    constexpr int HOFF = FH2 ? BOFF + SLOTS : (GUARD ? SLOTS + 2 * SPL : NS * SLOTS);  // where the header (minimum, base, highest slot) sits
     constexpr int HS = HOFF + 4;                        // floats per entry / hand-off slot
     constexpr int NPIECE = HS / 4;                      // its 16-byte pieces
     constexpr int HI = (NPIECE + 63) / 64;              // DMA instructions per hand-off slot (2 only for two slabs of 128)
@@ -564,8 +574,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                     const int di0 = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
                     const int di = mirror ? -di0 : di0;  // (mirrored strip: the fwd neighbour i + 1 is local i' - 1)
                     const float *src = entry(own ? ln : prow, own ? i - 1 : i + di);
-                    const relf2 hdr = *reinterpret_cast<const relf2 *>(src + HOFF);  // (minimum, base): one unconditional 8-byte read
-                    const float hmin = hdr.x, hbase = hdr.y;  // (scalars first: __builtin_bit_cast of the vector ELEMENT hdr[1] read element 0)
+                    const relf4 hdr = *reinterpret_cast<const relf4 *>(src + HOFF);  // (minimum, base, highest slot, -): one unconditional 16-byte read
+                    const float hmin = hdr.x, hbase = hdr.y, hhi = hdr.z;  // (scalars first: __builtin_bit_cast of the vector ELEMENT hdr[1] read element 0)
                     mk[k] = interior ? hmin : 0.0f;
                     const int sh = bp - __builtin_bit_cast(int, hbase);
                     const int idx0 = interior ? min(max(SPL * li + sh, -SPL), SLOTS) + GO : 0;
@@ -579,10 +589,34 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                     }
                     p1k[k] = P1 * D[k];
                     p2k[k] = P2 * D[k];
+                    if constexpr (FH2) {
+                        // FixBounrady_for_minConvTruncatedLinear (mgm_core.cc:166-186), slots of the NEIGHBOUR's frame: its range is
+                        // [1, qh], this pixel's range there [rl + sh, rh + sh]
+                        const int qh = interior ? __builtin_bit_cast(int, hhi) : 1;
+                        const int pa = rl + sh, pb = rh + sh;
+                        const bool hasL = interior && 1 < pa, hasR = interior && qh > pb;
+                        float TL = src[FOFF + (hasL ? min(pa, qh) : 1)];  // the forward pass at pa -- or at the neighbour's last label, a ramp from there
+                        float TR = src[BOFF + (hasR ? max(pb, 1) : 1)];   // the backward pass at pb -- or at its first label
+                        const int nL = hasL ? max(0, pa - qh) : 0, nR = hasR ? max(0, 1 - pb) : 0;
+                        for (int t = 0; __builtin_amdgcn_ballot_w64(t < nL || t < nR) != 0ull; t++) {  // T = min(T + P1, +INF), one label at a time
+                            TL = t < nL ? TL + p1k[k] : TL;
+                            TR = t < nR ? TR + p1k[k] : TR;
+                        }
+#pragma unroll
+                        for (int q = 0; q < SPL; q++) {
+                            const int o = SPL * li + q;
+                            if (hasL && o == rl) Mk[k][q] = fminf(Mk[k][q], TL);
+                            if (hasR && o == rh) Mk[k][q] = fminf(Mk[k][q], TR);
+                        }
+                    }
                 }
                 unsigned sw = 0;
                 fh_minconv_multi<SPL, GL, NK>(Mk, mk, p1k, p2k, lane, sw);
                 if constexpr (MGM_REL_PHASES != 0) nsweeps += sw;
+                if constexpr (FH2) {  // (M1[o] - min1 + M2[o] - min2) / 2, left to right (mgm_core.cc:216)
+#pragma unroll
+                    for (int q = 0; q < SPL; q++) e[q] = (((Mk[0][q] - mk[0]) + Mk[1][q]) - mk[1]) * 0.5f;
+                } else
 #pragma unroll
                 for (int k = 0; k < NK; k++)
 #pragma unroll
@@ -642,7 +676,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             float Lv[SPL];
 #pragma unroll
             for (int q = 0; q < SPL; q++)  // (NK: the divisor folds at compile time; update_cost2 has divided already)
-                Lv[q] = interior ? Cv[q] + ((PUBE && P.cost2) ? e[q] : div_small_rt(e[q], NK > 0 ? NK : MGM)) : Cv[q];
+                Lv[q] = interior ? Cv[q] + (((PUBE && P.cost2) || FH2) ? e[q] : div_small_rt(e[q], NK > 0 ? NK : MGM)) : Cv[q];
             if constexpr (MGM_REL_PHASES != 0) {
                 asm volatile("" : "+v"(Lv[0]), "+v"(Lv[1]), "+v"(Lv[2]), "+v"(Lv[3]));
                 c1 = clock64();
@@ -671,9 +705,17 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 for (int q = 0; q < SPL; q++) pubv[q] = fminf(fminf(Lv[q], N[q] + P1), cap) - m;
                 pubm = cap - m;
             }
+            float Fv[SPL], Bv[SPL];  // FH2: the forward and the backward pass of the raw slab in this pixel's own frame
+            if constexpr (FH2) {
+#pragma unroll
+                for (int q = 0; q < SPL; q++) Fv[q] = Bv[q] = Lv[q];
+                unsigned sw = 0;
+                fh_scan<SPL, true, GL>(Fv, P1, lane, sw);
+                fh_scan<SPL, false, GL>(Bv, P1, lane, sw);
+            }
             const float farv = PUBE ? pubm : f_inf();  // what a disparity this pixel does not have reads as
             const relf4 far4 = {farv, farv, farv, farv};
-            const relf4 hdr4 = {pubm, __builtin_bit_cast(float, bp), 0.0f, 0.0f};
+            const relf4 hdr4 = {pubm, __builtin_bit_cast(float, bp), __builtin_bit_cast(float, rh), 0.0f};  // (minimum, base, highest slot of the range)
             constexpr int GP = SPL / 4;  // 16-byte pieces of a guard (a lane's worth of words) and of a lane's values
             if (act) {
                 float *ent = ring + (ln * RD4 + (i & (RD4 - 1))) * HS;
@@ -681,6 +723,10 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 for (int h = 0; h < GP; h++) {
                     reinterpret_cast<relf4 *>(ent + GO + SPL * li)[h] = relf4{pubv[4 * h], pubv[4 * h + 1], pubv[4 * h + 2], pubv[4 * h + 3]};
                     if constexpr (NS == 2) reinterpret_cast<relf4 *>(ent + SLOTS + SPL * li)[h] = relf4{N[4 * h], N[4 * h + 1], N[4 * h + 2], N[4 * h + 3]};
+                    if constexpr (FH2) {
+                        reinterpret_cast<relf4 *>(ent + FOFF + SPL * li)[h] = relf4{Fv[4 * h], Fv[4 * h + 1], Fv[4 * h + 2], Fv[4 * h + 3]};
+                        reinterpret_cast<relf4 *>(ent + BOFF + SPL * li)[h] = relf4{Bv[4 * h], Bv[4 * h + 1], Bv[4 * h + 2], Bv[4 * h + 3]};
+                    }
                 }
                 if constexpr (GUARD) {  // lanes 0 .. GP-1: the guard before the values, GP .. 2 GP - 1: the one after, 2 GP: the header
                     if (li < 2 * GP + 1)
@@ -704,8 +750,12 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                         for (int h = 0; h < GP; h++) {
                             rel_st_sc1_x4(dstg + GO + SPL * li + 4 * h, tagged(relf4{pubv[4 * h], pubv[4 * h + 1], pubv[4 * h + 2], pubv[4 * h + 3]}));
                             if constexpr (NS == 2) rel_st_sc1_x4(dstg + SLOTS + SPL * li + 4 * h, tagged(relf4{N[4 * h], N[4 * h + 1], N[4 * h + 2], N[4 * h + 3]}));
+                            if constexpr (FH2) {
+                                rel_st_sc1_x4(dstg + FOFF + SPL * li + 4 * h, tagged(relf4{Fv[4 * h], Fv[4 * h + 1], Fv[4 * h + 2], Fv[4 * h + 3]}));
+                                rel_st_sc1_x4(dstg + BOFF + SPL * li + 4 * h, tagged(relf4{Bv[4 * h], Bv[4 * h + 1], Bv[4 * h + 2], Bv[4 * h + 3]}));
+                            }
                         }
-                        const relf4 hd = {pubm, __builtin_bit_cast(float, bp + REL_BIAS), 0.0f, 0.0f};
+                        const relf4 hd = {pubm, __builtin_bit_cast(float, bp + REL_BIAS), __builtin_bit_cast(float, rh), 0.0f};
                         if constexpr (GUARD) {
                             if (li < 2 * GP + 1)
                                 rel_st_sc1_x4(dstg + (li < GP ? 4 * li : (li < 2 * GP ? GO + SLOTS + 4 * (li - GP) : HOFF)), tagged(li == 2 * GP ? hd : far4));
@@ -732,12 +782,12 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         }
 }
 
-template <bool FH, bool PUBE, int NK, int SPL, int CB>
+template <bool FH, bool PUBE, int NK, int SPL, int CB, bool FH2 = false>
 static hipError_t launch_rel_one(const RelParams &p, int ntasks, int wg_per_cu, hipStream_t s)
 {
     constexpr int NS = (FH || PUBE) ? 1 : 2;
     constexpr int SLOTS = 16 * SPL;
-    constexpr int HS = (NS == 1 ? SLOTS + 2 * SPL : NS * SLOTS) + 4;
+    constexpr int HS = (FH2 ? 3 * SLOTS + 2 * SPL : (NS == 1 ? SLOTS + 2 * SPL : NS * SLOTS)) + 4;
     size_t shmem = sizeof(float) * ((size_t)RR * RD4 * HS + (size_t)SD * HS + 2 * SD * RR * 4) + (size_t)SD * RR * SLOTS * CB + sizeof(unsigned) * (SD + 4) + 16;
     // Occupancy through the LDS request, as for the second build: wg_per_cu workgroups (of 4 compute waves: one per SIMD) share a
     // CU -- one for a launch bound by its chains of bands, more for a batch (throughput)
@@ -745,7 +795,7 @@ static hipError_t launch_rel_one(const RelParams &p, int ntasks, int wg_per_cu, 
         const size_t want = (size_t)(160 * 1024) / (size_t)(wg_per_cu + 1) + 1024;  // more than a (wg_per_cu + 1)-th of the LDS
         if (shmem < want) shmem = want;
     }
-    auto kern = k_pass_rel<FH, PUBE, NK, SPL, CB>;
+    auto kern = k_pass_rel<FH, PUBE, NK, SPL, CB, FH2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(ntasks), dim3((NW + 1) * 64), shmem, s, p);
@@ -757,6 +807,7 @@ static hipError_t launch_rel_fmt(const RelParams &p, int ntasks, bool fh, bool p
     if (fh) {
         if constexpr (SPL == 4 && CB == 1)  // (the one-after-the-other build is kept for the form round 5 measured, as an A/B switch)
             if (!p.fh_multi) return launch_rel_one<true, false, 0, SPL, CB>(p, ntasks, wg_per_cu, s);
+        if (p.fh2) return launch_rel_one<true, false, 2, SPL, CB, true>(p, ntasks, wg_per_cu, s);  // update_cost2_trunclinear (TSGM = 2, no weights)
         switch (p.MGM) {
         case 1: return launch_rel_one<true, false, 1, SPL, CB>(p, ntasks, wg_per_cu, s);
         case 2: return launch_rel_one<true, false, 2, SPL, CB>(p, ntasks, wg_per_cu, s);
@@ -775,9 +826,7 @@ hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, i
 }
 int pass_rel_lines() { return RR; }
 int pass_rel_phases() { return MGM_REL_PHASES ? 16 : 0; }
-int pass_rel_hand_floats(bool one_slab, int slots)  // (one slab: a lane's worth of guard words + the values + another guard + the header's 4)
-{
-    return (one_slab ? slots + 2 * (slots / 16) : 2 * slots) + 4;
-}
+// (one slab: a lane's worth of guard words + the values + another guard + the header's 4; fh2: + the forward and backward passes)
+int pass_rel_hand_floats(bool one_slab, int slots, bool fh2) { return (fh2 ? 3 * slots + 2 * (slots / 16) : (one_slab ? slots + 2 * (slots / 16) : 2 * slots)) + 4; }
 
 }  // namespace mgm

@@ -1127,7 +1127,8 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     const bool fh = use_fh > 0;
     const bool pube = !fh && !(w8s && w8s[0]);  // unit weights, Hirschmueller: the producer publishes E (k_pass_rel, PUBE)
     const int slots = C->rel_slots, rcb = C->rel_cb;  // (every volume of the launch has this format: aggregate_batch_now)
-    const int R = pass_rel_lines(), HS = pass_rel_hand_floats(fh || pube, slots);
+    const bool fh2 = fh && MGM == 2 && !(w8s && w8s[0]);  // update_cost2_trunclinear (the caller passes weights only if some weight != 1)
+    const int R = pass_rel_lines(), HS = pass_rel_hand_floats(fh || pube, slots, fh2);
     int r;
     HIPCHK(c, hipSetDevice(c->device));
     if (int r0 = check_watchdog(c, false)) return r0;
@@ -1239,6 +1240,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     p.ld = (int)std::min(5LL, std::max(2LL, tune_num("rel_ld", nb <= 1 ? 2 : 3)));
     p.fh_multi = tune_num("rel_multi", 1) != 0 ? 1 : 0;
     p.cost2 = (pube && MGM == 2) ? 1 : 0;
+    p.fh2 = fh2 ? 1 : 0;
     p.slots = slots;
     p.cb = rcb;
     p.tl = nullptr;

@@ -105,8 +105,12 @@ SMALL = [
     ("t2_hirsch_jumps_o4", 75, 38, -150, 0, ("jumpy", 20), 0, 2, 4, 8.0, 32.0, None, "cubic", 0, True),
     ("t2_hirsch_ones_as_weights", 64, 33, -60, 0, ("win", 10, 12, 3), 0, 2, 8, 8.0, 32.0, "ones", "vfit", 1, True),  # planes of ones: the reference runs UNWEIGHTED (update_cost2)
     ("t2_hirsch_image_weights", 64, 33, -60, 0, ("win", 10, 12, 3), 0, 2, 8, 8.0, 32.0, "image", None, 1, True),     # update_costW with two neighbours
-    ("t2_fh_boundary_fix", 90, 41, -60, 0, ("win", 10, 12, 3), 1, 2, 8, 2.0, 30.0, None, "vfit", 1, False),  # update_cost2_trunclinear + fix-up
-    ("t2_fh_jumps", 61, 44, -100, 0, ("jumpy", 11), 1, 2, 4, 2.0, 30.0, None, "cubic", 0, False),
+    ("t2_fh_boundary_fix", 90, 41, -60, 0, ("win", 10, 12, 3), 1, 2, 8, 2.0, 30.0, None, "vfit", 1, True),  # update_cost2_trunclinear + fix-up (round 6: k_pass_rel FH2)
+    ("t2_fh_jumps", 61, 44, -100, 0, ("jumpy", 11), 1, 2, 4, 2.0, 30.0, None, "cubic", 0, True),   # neighbours' ranges disjoint from the pixel's: the fix-up's ramps
+    ("t2_fh_jumps_narrow", 57, 39, -200, 0, ("jumpy", 3), 1, 2, 8, 1.5, 20000.0, None, "vfit", 1, True),
+    ("t2_fh_wide_128_slots", 66, 35, -200, 10, ("exact", 110), 1, 2, 8, 2.0, 40.0, None, "parabola", 1, True),
+    ("t2_fh_colour_ad", 80, 36, -60, 0, ("win", 9, 13, 4), 1, 2, 4, 6.0, 90.0, None, "vfit", 1, True, "ad", 3),
+    ("t2_fh_ones_as_weights", 64, 33, -60, 0, ("win", 10, 12, 3), 1, 2, 8, 2.0, 30.0, "ones", "vfit", 1, True),
     ("t2_fh_image_weights", 61, 44, -100, 0, ("jumpy", 11), 1, 2, 4, 2.0, 30.0, "image", "vfit", 1, True),  # update_costW_trunclinear, two neighbours
 ]
 

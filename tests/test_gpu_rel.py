@@ -95,12 +95,12 @@ def test_rel_is_not_taken_where_it_does_not_apply():
         ctx.timing(True)
         ctx.aggregate_dev(cv, 8.0, 32.0, 8, 3, 0, 1, None, "vfit")
         assert "k_pass_rel" not in [n for n, _ in ctx.timings()]
-        # FH with TSGM = 2 without weights is update_cost2_trunclinear with its boundary fix-up -> the dense hull (round 6: the
-        # Hirschmueller TSGM = 2 function, update_cost2, runs on the range-proportional kernels); S wanted -> the dense hull
+        # P2 = +INF is the operand-order-faithful kernel's (all-INF slabs, INF - INF); S wanted -> the dense hull.  (Round 6: every
+        # update function runs on the range-proportional kernels, update_cost2 and update_cost2_trunclinear included.)
         lo, hi = ranges(gt, dmin, dmax, 8, 9)
         cv2 = ctx.costvolume(u, v, lo, hi, "none", "census", float("inf"), 5)
         ctx.timing_reset()
-        ctx.aggregate_dev(cv2, 2.0, 30.0, 4, 2, 1, 1, None, "vfit")
+        ctx.aggregate_dev(cv2, 2.0, float("inf"), 4, 2, 1, 1, None, "vfit")
         S, _, _ = ctx.aggregate_dev(cv2, 8.0, 32.0, 4, 3, 0, 1, None, "vfit", want_S=True)
         assert "k_pass_rel" not in [n for n, _ in ctx.timings()] and S is not None
         # unit weights, Hirschmueller, ONE volume: a tie where the hull exists (absolute differences: K2 writes the hull and the
@@ -141,7 +141,7 @@ def test_rel_random_cases_match_dense_hull(seed):
     dmax = int(rng.integers(0, 30))
     half = int(rng.integers(1, 29))
     FH = int(rng.integers(0, 2))
-    MGM = int(rng.choice([1, 3, 4]))
+    MGM = int(rng.choice([1, 3, 4])) if seed % 3 else int(rng.choice([1, 2, 3, 4]))  # (round 6: TSGM = 2 on a third of the seeds; the others keep their cases)
     NDIR = int(rng.choice([1, 2, 4, 8]))
     P1 = float(rng.choice([0.75, 1.5, 2.0, 8.0]))
     P2 = float(rng.choice([9.0, 32.0, 40.0, 20000.0]))
