@@ -506,7 +506,8 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
     // update_cost2_trunclinear with its boundary fix-up (not built here: the dense hull has it).
     bool rel_sign_ok = P1 >= 0.0f && P2 >= 0.0f;
     bool rel_weighted = w8 && w8[0];
-    const bool rel_candidate = !S && P2 < __builtin_huge_valf() && rel_pays && rel_sign_ok && rel_enabled();
+    // (round 6, last: S wanted is no reason for the hull any more -- k_rel_S expands the corrected sum from the range-proportional Lr volumes)
+    const bool rel_candidate = (!S || tune_num("rel_S", 1) != 0) && P2 < __builtin_huge_valf() && rel_pays && rel_sign_ok && rel_enabled();
     if (rel_candidate && rel_weighted) {
         bool odd = false, any = false;
         if ((r = weights_have_odd_values(c, w8, n, npix, &odd, &any))) return r;
@@ -530,7 +531,7 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
                 while (chunk > 1 && per_vol * chunk > (double)c->ws_limit) chunk--;
             for (int v0 = 0; v0 < n;) {
                 const int m = std::min(chunk, n - v0);
-                r = run_rel(c, C + v0, rel_weighted ? w8 + v0 : nullptr, m, P1, P2, MGM, use_fh, NDIR, fix_overcount, ridx, out + v0, outcost + v0);
+                r = run_rel(c, C + v0, rel_weighted ? w8 + v0 : nullptr, m, P1, P2, MGM, use_fh, NDIR, fix_overcount, ridx, out + v0, outcost + v0, S ? S + v0 : nullptr);
                 if (r == MGM_ERR_NOMEM && m > 1) {
                     chunk = std::max(1, m / 2);
                     (void)hipGetLastError();

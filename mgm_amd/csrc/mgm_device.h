@@ -156,6 +156,7 @@ struct WtaRelParams {
     int slots, cb;           // the volume's range-proportional format
 };
 hipError_t launch_wta_rel(const WtaRelParams &p, hipStream_t s);
+hipError_t launch_rel_S(const WtaRelParams &p, int L, int dmin, float *S, hipStream_t s);  // the corrected S on the dense hull from the range-proportional Lr volumes
 
 // the slow, operand-order-faithful pass kernel (mgm_pass_exact.hip): one pass of one volume
 struct ExactPass {       // one pass of the reference's table (mgm_core.cc:463-471, 481-484)

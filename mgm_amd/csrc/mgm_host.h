@@ -278,9 +278,9 @@ int rel_resolve(mgm_ctx *c, const mgm_cv *cv, bool *usable);
 int rel_alloc(mgm_ctx *c, mgm_cv *cv, int slots, int cb);  // (re)allocates relbuf for the format and sets rel_slots / rel_cb; MGM_OK also when the device has no room (relbuf stays null)
 int weights_have_odd_values(mgm_ctx *c, const mgm_img *const *w8s, int nb, long long npix, bool *odd, bool *any = nullptr);
 int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int nb, float P1, float P2, int MGM, int use_fh, int NDIR,
-            int fix_overcount, int ridx, mgm_img *const *outs, mgm_img *const *outcosts);
+            int fix_overcount, int ridx, mgm_img *const *outs, mgm_img *const *outcosts, mgm_cv **S = nullptr);
 int run_wta_rel(mgm_ctx *c, const mgm_cv *C, int slot, int NDIR, int fix_overcount, int ridx, const float *wlo, const float *whi, float *out,
-                float *outcost);
+                float *outcost, float *Sout = nullptr);
 int run_wta_refine(mgm_ctx *c, const mgm_cv *C, long long pix0, long long npix, const float *lr, long long lr_stride, int NDIR,
                    int fix_overcount, int ridx, float *out, float *outcost, float *Sout, const float *wlo = nullptr,
                    const float *whi = nullptr, int slot = -1);

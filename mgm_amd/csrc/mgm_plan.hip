@@ -1092,7 +1092,7 @@ int rel_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *usable)
 }
 
 int run_wta_rel(mgm_ctx *c, const mgm_cv *C, int slot, int NDIR, int fix_overcount, int ridx, const float *wlo, const float *whi, float *out,
-                float *outcost)
+                float *outcost, float *Sout)
 {
     const size_t npix = (size_t)C->nx * C->ny;
     WtaRelParams w{};
@@ -1113,13 +1113,19 @@ int run_wta_rel(mgm_ctx *c, const mgm_cv *C, int slot, int NDIR, int fix_overcou
     w.FIX = fix_overcount;
     w.refine = ridx;
     w.num_cu = c->num_cu;
-    TimeScope t(c, "k_wta");
-    HIPCHK(c, launch_wta_rel(w, c->stream));
+    {
+        TimeScope t(c, "k_wta");
+        HIPCHK(c, launch_wta_rel(w, c->stream));
+    }
+    if (Sout) {  // the caller wants the corrected aggregated volume mgm() returns: on the dense hull
+        TimeScope t(c, "k_rel_S");
+        HIPCHK(c, launch_rel_S(w, C->dmax - C->dmin + 1, C->dmin, Sout, c->stream));
+    }
     return MGM_OK;
 }
 
 int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int nb, float P1, float P2, int MGM, int use_fh, int NDIR,
-            int fix_overcount, int ridx, mgm_img *const *outs, mgm_img *const *outcosts)
+            int fix_overcount, int ridx, mgm_img *const *outs, mgm_img *const *outcosts, mgm_cv **S)
 {
     const mgm_cv *C = Cs[0];
     const int nx = C->nx, ny = C->ny;
@@ -1299,7 +1305,13 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
         c->rel_last_cvs[v] = v < nb ? Cs[v] : nullptr;
         c->rel_last_gens[v] = v < nb ? Cs[v]->gen : 0;
     }
-    for (int v = 0; v < nb; v++)
-        if ((r = run_wta_rel(c, Cs[v], v, NDIR, fix_overcount, ridx, nullptr, nullptr, outs[v]->d, outcosts[v]->d))) return r;
+    for (int v = 0; v < nb; v++) {
+        float *Sout = nullptr;
+        if (S) {
+            if ((r = mgm_cv_create(c, nx, ny, Cs[v]->dmin, Cs[v]->dmax, &S[v]))) return r;
+            Sout = S[v]->d;
+        }
+        if ((r = run_wta_rel(c, Cs[v], v, NDIR, fix_overcount, ridx, nullptr, nullptr, outs[v]->d, outcosts[v]->d, Sout))) return r;
+    }
     return MGM_OK;
 }

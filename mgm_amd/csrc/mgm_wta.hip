@@ -682,6 +682,34 @@ __global__ void __launch_bounds__(256) k_wta_rel(const WtaRelParams P)
         }
     }
 }
+// The corrected aggregated volume mgm() returns (mgm_core.cc:426, 582-601), on the dense hull, from the range-proportional Lr volumes
+// (round 6): one thread per (pixel, label).  A label the pixel owns: S = ((0 + L0) + L1) + ... in pass order, minus (NDIR - 1) C
+// with the over-count fix; a label it does not own holds what the dense-hull kernels leave there (C = +INF: +INF, or INF - INF =
+// NaN with the fix) -- the reference's S has no such label.
+__global__ void __launch_bounds__(256) k_rel_S(const WtaRelParams P, long long n, int L, int dmin, float *__restrict__ S)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const long long pix = t / L;
+    const int d = dmin + (int)(t - pix * L);
+    const int4 rec = reinterpret_cast<const int4 *>(P.base)[pix];
+    const float f = (float)(P.NDIR - 1);
+    float s = f_inf();
+    if (d >= rec.y && d <= rec.z) {
+        const long long k = pix * P.slots + (d - rec.x);
+        s = 0.0f;
+        for (int p = 0; p < P.NDIR; p++) s = s + P.Lr[(long long)p * P.nvol + k];
+        if (P.FIX == 1) s = s - f * (P.cb == 1 ? c8_decode((unsigned)P.c8[k]) : c16_decode((unsigned)reinterpret_cast<const uint16_t *>(P.c8)[k]));
+    } else if (P.FIX == 1)
+        s = s - f * f_inf();
+    S[t] = s;
+}
+hipError_t launch_rel_S(const WtaRelParams &p, int L, int dmin, float *S, hipStream_t s)
+{
+    const long long n = p.npix * L;
+    hipLaunchKernelGGL(k_rel_S, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, L, dmin, S);
+    return hipGetLastError();
+}
 hipError_t launch_wta_rel(const WtaRelParams &p, hipStream_t s)
 {
     const long long groups = (p.npix + 15) / 16;  // four waves of four pixels per block

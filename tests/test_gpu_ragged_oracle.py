@@ -157,12 +157,13 @@ def test_ragged_small_vs_oracle(oracle, case):
         else:
             oa_r, ca_r = oa, ca
         for mode in ("2", "0"):
-            got = run_hip(ctx, cv, mode, P1, P2, NDIR, MGM, FH, fix, w8, refine, want_S=(mode == "0"))
+            got = run_hip(ctx, cv, mode, P1, P2, NDIR, MGM, FH, fix, w8, refine, want_S=True)  # (round 6: S from the range-proportional kernels too, k_rel_S)
             ran_rel = "k_pass_rel" in got["names"]
             if mode == "0":
                 assert not ran_rel
             elif expect_rel is not None:
                 assert ran_rel == expect_rel, (name, got["names"])
+                assert ("k_rel_S" in got["names"]) == expect_rel, (name, got["names"])
             for p in range(NDIR):
                 d = int(np.sum((got["lr"][p].view(np.uint32) != lra[p].view(np.uint32)) & own))
                 assert d == 0, (name, mode, "Lr of pass %d" % p, d)
