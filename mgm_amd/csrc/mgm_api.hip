@@ -372,7 +372,10 @@ static int costvolume_fill(mgm_ctx *c, const mgm_img *u, const mgm_img *v, int d
     if (p.rlo && p.C && rel_enabled()) {
         // the narrowest form the cost function can have: one byte for single-word census and grey-level absolute differences, two for
         // the other absolute / squared differences; the flag word (read back by the first aggregation, rel_resolve) widens it
-        const int rcb = (costfn == 2 || (costfn == 0 && u->nch == 1)) ? 1 : 2;
+        // (... and the fp32 cost itself -- four bytes -- for what has no integer form: NCC, Birchfield-Tomasi, census over several words,
+        // differences of filtered images)
+        const int rcb = ((costfn == 2 && census_words == 1) || (costfn == 0 && u->nch == 1 && pre == 0)) ? 1
+                        : (((costfn == 0 || costfn == 1) && (pre == 0 || pre == 2)) ? 2 : 4);
         if ((r = rel_alloc(c, *out, 64, rcb))) return r;
         if ((*out)->relbuf) {
             HIPCHK(c, hipMemsetAsync((*out)->rel_flag(), 0, 4, c->stream));

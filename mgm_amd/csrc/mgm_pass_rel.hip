@@ -109,17 +109,29 @@ __global__ void __launch_bounds__(256) k_rel_gather(const float *__restrict__ C,
     unsigned bad = 0;
     if (hi - lo + 1 > slots - 2 || hi < lo) bad |= 1u;
     const int d = b + k;  // disparity of this slot
-    const unsigned none = cb == 1 ? 255u : 65535u;
-    unsigned code = none;
-    if (d >= lo && d <= hi && d - dmin >= 0 && d - dmin < L) {
-        code = cb == 1 ? c8_encode(C[p * L + (d - dmin)]) : c16_encode(C[p * L + (d - dmin)]);
-        if (code > none) {
-            bad |= 2u;
-            code = none;
+    if (cb == 4) {  // the cost itself (fp32: NCC, Birchfield-Tomasi, census over several words ...); a NaN cost has no place here (bit 1)
+        float x = __builtin_huge_valf();
+        if (d >= lo && d <= hi && d - dmin >= 0 && d - dmin < L) {
+            x = C[p * L + (d - dmin)];
+            if (x != x || x < 0.0f) {  // (NaN: the operand-order-faithful kernel's; a negative cost: the hand-off tags need L >= +0)
+                bad |= 2u;
+                x = __builtin_huge_valf();
+            }
         }
+        reinterpret_cast<float *>(rel8)[p * slots + k] = x;
+    } else {
+        const unsigned none = cb == 1 ? 255u : 65535u;
+        unsigned code = none;
+        if (d >= lo && d <= hi && d - dmin >= 0 && d - dmin < L) {
+            code = cb == 1 ? c8_encode(C[p * L + (d - dmin)]) : c16_encode(C[p * L + (d - dmin)]);
+            if (code > none) {
+                bad |= 2u;
+                code = none;
+            }
+        }
+        if (cb == 1) rel8[p * slots + k] = (uint8_t)code;
+        else reinterpret_cast<uint16_t *>(rel8)[p * slots + k] = (uint16_t)code;
     }
-    if (cb == 1) rel8[p * slots + k] = (uint8_t)code;
-    else reinterpret_cast<uint16_t *>(rel8)[p * slots + k] = (uint16_t)code;
     if (bad && *flag != (*flag | bad)) atomicOr(flag, bad);  // (look before raising: one word for everybody)
 }
 hipError_t launch_rel_gather(const float *C, const float *rlo, const float *rhi, long long npix, int L, int dmin, int slots, int cb, uint8_t *rel8, int *relb,
@@ -203,7 +215,9 @@ __global__ void __launch_bounds__(256) k_rel_expand(const uint8_t *__restrict__ 
     const int o = (int)(t - pix * L);
     const int k = dmin + o - relb[pix * 4];
     float v = __builtin_huge_valf();
-    if (k >= 0 && k < slots) v = cb == 1 ? c8_decode((unsigned)rel8[pix * slots + k]) : c16_decode((unsigned)reinterpret_cast<const uint16_t *>(rel8)[pix * slots + k]);
+    if (k >= 0 && k < slots)
+        v = cb == 1 ? c8_decode((unsigned)rel8[pix * slots + k])
+                    : (cb == 2 ? c16_decode((unsigned)reinterpret_cast<const uint16_t *>(rel8)[pix * slots + k]) : reinterpret_cast<const float *>(rel8)[pix * slots + k]);
     C[t] = v;
 }
 hipError_t launch_rel_expand(const uint8_t *rel8, const int *relb, long long npix, int L, int dmin, int slots, int cb, float *C, hipStream_t s)
@@ -278,7 +292,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     static_assert(!FH2 || (FH && NK == 2), "update_cost2_trunclinear: FH, two neighbours, side by side");
     static_assert(!(FH && PUBE), "FH potentials convolve over the RECEIVING pixel's range: consumer side only");
     static_assert(NK == 0 || FH, "side-by-side convolutions: FH only");
-    static_assert((SPL == 4 || SPL == 8) && (CB == 1 || CB == 2), "64 or 128 slots, one or two bytes per cost");
+    static_assert((SPL == 4 || SPL == 8) && (CB == 1 || CB == 2 || CB == 4), "64 or 128 slots; one- or two-byte cost codes, or the fp32 cost itself");
     constexpr int SLOTS = 16 * SPL;          // label slots per pixel
     constexpr int CBY = SLOTS * CB;          // cost bytes per pixel
     constexpr int CPP = CBY / 16;            // ... in 16-byte pieces
@@ -469,8 +483,9 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             const int n = (CI + 1 + HI + (weighted ? 1 : 0)) * (LD - 1);  // (3 .. 8 instructions per step, 1 .. 4 steps)
             switch (n) {
 #define MGM_REL_W(k) case k: rel_wait_vmcnt<k>(); break;
-                MGM_REL_W(3) MGM_REL_W(4) MGM_REL_W(5) MGM_REL_W(6) MGM_REL_W(7) MGM_REL_W(8) MGM_REL_W(9) MGM_REL_W(10) MGM_REL_W(12) MGM_REL_W(14)
-                MGM_REL_W(15) MGM_REL_W(16) MGM_REL_W(18) MGM_REL_W(20) MGM_REL_W(21) MGM_REL_W(24) MGM_REL_W(28) MGM_REL_W(32)
+                MGM_REL_W(3) MGM_REL_W(4) MGM_REL_W(5) MGM_REL_W(6) MGM_REL_W(7) MGM_REL_W(8) MGM_REL_W(9) MGM_REL_W(10) MGM_REL_W(11) MGM_REL_W(12) MGM_REL_W(14)
+                MGM_REL_W(15) MGM_REL_W(16) MGM_REL_W(18) MGM_REL_W(20) MGM_REL_W(21) MGM_REL_W(22) MGM_REL_W(24) MGM_REL_W(27) MGM_REL_W(28) MGM_REL_W(30)
+                MGM_REL_W(32) MGM_REL_W(33) MGM_REL_W(36) MGM_REL_W(40) MGM_REL_W(44) MGM_REL_W(48)
 #undef MGM_REL_W
             default: rel_wait_vmcnt<0>(); break;  // (a count not listed: wait for everything -- correct, only slower)
             }
@@ -554,7 +569,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 for (int w = 0; w < NWORD; w++) cw[w] = reinterpret_cast<const unsigned *>(cring + (sl * RR + ln) * CBY + SPL * CB * li)[w];
 #pragma unroll
                 for (int q = 0; q < SPL; q++)
-                    Cv[q] = CB == 1 ? c8_decode((cw[q / 4] >> (8 * (q % 4))) & 255u) : c16_decode((cw[q / 2] >> (16 * (q % 2))) & 65535u);
+                    Cv[q] = CB == 1 ? c8_decode((cw[q / 4] >> (8 * (q % 4))) & 255u)
+                                    : (CB == 2 ? c16_decode((cw[q / 2] >> (16 * (q % 2))) & 65535u) : __builtin_bit_cast(float, cw[q * CB / 4]));
             }
             const bool interior = act && has_prev && i >= 1 && i <= LL - 2;  // mgm_core.cc:538-541
             const float4 w4 = *reinterpret_cast<const float4 *>(wring + (sl * RR + ln) * 4);
@@ -821,8 +837,11 @@ static hipError_t launch_rel_fmt(const RelParams &p, int ntasks, bool fh, bool p
 // p.slots (64 / 128) and p.cb (1 / 2): the volumes' range-proportional format
 hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, int wg_per_cu, hipStream_t s)
 {
-    if (p.slots == 128) return p.cb == 2 ? launch_rel_fmt<8, 2>(p, ntasks, fh, pube, wg_per_cu, s) : launch_rel_fmt<8, 1>(p, ntasks, fh, pube, wg_per_cu, s);
-    return p.cb == 2 ? launch_rel_fmt<4, 2>(p, ntasks, fh, pube, wg_per_cu, s) : launch_rel_fmt<4, 1>(p, ntasks, fh, pube, wg_per_cu, s);
+    if (p.slots == 128)
+        return p.cb == 4 ? launch_rel_fmt<8, 4>(p, ntasks, fh, pube, wg_per_cu, s)
+                         : (p.cb == 2 ? launch_rel_fmt<8, 2>(p, ntasks, fh, pube, wg_per_cu, s) : launch_rel_fmt<8, 1>(p, ntasks, fh, pube, wg_per_cu, s));
+    return p.cb == 4 ? launch_rel_fmt<4, 4>(p, ntasks, fh, pube, wg_per_cu, s)
+                     : (p.cb == 2 ? launch_rel_fmt<4, 2>(p, ntasks, fh, pube, wg_per_cu, s) : launch_rel_fmt<4, 1>(p, ntasks, fh, pube, wg_per_cu, s));
 }
 int pass_rel_lines() { return RR; }
 int pass_rel_phases() { return MGM_REL_PHASES ? 16 : 0; }

@@ -1062,7 +1062,7 @@ int rel_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *usable)
         // the flag word of the gathered copy: bit 0 = a window wider than the format's slots - 2, bit 1 = a cost without the format's
         // code.  (round 6) The copy is then gathered again one step wider -- 64 -> 128 slots, one -> two bytes per cost -- while the
         // fp32 hull it is gathered from is current; what fits neither keeps the dense hull.
-        for (int round = 0; round < 3; round++) {
+        for (int round = 0; round < 4; round++) {
             HIPCHK(c, hipMemcpyAsync(c->h_words + 3, cv->rel_flag(), 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             const unsigned f = c->h_words[3];
@@ -1071,7 +1071,7 @@ int rel_resolve(mgm_ctx *c, const mgm_cv *ccv, bool *usable)
                 break;
             }
             const int slots = (f & 1u) ? cv->rel_slots * 2 : cv->rel_slots, cb = (f & 2u) ? cv->rel_cb * 2 : cv->rel_cb;
-            if (slots > 128 || cb > 2 || !cv->f32_state || !cv->d || tune_num("rel_wide", 1) == 0) {
+            if (slots > 128 || cb > 4 || !cv->f32_state || !cv->d || tune_num("rel_wide", 1) == 0) {  // (cb 4: the fp32 cost itself)
                 cv->rel_state = -1;
                 break;
             }

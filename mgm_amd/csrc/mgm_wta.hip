@@ -607,7 +607,8 @@ __global__ void __launch_bounds__(256) k_wta_rel(const WtaRelParams P)
             for (int w = 0; w < NWORD; w++) cw[w] = reinterpret_cast<const unsigned *>(P.c8 + (pix * SLOTS + SPL * li) * CB)[w];
 #pragma unroll
             for (int q = 0; q < SPL; q++)
-                a[q] = a[q] - f * (CB == 1 ? c8_decode((cw[q / 4] >> (8 * (q % 4))) & 255u) : c16_decode((cw[q / 2] >> (16 * (q % 2))) & 65535u));
+                a[q] = a[q] - f * (CB == 1 ? c8_decode((cw[q / 4] >> (8 * (q % 4))) & 255u)
+                                           : (CB == 2 ? c16_decode((cw[q / 2] >> (16 * (q % 2))) & 65535u) : __builtin_bit_cast(float, cw[q * CB / 4])));
         }
         float val[SPL];
         // (2) its own disparities inside the window: the first strict minimum by rising disparity = the smallest (value, disparity)
@@ -699,7 +700,9 @@ __global__ void __launch_bounds__(256) k_rel_S(const WtaRelParams P, long long n
         const long long k = pix * P.slots + (d - rec.x);
         s = 0.0f;
         for (int p = 0; p < P.NDIR; p++) s = s + P.Lr[(long long)p * P.nvol + k];
-        if (P.FIX == 1) s = s - f * (P.cb == 1 ? c8_decode((unsigned)P.c8[k]) : c16_decode((unsigned)reinterpret_cast<const uint16_t *>(P.c8)[k]));
+        if (P.FIX == 1)
+            s = s - f * (P.cb == 1 ? c8_decode((unsigned)P.c8[k])
+                                   : (P.cb == 2 ? c16_decode((unsigned)reinterpret_cast<const uint16_t *>(P.c8)[k]) : reinterpret_cast<const float *>(P.c8)[k]));
     } else if (P.FIX == 1)
         s = s - f * f_inf();
     S[t] = s;
@@ -716,10 +719,12 @@ hipError_t launch_wta_rel(const WtaRelParams &p, hipStream_t s)
     const long long cap = (long long)p.num_cu * 64;
     const dim3 grid((unsigned)std::max(1ll, std::min(groups, cap)));
     if (p.slots == 128) {
-        if (p.cb == 2) hipLaunchKernelGGL((k_wta_rel<8, 2>), grid, dim3(256), 0, s, p);
+        if (p.cb == 4) hipLaunchKernelGGL((k_wta_rel<8, 4>), grid, dim3(256), 0, s, p);
+        else if (p.cb == 2) hipLaunchKernelGGL((k_wta_rel<8, 2>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_wta_rel<8, 1>), grid, dim3(256), 0, s, p);
     } else {
-        if (p.cb == 2) hipLaunchKernelGGL((k_wta_rel<4, 2>), grid, dim3(256), 0, s, p);
+        if (p.cb == 4) hipLaunchKernelGGL((k_wta_rel<4, 4>), grid, dim3(256), 0, s, p);
+        else if (p.cb == 2) hipLaunchKernelGGL((k_wta_rel<4, 2>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_wta_rel<4, 1>), grid, dim3(256), 0, s, p);
     }
     return hipGetLastError();

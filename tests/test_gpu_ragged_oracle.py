@@ -94,6 +94,9 @@ SMALL = [
     ("ad_colour_two_bytes_hirsch_weights", 90, 40, -60, 0, ("win", 12, 14, 3), 0, 4, 8, 24.0, 96.0, "image", "cubic", 1, True, "ad", 3),
     ("ad_colour_t2_wide", 70, 36, -150, 0, ("exact", 101), 0, 2, 4, 24.0, 96.0, None, None, 1, True, "ad", 3),
     ("sd_grey_two_bytes_wide_fh", 70, 36, -150, 0, ("exact", 90), 1, 3, 8, 40.0, 4000.0, None, "vfit", 0, True, "sd", 1),
+    ("ncc_fp32_costs_fh", 90, 40, -60, 0, ("win", 12, 14, 3), 1, 3, 8, 2.0, 30.0, None, "vfit", 1, True, "ncc", 1),
+    ("btad_fp32_costs_hirsch_weights", 90, 40, -60, 0, ("win", 12, 14, 3), 0, 4, 8, 8.0, 32.0, "image", "cubic", 1, True, "btad", 1),
+    ("btsd_colour_fp32_costs_t2_wide", 70, 36, -150, 0, ("exact", 90), 0, 2, 4, 24.0, 96.0, None, None, 1, True, "btsd", 3),
     ("ad_grey_one_byte", 90, 40, -60, 0, ("win", 12, 14, 3), 1, 3, 8, 2.0, 30.0, None, "vfit", 1, True, "ad", 1),
     ("h17", 64, 17, -60, 0, ("win", 20, 22, 3), 1, 3, 8, 2.0, 20000.0, None, "vfit", 1, True),
     ("h33_w3", 50, 33, -60, 0, ("win", 20, 22, 3), 0, 3, 8, 8.0, 32.0, "three", "parabolaOCV", 1, True),
