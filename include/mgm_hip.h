@@ -143,7 +143,10 @@ int mgm_costvolume_build_dev(mgm_ctx *ctx, const mgm_img *u, const mgm_img *v, i
  * rule; mgm_aggregate* then searches the winner and gates the refinement inside each pixel's range.  The hull may
  * span any number of labels the device can hold (the reference's Dvec has no limit, dvec.cc:60; an index-arithmetic cap of
  * 4 194 304 aside): up to 1024 on the fast kernels, up to 2048 on the first build of the pass kernel, beyond that on the
- * generic ones (a second or more per full-HD volume); batched ragged volumes must share hull_min under FH potentials. */
+ * generic ones (a second or more per full-HD volume); batched ragged volumes must share hull_min under FH potentials.
+ * A ragged volume whose windows are at most 126 labels wide also keeps a RANGE-PROPORTIONAL copy (64 or 128 label slots per pixel at
+ * the pixel's own window, mgm_costvolume.h:275-299), which mgm_aggregate* then walks instead of the hull: same results, bytes and
+ * steps proportional to the labels that exist. */
 int mgm_costvolume_build(mgm_ctx *ctx, const float *u, const float *v, int nx, int ny, int nch, int vnx, int vny,
                          const float *dminI, const float *dmaxI, const char *prefilter, const char *distance,
                          float truncDist, int census_win, mgm_cv **C);
