@@ -1091,7 +1091,7 @@ def main():
                          "'pairs2' = one stereo pair per step and pair of GPUs, its two mgm() runs on one GPU each (strong)")
     ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
                     help="the cfg5-replicas and cfg4-directions legs after the headline; auto = on for the plain command line")
-    ap.add_argument("--extras-timeout", type=float, default=300.0, help="seconds the guarded extras may take altogether")
+    ap.add_argument("--extras-timeout", type=float, default=420.0, help="seconds the guarded extras may take altogether (round 6: the gated variants run CPU legs too)")
     ap.add_argument("--exchange-timeout", type=float, default=90.0, help="seconds one direction-sharded step may take")
     args = ap.parse_args()
     plain = args.workload is None and args.batch is None and args.mode == "pairs" and args.pipeline == 1
