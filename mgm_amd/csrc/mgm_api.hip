@@ -525,6 +525,9 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
             if ((r = rel_resolve(c, C[v], &u))) return r;
             all = u && C[v]->rel_slots == C[0]->rel_slots && C[v]->rel_cb == C[0]->rel_cb;  // (one format per launch)
         }
+        // the one combination whose LDS rings do not fit a CU: update_cost2_trunclinear ([L][F][B] entries) on 128 slots of fp32 costs
+        // (116 KB of rings + 64 KB of cost pieces): the dense hull keeps it
+        if (all && use_fh > 0 && MGM == 2 && !rel_weighted && C[0]->rel_slots == 128 && C[0]->rel_cb == 4) all = false;
         if (all) {
             //  the range-proportional launch honours the workspace limit too, and a batch the device cannot hold is run
             // in halves instead of failing: NDIR x npix x slots floats per volume (+ ~8 % of hand-off slots)

@@ -61,6 +61,10 @@ int fail(mgm_ctx *c, int code, const std::string &msg)
 }
 int hipfail(mgm_ctx *c, hipError_t e, const char *what)
 {
+    // (round 6) the runtime keeps its last error until somebody reads it, and every launch wrapper ends with `return hipGetLastError()`:
+    // an error that was returned DIRECTLY by a call (hipFuncSetAttribute refusing an LDS request, ...) would otherwise be reported once
+    // more by the next, innocent, launch of the process
+    (void)hipGetLastError();
     return fail(c, MGM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 #define HIPCHK(c, call)                                          \

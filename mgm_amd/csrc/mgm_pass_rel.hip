@@ -823,7 +823,10 @@ static hipError_t launch_rel_fmt(const RelParams &p, int ntasks, bool fh, bool p
     if (fh) {
         if constexpr (SPL == 4 && CB == 1)  // (the one-after-the-other build is kept for the form round 5 measured, as an A/B switch)
             if (!p.fh_multi) return launch_rel_one<true, false, 0, SPL, CB>(p, ntasks, wg_per_cu, s);
-        if (p.fh2) return launch_rel_one<true, false, 2, SPL, CB, true>(p, ntasks, wg_per_cu, s);  // update_cost2_trunclinear (TSGM = 2, no weights)
+        if (p.fh2) {  // update_cost2_trunclinear (TSGM = 2, no weights)
+            if constexpr (SPL == 8 && CB == 4) return hipErrorInvalidValue;  // (its rings + the cost pieces exceed the LDS: the host keeps this one on the dense hull)
+            else return launch_rel_one<true, false, 2, SPL, CB, true>(p, ntasks, wg_per_cu, s);
+        }
         switch (p.MGM) {
         case 1: return launch_rel_one<true, false, 1, SPL, CB>(p, ntasks, wg_per_cu, s);
         case 2: return launch_rel_one<true, false, 2, SPL, CB>(p, ntasks, wg_per_cu, s);

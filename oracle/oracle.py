@@ -201,7 +201,7 @@ class Oracle:
         if w8 is not None:
             w8 = np.ascontiguousarray(w8, np.float32)
             assert w8.shape == (8, ny, nx)
-        passes = tuple(range(NDIR)) if dump_lr is True else tuple(dump_lr or ())
+        passes = tuple(range(NDIR)) if dump_lr is True else tuple(sorted(set(dump_lr or ())))  # (one volume per DISTINCT pass, in pass order)
         lr = np.empty((len(passes), ny, nx, L), np.float32) if passes else None
         r = self.lib.orc_mgm_ranged(Cv, nx, ny, L, hmin, lo, hi, _optp(slo), _optp(shi), shmin, sL, _optp(w8), P1, P2,
                                     NDIR, MGM, FH, FIX, _optp(S), out, outc, _optp(lr), sum(1 << q for q in passes))

@@ -312,3 +312,77 @@ def test_big_ragged_volume_rel_and_hull_vs_oracle(oracle):
             got = run_hip(ctx, cv, mode, 2.0, 20000.0, 8, 3, 1, 1, None, "vfit", lr=False)
             assert ("k_pass_rel" in got["names"]) == (mode == "1"), got["names"]
             assert ndiff(got["c"], rca) == 0 and ndiff(got["o"], ra) == 0, mode
+
+
+# ---- random cases over everything the widened range-proportional path takes, against the ORACLE -------------------------------
+RFUZZ_N = int(os.environ.get("MGM_FUZZ_N", "0"))
+RFUZZ_BASE = int(os.environ.get("MGM_FUZZ_BASE", "0"))
+
+
+@pytest.mark.parametrize("seed", range(RFUZZ_BASE, RFUZZ_BASE + (RFUZZ_N or 32)))
+def test_ragged_random_cases_vs_oracle(oracle, seed):
+    """Random shapes, hulls, window widths up to 127 labels (64 or 128 slots per pixel; 127 = the dense hull), range images that are
+    smooth, jumpy or nested, every cost form (one- / two-byte codes, fp32), every update function (TSGM 1..4, both potentials, with and
+    without weights -- planes of ones included), refinements, over-count fix: range-proportional kernels AND dense hull against
+    orc_mgm_ranged (labels, costs, the first and last pass's Lr).  MGM_FUZZ_N / MGM_FUZZ_BASE run campaigns."""
+    rng = np.random.default_rng(424200 + seed)
+    nx, ny = int(rng.integers(24, 110)), int(rng.integers(18, 70))
+    cost, nch = [("census", 1), ("census", 1), ("ad", 1), ("ad", 3), ("sd", 1), ("ncc", 1), ("btad", 1), ("btsd", 3)][int(rng.integers(0, 8))]
+    win = 5 if nch == 1 else 3
+    dmin, dmax = -int(rng.integers(30, 220)), int(rng.integers(0, 12))
+    kind = rng.choice(["win", "exact", "jumpy"])
+    u, v, gt = synth.stereo_pair(nx, ny, dmin * 3 // 4, 0, seed=seed, nch=nch)
+    if kind == "exact":
+        width = int(min(rng.choice([5, 30, 61, 62, 63, 100, 126, 127]), dmax - dmin))
+        dminI, dmaxI = exact_width_ranges(gt, dmin, dmax, width, seed)
+    elif kind == "win":
+        dminI, dmaxI = window_ranges(gt, dmin, dmax, int(rng.integers(1, 60)), int(rng.integers(1, 60)), seed, int(rng.integers(0, 5)))
+    else:
+        dminI, dmaxI = jumpy_ranges(nx, ny, dmin, dmax, int(min(rng.integers(2, 100), dmax - dmin)), seed)
+    FH = int(rng.integers(0, 2))
+    MGM = int(rng.integers(1, 5))
+    NDIR = int(rng.choice([1, 2, 4, 8]))
+    scale = {"census": 1.0, "ad": 3.0 * nch, "sd": 40.0, "ncc": 2.0, "btad": 2.0, "btsd": 60.0}[cost]
+    P1 = float(rng.choice([0.75, 1.5, 2.0, 8.0])) * scale
+    P2 = float(rng.choice([9.0, 32.0, 40.0, 20000.0])) * scale
+    wkind = rng.choice(["none", "none", "three", "image", "ones"])
+    refine = rng.choice([None, "vfit", "parabola", "cubic", "parabolaOCV"])
+    fix = int(rng.integers(0, 2))
+    lo, hi = orc_mod.int_ranges(dminI, dmaxI)
+    hmin, hmax = int(lo.min()), int(hi.max())
+    own = own_mask(lo, hi, hmin, hmax - hmin + 1)
+    Ca = oracle.costvolume_ranged(u, v, lo, hi, hmin, hmax, "none", cost, np.inf, win)
+    what = (seed, nx, ny, cost, nch, dmin, dmax, kind, FH, MGM, NDIR, P1, P2, wkind, refine, fix, int((hi - lo).max()) + 1)
+    with mgm_amd.Context(0) as ctx:
+        os.environ["MGM_HIP_REL"] = "2"
+        cv = ctx.costvolume(u, v, dminI, dmaxI, "none", cost, float("inf"), win)
+        os.environ.pop("MGM_HIP_REL")
+        w8 = w8h = None
+        if wkind == "three":
+            w8h = rng.choice(np.array([1.0, 2.5, 4.0], np.float32), size=(8, ny, nx), p=[0.6, 0.25, 0.15])
+        elif wkind == "image":
+            w8h = oracle.weights(u, 4.0, 12.0)
+        elif wkind == "ones":
+            w8h = np.ones((8, ny, nx), np.float32)
+        if w8h is not None:
+            w8 = ctx.upload_image(w8h)
+        oracle.set_threads(min(8, len(os.sched_getaffinity(0))))
+        try:
+            Sa, oa, ca, lra = oracle.mgm_ranged(Ca, hmin, lo, hi, P1, P2, NDIR, MGM, FH, fix, w8h, dump_lr=(0, NDIR - 1))
+        finally:
+            oracle.set_threads(1)
+        oa_r, ca_r = oracle.refine_ranged(Sa, hmin, lo, hi, refine, oa, ca) if refine else (oa, ca)
+        for mode in ("2", "0"):
+            got = run_hip(ctx, cv, mode, P1, P2, NDIR, MGM, FH, fix, w8, refine, lr=False)
+            ran_rel = "k_pass_rel" in got["names"]
+            is_ragged = bool((lo != lo.flat[0]).any() or (hi != hi.flat[0]).any())
+            if mode == "2":
+                width = int((hi - lo).max()) + 1
+                # (the one combination that keeps the dense hull: update_cost2_trunclinear on 128 slots of fp32 costs -- its LDS rings do not fit)
+                lds = FH and MGM == 2 and wkind in ("none", "ones") and cost in ("ncc", "btad", "btsd") and width > 62
+                assert ran_rel == (is_ragged and width <= 126 and not lds), (what, got["names"])
+            assert ndiff(got["c"], ca_r) == 0 and ndiff(got["o"], oa_r) == 0, (what, mode, "maps")
+            for n, p in enumerate(sorted({0, NDIR - 1})):
+                lr = ctx.debug_lr(cv, p)
+                d = int(np.sum((lr.view(np.uint32) != lra[min(n, len(lra) - 1)].view(np.uint32)) & own))
+                assert d == 0, (what, mode, "Lr of pass %d" % p, d)
