@@ -284,7 +284,7 @@ int run_passes(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, i
     //     an all-INF slab and the next one INF - INF = NaN;
     //   * (found below, by the scan of an uploaded volume) NaN costs.
     //   * more than 2048 labels: no fast kernel is built that wide (the reference's Dvec has no label limit, dvec.cc:60).
-    //   * (round 6, found by tests/test_gpu_ragged_oracle.py) FH potentials on a ragged volume with a NEGATIVE slope -- P1 < 0, or a
+    //   * (round 6, found by the ragged parity tests of tests/) FH potentials on a ragged volume with a NEGATIVE slope -- P1 < 0, or a
     //     weight <= 0 / NaN scaling it: the fast kernels mask the neighbour's slab to the receiving pixel's range and convolve
     //     over the whole hull, which equals the reference's convolution over the range (mgm_core.cc:242-271) only while the
     //     ramp the forward pass leaves ABOVE the range cannot flow back into it (M[rh] + 2 P1 >= M[rh]).
