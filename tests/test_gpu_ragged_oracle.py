@@ -386,3 +386,41 @@ def test_ragged_random_cases_vs_oracle(oracle, seed):
                 lr = ctx.debug_lr(cv, p)
                 d = int(np.sum((lr.view(np.uint32) != lra[min(n, len(lra) - 1)].view(np.uint32)) & own))
                 assert d == 0, (what, mode, "Lr of pass %d" % p, d)
+
+
+def test_windowed_search_and_refill_across_formats(oracle):
+    """main()'s TSGM_ITER loop on a ragged volume of WIDE windows (128 slots per pixel): mgm_wta_windowed_dev searches the
+    range-proportional Lr volumes again in narrowed / shifted windows (S allocated from those, mgm_core.cc:426) -- against
+    orc_mgm_ranged with separate S ranges; then the SAME volume handle is refilled with narrow windows (64 slots), then wide
+    ones again: the copy's format follows, results stay the oracle's."""
+    nx, ny, dmin, dmax = 88, 47, -180, 10
+    u, v, gt = synth.stereo_pair(nx, ny, -130, 0, seed=12)
+    P1, P2, NDIR, MGM, FH = 2.0, 40.0, 8, 3, 1
+    with mgm_amd.Context(0) as ctx:
+        du, dv = ctx.upload_image(u), ctx.upload_image(v)
+        cv = None
+        for rep, width in enumerate((101, 31, 118)):
+            dminI, dmaxI = exact_width_ranges(gt, dmin, dmax, width, 40 + rep)
+            lo, hi = orc_mod.int_ranges(dminI, dmaxI)
+            hmin, hmax = dmin, dmax  # (the device form names its hull: the same for every refill of the handle)
+            dlo, dhi = ctx.upload_image(dminI[None]), ctx.upload_image(dmaxI[None])
+            cv = ctx.costvolume_ranged_dev(du, dv, dlo, dhi, hmin, hmax, "none", "census", float("inf"), 5, into=cv)
+            Ca = oracle.costvolume_ranged(u, v, lo, hi, hmin, hmax, "none", "census", np.inf, 5)
+            got = run_hip(ctx, cv, "1", P1, P2, NDIR, MGM, FH, 1, None, "vfit", lr=False)
+            assert "k_pass_rel" in got["names"], got["names"]
+            Sa, oa, ca = oracle.mgm_ranged(Ca, hmin, lo, hi, P1, P2, NDIR, MGM, FH, 1, None)
+            ra, rca = oracle.refine_ranged(Sa, hmin, lo, hi, "vfit", oa, ca)
+            assert ndiff(got["c"], rca) == 0 and ndiff(got["o"], ra) == 0, (width, "aggregate")
+            # a second search in windows narrowed around the solution and pushed partly outside the pixel's own range / the hull
+            rng = np.random.default_rng(rep)
+            wl = np.clip(np.where(np.isfinite(oa), oa, lo) - rng.integers(1, 9, size=oa.shape), hmin - 5, hmax).astype(np.float32)
+            wh = np.clip(wl + rng.integers(3, 20, size=oa.shape), wl + 1, hmax + 6).astype(np.float32)
+            slo, shi = orc_mod.int_ranges(wl, wh)
+            shmin, shmax = int(slo.min()), int(shi.max())
+            for fix, refine in ((1, "vfit"), (0, "cubic")):
+                if fix == 0:  # (the Lr volumes are those of the last aggregation: run it again without the fix)
+                    run_hip(ctx, cv, "1", P1, P2, NDIR, MGM, FH, 0, None, None, lr=False)
+                o2, c2 = ctx.wta_windowed_dev(cv, NDIR, fix, refine, ctx.upload_image(wl[None]), ctx.upload_image(wh[None]))
+                S2, oo, cc = oracle.mgm_ranged(Ca, hmin, lo, hi, P1, P2, NDIR, MGM, FH, fix, None, (slo, shi, shmin, shmax))
+                r2, rc2 = oracle.refine_ranged(S2, shmin, slo, shi, refine, oo, cc)
+                assert ndiff(c2.download()[0], rc2) == 0 and ndiff(o2.download()[0], r2) == 0, (width, "windowed", fix, refine)

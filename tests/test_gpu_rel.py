@@ -208,3 +208,44 @@ def test_rel_batch_honours_the_workspace_limit():
     assert res[0][2] == 1 and res[1][2] == 4, (res[0][2], res[1][2])
     for k in range(4):
         assert ndiff(res[0][0][k], res[1][0][k]) == 0 and ndiff(res[0][1][k], res[1][1][k]) == 0, k
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_pipelined_context_gathers_ragged_volumes(depth):
+    """mgm_ctx_set_pipeline with RAGGED volumes: the deferred calls run as one launch of k_pass_rel over the gathered volumes; every
+    pair gets the result of its own plain call (FH, weights; windows of 64 and of 128 slots)."""
+    nx, ny, dmin, dmax = 110, 60, -150, 0
+    for half, w8kind in ((10, None), (45, "image")):
+        seeds = list(range(5))
+        plain, piped = [], []
+        for pipelined in (False, True):
+            os.environ["MGM_HIP_REL"] = "1"
+            try:
+                with mgm_amd.Context(0) as ctx:
+                    if pipelined:
+                        ctx.set_pipeline(depth)
+                    outs, keep = [], []
+                    ctx.timing(True)
+                    for s in seeds:
+                        u, v, gt = synth.stereo_pair(nx, ny, -110, 0, seed=300 + s)
+                        lo, hi = ranges(gt, dmin, dmax, half, s)
+                        du, dv = ctx.upload_image(u), ctx.upload_image(v)  # (device-form calls: a host-buffer build would run what is deferred)
+                        cv = ctx.costvolume_ranged_dev(du, dv, ctx.upload_image(lo[None]), ctx.upload_image(hi[None]), dmin, dmax, "none", "census",
+                                                       float("inf"), 5)
+                        w8 = ctx.weights_dev(du, 4.0, 12.0) if w8kind else None
+                        o, c = ctx.new_image(nx, ny), ctx.new_image(nx, ny)
+                        ctx.aggregate_dev(cv, 2.0, 30.0, 8, 3, 1, 1, w8, "vfit", out=o, outcost=c)
+                        outs.append((o, c))
+                        keep += [cv, w8]
+                    ctx.synchronize()
+                    names = [n for n, _ in ctx.timings()]
+                    res = [(o.download(), c.download()) for o, c in outs]
+                (piped if pipelined else plain).extend(res)
+                if pipelined:
+                    assert names.count("k_pass_rel") < len(seeds), names.count("k_pass_rel")  # (gathered launches)
+                else:
+                    assert names.count("k_pass_rel") == len(seeds)
+            finally:
+                os.environ.pop("MGM_HIP_REL", None)
+        for k in range(len(seeds)):
+            assert ndiff(plain[k][0], piped[k][0]) == 0 and ndiff(plain[k][1], piped[k][1]) == 0, (half, k)
