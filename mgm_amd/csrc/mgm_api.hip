@@ -500,7 +500,10 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
     // range-proportional one: the hull would first have to be expanded and encoded again, 2.2 ms, so those go too: 8.1 + 1.5)
     bool only_rel = true;
     for (int v = 0; v < n; v++) only_rel = only_rel && C[v]->rel_only;
-    const bool rel_pays = use_fh > 0 || (w8 && w8[0]) || n >= 2 || only_rel || tune_num("rel", 1) >= 2;
+    // (round 6: with slope 1, two strips and the 5.6 ms launch the tie is gone -- one unit-weight Hirschmueller volume that HAS its hull,
+    // 1920x1080, windows of 49 labels: 5.3 + 3.7 ms on the hull's queue kernels against 5.6 + 0.8 here, the gather paid either way:
+    // every usable copy is walked; tune rel_tie=0 restores round 5's rule)
+    const bool rel_pays = use_fh > 0 || (w8 && w8[0]) || n >= 2 || only_rel || tune_num("rel", 1) >= 2 || tune_num("rel_tie", 1) != 0;
     //  the hand-off of k_pass_rel keeps the launch's tag in the sign bit of every published word, so every L / E / minimum
     // must be >= +0: non-negative penalties (the dense path's own gate, run_passes `first_build`) and, for weighted launches,
     // positive finite weights (a negative or NaN weight makes N + P1 D - m negative or NaN): those take the dense kernels.
