@@ -533,9 +533,9 @@ static int aggregate_batch_now(mgm_ctx *c, int n, const mgm_cv *const *C, const 
         if (all && use_fh > 0 && MGM == 2 && !rel_weighted && C[0]->rel_slots == 128 && C[0]->rel_cb == 4) all = false;
         if (all) {
             //  the range-proportional launch honours the workspace limit too, and a batch the device cannot hold is run
-            // in halves instead of failing: NDIR x npix x slots floats per volume (+ ~8 % of hand-off slots)
+            // in halves instead of failing: NDIR x npix x slots floats per volume (+ ~16 % of hand-off slots: two lines per band on the anti-diagonal passes)
             int chunk = n;
-            const double per_vol = 4.0 * ((double)npix * C[0]->rel_slots + (double)lr_pad_floats()) * NDIR * 1.08;
+            const double per_vol = 4.0 * ((double)npix * C[0]->rel_slots + (double)lr_pad_floats()) * NDIR * 1.16;
             if (c->ws_limit)
                 while (chunk > 1 && per_vol * chunk > (double)c->ws_limit) chunk--;
             for (int v0 = 0; v0 < n;) {

@@ -182,6 +182,8 @@ bool make_geom(int pass, int nx, int ny, int R, int MGM, bool slope1_ok, PassGeo
     g.nstrips = 1;
     g.split = g.LL;
     g.hand_base = 0;
+    g.diag = 0;
+    g.wmax = 0;
     return true;
 }
 

@@ -32,6 +32,8 @@ struct PassGeom {
     int nstrips, split;   // 2: the lines of this pass are walked as two strips [0, split) and [split, LL) by two workgroups per band
                           // (k_pass2, TAGS, form 1 with 2 or 3 neighbours: no in-line dependency), both from the image edge inwards
     long long hand_base;  // self-validating hand-off slabs (k_pass2, TAGS): first slab of this pass within a volume's region
+    int diag, wmax;       // k_pass_rel only (round 6): 1 = the pass is walked along the ANTI-DIAGONALS of (i, j), all lines of a band at the
+                          // same step (form 1 with 2 or 3 neighbours: every neighbour sits on the line before); wmax: hand-off slots per line
 };
 
 // One launch of the pass kernel may aggregate several cost volumes of identical geometry (the
@@ -130,6 +132,7 @@ struct RelParams {
     int fh2;            // FH potentials, TSGM = 2, no weights: update_cost2_trunclinear with its boundary fix-up (k_pass_rel, FH2)
     int cost2;          // TSGM = 2 without weights, Hirschmueller: update_cost2's association (every term halved before the sum)
     int fh_multi;       // FH: the pixel's TSGM min-convolutions side by side (k_pass_rel<true, false, TSGM>) instead of one after the other
+    int diag_any;       // some pass of the launch walks anti-diagonals (g.diag): the workgroups carry a second hand ring
     float P1, P2;
     unsigned long long *tl;  // nullptr, or 8 words per work item (MGM_HIP_TIMELINE; tools/timeline.py): start, end, waited, slow paths, where, steps, polls
     PassGeom g[kMaxDirs];
@@ -143,6 +146,7 @@ hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, i
 int pass_rel_lines();
 int pass_rel_phases();  // words per work item of phase clocks behind the timeline words (0: not a -DMGM_REL_PHASES=1 build)
 int pass_rel_hand_floats(bool one_slab, int slots, bool fh2);
+size_t pass_rel_lds_bytes(bool one_slab, int slots, int cb, bool fh2, bool diag);
 struct WtaRelParams {
     const uint8_t *c8;
     const int *base;

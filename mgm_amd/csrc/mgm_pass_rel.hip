@@ -311,11 +311,14 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *ring = smem;                                    // [RR][RD4][HS]   what the lines of the band publish
     float *hring = ring + RR * RD4 * HS;                   // [SD][HS]        the previous band's last line, by pixel & (SD - 1)
-    int *mring = reinterpret_cast<int *>(hring + SD * HS);  // [SD][RR][4]    records of the step's pixels: base, lo, hi
+    float *hring2 = hring + SD * HS;                       // [SD][HS]        (launches with anti-diagonal passes only) its last line but one
+    int *mring = reinterpret_cast<int *>(hring2 + (P.diag_any ? SD * HS : 0));  // [SD][RR][4]    records of the step's pixels: base, lo, hi
     float *wring = reinterpret_cast<float *>(mring + SD * RR * 4);  // [SD][RR][4]   edge weights of the step's pixels
     uint8_t *cring = reinterpret_cast<uint8_t *>(wring + SD * RR * 4);  // [SD][RR][CBY] cost bytes of the step's pixels
     unsigned *hprog = reinterpret_cast<unsigned *>(cring + SD * RR * CBY);  // [4]   scratch of the loader's slow path (the error word)
     int *s_task = reinterpret_cast<int *>(hprog + 4);
+    constexpr int LTW = 24;           // words per line of ...
+    int *ltab = s_task + 4;           // [RR][LTW]  the geometry table of the band's lines (compute waves, below)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int r = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -332,7 +335,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     if (!P.weighted)  // unit weights: the ring holds ones, nothing is fetched
         for (int k = tid; k < SD * RR * 4; k += (NW + 1) * 64) wring[k] = 1.0f;
     if constexpr (GUARD)  // entries nobody has written yet read as "no such disparity" everywhere
-        for (int k = tid; k < (RR * RD4 + SD) * HS; k += (NW + 1) * 64) ring[k] = f_inf();
+        for (int k = tid; k < (RR * RD4 + (P.diag_any ? 2 : 1) * SD) * HS; k += (NW + 1) * 64) ring[k] = f_inf();
     __syncthreads();
     const int2 tk = P.tasks[*s_task];
     const int vp = tk.x, band = tk.y & 0xffff, strip = (tk.y >> 16) & 0xff;  // vp = volume*8 + pass
@@ -354,10 +357,26 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     const bool strips = g.nstrips == 2;
     const bool mirror = strips && strip == 1;
     const int slen = !strips ? LL : (strip == 0 ? g.split : LL - g.split);
-    const int W = !strips ? LL : min(LL, slen + RR - 1);  // pixels of the band's first line
-    const long long istep = mirror ? -g.istep : g.istep;
-    const long long gbase = mirror ? g.base + (long long)(LL - 1) * g.istep : g.base;
+    // ANTI-DIAGONALS (round 6; g.diag: form 1 with TSGM <= 3 again).  All three neighbours of such a pixel sit on the line before it --
+    // (i + 1, j - 1), (i - 1, j - 1), (i, j - 1) -- so the dependency depth of the pass is its number of LINES, and a walk along the lines
+    // (two steps of lag per line: 2 NL steps, whatever the strips) wastes it.  Here the walk runs ACROSS the lines: step u is line j = u, and
+    // the "lines" of the bands are the anti-diagonals d = i + j, on which the three neighbours become (u - 1, d), (u - 1, d - 2),
+    // (u - 1, d - 1): the previous step of the own diagonal and of the two before it.  Every diagonal of a band is at the same step
+    // (slope 0), a band needs the last TWO diagonals of the band before it one step earlier, and the chain of a pass is
+    // NL + bands x (1 + lag) steps instead of 2 NL + LL / 2 + bands x lag.  Diagonal d has its pixels at u in [max(0, d - LL + 1),
+    // min(NL - 1, d)]; the band walks the union of its diagonals' ranges, [dlo, dhi], in local steps i = u - dlo.
+    const bool diag = g.diag != 0;
+    const int NLd = diag ? NL + LL - 1 : NL;                                   // lines of the walk
+    const int dlo = diag ? max(0, band * RR - LL + 1) : 0;                     // first line j of the original pass this band touches
+    const int W = diag ? min(NL - 1, band * RR + RR - 1) - dlo + 1 : (!strips ? LL : min(LL, slen + RR - 1));  // pixels of the band's first line / steps of the band
+    const long long istep = diag ? g.jstep - g.istep : (mirror ? -g.istep : g.istep);  // along the walk
+    const long long lstep = diag ? g.istep : g.jstep;                                   // from line to line
+    const long long gbase = diag ? g.base + (long long)dlo * istep : (mirror ? g.base + (long long)(LL - 1) * g.istep : g.base);
     const int nsteps = (W + 1 + SL * (RR - 1) + 3) / 4 * 4;
+    // line l of the band is walked over local pixels [la(l), lb(l)]
+    auto la = [&](int l) { return diag ? max(0, min(band * RR + l, NLd - 1) - LL + 1) - dlo : 0; };
+    auto lb = [&](int l) { return diag ? min(NL - 1, min(band * RR + l, NLd - 1)) - dlo : W - 1; };
+    const int wmax = g.wmax;
 
     // SELF-VALIDATING hand-off slots, one per (volume, pass, band, pixel), written once per launch with the launch's tag in the
     // sign bit of every word (values, minimum and biased base are non-negative; the padding words carry the tag alone): the
@@ -365,8 +384,10 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     // counted waits on the writing side (the second build's protocol, mgm_pass2.hip TAGS).  With progress words a band ran
     // ~51 steps behind its predecessor where the geometry asks for 32: 120 bands x 19 steps of a 6600-step chain.
     const long long hslot0 = (long long)(vp / kMaxDirs) * P.hand_vstride + g.hand_base;
-    float *hand_out = P.hand + (hslot0 + (long long)band * LL) * HS;
-    const float *hand_in = P.hand + (hslot0 + (long long)(band > 0 ? band - 1 : 0) * LL) * HS;  // (band 0 issues the same DMAs, from its own slots)
+    // (anti-diagonals: two lines of wmax slots per band, by the band's local step)
+    const long long hper = diag ? 2LL * wmax : (long long)LL;
+    float *hand_out = P.hand + (hslot0 + (long long)band * hper) * HS;
+    const float *hand_in = P.hand + (hslot0 + (long long)(band > 0 ? band - 1 : 0) * hper) * HS;  // (band 0 issues the same DMAs, from its own slots)
     const unsigned tag = P.tag;
 
     if (r == NW) {
@@ -381,23 +402,30 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         const bool weighted = P.weighted != 0;
         // cost pieces: instruction n moves piece (lane + 64 n) % CPP of line (lane + 64 n) / CPP -- [line][piece] order in the ring
         const uint8_t *cptr[CI];
-        int ci[CI];
+        int ci[CI], ca[CI], cb[CI];  // (the pointer stands at pixel clamp(ci, ca, cb) of its line)
 #pragma unroll
         for (int n = 0; n < CI; n++) {
             const int cl = (lane + 64 * n) / CPP;
-            const int cj = min(band * RR + cl, NL - 1);
-            cptr[n] = V.c8 + (gbase + (long long)cj * g.jstep) * CBY + ((lane + 64 * n) % CPP) * 16;
+            const int cj = min(band * RR + cl, NLd - 1);
+            ca[n] = la(cl), cb[n] = lb(cl);
+            cptr[n] = V.c8 + (gbase + (long long)cj * lstep + (long long)ca[n] * istep) * CBY + ((lane + 64 * n) % CPP) * 16;
             ci[n] = -1 - SL * cl;
         }
         const int wl = lane >> 2;  // edge weights: lane 4 l + k has neighbour k of line l's pixel
-        const long long wpix0 = gbase + (long long)min(band * RR + wl, NL - 1) * g.jstep;
+        const int wa = la(wl), wb = lb(wl);
+        const long long wpix0 = gbase + (long long)min(band * RR + wl, NLd - 1) * lstep + (long long)wa * istep;
         const float *wptr = weighted ? V.w8 + (long long)g.wplane[lane & 3] * P.npix + wpix0 : nullptr;
         int wi = -1 - SL * wl;
         const int ml = lane < RR ? lane : RR - 1;
-        const int mj = min(band * RR + ml, NL - 1);
-        const int4 *mptr = reinterpret_cast<const int4 *>(V.base) + (gbase + (long long)mj * g.jstep);
+        const int mj = min(band * RR + ml, NLd - 1);
+        const int ma = la(ml), mb = lb(ml);
+        const int4 *mptr = reinterpret_cast<const int4 *>(V.base) + (gbase + (long long)mj * lstep + (long long)ma * istep);
         int mi = -1 - SL * ml;
-        const float *hptr = hand_in + (mirror ? (long long)(LL - 1) * HS : 0) + lane * 4;  // (local pixel 0)
+        // the previous band's slots of local pixel 0 (anti-diagonals: its local step of the same line j, dsh further on; first the last
+        // line but one, wmax slots on the last)
+        const int dsh = diag ? dlo - max(0, (band > 0 ? band - 1 : 0) * RR - LL + 1) : 0;
+        const int hlast = diag ? wmax - 1 - dsh : LL - 1;  // the last local pixel that has a slot
+        const float *hptr = hand_in + (mirror ? (long long)(LL - 1) * HS : (long long)dsh * HS) + lane * 4;  // (local pixel 0)
         const long long hstep = mirror ? -(long long)HS : (long long)HS;
         int ht = 0;
         bool dead = false;
@@ -407,35 +435,37 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
 #pragma unroll
             for (int n = 0; n < CI; n++) {
                 rel_dma16<0>(cptr[n], cring + slot * RR * CBY + n * 1024);
-                const bool adv = ci[n] >= 0 && ci[n] < W - 1;
+                const bool adv = ci[n] >= ca[n] && ci[n] < cb[n];
                 cptr[n] += adv ? istep * CBY : 0;
                 ci[n]++;
             }
             if (weighted) {
                 rel_dma4<0>(wptr, wring + slot * RR * 4);
-                const bool adv = wi >= 0 && wi < W - 1;
+                const bool adv = wi >= wa && wi < wb;
                 wptr += adv ? istep : 0;
                 wi++;
             }
             if (lane < RR) rel_dma16<0>(mptr, mring + slot * RR * 4);
             {
-                const bool adv = mi >= 0 && mi < W - 1;
+                const bool adv = mi >= ma && mi < mb;
                 mptr += adv ? istep : 0;
                 mi++;
             }
             // the previous band's slot of pixel ht, whatever it holds by now: validate() looks at it when its step comes
 #pragma unroll
             for (int n = 0; n < HI; n++)
-                if (lane + 64 * n < NPIECE) rel_dma16<REL_SC1>(hptr + 256 * n, hring + slot * HS + 256 * n);
-            hptr += (ht < LL - 1) ? hstep : 0;
+                if (lane + 64 * n < NPIECE) rel_dma16<REL_SC1>(hptr + (diag ? (long long)wmax * HS : 0) + 256 * n, hring + slot * HS + 256 * n);
+            if (diag)
+#pragma unroll
+                for (int n = 0; n < HI; n++)
+                    if (lane + 64 * n < NPIECE) rel_dma16<REL_SC1>(hptr + 256 * n, hring2 + slot * HS + 256 * n);
+            hptr += (ht < hlast) ? hstep : 0;
             ht++;
         };
         // The slot of pixel t has landed in the hand ring: make sure it is THIS launch's (every word's sign bit = the tag),
         // fetching it again until it is; then take the tags off (and the bias off the base) so that the compute waves read it like
         // any ring entry.
-        auto validate = [&](int t) {
-            if (!from_global || t >= LL || t > W || dead) return;  // (beyond local pixel W nobody of this item reads: the other strip's business)
-            float *ent = hring + (t & (SD - 1)) * HS;
+        auto validate_one = [&](float *ent, const float *slot) {
             rel_u4 v[HI];
             unsigned spins = 0;
             unsigned long long w0 = 0;
@@ -456,7 +486,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 __builtin_amdgcn_s_sleep(2);
 #pragma unroll
                 for (int n = 0; n < HI; n++)
-                    if (lane + 64 * n < NPIECE) rel_dma16<REL_SC1>(hand_in + (long long)(mirror ? LL - 1 - t : t) * HS + (lane + 64 * n) * 4, ent + 256 * n);
+                    if (lane + 64 * n < NPIECE) rel_dma16<REL_SC1>(slot + (lane + 64 * n) * 4, ent + 256 * n);
                 rel_wait_vmcnt<0>();
                 if (((++spins) & 255u) == 0) {
                     if (lane == 0) rel_dma4<REL_SC1>(P.err, hprog);
@@ -478,14 +508,31 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                     rel_lds_write128_opaque(ent + (lane + 64 * n) * 4, v[n]);
                 }
         };
+        auto validate = [&](int t) {
+            if (!from_global || dead) return;
+            if (!diag) {
+                if (t >= LL || t > W) return;  // (beyond local pixel W nobody of this item reads: the other strip's business)
+                validate_one(hring + (t & (SD - 1)) * HS, hand_in + (long long)(mirror ? LL - 1 - t : t) * HS);
+            } else {
+                if (t >= W) return;
+                const int u = dlo + t;  // the slots of line j = u: written where the previous band's last two diagonals have a pixel there
+#pragma unroll
+                for (int which = 1; which >= 0; which--) {
+                    const int dp = (band - 1) * RR + RR - 2 + which;
+                    if (u >= max(0, dp - LL + 1) && u <= min(NL - 1, dp) && !dead)
+                        validate_one((which ? hring : hring2) + (t & (SD - 1)) * HS, hand_in + ((long long)which * wmax + t + dsh) * HS);
+                }
+            }
+        };
         const int LD = P.ld;  // steps of DMA in flight (2 .. 5: the rings have SD = 8 slots, three of them being read)
         auto retire = [&]() {  // all but the newest LD - 1 steps of DMA have landed
-            const int n = (CI + 1 + HI + (weighted ? 1 : 0)) * (LD - 1);  // (3 .. 8 instructions per step, 1 .. 4 steps)
+            const int n = (CI + 1 + (diag ? 2 * HI : HI) + (weighted ? 1 : 0)) * (LD - 1);  // (3 .. 14 instructions per step, 1 .. 4 steps)
             switch (n) {
 #define MGM_REL_W(k) case k: rel_wait_vmcnt<k>(); break;
-                MGM_REL_W(3) MGM_REL_W(4) MGM_REL_W(5) MGM_REL_W(6) MGM_REL_W(7) MGM_REL_W(8) MGM_REL_W(9) MGM_REL_W(10) MGM_REL_W(11) MGM_REL_W(12) MGM_REL_W(14)
-                MGM_REL_W(15) MGM_REL_W(16) MGM_REL_W(18) MGM_REL_W(20) MGM_REL_W(21) MGM_REL_W(22) MGM_REL_W(24) MGM_REL_W(27) MGM_REL_W(28) MGM_REL_W(30)
-                MGM_REL_W(32) MGM_REL_W(33) MGM_REL_W(36) MGM_REL_W(40) MGM_REL_W(44) MGM_REL_W(48)
+#define MGM_REL_W4(k) MGM_REL_W(k) MGM_REL_W(k + 1) MGM_REL_W(k + 2) MGM_REL_W(k + 3)
+                MGM_REL_W(3) MGM_REL_W4(4) MGM_REL_W4(8) MGM_REL_W4(12) MGM_REL_W4(16) MGM_REL_W4(20) MGM_REL_W4(24) MGM_REL_W4(28) MGM_REL_W4(32) MGM_REL_W4(36)
+                MGM_REL_W4(40) MGM_REL_W4(44) MGM_REL_W4(48) MGM_REL_W4(52) MGM_REL_W(56)
+#undef MGM_REL_W4
 #undef MGM_REL_W
             default: rel_wait_vmcnt<0>(); break;  // (a count not listed: wait for everything -- correct, only slower)
             }
@@ -532,22 +579,62 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     const int grp = lane >> 4, li = lane & 15;  // the lane's line within the wave; its label slots are SPL li .. SPL li + SPL - 1
     const int ln = GL * r + grp;                // line within the band = ring row
     const int j = band * RR + ln;
-    const bool line_ok = j < NL;
+    const bool line_ok = j < NLd;
     const bool has_prev = line_ok && (j >= 1);
     const bool to_global = (r == NW - 1) && (band + 1 < g.nbands);  // (the wave that holds the band's last line)
     const int prow = ln > 0 ? ln - 1 : RR;  // ring row of the line before this one
+    const int prow2 = ln > 1 ? ln - 2 : RR + 1 - ln;  // ... and of the one before that (anti-diagonals; RR + 1: the second hand ring)
     float *__restrict__ Lrb = V.Lr + (long long)(pass - P.pass0) * P.nvol;
-    const long long pix0 = gbase + (long long)(line_ok ? j : 0) * g.jstep;
-    const int Wl = !strips ? LL : min(LL, slen + RR - 1 - ln);  // this line is walked over [0, Wl)
+    const long long pix0 = gbase + (long long)(line_ok ? j : 0) * lstep;
+    // Everything the walk's geometry decides -- line walk or anti-diagonals, the pass's form, a mirrored strip -- is settled HERE, per LINE,
+    // in a small LDS table the step loop reads the same way whatever the geometry:
+    //   the line's pixels [Wa, Wb]; those among them that take neighbours [Ia, Ib] (mgm_core.cc:538-541: not on the image's border);
+    //   neighbour k's ring row (its first entry + the mask of its ring) and its step relative to this pixel's.
+    // (The first anti-diagonal build selected at every step: 15 more live scalar registers, spilled, x 4 13.0 -> 17.1 ms with the switch off;
+    // the second kept these in registers per lane: 100 instead of 92, four waves per SIMD instead of five, and the third workgroup of a
+    // CU often found no room -- 14.3 ms; forcing 96 registers spilled the Lr pointer: a scratch reload + vmcnt(0) behind every step's
+    // stores.  A read of 16 bytes per use instead: the values are dead again before the convolutions need the registers.)
+    const int Wa = la(ln);
+    const int Wl = diag ? lb(ln) + 1 : (!strips ? LL : min(LL, slen + RR - 1 - ln));
+    const int Wb = line_ok ? Wl - 1 : Wa - 1;
+    const int i0d = j - dlo;  // anti-diagonals: the pixel's place on its line of the original pass is i0d - i, its line dlo + i
+    const int Ia = diag ? max(Wa, max(1 - dlo, i0d - LL + 2)) : 1;
+    const int Ib = diag ? min(Wb, i0d - 1) : (has_prev ? min(Wb, LL - 2) : 0);
     const bool f0 = form == 0;
-
-    // slab(s) `row`/`pixel n` as the pixel with base bp sees them: the same disparities, +INF (PUBE: FAR) where n has no slot
-    // for them.  ok = false (a pixel that takes no neighbours, a lane group without a pixel): nothing is believed of the ring.
-    auto entry = [&](int row, int n) -> const float * {
-        return row == RR ? hring + (n & (SD - 1)) * HS : ring + (row * RD4 + (n & (RD4 - 1))) * HS;
+    int *const lt = ltab + ln * LTW;
+    if (li == 0) *reinterpret_cast<int4 *>(lt) = make_int4(Wa, Wb, Ia, Ib);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        // form 0: the pixel before on this line, then the line before at i, i - 1, i + 1; form 1: the same four the other way round (mgm_core.cc:520-575);
+        // a mirrored strip: the fwd neighbour i + 1 is local i' - 1; anti-diagonals: fwd, back, same = the previous step of this line, of the
+        // line two before, of the line before
+        const bool own = f0 ? k == 0 : k == 3;
+        const int di0 = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
+        const int row = diag ? (k == 0 ? ln : (k == 1 ? prow2 : prow)) : (own ? ln : prow);
+        const int nstep = (diag || own) ? -1 : (mirror ? -di0 : di0);
+        const int nent = (int)((row >= RR ? (row == RR ? hring : hring2) : ring + row * RD4 * HS) - smem);
+        if (li == 0) *reinterpret_cast<int4 *>(lt + 4 + 4 * k) = make_int4(nent, row >= RR ? SD - 1 : RD4 - 1, nstep, 0);
+    }
+    // slab(s) of neighbour k as the pixel with base bp sees them: the same disparities, +INF (PUBE: FAR) where the neighbour has no slot for them
+    // (read at the END of a step for the next one -- behind the convolutions, ahead of the barrier's wait: no register of it is live while
+    // the convolutions run, and no step begins with a round trip to LDS: x 1 7.3 -> 6.7 ms against reading at the step's head)
+    constexpr int NKK = NK > 0 ? NK : 4;
+    int4 lr, nt[NKK];
+    auto read_table = [&]() {
+        asm volatile("" ::: "memory");  // (the table must not come back as loop-invariant registers)
+        lr = *reinterpret_cast<const int4 *>(lt);  // Wa, Wb, Ia, Ib
+#pragma unroll
+        for (int k = 0; k < NKK; k++) nt[k] = *reinterpret_cast<const int4 *>(lt + 4 + 4 * k);
     };
+    auto entry = [&](int k, int i) -> const float * { return smem + nt[k].x + ((i + nt[k].z) & nt[k].y) * HS; };
+    // the hand-off to the next band: the lanes that hold its source lines (the band's last line; anti-diagonals: its last two), slot of local pixel 0, stride
+    // (these two stay in registers: the band's last wave needs them behind its convolutions, where a table read would be a round trip)
+    const bool pubs = to_global && (diag ? grp >= GL - 2 : grp == GL - 1);
+    const int hpub0 = (diag ? (grp - (GL - 2)) * wmax : (mirror ? LL - 1 : 0)) * HS;  // (floats: < 2^31, the host checks)
+    const int hpubs = mirror ? -HS : HS;
 
     lds_barrier();  // B0: the loader's first step has landed
+    read_table();
     unsigned long long cph[3] = {0, 0, 0}, nsweeps = 0;
     (void)cph;
     (void)nsweeps;
@@ -555,7 +642,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         const unsigned long long c0 = MGM_REL_PHASES ? clock64() : 0;
         unsigned long long c1 = c0;
         const int i = s - 1 - SL * ln;
-        const bool act = line_ok && i >= 0 && i < Wl;
+        const bool act = i >= lr.x && i <= lr.y;
         if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
             const long long pix = pix0 + (long long)(act ? i : 0) * istep;
             const int sl = s & (SD - 1);
@@ -572,7 +659,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                     Cv[q] = CB == 1 ? c8_decode((cw[q / 4] >> (8 * (q % 4))) & 255u)
                                     : (CB == 2 ? c16_decode((cw[q / 2] >> (16 * (q % 2))) & 65535u) : __builtin_bit_cast(float, cw[q * CB / 4]));
             }
-            const bool interior = act && has_prev && i >= 1 && i <= LL - 2;  // mgm_core.cc:538-541
+            const bool interior = i >= lr.z && i <= lr.w;  // mgm_core.cc:538-541
             const float4 w4 = *reinterpret_cast<const float4 *>(wring + (sl * RR + ln) * 4);
             const float D[4] = {w4.x, w4.y, w4.z, w4.w};
             const int rl = rec.y - bp, rh = rec.z - bp;  // the pixel's own range, in slots
@@ -586,10 +673,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 float Mk[NK][SPL], mk[NK], p1k[NK], p2k[NK];
 #pragma unroll
                 for (int k = 0; k < NK; k++) {
-                    const bool own = f0 ? k == 0 : k == 3;
-                    const int di0 = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
-                    const int di = mirror ? -di0 : di0;  // (mirrored strip: the fwd neighbour i + 1 is local i' - 1)
-                    const float *src = entry(own ? ln : prow, own ? i - 1 : i + di);
+                    const float *src = entry(k, i);
                     const relf4 hdr = *reinterpret_cast<const relf4 *>(src + HOFF);  // (minimum, base, highest slot, -): one unconditional 16-byte read
                     const float hmin = hdr.x, hbase = hdr.y, hhi = hdr.z;  // (scalars first: __builtin_bit_cast of the vector ELEMENT hdr[1] read element 0)
                     mk[k] = interior ? hmin : 0.0f;
@@ -641,10 +725,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (k < MGM) {
-                    const bool own = f0 ? k == 0 : k == 3;
-                    const int di0 = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
-                    const int di = mirror ? -di0 : di0;
-                    const float *src = entry(own ? ln : prow, own ? i - 1 : i + di);
+                    const float *src = entry(k, i);
                     const float m = interior ? src[HOFF] : 0.0f;                                   // minimum (or FAR)
                     const int sh = bp - reinterpret_cast<const int *>(src)[HOFF + 1];              // base
                     float w[NS][SPL];
@@ -697,6 +778,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 asm volatile("" : "+v"(Lv[0]), "+v"(Lv[1]), "+v"(Lv[2]), "+v"(Lv[3]));
                 c1 = clock64();
             }
+            read_table();  // (for the next step: the convolutions are over, the stores and the publication below cover the reads)
             if (act)
 #pragma unroll
                 for (int h = 0; h < SPL / 4; h++)
@@ -752,11 +834,11 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
                 }
             }
             if (to_global) {
-                const int iL = s - 1 - SL * (RR - 1);  // the band's last line: lane group GL - 1 of this wave
-                if (iL >= 0 && iL < min(LL, slen)) {  // (strips: the band's last line covers exactly its strip -- no slot is written twice)
+                // (strips: the band's last line covers exactly its strip -- no slot is written twice; anti-diagonals: the last TWO lines, each where it has a pixel)
+                if (__builtin_amdgcn_ballot_w64(pubs && act) != 0ull) {
                     // the hand-off to the next band: write-through 16-byte stores straight from the registers, every word tagged
-                    float *dstg = hand_out + (long long)(mirror ? LL - 1 - iL : iL) * HS;
-                    if (grp == GL - 1) {
+                    float *dstg = hand_out + (hpub0 + i * hpubs);
+                    if (pubs && act) {
                         auto tagged = [&](relf4 x) {
                             rel_u4 u = __builtin_bit_cast(rel_u4, x);
                             u.x |= tag, u.y |= tag, u.z |= tag, u.w |= tag;
@@ -804,7 +886,7 @@ static hipError_t launch_rel_one(const RelParams &p, int ntasks, int wg_per_cu, 
     constexpr int NS = (FH || PUBE) ? 1 : 2;
     constexpr int SLOTS = 16 * SPL;
     constexpr int HS = (FH2 ? 3 * SLOTS + 2 * SPL : (NS == 1 ? SLOTS + 2 * SPL : NS * SLOTS)) + 4;
-    size_t shmem = sizeof(float) * ((size_t)RR * RD4 * HS + (size_t)SD * HS + 2 * SD * RR * 4) + (size_t)SD * RR * SLOTS * CB + sizeof(unsigned) * (SD + 4) + 16;
+    size_t shmem = sizeof(float) * ((size_t)RR * RD4 * HS + (size_t)(p.diag_any ? 2 : 1) * SD * HS + 2 * SD * RR * 4) + (size_t)SD * RR * SLOTS * CB + sizeof(unsigned) * (SD + 4) + 16 + sizeof(int) * RR * 24;
     // Occupancy through the LDS request, as for the second build: wg_per_cu workgroups (of 4 compute waves: one per SIMD) share a
     // CU -- one for a launch bound by its chains of bands, more for a batch (throughput)
     if (wg_per_cu >= 1) {
@@ -849,6 +931,12 @@ hipError_t launch_pass_rel(const RelParams &p, int ntasks, bool fh, bool pube, i
 int pass_rel_lines() { return RR; }
 int pass_rel_phases() { return MGM_REL_PHASES ? 16 : 0; }
 // (one slab: a lane's worth of guard words + the values + another guard + the header's 4; fh2: + the forward and backward passes)
+// LDS bytes of a workgroup (launch_rel_one's request): with anti-diagonal passes a second hand ring -- the host asks before it plans them
+size_t pass_rel_lds_bytes(bool one_slab, int slots, int cb, bool fh2, bool diag)
+{
+    const size_t HS = (size_t)pass_rel_hand_floats(one_slab, slots, fh2);
+    return sizeof(float) * ((size_t)RR * RD4 * HS + (size_t)(diag ? 2 : 1) * SD * HS + 2 * SD * RR * 4) + (size_t)SD * RR * slots * cb + sizeof(unsigned) * (SD + 4) + 16 + sizeof(int) * RR * 24;
+}
 int pass_rel_hand_floats(bool one_slab, int slots, bool fh2) { return (fh2 ? 3 * slots + 2 * (slots / 16) : (one_slab ? slots + 2 * (slots / 16) : 2 * slots)) + 4; }
 
 }  // namespace mgm

@@ -123,6 +123,13 @@ int weights_have_odd_values(mgm_ctx *c, const mgm_img *const *w8s, int nb, long 
 struct SimChain {
     int x, st, nb, sib, chain;
     double skew, len;
+    // bands that differ (the anti-diagonal passes of k_pass_rel): band b is ready bskew[b] steps after band b-1 started, runs blen[b]
+    // steps, and brem[b] steps of the chain remain behind its start; empty: skew / len for every band
+    std::vector<double> bskew, blen, brem;
+    double skew_of(int b) const { return bskew.empty() ? skew : bskew[b]; }
+    double len_of(int b) const { return blen.empty() ? len : blen[b]; }
+    double rem_of(int b) const { return brem.empty() ? (double)(nb - 1 - b) * skew + len : brem[b]; }
+    double gap_of(int b) const { return bskew.empty() ? skew : std::min(bskew[b], 4.0); }  // (a band cannot end before its predecessor + this)
 };
 static double simulate_schedule(const std::vector<SimChain> &chains, int nqueues, int slots, int QK, std::vector<int2> &order)
 {
@@ -163,10 +170,10 @@ static double simulate_schedule(const std::vector<SimChain> &chains, int nqueues
             }
             double ready = 0.0;
             if (b > 0) {
-                ready = start[i][b - 1] + k.skew;
+                ready = start[i][b - 1] + k.skew_of(b);
                 if (k.sib >= 0) ready = next[k.sib] > b - 1 ? std::max(ready, start[k.sib][b - 1] + k.skew) : INF;
             }
-            const double rem = (double)(k.nb - 1 - b) * k.skew + k.len;
+            const double rem = k.rem_of(b);
             const bool is_ready = ready <= t;
             const bool better = best < 0 || (is_ready != best_is_ready ? is_ready : (is_ready ? rem > best_rem : (ready != best_ready ? ready < best_ready : rem > best_rem)));
             if (better) best = i, best_rem = rem, best_ready = ready, best_is_ready = is_ready;
@@ -183,8 +190,8 @@ static double simulate_schedule(const std::vector<SimChain> &chains, int nqueues
         const SimChain &k = chains[best];
         const int b = next[best]++;
         const double st_eff = std::max(t, best_ready);
-        double en = st_eff + k.len;
-        if (b > 0) en = std::max(en, end[best][b - 1] + k.skew);  // (it cannot overtake its predecessor)
+        double en = st_eff + k.len_of(b);
+        if (b > 0) en = std::max(en, end[best][b - 1] + k.gap_of(b));  // (it cannot overtake its predecessor)
         start[best][b] = st_eff;
         end[best][b] = en;
         makespan = std::max(makespan, en);
@@ -1150,10 +1157,22 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
         // (round 6) two strips per line for the form-1 passes: no pixel of those passes depends on its own line with TSGM <= 3, so the
         // two halves of a band's lines are two work items (k_pass_rel).  Measured, 1920x1080, windows of 49 labels: FH x 1 8.91 -> 8.12 ms,
         // x 4 13.33 -> 12.89; Hirschmueller x 1 6.13 -> 5.53 (tune rel_strips=0: none)
-        if (tune_num("rel_strips", 1) != 0 && p.g[q].form == 1 && MGM <= 3 && p.g[q].LL >= 8 * R) {
+        // (round 6, later) ... and better: those passes ACROSS their lines, bands of anti-diagonals in lock step (k_pass_rel, g.diag) -- the
+        // chain of a pass is NL + bands x lag steps instead of 2 NL + LL / 2 + bands x lag.  Two hand-off lines per band and a second hand
+        // ring in LDS: where that does not fit (the three-slab entries of 128 slots with two-byte costs) the strips stay.  tune rel_diag=0: strips
+        const bool diag_ok = tune_num("rel_diag", 1) != 0 && p.g[q].form == 1 && MGM <= 3 && pass_rel_lds_bytes(fh || pube, slots, rcb, fh2, true) <= (size_t)160 * 1024;
+        if (diag_ok) {
+            PassGeom &g = p.g[q];
+            g.diag = 1;
+            g.slope = 0;
+            g.nbands = (g.NL + g.LL - 1 + R - 1) / R;
+            g.wmax = std::min(g.NL, g.LL + R);
+            p.diag_any = 1;
+        } else if (tune_num("rel_strips", 1) != 0 && p.g[q].form == 1 && MGM <= 3 && p.g[q].LL >= 8 * R) {
             p.g[q].nstrips = 2;
             p.g[q].split = p.g[q].LL / 2;
         }
+        maxbands = std::max(maxbands, p.g[q].nbands);
     }
     if (maxbands > kMaxBands) return fail(c, MGM_ERR_UNSUPPORTED, "image side exceeds 65536 pixels");
     const long long stride = npix * slots + lr_pad_floats();
@@ -1163,7 +1182,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     long long per_vol = 0;
     for (int q = 0; q < NDIR; q++) {
         p.g[q].hand_base = per_vol;
-        per_vol += (long long)p.g[q].nbands * p.g[q].LL;
+        per_vol += (long long)p.g[q].nbands * (p.g[q].diag ? 2LL * p.g[q].wmax : (long long)p.g[q].LL);
     }
     p.hand_vstride = per_vol;
     std::string tag_key;
@@ -1172,7 +1191,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
         const void *before = c->hand_rel.p;
         if ((r = reserve(c, c->hand_rel, bytes))) return r;
         char hk[128];
-        snprintf(hk, sizeof hk, "%d %d %d %d %d %d %d", nx, ny, NDIR, nb, HS, R, slots);
+        snprintf(hk, sizeof hk, "%d %d %d %d %d %d %d %d", nx, ny, NDIR, nb, HS, R, slots, p.diag_any);
         if (c->hand_rel.p != before || c->hand_rel_key != hk) {
             HIPCHK(c, hipMemsetAsync(c->hand_rel.p, 0xff, bytes, c->stream));
             c->hand_rel_key = hk;
@@ -1191,8 +1210,10 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     const long long wgs = tune_num("rel_wg", 0);
     // (measured, round 6, 1920x1080 windows of 49 labels, FH with the side-by-side convolutions: x 1 7.87 / 8.20 / 8.53 ms at 1 / 2 / 3 per CU,
     // x 2 13.0 / 8.6 / 9.6, x 4 24.3 / 14.1 / 12.9; Hirschmueller the same order)
-    const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 1 ? (fh ? 1 : 2) : (nb <= 2 ? 2 : 3));
-    snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d", nx, ny, NDIR, nb, rel_wg, p.g[0].slope, MGM, p.g[NDIR - 1].nstrips);
+    // (with the anti-diagonal passes a single launch is no longer one long chain: x 1 6.89 / 6.32 / 6.47 ms at 1 / 2 / 3, x 2 11.5 / 7.82 / 7.76,
+    // x 4 22.0 / 13.0 / 12.3; Hirschmueller x 1 5.45 / 4.62 / 4.36)
+    const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 1 ? (fh ? 2 : 3) : 3);
+    snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d %d", nx, ny, NDIR, nb, rel_wg, p.g[0].slope, MGM, p.g[NDIR - 1].nstrips, p.diag_any);
     if (c->tasks_rel_key != key) {
         std::vector<SimChain> ch;
         for (int v = 0; v < nb; v++)
@@ -1204,6 +1225,16 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
                     k.sib = g.nstrips == 2 ? (int)ch.size() + (st == 0 ? 1 : -1) : -1;  // (a band waits for BOTH strips of the band before it)
                     k.skew = (double)g.slope * R + 4.0;  // (slope of the lock-step diagonal x lines; loader lead + one fetch: ~4 steps of lag)
                     k.len = (g.nstrips == 2 ? (st == 0 ? g.split : g.LL - g.split) + R - 1 : g.LL) + (double)g.slope * (R - 1) + 1.0;
+                    if (g.diag) {  // band b walks lines [lo_b, hi_b] of the pass, one step behind band b - 1 (+ the lag)
+                        auto lo = [&](int b) { return std::max(0, b * R - g.LL + 1); };
+                        auto hi = [&](int b) { return std::min(g.NL - 1, b * R + R - 1); };
+                        k.bskew.assign(g.nbands, 0.0), k.blen.assign(g.nbands, 0.0), k.brem.assign(g.nbands, 0.0);
+                        for (int b = 0; b < g.nbands; b++) {
+                            k.bskew[b] = b > 0 ? (double)(lo(b) - lo(b - 1)) + 4.0 : 0.0;
+                            k.blen[b] = (double)(hi(b) - lo(b)) + 2.0;
+                        }
+                        for (int b = g.nbands - 1; b >= 0; b--) k.brem[b] = b == g.nbands - 1 ? k.blen[b] : std::max(k.blen[b], k.bskew[b + 1] + k.brem[b + 1]);
+                    }
                     ch.push_back(k);
                 }
         std::vector<int2> order;
@@ -1242,8 +1273,8 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     p.weighted = weighted ? 1 : 0;
     p.P1 = P1;
     p.P2 = P2;
-    // a launch bound by its chains of bands wants a short lead (lag per band); a batch has the slack and wants the loads covered
-    p.ld = (int)std::min(5LL, std::max(2LL, tune_num("rel_ld", nb <= 1 ? 2 : 3)));
+    // the loader's lead: every step of it is a step of lag per band (round 5: 3 for batches; with the anti-diagonal passes 2 is as good there)
+    p.ld = (int)std::min(5LL, std::max(2LL, tune_num("rel_ld", 2)));  // (2 against 3: x 2 7.76 / 7.81 ms, x 4 12.30 / 12.39)
     p.fh_multi = tune_num("rel_multi", 1) != 0 ? 1 : 0;
     p.cost2 = (pube && MGM == 2) ? 1 : 0;
     p.fh2 = fh2 ? 1 : 0;
