@@ -339,6 +339,8 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     __syncthreads();
     const int2 tk = P.tasks[*s_task];
     const int vp = tk.x, band = tk.y & 0xffff, strip = (tk.y >> 16) & 0xff;  // vp = volume*8 + pass
+    // the bands of the launch's LONGEST chains issue first where two workgroups share a SIMD (the host marks them: run_rel)
+    if ((tk.y >> 24) & 1) __builtin_amdgcn_s_setprio(2);
     const int pass = vp & (kMaxDirs - 1);
     const RelVolume &V = P.vol[vp / kMaxDirs];
     const PassGeom &g = P.g[pass];
@@ -537,10 +539,14 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             default: rel_wait_vmcnt<0>(); break;  // (a count not listed: wait for everything -- correct, only slower)
             }
         };
+        // Step s + 1 reads, of the previous band's line(s), the slots of local pixels <= s + 1 where the walk reads the fwd neighbour
+        // (slope 2), <= s where it does not (slope 1), <= s - 1 on the anti-diagonals (every neighbour one step back): the slot made sure of
+        // during step s is s + vlead -- each one less is a step less of distance between a band and the band before it
+        const int vlead = diag ? -1 : (SL == 1 ? 0 : 1);
 #pragma unroll 1
         for (int u = 0; u < LD; u++) issue();
         retire();
-        validate(0);
+        if (vlead > 0) validate(0);
         lds_barrier();  // B0
         unsigned long long lph[3] = {0, 0, 0};
         (void)lph;
@@ -550,7 +556,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
             issue();   // step s + LD
             const unsigned long long l1 = MGM_REL_PHASES ? clock64() : 0;
             retire();  // step s + 1 is in the rings
-            validate(s + 1);
+            if (s + vlead >= 0) validate(s + vlead);
             const unsigned long long l2 = MGM_REL_PHASES ? clock64() : 0;
             lds_barrier();
             if constexpr (MGM_REL_PHASES != 0) {
