@@ -16,5 +16,5 @@ done
 MGM_FUZZ_N=1500 MGM_FUZZ_BASE=20000 timeout 1500 python -m pytest tests/test_gpu_rel.py -q -k "random" 2>&1 | tail -n 3 > $O/fuzz_rel.log; cat $O/fuzz_rel.log
 # ... and both ragged paths against the ragged ORACLE over everything the widened layout takes (cost forms, widths, update functions, weights)
 MGM_FUZZ_N=4000 MGM_FUZZ_BASE=40000 timeout 1500 python -m pytest tests/test_gpu_ragged_oracle.py -q -k "random" 2>&1 | tail -n 3 > $O/fuzz_ragged_oracle.log; cat $O/fuzz_ragged_oracle.log
-tools/rel_phases_run.sh rel_multi=1 rel_multi=0 > $O/rel_phases.txt 2>&1
+tools/rel_phases_run.sh rel_diag=1 rel_diag=0 > $O/rel_phases.txt 2>&1
 head -40 $O/rel_phases.txt
