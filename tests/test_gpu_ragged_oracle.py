@@ -115,6 +115,16 @@ SMALL = [
     ("t2_fh_colour_ad", 80, 36, -60, 0, ("win", 9, 13, 4), 1, 2, 4, 6.0, 90.0, None, "vfit", 1, True, "ad", 3),
     ("t2_fh_ones_as_weights", 64, 33, -60, 0, ("win", 10, 12, 3), 1, 2, 8, 2.0, 30.0, "ones", "vfit", 1, True),
     ("t2_fh_image_weights", 61, 44, -100, 0, ("jumpy", 11), 1, 2, 4, 2.0, 30.0, "image", "vfit", 1, True),  # update_costW_trunclinear, two neighbours
+    # shapes at the corners of the anti-diagonal walk of the form-1 passes (bands of diagonals that start late, end early, or hold one pixel)
+    ("three_rows_fh", 90, 3, -40, 0, ("win", 8, 10, 2), 1, 3, 8, 2.0, 30.0, None, "vfit", 1, True),
+    ("three_columns_hirsch", 3, 70, -40, 0, ("win", 8, 10, 2), 0, 3, 8, 8.0, 32.0, None, None, 1, True),
+    ("one_row", 50, 1, -40, 0, ("win", 8, 10, 2), 1, 3, 8, 2.0, 30.0, None, None, 0, True),
+    ("one_column", 1, 50, -40, 0, ("win", 8, 10, 2), 0, 2, 8, 8.0, 32.0, None, None, 0, True),
+    ("square_16", 16, 16, -40, 0, ("win", 8, 10, 2), 1, 3, 8, 2.0, 30.0, "image", "vfit", 1, True),
+    ("square_17_t2_fh", 17, 17, -40, 0, ("win", 8, 10, 2), 1, 2, 8, 2.0, 30.0, None, "cubic", 1, True),
+    ("tall_15x33_three_weights", 15, 33, -40, 0, ("jumpy", 12), 1, 3, 8, 2.0, 30.0, "three", "vfit", 1, True),
+    ("wide_33x15_t1", 33, 15, -40, 0, ("jumpy", 12), 0, 1, 8, 8.0, 32.0, None, "parabola", 0, True),
+    ("wide_128_slots_49x31", 49, 31, -200, 10, ("exact", 100), 1, 3, 8, 2.0, 40.0, None, "vfit", 1, True),
 ]
 
 
