@@ -17,7 +17,8 @@
 // (mgm_core.cc:242-271: M[] is copied over [Lp.min, Lp.max]): combine_wfh masks to it.  Same neighbours, same operands,
 // same order as the dense kernels on the hull => the same bits on every label that exists.
 //
-// Structure: bands of 16 scan lines per workgroup in lock-step on the slope-2 diagonal -- 4 compute waves of FOUR lines each
+// Structure: bands of 16 scan lines per workgroup in lock-step on the slope-2 diagonal (round 6: slope 1 where the fwd neighbour is not read;
+// the form-1 passes with TSGM <= 3 ACROSS their lines, bands of 16 anti-diagonals all at the same step: see `diag` in k_pass_rel) -- 4 compute waves of FOUR lines each
 // (a pixel's 64 slots on a row of 16 lanes, 4 per lane: see k_pass_rel) + a loader wave that feeds LDS rings by LDS-DMA --, a
 // 4-deep LDS ring per line (a slab is read by the next line at three consecutive steps, each time at another shift), the band
 // hand-off through global memory in self-validating slots (the launch's tag in every word's sign bit), work items by atomic ticket.  Not built here (the dense path keeps them): FH with TSGM = 2 without weights
