@@ -125,6 +125,9 @@ SMALL = [
     ("tall_15x33_three_weights", 15, 33, -40, 0, ("jumpy", 12), 1, 3, 8, 2.0, 30.0, "three", "vfit", 1, True),
     ("wide_33x15_t1", 33, 15, -40, 0, ("jumpy", 12), 0, 1, 8, 8.0, 32.0, None, "parabola", 0, True),
     ("wide_128_slots_49x31", 49, 31, -200, 10, ("exact", 100), 1, 3, 8, 2.0, 40.0, None, "vfit", 1, True),
+    # ... and many bands of anti-diagonals either way round (more lines than pixels per line, and the reverse)
+    ("portrait_300x700_fh", 300, 700, -60, 0, ("win", 10, 12, 3), 1, 3, 8, 2.0, 20000.0, None, "vfit", 1, True),
+    ("landscape_700x300_hirsch_weights", 700, 300, -60, 0, ("win", 10, 12, 3), 0, 3, 8, 8.0, 32.0, "image", None, 1, True),
 ]
 
 
