@@ -318,7 +318,7 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     uint8_t *cring = reinterpret_cast<uint8_t *>(wring + SD * RR * 4);  // [SD][RR][CBY] cost bytes of the step's pixels
     unsigned *hprog = reinterpret_cast<unsigned *>(cring + SD * RR * CBY);  // [4]   scratch of the loader's slow path (the error word)
     int *s_task = reinterpret_cast<int *>(hprog + 4);
-    constexpr int LTW = 24;           // words per line of ...
+    constexpr int LTW = 24;           // words per line of the table below: 4 of ranges + 4 per neighbour (+ 4 spare)
     int *ltab = s_task + 4;           // [RR][LTW]  the geometry table of the band's lines (compute waves, below)
 
     const int tid = threadIdx.x, lane = tid & 63;
