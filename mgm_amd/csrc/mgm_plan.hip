@@ -1213,7 +1213,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     // (with the anti-diagonal passes a single launch is no longer one long chain: x 1 6.89 / 6.32 / 6.47 ms at 1 / 2 / 3, x 2 11.5 / 7.82 / 7.76,
     // x 4 22.0 / 13.0 / 12.3; Hirschmueller x 1 5.45 / 4.62 / 4.36)
     const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 1 ? (fh ? 2 : 3) : 3);
-    snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d %d %lld", nx, ny, NDIR, nb, rel_wg, p.g[0].slope, MGM, p.g[NDIR - 1].nstrips, p.diag_any, tune_num("rel_prio", nb <= 1 ? 5 : 0));
+    snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d %d %lld", nx, ny, NDIR, nb, rel_wg, p.g[0].slope, MGM, p.g[NDIR - 1].nstrips, p.diag_any, tune_num("rel_prio", nb <= 1 ? 5 : 0) + 1000 * tune_num("rel_lag", 0) + 100000 * tune_num("rel_lagd", 0) + 10000000 * tune_num("rel_slots", 100));
     if (c->tasks_rel_key != key) {
         std::vector<SimChain> ch;
         for (int v = 0; v < nb; v++)
@@ -1223,14 +1223,19 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
                     SimChain k;
                     k.x = v * kMaxDirs + q, k.st = st, k.nb = g.nbands, k.chain = v * NDIR + q;
                     k.sib = g.nstrips == 2 ? (int)ch.size() + (st == 0 ? 1 : -1) : -1;  // (a band waits for BOTH strips of the band before it)
-                    k.skew = (double)g.slope * R + (g.slope == 1 ? 3.0 : 4.0);  // (slope of the lock-step diagonal x lines; loader lead + one fetch: ~4 steps of lag)
+                    // (slope of the lock-step diagonal x lines + the lag the MODEL assumes per band.  The tickets are the start order of the
+                    // simulated schedule, so these constants decide who holds a band slot while it waits: with the hand-off's real ~4 steps on
+                    // every chain, the anti-diagonal bands -- ready every few steps -- took the first 400 of 512 slots and sat in them.  Measured
+                    // (tools/ab_rel_lag.sh): 1-2 steps on the line walks, 7 on the anti-diagonals: x 1 6.15 -> 5.72 ms, Hirschmueller x 2 5.42 -> 5.0,
+                    // windows of 101 labels 9.09 -> 8.5, four volumes unchanged; tune rel_lag / rel_lagd: added to them)
+                    k.skew = (double)g.slope * R + (g.slope == 1 ? 1.0 : 2.0) + (double)tune_num("rel_lag", 0);
                     k.len = (g.nstrips == 2 ? (st == 0 ? g.split : g.LL - g.split) + R - 1 : g.LL) + (double)g.slope * (R - 1) + 1.0;
                     if (g.diag) {  // band b walks lines [lo_b, hi_b] of the pass, one step behind band b - 1 (+ the lag)
                         auto lo = [&](int b) { return std::max(0, b * R - g.LL + 1); };
                         auto hi = [&](int b) { return std::min(g.NL - 1, b * R + R - 1); };
                         k.bskew.assign(g.nbands, 0.0), k.blen.assign(g.nbands, 0.0), k.brem.assign(g.nbands, 0.0);
                         for (int b = 0; b < g.nbands; b++) {
-                            k.bskew[b] = b > 0 ? (double)(lo(b) - lo(b - 1)) + 3.0 : 0.0;
+                            k.bskew[b] = b > 0 ? (double)(lo(b) - lo(b - 1)) + 7.0 + (double)tune_num("rel_lagd", 0) : 0.0;
                             k.blen[b] = (double)(hi(b) - lo(b)) + 2.0;
                         }
                         for (int b = g.nbands - 1; b >= 0; b--) k.brem[b] = b == g.nbands - 1 ? k.blen[b] : std::max(k.blen[b], k.bskew[b + 1] + k.brem[b + 1]);
@@ -1238,7 +1243,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
                     ch.push_back(k);
                 }
         std::vector<int2> order;
-        (void)simulate_schedule(ch, 1, std::max(1, c->num_cu * rel_wg), 1 << 20, order);
+        (void)simulate_schedule(ch, 1, std::max(1, (int)(c->num_cu * rel_wg * tune_num("rel_slots", 100) / 100)), 1 << 20, order);
         // workgroups that share a CU slow each other down (a step of 1.07 us becomes ~1.5): the bands of the longest chains -- what the
         // launch ends with -- get the issue priority (bit 24 of the task word; tune rel_prio=0: none, =100: every chain within x % of the longest)
         {
