@@ -184,6 +184,7 @@ bool make_geom(int pass, int nx, int ny, int R, int MGM, bool slope1_ok, PassGeo
     g.hand_base = 0;
     g.diag = 0;
     g.wmax = 0;
+    g.swap = 0;
     return true;
 }
 

@@ -32,6 +32,8 @@ struct PassGeom {
     int nstrips, split;   // 2: the lines of this pass are walked as two strips [0, split) and [split, LL) by two workgroups per band
                           // (k_pass2, TAGS, form 1 with 2 or 3 neighbours: no in-line dependency), both from the image edge inwards
     long long hand_base;  // self-validating hand-off slabs (k_pass2, TAGS): first slab of this pass within a volume's region
+    int swap;             // k_pass_rel only (round 6): a form-0 pass with 2 or 3 neighbours walked with the roles of i and j exchanged (NL, LL, istep,
+                          // jstep are the exchanged ones): the in-line neighbour and the one on the line before swap places, the third stays
     int diag, wmax;       // k_pass_rel only (round 6): 1 = the pass is walked along the ANTI-DIAGONALS of (i, j), all lines of a band at the
                           // same step (form 1 with 2 or 3 neighbours: every neighbour sits on the line before); wmax: hand-off slots per line
 };

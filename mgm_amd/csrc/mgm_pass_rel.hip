@@ -605,8 +605,10 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
     const int Wl = diag ? lb(ln) + 1 : (!strips ? LL : min(LL, slen + RR - 1 - ln));
     const int Wb = line_ok ? Wl - 1 : Wa - 1;
     const int i0d = j - dlo;  // anti-diagonals: the pixel's place on its line of the original pass is i0d - i, its line dlo + i
+    // (g.swap: the roles of i and j exchanged -- the pixels that take neighbours are those of the lines 1 .. NL - 2 from pixel 1 on)
+    const bool swp = g.swap != 0;
     const int Ia = diag ? max(Wa, max(1 - dlo, i0d - LL + 2)) : 1;
-    const int Ib = diag ? min(Wb, i0d - 1) : (has_prev ? min(Wb, LL - 2) : 0);
+    const int Ib = diag ? min(Wb, i0d - 1) : (swp ? ((has_prev && j <= NL - 2) ? Wb : 0) : (has_prev ? min(Wb, LL - 2) : 0));
     const bool f0 = form == 0;
     int *const lt = ltab + ln * LTW;
     if (li == 0) *reinterpret_cast<int4 *>(lt) = make_int4(Wa, Wb, Ia, Ib);
@@ -617,8 +619,10 @@ __global__ void __launch_bounds__((NW + 1) * 64) k_pass_rel(const RelParams P)
         // line two before, of the line before
         const bool own = f0 ? k == 0 : k == 3;
         const int di0 = f0 ? (k == 1 ? 0 : (k == 2 ? -1 : 1)) : (k == 0 ? 1 : (k == 1 ? -1 : 0));
-        const int row = diag ? (k == 0 ? ln : (k == 1 ? prow2 : prow)) : (own ? ln : prow);
-        const int nstep = (diag || own) ? -1 : (mirror ? -di0 : di0);
+        // exchanged roles (form 0, TSGM <= 3): the first neighbour (i - 1, j) of the pass is the same pixel of the line before, the second
+        // (i, j - 1) the pixel before on this line, the third (i - 1, j - 1) stays what it was
+        const int row = diag ? (k == 0 ? ln : (k == 1 ? prow2 : prow)) : (swp ? (k == 1 ? ln : prow) : (own ? ln : prow));
+        const int nstep = swp ? (k == 0 ? 0 : -1) : ((diag || own) ? -1 : (mirror ? -di0 : di0));
         const int nent = (int)((row >= RR ? (row == RR ? hring : hring2) : ring + row * RD4 * HS) - smem);
         if (li == 0) *reinterpret_cast<int4 *>(lt + 4 + 4 * k) = make_int4(nent, row >= RR ? SD - 1 : RD4 - 1, nstep, 0);
     }

@@ -1160,6 +1160,21 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
         // (round 6, later) ... and better: those passes ACROSS their lines, bands of anti-diagonals in lock step (k_pass_rel, g.diag) -- the
         // chain of a pass is NL + bands x lag steps instead of 2 NL + LL / 2 + bands x lag.  Two hand-off lines per band and a second hand
         // ring in LDS: where that does not fit (the three-slab entries of 128 slots with two-byte costs) the strips stay.  tune rel_diag=0: strips
+        // (round 6, last) form-0 passes with TSGM <= 3 and more lines than pixels per line (the column passes of a landscape image) are walked
+        // with the roles of i and j exchanged: (i - 1, j), (i, j - 1), (i - 1, j - 1) is symmetric in them, the depth NL + LL stays, but a band
+        // trails the band before it by ~2 x 16 steps in practice (the pace of a chain is that of its slowest band), so FEWER bands of longer
+        // lines end sooner: 68 x D + 1920 against 120 x D + 1080.  tune rel_swap=0: none
+        // (FH x 1 5.73 -> 5.27 ms, x 2 7.34 -> 7.04, windows of 101 labels 8.58 -> 7.9, x 4 unchanged; the short steps of the Hirschmueller launches lose
+        // 1-2 % with it -- 4.17 / 5.03 / 8.05 -> 4.19 / 5.16 / 8.16 -- and keep their walks: rel_swap=2 forces it there too)
+        if ((tune_num("rel_swap", 1) >= 2 || (tune_num("rel_swap", 1) == 1 && fh)) && p.g[q].form == 0 && MGM <= 3 && p.g[q].slope == 1 && p.g[q].NL > p.g[q].LL) {
+            PassGeom &g = p.g[q];
+            std::swap(g.NL, g.LL);
+            std::swap(g.istep, g.jstep);
+            g.swap = 1;
+            g.nbands = (g.NL + R - 1) / R;
+            g.split = g.LL;
+            maxLL = std::max(maxLL, g.LL);
+        }
         const bool diag_ok = tune_num("rel_diag", 1) != 0 && p.g[q].form == 1 && MGM <= 3 && pass_rel_lds_bytes(fh || pube, slots, rcb, fh2, true) <= (size_t)160 * 1024;
         if (diag_ok) {
             PassGeom &g = p.g[q];
@@ -1191,7 +1206,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
         const void *before = c->hand_rel.p;
         if ((r = reserve(c, c->hand_rel, bytes))) return r;
         char hk[128];
-        snprintf(hk, sizeof hk, "%d %d %d %d %d %d %d %d", nx, ny, NDIR, nb, HS, R, slots, p.diag_any);
+        snprintf(hk, sizeof hk, "%d %d %d %d %d %d %d %d", nx, ny, NDIR, nb, HS, R, slots, p.diag_any + 2 * (int)tune_num("rel_swap", 1));
         if (c->hand_rel.p != before || c->hand_rel_key != hk) {
             HIPCHK(c, hipMemsetAsync(c->hand_rel.p, 0xff, bytes, c->stream));
             c->hand_rel_key = hk;
@@ -1213,7 +1228,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     // (with the anti-diagonal passes a single launch is no longer one long chain: x 1 6.89 / 6.32 / 6.47 ms at 1 / 2 / 3, x 2 11.5 / 7.82 / 7.76,
     // x 4 22.0 / 13.0 / 12.3; Hirschmueller x 1 5.45 / 4.62 / 4.36)
     const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 1 ? (fh ? 2 : 3) : 3);
-    snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d %d %lld", nx, ny, NDIR, nb, rel_wg, p.g[0].slope, MGM, p.g[NDIR - 1].nstrips, p.diag_any, tune_num("rel_prio", nb <= 1 ? 5 : 0) + 1000 * tune_num("rel_lag", 0) + 100000 * tune_num("rel_lagd", 0) + 10000000 * tune_num("rel_slots", 100));
+    snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d %d %lld", nx, ny, NDIR, nb, rel_wg, p.g[0].slope, MGM, p.g[NDIR - 1].nstrips, p.diag_any + 2 * (int)tune_num("rel_swap", 1), tune_num("rel_prio", nb <= 1 ? 5 : 0) + 1000 * tune_num("rel_lag", 0) + 100000 * tune_num("rel_lagd", 0) + 10000000 * tune_num("rel_slots", 100));
     if (c->tasks_rel_key != key) {
         std::vector<SimChain> ch;
         for (int v = 0; v < nb; v++)
