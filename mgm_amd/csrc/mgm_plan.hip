@@ -1149,6 +1149,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     unsigned *words = (unsigned *)c->words.p;
     RelParams p{};
     int maxLL = 0, maxbands = 0;
+    int swapmask = 0;  // the passes walked with exchanged roles: part of what the hand-off region's layout and the task table depend on
     for (int q = 0; q < NDIR; q++) {
         // (round 6) form-0 passes with TSGM <= 3 walk slope 1 (make_geom decides; tune rel_slope1=0: slope 2 everywhere, as in round 5)
         if (!make_geom(q, nx, ny, R, MGM, tune_num("rel_slope1", 1) != 0, p.g[q])) return fail(c, MGM_ERR_INTERNAL, "pass table does not reduce to canonical form");
@@ -1171,6 +1172,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
             std::swap(g.NL, g.LL);
             std::swap(g.istep, g.jstep);
             g.swap = 1;
+            swapmask |= 1 << q;
             g.nbands = (g.NL + R - 1) / R;
             g.split = g.LL;
             maxLL = std::max(maxLL, g.LL);
@@ -1206,7 +1208,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
         const void *before = c->hand_rel.p;
         if ((r = reserve(c, c->hand_rel, bytes))) return r;
         char hk[128];
-        snprintf(hk, sizeof hk, "%d %d %d %d %d %d %d %d", nx, ny, NDIR, nb, HS, R, slots, p.diag_any + 2 * (int)tune_num("rel_swap", 1));
+        snprintf(hk, sizeof hk, "%d %d %d %d %d %d %d %d", nx, ny, NDIR, nb, HS, R, slots, p.diag_any + 2 * swapmask);
         if (c->hand_rel.p != before || c->hand_rel_key != hk) {
             HIPCHK(c, hipMemsetAsync(c->hand_rel.p, 0xff, bytes, c->stream));
             c->hand_rel_key = hk;
@@ -1228,7 +1230,7 @@ int run_rel(mgm_ctx *c, const mgm_cv *const *Cs, const mgm_img *const *w8s, int 
     // (with the anti-diagonal passes a single launch is no longer one long chain: x 1 6.89 / 6.32 / 6.47 ms at 1 / 2 / 3, x 2 11.5 / 7.82 / 7.76,
     // x 4 22.0 / 13.0 / 12.3; Hirschmueller x 1 5.45 / 4.62 / 4.36)
     const int rel_wg = wgs > 0 ? (int)std::min(wgs, 6LL) : (nb <= 1 ? (fh ? 2 : 3) : 3);
-    snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d %d %lld", nx, ny, NDIR, nb, rel_wg, p.g[0].slope, MGM, p.g[NDIR - 1].nstrips, p.diag_any + 2 * (int)tune_num("rel_swap", 1), tune_num("rel_prio", nb <= 1 ? 5 : 0) + 1000 * tune_num("rel_lag", 0) + 100000 * tune_num("rel_lagd", 0) + 10000000 * tune_num("rel_slots", 100));
+    snprintf(key, sizeof key, "%d %d %d %d %d %d %d %d %d %lld", nx, ny, NDIR, nb, rel_wg, p.g[0].slope, MGM, p.g[NDIR - 1].nstrips, p.diag_any + 2 * swapmask, tune_num("rel_prio", nb <= 1 ? 5 : 0) + 1000 * tune_num("rel_lag", 0) + 100000 * tune_num("rel_lagd", 0) + 10000000 * tune_num("rel_slots", 100));
     if (c->tasks_rel_key != key) {
         std::vector<SimChain> ch;
         for (int v = 0; v < nb; v++)

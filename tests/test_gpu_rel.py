@@ -179,6 +179,39 @@ def test_rel_random_cases_match_dense_hull(seed):
     assert ndiff(res["2"][0], res["0"][0]) == 0 and ndiff(res["2"][1], res["0"][1]) == 0, what
 
 
+def test_rel_launches_of_different_walks_share_a_context():
+    """FH launches walk their form-0 column passes with exchanged roles (fewer bands), Hirschmueller launches do not: the hand-off region's
+    layout and the task table differ although shape, batch and workgroups per CU are the same -- alternating them on one context must not
+    reuse either (found by the end-of-round suite: the cache keys named the switch, not what the launch did with it)."""
+    nx, ny, dmin, dmax = 150, 60, -60, 0
+    pairs = [synth.stereo_pair(nx, ny, -45, 0, seed=170 + k) for k in range(2)]
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["MGM_HIP_REL"] = mode
+        try:
+            with mgm_amd.Context(0) as ctx:
+                cvs = []
+                for k, (u, v, gt) in enumerate(pairs):
+                    lo, hi = ranges(gt, dmin, dmax, 10, 130 + k)
+                    lo[0, 0], hi[0, 1] = dmin, dmax  # (batched volumes share their hull)
+                    cvs.append(ctx.costvolume(u, v, lo, hi, "none", "census", float("inf"), 5))
+                out = []
+                for FH in (1, 0, 1, 0):
+                    ctx.timing(True)
+                    ctx.timing_reset()
+                    _, outs, outcs = ctx.aggregate_batch_dev(cvs, 2.0 if FH else 8.0, 30.0, 8, 3, FH, 1, None, "vfit")
+                    names = [n for n, _ in ctx.timings()]
+                    ctx.timing(False)
+                    assert ("k_pass_rel" in names) == (mode == "1"), (mode, FH, names)
+                    out.append(([o.download() for o in outs], [c.download() for c in outcs]))
+                res[mode] = out
+        finally:
+            os.environ.pop("MGM_HIP_REL", None)
+    for r in range(4):
+        for k in range(2):
+            assert ndiff(res["1"][r][0][k], res["0"][r][0][k]) == 0 and ndiff(res["1"][r][1][k], res["0"][r][1][k]) == 0, (r, k)
+
+
 def test_rel_batch_honours_the_workspace_limit():
     """a batch of ragged volumes whose range-proportional Lr volumes exceed mgm_ctx_set_workspace_limit runs as several
     launches of k_pass_rel (as the dense path does) -- same maps as the unlimited launch."""
